@@ -1,0 +1,113 @@
+"""ctypes binding of libcloudct.so (the C ABI declared in include/cloudct.h).
+
+The shared library is built in-tree by `build()` (hipcc, gfx950 only) and loaded
+lazily.  There is NO CPU fallback: if the library is missing or a tensor is not
+on a HIP device the ops raise.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcloudct.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+HIP_SOURCES = ["ct_raster.hip", "ct_chamfer.hip", "ct_emd.hip"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+               # index/weight math must round exactly like the reference's fp32 op sequence
+               "-ffp-contract=off"]
+
+CT_OK = 0
+REDUCE = {"max": 0, "sum": 1}
+PAD_NONE, PAD_F32, PAD_I32 = 0, 1, 2
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "cloudct.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into lib/libcloudct.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE] + srcs + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); mirrors include/cloudct.h one to one
+SIGNATURES = {
+    "ct_abi_version": (_i, []),
+    "ct_strerror": (ctypes.c_char_p, [_i]),
+    "ct_positions_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ip, _vp]),
+    "ct_positions_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ip, _vp]),
+    "ct_splat_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
+    "ct_splat_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip, _i]),
+    "ct_splat_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _vp]),
+    "ct_slice_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_splat_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
+    "ct_splat_lc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _vp]),
+    "ct_slice_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_lc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_grid_occupancy": (_i, [_vp, ctypes.c_int64, _vp, _vp]),
+    "ct_chamfer_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ct_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+
+def load():
+    """Return the loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(cloud_transformers_amd has no CPU or PyTorch fallback)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+                fn.restype = res
+                fn.argtypes = args
+            if lib.ct_abi_version() != 1:
+                raise RuntimeError("libcloudct.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != CT_OK:
+        msg = load().ct_strerror(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])

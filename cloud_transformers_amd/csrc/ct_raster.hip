@@ -1,0 +1,742 @@
+// Differentiable rasterize (Splat) / de-rasterize (Slice) for gfx950.
+//
+// Generic kernels: any dim in {2,3}, any extents, any C, optional padding mask,
+// corners either recomputed from keys (fused hot path) or read from explicit
+// (local_coord, flat_idx) tensors (API-compatible path).
+//
+// Work decomposition: one workgroup owns one (b, h, channel-chunk) tile of the
+// grid and keeps it in LDS, so that the random-access part of the op (atomic
+// max / atomic add for the scatter passes, corner reads for the gather passes)
+// never leaves the CU; HBM only sees coalesced streams of keys / features along
+// N and one linear copy of the tile.  Grids whose single-channel tile exceeds
+// the LDS budget fall back to global atomics / global gathers.
+//
+// Math spec: SURVEY.md Appendix A (derived from layers/cloud_transform.py:72-227
+// and layers/utils.py:100-186 of the reference).
+#include "ct_common.h"
+
+namespace {
+
+constexpr int kMaxLdsBytes = 64 * 1024;        // tile budget per workgroup (2 WGs / CU)
+constexpr int kBigLdsBytes = 160 * 1024 - 512; // whole-CU budget for huge single-channel tiles
+
+struct PosSrc {
+  const float* keys;        // (B, H*DIM, N)            when FROM_KEYS
+  const float* lc;          // (B, H, V, N)             otherwise
+  const long long* idx;     // (B, H, V, N) int64
+};
+
+struct RasterArgs {
+  PosSrc pos;
+  const float* src;     // point-sized input  (B, H*C, N): feat or g_out
+  const void* pad;      // (B, N) or null
+  int pad_dtype;
+  float* tile_out;      // grid-sized output  (B, H*C, G)
+  const float* tile_in; // grid-sized input   (B, H*C, G)
+  const float* tile_in2;// second grid-sized input (g_grid for splat-max bwd)
+  float* dst;           // point-sized output (B, H*C, N)
+  float* g_pos;         // g_keys (B,H*DIM,N) or g_lc (B,H,V,N)
+  unsigned* claim;      // global copy of z used for single-winner claims (no-LDS fallback)
+  int B, H, C, N;
+  int CC;               // channels per tile
+  int nchunks;          // ceil(C / CC)
+  int ncg;              // chunk groups (grid.x split of the chunk loop in gather-reduce kernels)
+  int nsplit;           // splits of N for pure gather kernels
+  int atomic_gpos;      // accumulate g_pos with global atomics (ncg > 1)
+};
+
+template <int DIM, bool FROM_KEYS>
+struct PointPos {
+  float w0[DIM], w1[DIM];
+  float mask[DIM];
+};
+
+// Loads one point's corners. bh = b*H + h.
+template <int DIM, bool FROM_KEYS>
+__device__ __forceinline__ void load_point(const PosSrc& P, const GridW<DIM>& g, size_t bh, int N, int n,
+                                           Corners<DIM>& c, PointPos<DIM, FROM_KEYS>& pp) {
+  constexpr int V = 1 << DIM;
+  if constexpr (FROM_KEYS) {
+    int f[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      float k = P.keys[(bh * DIM + j) * N + n];
+      ct_axis(k, g.hw[j], g.W[j], pp.w0[j], pp.w1[j], f[j]);
+      pp.mask[j] = ct_key_mask(k);
+    }
+    ct_corners<DIM>(pp.w0, pp.w1, f, g, c);
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      c.w[v] = P.lc[(bh * V + v) * N + n];
+      c.cell[v] = (int)P.idx[(bh * V + v) * N + n];
+    }
+  }
+}
+
+// Writes / accumulates one point's position cotangent.
+template <int DIM, bool FROM_KEYS>
+__device__ __forceinline__ void store_gpos(float* g_pos, size_t bh, int N, int n,
+                                           const PointPos<DIM, FROM_KEYS>& pp, const float (&gw)[1 << DIM],
+                                           bool first, bool atomic) {
+  constexpr int V = 1 << DIM;
+  if constexpr (FROM_KEYS) {
+    float gs[DIM];
+    ct_corner_grad<DIM>(pp.w0, pp.w1, gw, gs);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      float val = gs[j] * pp.mask[j];
+      float* p = g_pos + (bh * DIM + j) * N + n;
+      if (atomic) atomicAdd(p, val);
+      else if (first) *p = val;
+      else *p += val;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float* p = g_pos + (bh * V + v) * N + n;
+      if (atomic) atomicAdd(p, gw[v]);
+      else if (first) *p = gw[v];
+      else *p += gw[v];
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_fill_zero(float* tile, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) tile[i] = 0.0f;
+}
+
+__device__ __forceinline__ void copy_linear(float* __restrict__ dst, const float* __restrict__ src, int count) {
+  // both sides are 16-byte aligned whenever count % 4 == 0 (tiles start at multiples of G*CC)
+  if ((count & 3) == 0 && ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
+    const float4* s4 = (const float4*)src;
+    float4* d4 = (float4*)dst;
+    for (int i = threadIdx.x; i < (count >> 2); i += blockDim.x) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1: scatter pass.  tile_out[(b,h,c), cell_v(n)] (max0|+)= (src[(b,h,c), n] * pad[b,n]) * w_v(n)
+//   Splat forward (both reduce modes) and the g_grid half of Slice backward
+//   (a scatter-add of g_out, layers/cloud_transform.py:216-221 autograd).
+//   grid = (nchunks, H, B).  LDS_TILE=false: tile_out pre-zeroed, global atomics.
+// ---------------------------------------------------------------------------
+template <int DIM, bool FROM_KEYS, bool SUM, bool LDS_TILE>
+__global__ void __launch_bounds__(1024) scatter_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
+  float* T = LDS_TILE ? lds : gout;
+  if (LDS_TILE) {
+    lds_fill_zero(lds, cc * g.G);
+    __syncthreads();
+  }
+  const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+  for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+    Corners<DIM> c;
+    PointPos<DIM, FROM_KEYS> pp;
+    load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+    const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    for (int ch = 0; ch < cc; ++ch) {
+      float f = src[(size_t)ch * a.N + n];
+      if (has_pad) f = f * p;
+      float* Tc = T + (size_t)ch * g.G;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float prod = f * c.w[v];
+        if (SUM) {
+          atomicAdd(&Tc[c.cell[v]], prod);
+        } else {
+          // zero floor: only positive products can win, and positive IEEE-754
+          // floats order like their bit patterns
+          if (prod > 0.0f) atomicMax((unsigned*)&Tc[c.cell[v]], __float_as_uint(prod));
+        }
+      }
+    }
+  }
+  if (LDS_TILE) {
+    __syncthreads();
+    copy_linear(gout, lds, cc * g.G);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: gather pass.  dst[(b,h,c), n] = (sum_v tile_in[(b,h,c), cell_v(n)] * w_v(n)) * pad[b,n]
+//   Slice forward; also the g_feat half of Splat(sum) backward.
+//   grid = (nchunks * nsplit, H, B)
+// ---------------------------------------------------------------------------
+template <int DIM, bool FROM_KEYS, bool LDS_TILE>
+__global__ void __launch_bounds__(1024) gather_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)g.G;
+  const float* T = LDS_TILE ? lds : gin;
+  if (LDS_TILE) {
+    copy_linear(lds, gin, cc * g.G);
+    __syncthreads();
+  }
+  const int per = (a.N + a.nsplit - 1) / a.nsplit;
+  const int n_beg = sp * per, n_end = min(a.N, n_beg + per);
+  float* dst = a.dst + (bh * a.C + c0) * (size_t)a.N;
+  for (int n = n_beg + threadIdx.x; n < n_end; n += blockDim.x) {
+    Corners<DIM> c;
+    PointPos<DIM, FROM_KEYS> pp;
+    load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+    const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    for (int ch = 0; ch < cc; ++ch) {
+      const float* Tc = T + (size_t)ch * g.G;
+      float acc = Tc[c.cell[0]] * c.w[0];
+#pragma unroll
+      for (int v = 1; v < V; ++v) acc += Tc[c.cell[v]] * c.w[v];
+      if (has_pad) acc = acc * p;
+      dst[(size_t)ch * a.N + n] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: corner-cotangent pass of a gather:  gw[v,n] = sum_c tile_in[(b,h,c), cell_v(n)] * (src[(b,h,c), n] * pad)
+//   Slice backward wrt the weights (tile_in = conv output, src = g_out);
+//   Splat(sum) backward wrt the weights (tile_in = g_grid, src = feat).
+//   Result goes through the positions backward (FROM_KEYS) or to g_local_coord.
+//   grid = (ncg * nsplit, H, B); each workgroup loops over its share of chunks.
+// ---------------------------------------------------------------------------
+template <int DIM, bool FROM_KEYS, bool LDS_TILE>
+__global__ void __launch_bounds__(1024) gather_gw_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  const int cg = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int per = (a.N + a.nsplit - 1) / a.nsplit;
+  const int n_beg = sp * per, n_end = min(a.N, n_beg + per);
+  const bool atomic = a.atomic_gpos != 0;
+  bool first = true;
+  for (int chunk = cg; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * a.CC;
+    const int cc = min(a.CC, a.C - c0);
+    const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)g.G;
+    const float* T = LDS_TILE ? lds : gin;
+    if (LDS_TILE) {
+      __syncthreads();
+      copy_linear(lds, gin, cc * g.G);
+      __syncthreads();
+    }
+    const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+    for (int n = n_beg + threadIdx.x; n < n_end; n += blockDim.x) {
+      Corners<DIM> c;
+      PointPos<DIM, FROM_KEYS> pp;
+      load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+      const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+      const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+      float gw[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) gw[v] = 0.0f;
+      for (int ch = 0; ch < cc; ++ch) {
+        float s = src[(size_t)ch * a.N + n];
+        if (has_pad) s = s * p;
+        const float* Tc = T + (size_t)ch * g.G;
+#pragma unroll
+        for (int v = 0; v < V; ++v) gw[v] += Tc[c.cell[v]] * s;
+      }
+      store_gpos<DIM, FROM_KEYS>(a.g_pos, bh, a.N, n, pp, gw, first, atomic);
+    }
+    first = false;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: Splat(max0) backward.  tile_in = z (forward output), tile_in2 = g_z.
+//   A contribution (c, v, n) is the winner of its cell iff its product is
+//   positive and bit-equal to z[c, cell]; the first such contribution to CLAIM
+//   the cell (atomic compare-and-swap of the tile copy to 0) receives g_z, so
+//   that exactly one contribution wins even on exact ties (torch_scatter's
+//   backward routes the cotangent to a single arg-max element).
+//     g_feat[c,n] = pad * sum_v win * g_z[c,cell_v] * w_v
+//     gw[v,n]     = sum_c win * g_z[c,cell_v] * feat[c,n]*pad
+//   grid = (ncg, H, B); the whole N range stays in one workgroup per chunk so
+//   that claims are unique.
+// ---------------------------------------------------------------------------
+template <int DIM, bool FROM_KEYS, bool LDS_TILE>
+__global__ void __launch_bounds__(1024) splat_max_bwd_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  const int cg = blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const bool atomic = a.atomic_gpos != 0;
+  bool first = true;
+  for (int chunk = cg; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * a.CC;
+    const int cc = min(a.CC, a.C - c0);
+    const size_t toff = (bh * a.C + c0) * (size_t)g.G;
+    unsigned* T = LDS_TILE ? (unsigned*)lds : (a.claim + toff);
+    if (LDS_TILE) {
+      __syncthreads();
+      copy_linear(lds, a.tile_in + toff, cc * g.G);
+      __syncthreads();
+    }
+    const float* gz = a.tile_in2 + toff;
+    const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+    float* dst = a.dst + (bh * a.C + c0) * (size_t)a.N;
+    for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+      Corners<DIM> c;
+      PointPos<DIM, FROM_KEYS> pp;
+      load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+      const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+      const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+      float gw[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) gw[v] = 0.0f;
+      for (int ch = 0; ch < cc; ++ch) {
+        float f = src[(size_t)ch * a.N + n];
+        if (has_pad) f = f * p;
+        unsigned* Tc = T + (size_t)ch * g.G;
+        float gf = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float prod = f * c.w[v];
+          unsigned bits = __float_as_uint(prod);
+          if (prod > 0.0f && Tc[c.cell[v]] == bits) {
+            if (atomicCAS(&Tc[c.cell[v]], bits, 0u) == bits) {
+              float gzv = gz[(size_t)ch * g.G + c.cell[v]];
+              gf += gzv * c.w[v];
+              gw[v] += gzv * f;
+            }
+          }
+        }
+        if (has_pad) gf = gf * p;
+        dst[(size_t)ch * a.N + n] = gf;
+      }
+      store_gpos<DIM, FROM_KEYS>(a.g_pos, bh, a.N, n, pp, gw, first, atomic);
+    }
+    first = false;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K0: DifferentiablePositions forward / backward (API path only)
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void positions_fwd_kernel(const float* keys, float* lc, long long* idx, int BH, int N, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)BH * N) return;
+  size_t bh = i / N;
+  int n = (int)(i % N);
+  float w0[DIM], w1[DIM];
+  int f[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) ct_axis(keys[(bh * DIM + j) * N + n], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+  Corners<DIM> c;
+  ct_corners<DIM>(w0, w1, f, g, c);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    lc[(bh * V + v) * N + n] = c.w[v];
+    idx[(bh * V + v) * N + n] = (long long)c.cell[v];
+  }
+}
+
+template <int DIM>
+__global__ void positions_bwd_kernel(const float* keys, const float* g_lc, float* g_keys, int BH, int N, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)BH * N) return;
+  size_t bh = i / N;
+  int n = (int)(i % N);
+  float w0[DIM], w1[DIM], mask[DIM], gw[V], gs[DIM];
+  int f[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) {
+    float k = keys[(bh * DIM + j) * N + n];
+    ct_axis(k, g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+    mask[j] = ct_key_mask(k);
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) gw[v] = g_lc[(bh * V + v) * N + n];
+  ct_corner_grad<DIM>(w0, w1, gw, gs);
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) g_keys[(bh * DIM + j) * N + n] = gs[j] * mask[j];
+}
+
+__global__ void occupancy_kernel(const float* grid, long long n, unsigned long long* count) {
+  unsigned long long local = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    local += fabsf(grid[i]) > 1e-9f ? 1ull : 0ull;
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+// ---------------------------------------------------------------------------
+// host-side planning
+// ---------------------------------------------------------------------------
+struct Plan {
+  int CC, nchunks, threads;
+  size_t lds_bytes;
+  bool lds_tile;
+};
+
+bool valid_common(int B, int H, int C, int N, int dim, const int* W) {
+  if (B <= 0 || H <= 0 || C <= 0 || N <= 0 || (dim != 2 && dim != 3) || !W) return false;
+  long long G = 1;
+  for (int j = 0; j < dim; ++j) {
+    if (W[j] < 2) return false;
+    G *= W[j];
+    if (G > (1ll << 30)) return false;
+  }
+  if (H > 65535 || B > 65535) return false;
+  return true;
+}
+
+template <int DIM>
+GridW<DIM> make_grid(const int* W) {
+  GridW<DIM> g;
+  g.G = 1;
+  for (int j = 0; j < DIM; ++j) {
+    g.W[j] = W[j];
+    g.hw[j] = (float)(W[j] - 1) * 0.5f;
+    g.G *= W[j];
+  }
+  return g;
+}
+
+int round_threads(int n) {
+  int t = ((n + 63) / 64) * 64;
+  return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
+// Choose channels-per-tile: the largest chunk that fits the LDS budget while
+// leaving at least ~2 workgroups per CU chip-wide when C allows it.
+Plan make_plan(int B, int H, int C, int N, int G, int tiles_per_wg /*1 or 2 tiles resident*/) {
+  Plan p;
+  size_t per_ch = (size_t)G * 4 * tiles_per_wg;
+  p.lds_tile = true;
+  if (per_ch > (size_t)kBigLdsBytes) {  // not even one channel fits: global path
+    p.lds_tile = false;
+    p.CC = C;
+    p.nchunks = 1;
+    p.lds_bytes = 0;
+    p.threads = round_threads(N);
+    return p;
+  }
+  int cc_fit = (int)(kMaxLdsBytes / per_ch);
+  if (cc_fit < 1) cc_fit = 1;  // single channel between 64 KiB and 160 KiB: one WG per CU
+  int cc = cc_fit < C ? cc_fit : C;
+  // enough workgroups to fill 256 CUs
+  const long long want = 512;
+  while (cc > 1 && (long long)B * H * ((C + cc - 1) / cc) < want) cc = (cc + 1) / 2;
+  p.CC = cc;
+  p.nchunks = (C + cc - 1) / cc;
+  p.lds_bytes = (size_t)cc * per_ch;
+  p.threads = round_threads(N);
+  return p;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+      return CT_ELAUNCH;
+  }
+  return CT_OK;
+}
+
+#define CT_LAUNCH(KERNEL, GRID, THREADS, LDS, STREAM, ...)                   \
+  do {                                                                      \
+    if (set_lds(KERNEL, LDS) != CT_OK) return CT_ELAUNCH;                   \
+    hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, STREAM, __VA_ARGS__); \
+    CT_CHECK_LAUNCH();                                                      \
+  } while (0)
+
+// scatter: Splat fwd (max/sum) and Slice bwd g_grid
+template <int DIM, bool FROM_KEYS>
+int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
+  GridW<DIM> g = make_grid<DIM>(W);
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  a.CC = p.CC;
+  a.nchunks = p.nchunks;
+  dim3 grid(p.nchunks, a.H, a.B);
+  if (p.lds_tile) {
+    if (sum) CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+  } else {
+    if (hipMemsetAsync(a.tile_out, 0, (size_t)a.B * a.H * a.C * g.G * 4, st) != hipSuccess) return CT_ELAUNCH;
+    if (sum) CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, 0, st, a, g);
+    else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
+  }
+  return CT_OK;
+}
+
+int pick_nsplit(int B, int H, int nchunks, int N) {
+  // pure gather kernels may split N freely (the tile is re-staged per split)
+  int ns = 1;
+  while ((long long)B * H * nchunks * ns < 512 && N / (ns * 2) >= 256) ns *= 2;
+  return ns;
+}
+
+template <int DIM, bool FROM_KEYS>
+int run_gather(RasterArgs a, const int* W, hipStream_t st) {
+  GridW<DIM> g = make_grid<DIM>(W);
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  a.CC = p.CC;
+  a.nchunks = p.nchunks;
+  a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N);
+  int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
+  dim3 grid(p.nchunks * a.nsplit, a.H, a.B);
+  if (p.lds_tile) CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
+  else CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
+  return CT_OK;
+}
+
+template <int DIM, bool FROM_KEYS>
+size_t gpos_bytes(const RasterArgs& a) {
+  return (size_t)a.B * a.H * (FROM_KEYS ? DIM : (1 << DIM)) * a.N * 4;
+}
+
+template <int DIM, bool FROM_KEYS>
+int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
+  GridW<DIM> g = make_grid<DIM>(W);
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  a.CC = p.CC;
+  a.nchunks = p.nchunks;
+  a.nsplit = pick_nsplit(a.B, a.H, 1, a.N);
+  a.ncg = 1;
+  while ((long long)a.B * a.H * a.nsplit * a.ncg < 512 && a.ncg * 2 <= p.nchunks) a.ncg *= 2;
+  a.atomic_gpos = a.ncg > 1;
+  if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
+  int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
+  dim3 grid(a.ncg * a.nsplit, a.H, a.B);
+  if (p.lds_tile) CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
+  else CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
+  return CT_OK;
+}
+
+template <int DIM, bool FROM_KEYS>
+int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
+  GridW<DIM> g = make_grid<DIM>(W);
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  a.CC = p.CC;
+  a.nchunks = p.nchunks;
+  a.nsplit = 1;
+  a.ncg = 1;
+  while ((long long)a.B * a.H * a.ncg < 512 && a.ncg * 2 <= p.nchunks) a.ncg *= 2;
+  a.atomic_gpos = a.ncg > 1;
+  if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
+  dim3 grid(a.ncg, a.H, a.B);
+  if (p.lds_tile) {
+    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true>), grid, p.threads, p.lds_bytes, st, a, g);
+  } else {
+    size_t need = (size_t)a.B * a.H * a.C * g.G * 4;
+    if (!ws || ws_bytes < need) return CT_EWORKSPACE;
+    if (hipMemcpyAsync(ws, a.tile_in, need, hipMemcpyDeviceToDevice, st) != hipSuccess) return CT_ELAUNCH;
+    a.claim = (unsigned*)ws;
+    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false>), grid, p.threads, 0, st, a, g);
+  }
+  return CT_OK;
+}
+
+bool valid_pad(const void* pad, int pad_dtype) {
+  if (pad_dtype == CT_PAD_NONE) return true;
+  return (pad_dtype == CT_PAD_F32 || pad_dtype == CT_PAD_I32) && pad != nullptr;
+}
+
+RasterArgs base_args(int B, int H, int C, int N, const void* pad, int pad_dtype) {
+  RasterArgs a = {};
+  a.B = B; a.H = H; a.C = C; a.N = N;
+  a.pad = pad_dtype == CT_PAD_NONE ? nullptr : pad;
+  a.pad_dtype = pad_dtype;
+  a.nsplit = 1; a.ncg = 1; a.nchunks = 1; a.CC = C;
+  return a;
+}
+
+template <bool FROM_KEYS>
+int splat_fwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype, float* grid,
+                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st) {
+  if (!valid_common(B, H, C, N, dim, W) || !feat || !grid || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  if (reduce != CT_REDUCE_MAX0 && reduce != CT_REDUCE_SUM) return CT_EINVAL;
+  RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+  a.pos = pos; a.src = feat; a.tile_out = grid;
+  return dim == 2 ? run_scatter<2, FROM_KEYS>(a, W, reduce == CT_REDUCE_SUM, st)
+                  : run_scatter<3, FROM_KEYS>(a, W, reduce == CT_REDUCE_SUM, st);
+}
+
+template <bool FROM_KEYS>
+int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype, const float* grid,
+                   const float* g_grid, float* g_feat, float* g_pos, void* ws, size_t ws_bytes,
+                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st) {
+  if (!valid_common(B, H, C, N, dim, W) || !feat || !g_grid || !g_feat || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+  a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos;
+  if (reduce == CT_REDUCE_MAX0) {
+    if (!grid) return CT_EINVAL;
+    a.tile_in = grid; a.tile_in2 = g_grid;
+    return dim == 2 ? run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, ws_bytes, st)
+                    : run_splat_max_bwd<3, FROM_KEYS>(a, W, ws, ws_bytes, st);
+  } else if (reduce == CT_REDUCE_SUM) {
+    // linear op: g_feat = Slice(g_grid), gw = sum_c g_grid * feat
+    a.tile_in = g_grid;
+    int r = dim == 2 ? run_gather<2, FROM_KEYS>(a, W, st) : run_gather<3, FROM_KEYS>(a, W, st);
+    if (r != CT_OK) return r;
+    return dim == 2 ? run_gather_gw<2, FROM_KEYS>(a, W, st) : run_gather_gw<3, FROM_KEYS>(a, W, st);
+  }
+  return CT_EINVAL;
+}
+
+template <bool FROM_KEYS>
+int slice_fwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, float* out,
+                   int B, int H, int C, int N, int dim, const int* W, hipStream_t st) {
+  if (!valid_common(B, H, C, N, dim, W) || !grid || !out || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+  a.pos = pos; a.tile_in = grid; a.dst = out;
+  return dim == 2 ? run_gather<2, FROM_KEYS>(a, W, st) : run_gather<3, FROM_KEYS>(a, W, st);
+}
+
+template <bool FROM_KEYS>
+int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                   float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st) {
+  if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+  a.pos = pos; a.src = g_out; a.tile_out = g_grid;
+  int r = dim == 2 ? run_scatter<2, FROM_KEYS>(a, W, true, st) : run_scatter<3, FROM_KEYS>(a, W, true, st);
+  if (r != CT_OK) return r;
+  a.tile_out = nullptr; a.tile_in = grid; a.g_pos = g_pos;
+  return dim == 2 ? run_gather_gw<2, FROM_KEYS>(a, W, st) : run_gather_gw<3, FROM_KEYS>(a, W, st);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+const char* ct_strerror(int status) {
+  switch (status) {
+    case CT_OK: return "ok";
+    case CT_EINVAL: return "invalid argument";
+    case CT_ELAUNCH: return "HIP launch error";
+    case CT_EWORKSPACE: return "workspace too small";
+    case CT_EPRECOND: return "reference precondition violated";
+    default: return "unknown status";
+  }
+}
+
+int ct_positions_fwd(const float* keys, float* lc, int64_t* idx, int B, int H, int N, int dim, const int* W, ct_stream_t s) {
+  if (!valid_common(B, H, 1, N, dim, W) || !keys || !lc || !idx) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  size_t total = (size_t)B * H * N;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dim == 2) hipLaunchKernelGGL(positions_fwd_kernel<2>, grid, dim3(256), 0, st, keys, lc, (long long*)idx, B * H, N, make_grid<2>(W));
+  else hipLaunchKernelGGL(positions_fwd_kernel<3>, grid, dim3(256), 0, st, keys, lc, (long long*)idx, B * H, N, make_grid<3>(W));
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_positions_bwd(const float* keys, const float* g_lc, float* g_keys, int B, int H, int N, int dim, const int* W, ct_stream_t s) {
+  if (!valid_common(B, H, 1, N, dim, W) || !keys || !g_lc || !g_keys) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  size_t total = (size_t)B * H * N;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dim == 2) hipLaunchKernelGGL(positions_bwd_kernel<2>, grid, dim3(256), 0, st, keys, g_lc, g_keys, B * H, N, make_grid<2>(W));
+  else hipLaunchKernelGGL(positions_bwd_kernel<3>, grid, dim3(256), 0, st, keys, g_lc, g_keys, B * H, N, make_grid<3>(W));
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_splat_fwd(const float* keys, const float* feat, const void* pad, int pad_dtype, float* grid,
+                 int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return splat_fwd_impl<true>(pos, feat, pad, pad_dtype, grid, B, H, C, N, dim, W, reduce, (hipStream_t)s);
+}
+
+size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce) {
+  if (!valid_common(B, H, C, N, dim, W) || reduce != CT_REDUCE_MAX0) return 0;
+  size_t G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  if (G * 4 <= (size_t)kBigLdsBytes) return 0;   // tile lives in LDS
+  return (size_t)B * H * C * G * 4;
+}
+
+int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,
+                 const float* g_grid, float* g_feat, float* g_keys, void* ws, size_t ws_bytes,
+                 int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
+                              B, H, C, N, dim, W, reduce, (hipStream_t)s);
+}
+
+int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_dtype, float* out,
+                 int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return slice_fwd_impl<true>(pos, grid, pad, pad_dtype, out, B, H, C, N, dim, W, (hipStream_t)s);
+}
+
+int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                 float* g_grid, float* g_keys, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s);
+}
+
+int ct_splat_lc_fwd(const float* lc, const int64_t* idx, const float* feat, const void* pad, int pad_dtype,
+                    float* grid, int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
+  if (!lc || !idx) return CT_EINVAL;
+  PosSrc pos = {nullptr, lc, (const long long*)idx};
+  return splat_fwd_impl<false>(pos, feat, pad, pad_dtype, grid, B, H, C, N, dim, W, reduce, (hipStream_t)s);
+}
+
+int ct_splat_lc_bwd(const float* lc, const int64_t* idx, const float* feat, const void* pad, int pad_dtype,
+                    const float* grid, const float* g_grid, float* g_feat, float* g_lc, void* ws, size_t ws_bytes,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
+  if (!lc || !idx) return CT_EINVAL;
+  PosSrc pos = {nullptr, lc, (const long long*)idx};
+  return splat_bwd_impl<false>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_lc, ws, ws_bytes,
+                               B, H, C, N, dim, W, reduce, (hipStream_t)s);
+}
+
+int ct_slice_lc_fwd(const float* lc, const int64_t* idx, const float* grid, const void* pad, int pad_dtype,
+                    float* out, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!lc || !idx) return CT_EINVAL;
+  PosSrc pos = {nullptr, lc, (const long long*)idx};
+  return slice_fwd_impl<false>(pos, grid, pad, pad_dtype, out, B, H, C, N, dim, W, (hipStream_t)s);
+}
+
+int ct_slice_lc_bwd(const float* lc, const int64_t* idx, const float* grid, const void* pad, int pad_dtype,
+                    const float* g_out, float* g_grid, float* g_lc, int B, int H, int C, int N, int dim,
+                    const int* W, ct_stream_t s) {
+  if (!lc || !idx) return CT_EINVAL;
+  PosSrc pos = {nullptr, lc, (const long long*)idx};
+  return slice_bwd_impl<false>(pos, grid, pad, pad_dtype, g_out, g_grid, g_lc, B, H, C, N, dim, W, (hipStream_t)s);
+}
+
+int ct_grid_occupancy(const float* grid, int64_t n, int64_t* count, ct_stream_t s) {
+  if (!grid || !count || n < 0) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(count, 0, sizeof(int64_t), st) != hipSuccess) return CT_ELAUNCH;
+  if (n == 0) return CT_OK;
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(256), 0, st, grid, (long long)n, (unsigned long long*)count);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cloudct.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream;
+every computation happens inside libcloudct.so.  Tensors that are not on a HIP
+device raise — there is no CPU path in the product.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def sizes_of(tensor_size, dim):
+    """int -> [W]*dim; tuple/list of len dim kept (layers/cloud_transform.py:41-46)."""
+    if isinstance(tensor_size, int):
+        return [tensor_size] * dim
+    sizes = [int(w) for w in tensor_size]
+    assert len(sizes) == dim
+    return sizes
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "cloud_transformers_amd ops need tensors on a HIP device (MI355X); "
+                "got a %s tensor and there is no CPU fallback" % t.device.type)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _pad_args(pad, B, N):
+    """pts_padding (B,N) float or int32 (datasets/s3dis_closer.py:330) -> (tensor, dtype code)."""
+    if pad is None:
+        return None, _lib.PAD_NONE
+    assert pad.shape == (B, N), "pts_padding must be [batch, num_points]"
+    if pad.dtype == torch.float32:
+        return pad.contiguous(), _lib.PAD_F32
+    if pad.dtype == torch.int32:
+        return pad.contiguous(), _lib.PAD_I32
+    return pad.to(torch.float32).contiguous(), _lib.PAD_F32
+
+
+# ---------------------------------------------------------------------------
+# DifferentiablePositions
+# ---------------------------------------------------------------------------
+class PositionsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, keys, W, H):
+        _dev(keys)
+        keys = _f32c(keys)
+        dim = len(W)
+        B, HD, N = keys.shape
+        assert HD == H * dim
+        V = 1 << dim
+        lc = torch.empty(B, H, V, N, device=keys.device, dtype=torch.float32)
+        idx = torch.empty(B, H, V, N, device=keys.device, dtype=torch.int64)
+        lib = _lib.load()
+        with torch.cuda.device(keys.device):
+            _lib.check(lib.ct_positions_fwd(_ptr(keys), _ptr(lc), _ptr(idx), B, H, N, dim,
+                                            _lib.int_array(W), _stream()), "ct_positions_fwd")
+        ctx.save_for_backward(keys)
+        ctx.W, ctx.H = W, H
+        ctx.mark_non_differentiable(idx)
+        return lc, idx
+
+    @staticmethod
+    def backward(ctx, g_lc, _g_idx):
+        (keys,) = ctx.saved_tensors
+        W, H = ctx.W, ctx.H
+        B, _, N = keys.shape
+        g_lc = _f32c(g_lc)
+        g_keys = torch.empty_like(keys)
+        lib = _lib.load()
+        with torch.cuda.device(keys.device):
+            _lib.check(lib.ct_positions_bwd(_ptr(keys), _ptr(g_lc), _ptr(g_keys), B, H, N, len(W),
+                                            _lib.int_array(W), _stream()), "ct_positions_bwd")
+        return g_keys, None, None
+
+
+# ---------------------------------------------------------------------------
+# fused (keys-based) Splat / Slice — the hot path
+# ---------------------------------------------------------------------------
+class SplatKeysFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, keys, feat, pad, W, H, reduce):
+        _dev(keys, feat, pad)
+        keys, feat = _f32c(keys), _f32c(feat)
+        dim = len(W)
+        B, HC, N = feat.shape
+        assert HC % H == 0 and keys.shape == (B, H * dim, N)
+        C = HC // H
+        padt, pad_code = _pad_args(pad, B, N)
+        grid = torch.empty(B, HC, *W, device=feat.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(feat.device):
+            _lib.check(lib.ct_splat_fwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
+                                        B, H, C, N, dim, _lib.int_array(W), _lib.REDUCE[reduce], _stream()),
+                       "ct_splat_fwd")
+        ctx.save_for_backward(keys, feat, padt, grid if reduce == "max" else None)
+        ctx.meta = (W, H, C, reduce, pad_code)
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        keys, feat, padt, grid = ctx.saved_tensors
+        W, H, C, reduce, pad_code = ctx.meta
+        dim = len(W)
+        B, HC, N = feat.shape
+        g_grid = _f32c(g_grid)
+        g_feat = torch.empty_like(feat)
+        g_keys = torch.empty_like(keys)
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        ws_bytes = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, _lib.REDUCE[reduce])
+        ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
+        with torch.cuda.device(feat.device):
+            _lib.check(lib.ct_splat_bwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid), _ptr(g_grid),
+                                        _ptr(g_feat), _ptr(g_keys), _ptr(ws), ws_bytes,
+                                        B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_bwd")
+        return g_keys, g_feat, None, None, None, None
+
+
+class SliceKeysFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, keys, grid, pad, W, H):
+        _dev(keys, grid, pad)
+        keys, grid = _f32c(keys), _f32c(grid)
+        dim = len(W)
+        B, HC = grid.shape[:2]
+        N = keys.shape[-1]
+        assert HC % H == 0 and keys.shape == (B, H * dim, N) and list(grid.shape[2:]) == list(W)
+        C = HC // H
+        padt, pad_code = _pad_args(pad, B, N)
+        out = torch.empty(B, HC, N, device=grid.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(grid.device):
+            _lib.check(lib.ct_slice_fwd(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(out),
+                                        B, H, C, N, dim, _lib.int_array(W), _stream()), "ct_slice_fwd")
+        ctx.save_for_backward(keys, grid, padt)
+        ctx.meta = (W, H, C, pad_code)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        keys, grid, padt = ctx.saved_tensors
+        W, H, C, pad_code = ctx.meta
+        dim = len(W)
+        B, _, N = keys.shape
+        g_out = _f32c(g_out)
+        g_grid = torch.empty_like(grid)
+        g_keys = torch.empty_like(keys)
+        lib = _lib.load()
+        with torch.cuda.device(grid.device):
+            _lib.check(lib.ct_slice_bwd(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
+                                        _ptr(g_grid), _ptr(g_keys), B, H, C, N, dim, _lib.int_array(W), _stream()),
+                       "ct_slice_bwd")
+        return g_keys, g_grid, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# explicit (local_coordinate, flattened_index) Splat / Slice — API-compatible path
+# ---------------------------------------------------------------------------
+def _check_idx(idx):
+    if idx.dtype != torch.int64:
+        raise TypeError("flattened_index must be int64 (layers/cloud_transform.py:81)")
+    return idx.contiguous()
+
+
+class SplatLcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lc, idx, feat, pad, W, H, reduce):
+        _dev(lc, idx, feat, pad)
+        lc, feat, idx = _f32c(lc), _f32c(feat), _check_idx(idx)
+        dim = len(W)
+        B, HC, N = feat.shape
+        V = 1 << dim
+        assert HC % H == 0 and lc.shape == (B, H, V, N) and idx.shape == (B, H, V, N)
+        C = HC // H
+        padt, pad_code = _pad_args(pad, B, N)
+        grid = torch.empty(B, HC, *W, device=feat.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(feat.device):
+            _lib.check(lib.ct_splat_lc_fwd(_ptr(lc), _ptr(idx), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
+                                           B, H, C, N, dim, _lib.int_array(W), _lib.REDUCE[reduce], _stream()),
+                       "ct_splat_lc_fwd")
+        ctx.save_for_backward(lc, idx, feat, padt, grid if reduce == "max" else None)
+        ctx.meta = (W, H, C, reduce, pad_code)
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        lc, idx, feat, padt, grid = ctx.saved_tensors
+        W, H, C, reduce, pad_code = ctx.meta
+        dim = len(W)
+        B, HC, N = feat.shape
+        g_grid = _f32c(g_grid)
+        g_feat = torch.empty_like(feat)
+        g_lc = torch.empty_like(lc)
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        ws_bytes = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, _lib.REDUCE[reduce])
+        ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
+        with torch.cuda.device(feat.device):
+            _lib.check(lib.ct_splat_lc_bwd(_ptr(lc), _ptr(idx), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
+                                           _ptr(g_grid), _ptr(g_feat), _ptr(g_lc), _ptr(ws), ws_bytes,
+                                           B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_lc_bwd")
+        return g_lc, None, g_feat, None, None, None, None
+
+
+class SliceLcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lc, idx, grid, pad, W, H):
+        _dev(lc, idx, grid, pad)
+        lc, grid, idx = _f32c(lc), _f32c(grid), _check_idx(idx)
+        dim = len(W)
+        B, HC = grid.shape[:2]
+        V = 1 << dim
+        N = lc.shape[-1]
+        assert HC % H == 0 and lc.shape == (B, H, V, N) and idx.shape == (B, H, V, N)
+        assert math.prod(grid.shape[2:]) == math.prod(W)
+        C = HC // H
+        padt, pad_code = _pad_args(pad, B, N)
+        out = torch.empty(B, HC, N, device=grid.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(grid.device):
+            _lib.check(lib.ct_slice_lc_fwd(_ptr(lc), _ptr(idx), _ptr(grid), _ptr(padt), pad_code, _ptr(out),
+                                           B, H, C, N, dim, _lib.int_array(W), _stream()), "ct_slice_lc_fwd")
+        ctx.save_for_backward(lc, idx, grid, padt)
+        ctx.meta = (W, H, C, pad_code)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lc, idx, grid, padt = ctx.saved_tensors
+        W, H, C, pad_code = ctx.meta
+        dim = len(W)
+        B, _, _, N = lc.shape
+        g_out = _f32c(g_out)
+        g_grid = torch.empty_like(grid)
+        g_lc = torch.empty_like(lc)
+        lib = _lib.load()
+        with torch.cuda.device(grid.device):
+            _lib.check(lib.ct_slice_lc_bwd(_ptr(lc), _ptr(idx), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
+                                           _ptr(g_grid), _ptr(g_lc), B, H, C, N, dim, _lib.int_array(W), _stream()),
+                       "ct_slice_lc_bwd")
+        return g_lc, None, g_grid, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# functional entry points
+# ---------------------------------------------------------------------------
+def positions(keys, tensor_size, heads, dim):
+    return PositionsFn.apply(keys, sizes_of(tensor_size, dim), heads)
+
+
+def splat_keys(keys, features, pts_padding, tensor_size, heads, dim, reduce="max"):
+    return SplatKeysFn.apply(keys, features, pts_padding, sizes_of(tensor_size, dim), heads, reduce)
+
+
+def slice_keys(keys, grid, pts_padding, tensor_size, heads, dim):
+    return SliceKeysFn.apply(keys, grid, pts_padding, sizes_of(tensor_size, dim), heads)
+
+
+def splat_lc(lc, idx, features, pts_padding, tensor_size, heads, dim, reduce="max"):
+    return SplatLcFn.apply(lc, idx, features, pts_padding, sizes_of(tensor_size, dim), heads, reduce)
+
+
+def slice_lc(lc, idx, grid, pts_padding, tensor_size, heads, dim):
+    return SliceLcFn.apply(lc, idx, grid, pts_padding, sizes_of(tensor_size, dim), heads)
+
+
+def grid_occupancy_count(grid):
+    """Number of elements with |z| > 1e-9 as a 0-dim int64 device tensor
+    (layers/multihead_ct.py:104-105 divides it by B*C*H)."""
+    _dev(grid)
+    grid = _f32c(grid)
+    count = torch.empty((), device=grid.device, dtype=torch.int64)
+    lib = _lib.load()
+    with torch.cuda.device(grid.device):
+        _lib.check(lib.ct_grid_occupancy(_ptr(grid), grid.numel(), _ptr(count), _stream()), "ct_grid_occupancy")
+    return count

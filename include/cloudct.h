@@ -1,0 +1,142 @@
+/*
+ * cloudct.h — C ABI of libcloudct.so, the MI355X (gfx950) implementation of the
+ * Multi-Headed Cloud Transform hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes and a
+ * HIP stream (passed as void* so that this header needs no HIP include), never
+ * allocates, never synchronises the device, keeps no global state and returns
+ * an int status: CT_OK (0) or a negative CT_E* code (ct_strerror() names it).
+ * All tensors are fp32, contiguous, channels-first with the point index N
+ * fastest — the reference's layout (layers/cloud_transform.py:140,156).  Work is
+ * enqueued on the given stream (the caller's torch current stream), never on
+ * the legacy default stream the reference's extensions use
+ * (chamfer_extension/chamfer.cu:142, emd_linear/emd_cuda.cu:257).
+ *
+ * Notation: B batch, H heads, C features per head, N points, dim in {2,3},
+ * W[dim] grid extents (x slowest), G = prod(W), V = 2^dim corners.
+ *
+ * Each function cites the reference interface it replaces (paths are into the
+ * reference repository).
+ */
+#ifndef CLOUDCT_H
+#define CLOUDCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_ABI_VERSION 1
+
+/* status codes */
+#define CT_OK 0
+#define CT_EINVAL (-1)    /* bad argument (null pointer, size, dim, reduce ...) */
+#define CT_ELAUNCH (-2)   /* HIP reported an error at launch                     */
+#define CT_EWORKSPACE (-3)/* workspace too small: see ct_*_workspace_bytes       */
+#define CT_EPRECOND (-4)  /* reference precondition violated (e.g. EMD n%1024)   */
+
+/* reduce modes of Splat */
+#define CT_REDUCE_MAX0 0  /* max with a zero floor: what the reference executes
+                             (torch_scatter.scatter_max into zeros,
+                             layers/cloud_transform.py:164-173)                  */
+#define CT_REDUCE_SUM 1   /* scatter-add: the variant BASELINE.json names        */
+
+/* dtype of the optional pts_padding mask (B,N) */
+#define CT_PAD_NONE 0
+#define CT_PAD_F32 1
+#define CT_PAD_I32 2      /* datasets/s3dis_closer.py:330,336 builds an int32 mask */
+
+typedef void* ct_stream_t; /* hipStream_t */
+
+int ct_abi_version(void);
+const char* ct_strerror(int status);
+
+/* ------------------------------------------------------------------------
+ * DifferentiablePositions  (layers/cloud_transform.py:72-121,
+ *                           layers/utils.py:100-186 bi/tri-linear corners)
+ * keys f32[B,H*dim,N] -> local_coord f32[B,H,V,N], flat_idx i64[B,H,V,N]
+ * ---------------------------------------------------------------------- */
+int ct_positions_fwd(const float* keys, float* local_coord, int64_t* flat_idx,
+                     int B, int H, int N, int dim, const int* W, ct_stream_t s);
+/* g_keys[B,H*dim,N] = d(local_coord)/d(keys)^T g_local_coord, with the
+ * GradientBalancing rule (cloud_transform.py:12-26: no (W-1)/2 factor) and the
+ * clamp mask (:91).  Overwrites g_keys. */
+int ct_positions_bwd(const float* keys, const float* g_local_coord, float* g_keys,
+                     int B, int H, int N, int dim, const int* W, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Fused hot path: corners are recomputed from `keys` inside the kernels, so
+ * local_coord / flat_idx never touch HBM.  Used by the MultiHead* blocks.
+ *
+ * Splat.forward  (layers/cloud_transform.py:131-180)
+ *   grid f32[B,H*C,G] (fully overwritten)
+ * Splat backward (torch_scatter.scatter_max backward: the single arg-max
+ *   contribution of a cell receives the cotangent; on EXACT ties exactly one of
+ *   the tied contributions receives it, which one is unspecified — as in
+ *   torch_scatter's CUDA path)
+ *   needs `grid` = the forward output, g_grid f32[B,H*C,G];
+ *   writes g_feat f32[B,H*C,N] and g_keys f32[B,H*dim,N] (both overwritten).
+ * workspace: scratch of ct_splat_bwd_workspace_bytes(...) bytes (may be 0).
+ * ---------------------------------------------------------------------- */
+int ct_splat_fwd(const float* keys, const float* feat, const void* pad, int pad_dtype,
+                 float* grid, int B, int H, int C, int N, int dim, const int* W,
+                 int reduce, ct_stream_t s);
+size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce);
+int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype,
+                 const float* grid, const float* g_grid, float* g_feat, float* g_keys,
+                 void* workspace, size_t workspace_bytes,
+                 int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s);
+
+/* Slice.forward  (layers/cloud_transform.py:190-227): out f32[B,H*C,N].
+ * Slice backward (autograd of torch.gather = scatter-add, :216-221):
+ *   g_grid f32[B,H*C,G] and g_keys f32[B,H*dim,N], both overwritten. */
+int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                 float* out, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                 const float* g_out, float* g_grid, float* g_keys,
+                 int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * The same four passes with EXPLICIT local_coord / flat_idx tensors — the
+ * signature-compatible Splat / Slice nn.Modules call these when handed
+ * arbitrary (local_coordinate, flattened_index) inputs.  g_local_coord
+ * f32[B,H,V,N] is overwritten.  Every flat_idx must be in [0, G).
+ * ---------------------------------------------------------------------- */
+int ct_splat_lc_fwd(const float* local_coord, const int64_t* flat_idx, const float* feat,
+                    const void* pad, int pad_dtype, float* grid,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s);
+int ct_splat_lc_bwd(const float* local_coord, const int64_t* flat_idx, const float* feat,
+                    const void* pad, int pad_dtype, const float* grid, const float* g_grid,
+                    float* g_feat, float* g_local_coord, void* workspace, size_t workspace_bytes,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s);
+int ct_slice_lc_fwd(const float* local_coord, const int64_t* flat_idx, const float* grid,
+                    const void* pad, int pad_dtype, float* out,
+                    int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+int ct_slice_lc_bwd(const float* local_coord, const int64_t* flat_idx, const float* grid,
+                    const void* pad, int pad_dtype, const float* g_out,
+                    float* g_grid, float* g_local_coord,
+                    int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+
+/* Occupancy statistic of a rasterised grid (layers/multihead_ct.py:104-105):
+ * count[0] = number of elements with |z| > 1e-9 (the caller divides by B*C*H).
+ * count is a device int64 and is overwritten. */
+int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Chamfer distance (chamfer_extension/chamfer_cuda.cpp:30-33 `forward`,
+ * `backward`; kernels chamfer.cu:12-195).  xyz1 f32[B,n,3], xyz2 f32[B,m,3];
+ * dist1 f32[B,n], idx1 i32[B,n] (nearest point of cloud 2, lowest index on
+ * ties), dist2/idx2 symmetric.  Backward overwrites g_xyz1, g_xyz2.
+ * ---------------------------------------------------------------------- */
+int ct_chamfer_fwd(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
+                   int32_t* idx1, int32_t* idx2, int B, int n, int m, ct_stream_t s);
+int ct_chamfer_bwd(const float* xyz1, const float* xyz2, const float* g_dist1, const float* g_dist2,
+                   const int32_t* idx1, const int32_t* idx2, float* g_xyz1, float* g_xyz2,
+                   int B, int n, int m, ct_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDCT_H */

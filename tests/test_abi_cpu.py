@@ -1,0 +1,81 @@
+"""CPU-side checks of the boundary: the shared library builds, loads and exports
+every symbol include/cloudct.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cloudct.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ct_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cloud_transformers_amd import _lib
+    _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    from cloud_transformers_amd import _lib
+    syms = _declared_symbols()
+    assert "ct_splat_fwd" in syms and "ct_slice_bwd" in syms and "ct_chamfer_fwd" in syms
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in cloudct.h but not exported"
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_abi_version_and_strerror(lib):
+    assert lib.ct_abi_version() == 1
+    assert lib.ct_strerror(0) == b"ok"
+    assert b"invalid" in lib.ct_strerror(-1)
+    assert b"workspace" in lib.ct_strerror(-3)
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad arguments are rejected before anything touches the device."""
+    from cloud_transformers_amd import _lib
+    W = _lib.int_array([32, 32])
+    assert lib.ct_splat_fwd(None, None, None, 0, None, 1, 1, 1, 1, 2, W, 0, None) == -1
+    assert lib.ct_slice_fwd(None, None, None, 0, None, 1, 1, 1, 1, 2, W, None) == -1
+    assert lib.ct_positions_fwd(None, None, None, 1, 1, 1, 4, W, None) == -1      # dim = 4
+    assert lib.ct_chamfer_fwd(None, None, None, None, None, None, 1, 1, 1, None) == -1
+    one = _lib.int_array([1, 8])                                                   # W < 2 is rejected
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.ct_positions_fwd(p, p, p, 1, 1, 1, 2, one, None) == -1
+    # workspace query is pure host arithmetic
+    assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 2, W, 0) == 0
+    big = _lib.int_array([64, 64, 64])
+    assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 3, big, 0) == 2 * 4 * 8 * 64 ** 3 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.chamfer import chamfer_with_indices
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.positions(torch.zeros(1, 2, 4), 8, 1, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        chamfer_with_indices(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+
+
+def test_module_state_dict_names():
+    """Checkpoint compatibility: every DifferentiableGridModule contributes a
+    `tensor_mod` buffer of shape [1, dim, 1] (layers/cloud_transform.py:48-51)."""
+    from cloud_transformers_amd.layers.cloud_transform import DifferentiablePositions, Splat, Slice
+    for cls in (DifferentiablePositions, Splat, Slice):
+        m = cls(tensor_size=(16, 24), heads=3, dim=2)
+        sd = m.state_dict()
+        assert list(sd) == ["tensor_mod"]
+        assert sd["tensor_mod"].shape == (1, 2, 1) and sd["tensor_mod"].flatten().tolist() == [16.0, 24.0]
+        assert m.spread_size == 4 and m.tensor_size == [16, 24]
+    assert Splat(8, 2, 3).spread_size == 8
