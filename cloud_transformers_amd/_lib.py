@@ -9,6 +9,11 @@ import os
 import subprocess
 import threading
 
+# torch must be imported BEFORE libcloudct.so is loaded: PyTorch-ROCm bundles its
+# own libamdhip64; if ours pulled /opt/rocm's copy in first, the process would mix
+# two HIP runtimes and every launch on a torch stream would fail.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")

@@ -120,6 +120,7 @@ int ct_chamfer_fwd(const float* xyz1, const float* xyz2, float* dist1, float* di
   if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || B <= 0 || n <= 0 || m <= 0 || B > 65535) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
   const int per = 64 * kQ;
+  CT_CLEAR_ERROR();
   hipLaunchKernelGGL(nn_kernel, dim3((n + per - 1) / per, B), dim3(256), 0, st, xyz1, xyz2, dist1, idx1, n, m);
   hipLaunchKernelGGL(nn_kernel, dim3((m + per - 1) / per, B), dim3(256), 0, st, xyz2, xyz1, dist2, idx2, m, n);
   CT_CHECK_LAUNCH();
@@ -134,6 +135,7 @@ int ct_chamfer_bwd(const float* xyz1, const float* xyz2, const float* g_dist1, c
   hipStream_t st = (hipStream_t)s;
   if (hipMemsetAsync(g_xyz1, 0, (size_t)B * n * 3 * 4, st) != hipSuccess) return CT_ELAUNCH;
   if (hipMemsetAsync(g_xyz2, 0, (size_t)B * m * 3 * 4, st) != hipSuccess) return CT_ELAUNCH;
+  CT_CLEAR_ERROR();
   hipLaunchKernelGGL(nn_grad_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, xyz1, xyz2, g_dist1, idx1, g_xyz1, g_xyz2, n, m);
   hipLaunchKernelGGL(nn_grad_kernel, dim3((m + 255) / 256, B), dim3(256), 0, st, xyz2, xyz1, g_dist2, idx2, g_xyz2, g_xyz1, m, n);
   CT_CHECK_LAUNCH();

@@ -104,6 +104,10 @@ __device__ __forceinline__ float ct_load_pad(const void* pad, int pad_dtype, siz
   return 1.0f;
 }
 
+// hipGetLastError() is sticky across unrelated runtime calls of the host
+// framework (e.g. a hipEventQuery that returned hipErrorNotReady), so every
+// entry point clears it first (CT_CLEAR_ERROR) and checks after its launches.
+#define CT_CLEAR_ERROR() ((void)hipGetLastError())
 #define CT_CHECK_LAUNCH()                         \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

@@ -168,6 +168,116 @@ __global__ void __launch_bounds__(1024) scatter_kernel(RasterArgs a, GridW<DIM> 
 }
 
 // ---------------------------------------------------------------------------
+// K1s: scatter-ADD pass in 32-bit fixed point (LDS tile only).
+//   gfx950's LDS float atomic add (ds_add_f32) retires ~1 lane per 3 clocks
+//   (81 ns per wave-instruction, measured: tools/microbench/lds_atomics.hip)
+//   while the integer LDS atomics run at the ds_write rate (2-3 ns).  So the
+//   tile is accumulated as int32 multiples of a per-tile power-of-two quantum
+//        q = 2^ceil(log2(M*K)) / 2^30,   M = max |src*pad| of the slab,
+//                                       K = max contributions per cell,
+//   which cannot overflow (|sum| <= K*M) and resolves M*K*2^-30 (<= fp32 eps of
+//   the largest possible sum).  Every product is formed in fp32 exactly as the
+//   reference does ((src*pad)*w), rounded once to the quantum, and integer adds
+//   commute: the result is BITWISE REPRODUCIBLE, unlike a float scatter-add.
+//   Slabs with non-finite values fall back to float atomics.
+//   grid = (nchunks, H, B).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, float* red) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, red[w]);
+  return r;
+}
+
+template <int DIM, bool FROM_KEYS>
+__global__ void __launch_bounds__(1024) scatter_add_fx_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  __shared__ float red[16];
+  int* acc = (int*)lds;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
+  const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+  const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+  lds_fill_zero(lds, cc * g.G);
+  __syncthreads();
+  // phase 1: contributions per cell (counted in the first channel's tile) and max |src*pad|
+  float m = 0.0f;
+  bool finite = true;
+  for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+    Corners<DIM> c;
+    PointPos<DIM, FROM_KEYS> pp;
+    load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+#pragma unroll
+    for (int v = 0; v < V; ++v) atomicAdd(&acc[c.cell[v]], 1);
+    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    for (int ch = 0; ch < cc; ++ch) {
+      float f = src[(size_t)ch * a.N + n];
+      if (has_pad) f = f * p;
+      float af = fabsf(f);
+      finite = finite && (af < __builtin_inff());   // false for inf and NaN
+      m = fmaxf(m, af);
+    }
+  }
+  __syncthreads();
+  float k = 0.0f;
+  for (int i = threadIdx.x; i < g.G; i += blockDim.x) k = fmaxf(k, (float)acc[i]);
+  const float M = block_max(finite ? m : __builtin_inff(), red);
+  const float K = block_max(k, red);
+  for (int i = threadIdx.x; i < g.G; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  const float MK = M * K;
+  if (MK < 1e37f) {
+    int ex = 0;
+    if (MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
+    ex = max(ex, -90);
+    const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
+    if (MK > 0.0f) {
+      for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+        Corners<DIM> c;
+        PointPos<DIM, FROM_KEYS> pp;
+        load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+        const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+        for (int ch = 0; ch < cc; ++ch) {
+          float f = src[(size_t)ch * a.N + n];
+          if (has_pad) f = f * p;
+          int* Tc = acc + (size_t)ch * g.G;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float prod = f * c.w[v];
+            atomicAdd(&Tc[c.cell[v]], __float2int_rn(prod * inv_q));
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = (float)acc[i] * q;
+  } else {
+    // non-finite or astronomically large slab: plain float atomics keep IEEE semantics
+    for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+      Corners<DIM> c;
+      PointPos<DIM, FROM_KEYS> pp;
+      load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+      const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+      for (int ch = 0; ch < cc; ++ch) {
+        float f = src[(size_t)ch * a.N + n];
+        if (has_pad) f = f * p;
+#pragma unroll
+        for (int v = 0; v < V; ++v) atomicAdd(&lds[(size_t)ch * g.G + c.cell[v]], f * c.w[v]);
+      }
+    }
+    __syncthreads();
+    copy_linear(gout, lds, cc * g.G);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K2: gather pass.  dst[(b,h,c), n] = (sum_v tile_in[(b,h,c), cell_v(n)] * w_v(n)) * pad[b,n]
 //   Slice forward; also the g_feat half of Splat(sum) backward.
 //   grid = (nchunks * nsplit, H, B)
@@ -270,7 +380,7 @@ __global__ void __launch_bounds__(1024) gather_gw_kernel(RasterArgs a, GridW<DIM
 //   grid = (ncg, H, B); the whole N range stays in one workgroup per chunk so
 //   that claims are unique.
 // ---------------------------------------------------------------------------
-template <int DIM, bool FROM_KEYS, bool LDS_TILE>
+template <int DIM, bool FROM_KEYS, bool LDS_TILE, bool GZ_LDS>
 __global__ void __launch_bounds__(1024) splat_max_bwd_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
@@ -284,12 +394,13 @@ __global__ void __launch_bounds__(1024) splat_max_bwd_kernel(RasterArgs a, GridW
     const int cc = min(a.CC, a.C - c0);
     const size_t toff = (bh * a.C + c0) * (size_t)g.G;
     unsigned* T = LDS_TILE ? (unsigned*)lds : (a.claim + toff);
+    const float* gz = GZ_LDS ? (lds + (size_t)a.CC * g.G) : (a.tile_in2 + toff);
     if (LDS_TILE) {
       __syncthreads();
       copy_linear(lds, a.tile_in + toff, cc * g.G);
+      if (GZ_LDS) copy_linear(lds + (size_t)a.CC * g.G, a.tile_in2 + toff, cc * g.G);
       __syncthreads();
     }
-    const float* gz = a.tile_in2 + toff;
     const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
     float* dst = a.dst + (bh * a.C + c0) * (size_t)a.N;
     for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
@@ -457,6 +568,7 @@ int set_lds(K kernel, size_t bytes) {
 #define CT_LAUNCH(KERNEL, GRID, THREADS, LDS, STREAM, ...)                   \
   do {                                                                      \
     if (set_lds(KERNEL, LDS) != CT_OK) return CT_ELAUNCH;                   \
+    CT_CLEAR_ERROR();                                                       \
     hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, STREAM, __VA_ARGS__); \
     CT_CHECK_LAUNCH();                                                      \
   } while (0)
@@ -470,7 +582,7 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
   a.nchunks = p.nchunks;
   dim3 grid(p.nchunks, a.H, a.B);
   if (p.lds_tile) {
-    if (sum) CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    if (sum) CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
     else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
   } else {
     if (hipMemsetAsync(a.tile_out, 0, (size_t)a.B * a.H * a.C * g.G * 4, st) != hipSuccess) return CT_ELAUNCH;
@@ -527,7 +639,9 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
 template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
-  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
+  const bool two = (size_t)g.G * 8 <= (size_t)kMaxLdsBytes;
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, two ? 2 : 1);
   a.CC = p.CC;
   a.nchunks = p.nchunks;
   a.nsplit = 1;
@@ -537,13 +651,14 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
   dim3 grid(a.ncg, a.H, a.B);
   if (p.lds_tile) {
-    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    if (two) CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    else CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, p.lds_bytes, st, a, g);
   } else {
     size_t need = (size_t)a.B * a.H * a.C * g.G * 4;
     if (!ws || ws_bytes < need) return CT_EWORKSPACE;
     if (hipMemcpyAsync(ws, a.tile_in, need, hipMemcpyDeviceToDevice, st) != hipSuccess) return CT_ELAUNCH;
     a.claim = (unsigned*)ws;
-    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false>), grid, p.threads, 0, st, a, g);
+    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
   }
   return CT_OK;
 }
@@ -639,6 +754,7 @@ const char* ct_strerror(int status) {
 int ct_positions_fwd(const float* keys, float* lc, int64_t* idx, int B, int H, int N, int dim, const int* W, ct_stream_t s) {
   if (!valid_common(B, H, 1, N, dim, W) || !keys || !lc || !idx) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
+  CT_CLEAR_ERROR();
   size_t total = (size_t)B * H * N;
   dim3 grid((unsigned)((total + 255) / 256));
   if (dim == 2) hipLaunchKernelGGL(positions_fwd_kernel<2>, grid, dim3(256), 0, st, keys, lc, (long long*)idx, B * H, N, make_grid<2>(W));
@@ -650,6 +766,7 @@ int ct_positions_fwd(const float* keys, float* lc, int64_t* idx, int B, int H, i
 int ct_positions_bwd(const float* keys, const float* g_lc, float* g_keys, int B, int H, int N, int dim, const int* W, ct_stream_t s) {
   if (!valid_common(B, H, 1, N, dim, W) || !keys || !g_lc || !g_keys) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
+  CT_CLEAR_ERROR();
   size_t total = (size_t)B * H * N;
   dim3 grid((unsigned)((total + 255) / 256));
   if (dim == 2) hipLaunchKernelGGL(positions_bwd_kernel<2>, grid, dim3(256), 0, st, keys, g_lc, g_keys, B * H, N, make_grid<2>(W));
@@ -732,6 +849,7 @@ int ct_grid_occupancy(const float* grid, int64_t n, int64_t* count, ct_stream_t 
   hipStream_t st = (hipStream_t)s;
   if (hipMemsetAsync(count, 0, sizeof(int64_t), st) != hipSuccess) return CT_ELAUNCH;
   if (n == 0) return CT_OK;
+  CT_CLEAR_ERROR();
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(256), 0, st, grid, (long long)n, (unsigned long long*)count);
