@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libcloudct.so")
+LIB_PATH = os.environ.get("CLOUDCT_LIB") or os.path.join(LIB_DIR, "libcloudct.so")   # override: A/B builds
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["ct_raster.hip", "ct_chamfer.hip", "ct_emd.hip"]

@@ -124,7 +124,7 @@ __device__ __forceinline__ void copy_linear(float* __restrict__ dst, const float
 //   grid = (nchunks, H, B).  LDS_TILE=false: tile_out pre-zeroed, global atomics.
 // ---------------------------------------------------------------------------
 template <int DIM, bool FROM_KEYS, bool SUM, bool LDS_TILE>
-__global__ void __launch_bounds__(1024) scatter_kernel(RasterArgs a, GridW<DIM> g) {
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -193,7 +193,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 template <int DIM, bool FROM_KEYS>
-__global__ void __launch_bounds__(1024) scatter_add_fx_kernel(RasterArgs a, GridW<DIM> g) {
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[16];
@@ -278,12 +278,132 @@ __global__ void __launch_bounds__(1024) scatter_add_fx_kernel(RasterArgs a, Grid
 }
 
 // ---------------------------------------------------------------------------
+// K1r: register-resident form of K1s for the hot path (corners from keys,
+//   N <= blockDim*PPT, N % 4 == 0): each thread owns PPT consecutive points and
+//   keeps their src values for the whole channel chunk (<= CCR channels) in
+//   registers, so the slab is read from HBM exactly once (dwordx4 along N) and the
+//   quantum is known before the first atomic.
+// ---------------------------------------------------------------------------
+#ifndef CT_FXREG_WAVES
+#define CT_FXREG_WAVES 8
+#endif
+template <int DIM, int PPT, int CCR>
+__global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kernel(RasterArgs a, GridW<DIM> g) {
+  static_assert(PPT == 4, "one float4 per channel row");
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  __shared__ float red[16];
+  int* acc = (int*)lds;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
+  const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+  const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+  const int n0 = threadIdx.x * PPT;
+  const bool active = n0 < a.N;
+
+  // issue every global load first: keys, pad, then the src slab
+  float kv[DIM][PPT];
+  float pv[PPT];
+  float sv[CCR][PPT];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) {
+    float4 t = active ? *(const float4*)(a.pos.keys + (bh * DIM + j) * a.N + n0) : make_float4(0, 0, 0, 0);
+    kv[j][0] = t.x; kv[j][1] = t.y; kv[j][2] = t.z; kv[j][3] = t.w;
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) pv[i] = (active && has_pad) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n0 + i) : 1.0f;
+#pragma unroll
+  for (int ch = 0; ch < CCR; ++ch) {
+    float4 t = (active && ch < cc) ? *(const float4*)(src + (size_t)ch * a.N + n0) : make_float4(0, 0, 0, 0);
+    sv[ch][0] = t.x; sv[ch][1] = t.y; sv[ch][2] = t.z; sv[ch][3] = t.w;
+  }
+  for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
+  for (int i = ((cc * g.G) & ~3) + threadIdx.x; i < cc * g.G; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+
+  // contributions per cell (in channel 0's tile) while the src loads are in flight
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      float w0[DIM], w1[DIM];
+      int f[DIM];
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) ct_axis(kv[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+      Corners<DIM> c;
+      ct_corners<DIM>(w0, w1, f, g, c);
+#pragma unroll
+      for (int v = 0; v < V; ++v) atomicAdd(&acc[c.cell[v]], 1);
+    }
+  }
+  float m = 0.0f;
+  bool finite = true;
+#pragma unroll
+  for (int ch = 0; ch < CCR; ++ch) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (has_pad) sv[ch][i] = sv[ch][i] * pv[i];
+      float af = fabsf(sv[ch][i]);
+      finite = finite && (af < __builtin_inff());
+      m = fmaxf(m, af);
+    }
+  }
+  __syncthreads();
+  float k = 0.0f;
+  for (int i = threadIdx.x; i < g.G; i += blockDim.x) k = fmaxf(k, (float)acc[i]);
+  const float M = block_max(finite ? m : __builtin_inff(), red);
+  const float K = block_max(k, red);
+  for (int i = threadIdx.x; i < g.G; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  const float MK = M * K;
+  const bool fixed = MK < 1e37f;
+  int ex = 0;
+  if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
+  ex = max(ex, -90);
+  const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
+  if (active && MK > 0.0f) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      float w0[DIM], w1[DIM];
+      int f[DIM];
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) ct_axis(kv[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+      Corners<DIM> c;
+      ct_corners<DIM>(w0, w1, f, g, c);
+#pragma unroll
+      for (int ch = 0; ch < CCR; ++ch) {
+        if (ch < cc) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float prod = sv[ch][i] * c.w[v];
+            if (fixed) atomicAdd(&acc[ch * g.G + c.cell[v]], __float2int_rn(prod * inv_q));
+            else atomicAdd(&lds[ch * g.G + c.cell[v]], prod);   // non-finite slab: IEEE semantics
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (fixed) {
+    for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) {
+      int4 t = ((const int4*)acc)[i];
+      ((float4*)gout)[i] = make_float4((float)t.x * q, (float)t.y * q, (float)t.z * q, (float)t.w * q);
+    }
+    for (int i = ((cc * g.G) & ~3) + threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = (float)acc[i] * q;
+  } else {
+    copy_linear(gout, lds, cc * g.G);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K2: gather pass.  dst[(b,h,c), n] = (sum_v tile_in[(b,h,c), cell_v(n)] * w_v(n)) * pad[b,n]
 //   Slice forward; also the g_feat half of Splat(sum) backward.
 //   grid = (nchunks * nsplit, H, B)
 // ---------------------------------------------------------------------------
 template <int DIM, bool FROM_KEYS, bool LDS_TILE>
-__global__ void __launch_bounds__(1024) gather_kernel(RasterArgs a, GridW<DIM> g) {
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
@@ -325,7 +445,7 @@ __global__ void __launch_bounds__(1024) gather_kernel(RasterArgs a, GridW<DIM> g
 //   grid = (ncg * nsplit, H, B); each workgroup loops over its share of chunks.
 // ---------------------------------------------------------------------------
 template <int DIM, bool FROM_KEYS, bool LDS_TILE>
-__global__ void __launch_bounds__(1024) gather_gw_kernel(RasterArgs a, GridW<DIM> g) {
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_gw_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
   const int cg = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
@@ -381,7 +501,7 @@ __global__ void __launch_bounds__(1024) gather_gw_kernel(RasterArgs a, GridW<DIM
 //   that claims are unique.
 // ---------------------------------------------------------------------------
 template <int DIM, bool FROM_KEYS, bool LDS_TILE, bool GZ_LDS>
-__global__ void __launch_bounds__(1024) splat_max_bwd_kernel(RasterArgs a, GridW<DIM> g) {
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
   const int cg = blockIdx.x;
@@ -412,21 +532,38 @@ __global__ void __launch_bounds__(1024) splat_max_bwd_kernel(RasterArgs a, GridW
       float gw[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) gw[v] = 0.0f;
+#pragma unroll 2
       for (int ch = 0; ch < cc; ++ch) {
         float f = src[(size_t)ch * a.N + n];
         if (has_pad) f = f * p;
         unsigned* Tc = T + (size_t)ch * g.G;
-        float gf = 0.0f;
+        const float* Gc = gz + (size_t)ch * g.G;
+        // all LDS reads of this channel are issued back to back (one wait), then the
+        // rare claims, instead of one dependent read->CAS->read chain per corner
+        unsigned zb[V], bits[V], old[V];
+        float gzv[V];
+        bool m[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) zb[v] = Tc[c.cell[v]];
+        if (GZ_LDS) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) gzv[v] = Gc[c.cell[v]];
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           float prod = f * c.w[v];
-          unsigned bits = __float_as_uint(prod);
-          if (prod > 0.0f && Tc[c.cell[v]] == bits) {
-            if (atomicCAS(&Tc[c.cell[v]], bits, 0u) == bits) {
-              float gzv = gz[(size_t)ch * g.G + c.cell[v]];
-              gf += gzv * c.w[v];
-              gw[v] += gzv * f;
-            }
+          bits[v] = __float_as_uint(prod);
+          m[v] = prod > 0.0f && zb[v] == bits[v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) old[v] = m[v] ? atomicCAS(&Tc[c.cell[v]], bits[v], 0u) : 0u;
+        float gf = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          if (m[v] && old[v] == bits[v]) {
+            float gzw = GZ_LDS ? gzv[v] : Gc[c.cell[v]];
+            gf += gzw * c.w[v];
+            gw[v] += gzw * f;
           }
         }
         if (has_pad) gf = gf * p;
@@ -582,8 +719,23 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
   a.nchunks = p.nchunks;
   dim3 grid(p.nchunks, a.H, a.B);
   if (p.lds_tile) {
-    if (sum) CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
-    else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    if (sum) {
+      constexpr int kRegCh = 8;
+      const bool aligned = ((((uintptr_t)a.src) | ((uintptr_t)a.pos.keys) | ((uintptr_t)a.tile_out)) & 15) == 0;
+      if (FROM_KEYS && aligned && (a.N & 3) == 0 && a.N <= 4096 && (g.G & 3) == 0) {
+        if (a.CC > kRegCh) {
+          a.CC = kRegCh;
+          a.nchunks = (a.C + kRegCh - 1) / kRegCh;
+        }
+        dim3 rgrid(a.nchunks, a.H, a.B);
+        CT_LAUNCH((scatter_add_fx_reg_kernel<DIM, 4, kRegCh>), rgrid, round_threads(a.N / 4),
+                  (size_t)a.CC * g.G * 4, st, a, g);
+      } else {
+        CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
+      }
+    } else {
+      CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+    }
   } else {
     if (hipMemsetAsync(a.tile_out, 0, (size_t)a.B * a.H * a.C * g.G * 4, st) != hipSuccess) return CT_ELAUNCH;
     if (sum) CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, 0, st, a, g);
