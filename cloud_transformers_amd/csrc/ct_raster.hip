@@ -15,6 +15,16 @@
 // and layers/utils.py:100-186 of the reference).
 #include "ct_common.h"
 
+#ifndef CT_QUAD_THREADS
+#define CT_QUAD_THREADS 512
+#endif
+#ifndef CT_QUAD_WAVES
+#define CT_QUAD_WAVES 4
+#endif
+#ifndef CT_QUAD_CG
+#define CT_QUAD_CG 4
+#endif
+
 namespace {
 
 constexpr int kMaxLdsBytes = 64 * 1024;        // tile budget per workgroup (2 WGs / CU)
@@ -281,18 +291,26 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(
 // K1r: register-resident form of K1s for the hot path (corners from keys,
 //   N <= blockDim*PPT, N % 4 == 0): each thread owns PPT consecutive points and
 //   keeps their src values for the whole channel chunk (<= CCR channels) in
-//   registers, so the slab is read from HBM exactly once (dwordx4 along N) and the
-//   quantum is known before the first atomic.
+//   registers, so the slab is read from HBM exactly once (dwordx4 along N).
+//   The chunk is processed in groups of CG channels, each with its own quantum:
+//   the atomics of group k run while the loads of groups k+1.. are still in
+//   flight (vmcnt is in order), instead of after the whole slab has landed.
 // ---------------------------------------------------------------------------
 #ifndef CT_FXREG_WAVES
 #define CT_FXREG_WAVES 8
 #endif
-template <int DIM, int PPT, int CCR>
+#ifndef CT_FXREG_CG
+#define CT_FXREG_CG 4
+#endif
+template <int DIM, int PPT, int CCR, int CG>
 __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kernel(RasterArgs a, GridW<DIM> g) {
   static_assert(PPT == 4, "one float4 per channel row");
+  static_assert(CCR % CG == 0, "groups tile the chunk");
   constexpr int V = 1 << DIM;
+  constexpr int NG = CCR / CG;
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[16];
+  __shared__ float qs[CCR];     // quantum per channel; < 0 marks a float (non-finite) group
   int* acc = (int*)lds;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const size_t bh = (size_t)b * a.H + h;
@@ -304,7 +322,7 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
   const int n0 = threadIdx.x * PPT;
   const bool active = n0 < a.N;
 
-  // issue every global load first: keys, pad, then the src slab
+  // issue every global load first: keys, pad, then the src slab in channel order
   float kv[DIM][PPT];
   float pv[PPT];
   float sv[CCR][PPT];
@@ -324,7 +342,7 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
   for (int i = ((cc * g.G) & ~3) + threadIdx.x; i < cc * g.G; i += blockDim.x) acc[i] = 0;
   __syncthreads();
 
-  // contributions per cell (in channel 0's tile) while the src loads are in flight
+  // contributions per cell (counted in channel 0's tile) — needs the keys only
   if (active) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -338,62 +356,72 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
       for (int v = 0; v < V; ++v) atomicAdd(&acc[c.cell[v]], 1);
     }
   }
-  float m = 0.0f;
-  bool finite = true;
-#pragma unroll
-  for (int ch = 0; ch < CCR; ++ch) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      if (has_pad) sv[ch][i] = sv[ch][i] * pv[i];
-      float af = fabsf(sv[ch][i]);
-      finite = finite && (af < __builtin_inff());
-      m = fmaxf(m, af);
-    }
-  }
   __syncthreads();
   float k = 0.0f;
   for (int i = threadIdx.x; i < g.G; i += blockDim.x) k = fmaxf(k, (float)acc[i]);
-  const float M = block_max(finite ? m : __builtin_inff(), red);
   const float K = block_max(k, red);
   for (int i = threadIdx.x; i < g.G; i += blockDim.x) acc[i] = 0;
-  __syncthreads();
-  const float MK = M * K;
-  const bool fixed = MK < 1e37f;
-  int ex = 0;
-  if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
-  ex = max(ex, -90);
-  const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
-  if (active && MK > 0.0f) {
+  // (the barrier inside the first block_max below orders this re-zeroing before any atomic)
+
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      float w0[DIM], w1[DIM];
-      int f[DIM];
+  for (int gi = 0; gi < NG; ++gi) {
+    if (gi * CG < cc) {     // block-uniform
+      float m = 0.0f;
+      bool finite = true;
 #pragma unroll
-      for (int j = 0; j < DIM; ++j) ct_axis(kv[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
-      Corners<DIM> c;
-      ct_corners<DIM>(w0, w1, f, g, c);
+      for (int cj = 0; cj < CG; ++cj) {
 #pragma unroll
-      for (int ch = 0; ch < CCR; ++ch) {
-        if (ch < cc) {
+        for (int i = 0; i < PPT; ++i) {
+          float x = sv[gi * CG + cj][i];
+          if (has_pad) x = x * pv[i];
+          sv[gi * CG + cj][i] = x;
+          float af = fabsf(x);
+          finite = finite && (af < __builtin_inff());
+          m = fmaxf(m, af);
+        }
+      }
+      const float M = block_max(finite ? m : __builtin_inff(), red);
+      const float MK = M * K;
+      const bool fixed = MK < 1e37f;
+      int ex = 0;
+      if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
+      ex = max(ex, -90);
+      const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
+      if (threadIdx.x < CG) qs[gi * CG + threadIdx.x] = fixed ? q : -1.0f;
+      if (active && MK > 0.0f) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            float prod = sv[ch][i] * c.w[v];
-            if (fixed) atomicAdd(&acc[ch * g.G + c.cell[v]], __float2int_rn(prod * inv_q));
-            else atomicAdd(&lds[ch * g.G + c.cell[v]], prod);   // non-finite slab: IEEE semantics
+        for (int i = 0; i < PPT; ++i) {
+          float w0[DIM], w1[DIM];
+          int f[DIM];
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) ct_axis(kv[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+          Corners<DIM> c;
+          ct_corners<DIM>(w0, w1, f, g, c);
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj) {
+            const int ch = gi * CG + cj;
+            if (ch < cc) {
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                float prod = sv[ch][i] * c.w[v];
+                if (fixed) atomicAdd(&acc[ch * g.G + c.cell[v]], __float2int_rn(prod * inv_q));
+                else atomicAdd(&lds[ch * g.G + c.cell[v]], prod);   // non-finite group: IEEE semantics
+              }
+            }
           }
         }
       }
     }
   }
   __syncthreads();
-  if (fixed) {
-    for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) {
+  for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) {
+    const float q = qs[(i << 2) / g.G];   // G % 4 == 0: a float4 never straddles channels
+    if (q < 0.0f) {
+      ((float4*)gout)[i] = ((const float4*)lds)[i];
+    } else {
       int4 t = ((const int4*)acc)[i];
       ((float4*)gout)[i] = make_float4((float)t.x * q, (float)t.y * q, (float)t.z * q, (float)t.w * q);
     }
-    for (int i = ((cc * g.G) & ~3) + threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = (float)acc[i] * q;
-  } else {
-    copy_linear(gout, lds, cc * g.G);
   }
 }
 
@@ -576,6 +604,204 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
 }
 
 // ---------------------------------------------------------------------------
+// KQ: "quad" form of the gather-type passes for the hot path (corners from keys,
+//   N % 4 == 0, 16-byte aligned rows).  Each thread owns 4 consecutive points:
+//   keys, src and dst move as dwordx4 along N, and the src values of a group of
+//   CG channels are fetched into registers BEFORE the LDS work of that group, so
+//   a wave keeps CG*1 KiB of HBM reads in flight instead of one dependent dword
+//   load per (point, channel).
+//     QM_GATHER        : Slice forward / Splat(sum) backward wrt features
+//     QM_GATHER_GW     : corner cotangents -> g_keys (Slice backward, Splat(sum) backward)
+//     QM_SPLAT_MAX_BWD : Splat(max0) backward (z tile + g_z tile in LDS, single-winner claims)
+//   grid = (ncg * nsplit, H, B); each workgroup loops over its chunks.
+// ---------------------------------------------------------------------------
+enum { QM_GATHER = 0, QM_GATHER_GW = 1, QM_SPLAT_MAX_BWD = 2 };
+
+template <int DIM, int MODE, int CG>
+__global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  constexpr bool kSrc = MODE != QM_GATHER;          // reads a point-sized input
+  constexpr bool kDst = MODE != QM_GATHER_GW;       // writes a point-sized output
+  constexpr bool kGw = MODE != QM_GATHER;           // produces g_keys
+  extern __shared__ __align__(16) float lds[];
+  const int cgi = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+  const bool atomic = a.atomic_gpos != 0;
+  const int nq = a.N >> 2;
+  const int per = (nq + a.nsplit - 1) / a.nsplit;
+  const int q_beg = sp * per, q_end = min(nq, q_beg + per);
+  bool first = true;
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * a.CC;
+    const int cc = min(a.CC, a.C - c0);
+    const size_t toff = (bh * a.C + c0) * (size_t)g.G;
+    float* T = lds;                                   // tile_in chunk (z for SPLAT_MAX_BWD)
+    float* T2 = lds + (size_t)a.CC * g.G;             // g_z chunk (SPLAT_MAX_BWD only)
+    __syncthreads();
+    copy_linear(T, a.tile_in + toff, cc * g.G);
+    if (MODE == QM_SPLAT_MAX_BWD) copy_linear(T2, a.tile_in2 + toff, cc * g.G);
+    __syncthreads();
+    const float* src = kSrc ? a.src + (bh * a.C + c0) * (size_t)a.N : nullptr;
+    float* dst = kDst ? a.dst + (bh * a.C + c0) * (size_t)a.N : nullptr;
+    for (int q = q_beg + (int)threadIdx.x; q < q_end; q += blockDim.x) {
+      const int n0 = q << 2;
+      // corner weights and base cell of the 4 points (per-axis terms are recomputed
+      // from the keys for the positions backward, to keep the register footprint low)
+      float cw[4][V], pv[4];
+      int base[4];
+      {
+        float kk[DIM][4];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          const float4 t = *(const float4*)(a.pos.keys + (bh * DIM + j) * a.N + n0);
+          kk[j][0] = t.x; kk[j][1] = t.y; kk[j][2] = t.z; kk[j][3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float w0[DIM], w1[DIM];
+          int f[DIM];
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) ct_axis(kk[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+          Corners<DIM> c;
+          ct_corners<DIM>(w0, w1, f, g, c);
+          base[i] = c.cell[0];
+#pragma unroll
+          for (int v = 0; v < V; ++v) cw[i][v] = c.w[v];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pv[i] = has_pad ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n0 + i) : 1.0f;
+      float gw[4][V];
+      if (kGw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int v = 0; v < V; ++v) gw[i][v] = 0.0f;
+      }
+      for (int cg0 = 0; cg0 < cc; cg0 += CG) {
+        float fv[CG][4];
+        if (kSrc) {
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj) {
+            const float4 t = (cg0 + cj < cc) ? *(const float4*)(src + (size_t)(cg0 + cj) * a.N + n0) : make_float4(0, 0, 0, 0);
+            fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Corners<DIM> c;
+          {
+            // cell offsets of the V corners relative to the base cell
+            const float one[DIM] = {};
+            int f0[DIM];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) f0[j] = 0;
+            Corners<DIM> off;
+            ct_corners<DIM>(one, one, f0, g, off);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              c.cell[v] = base[i] + off.cell[v];
+              c.w[v] = cw[i][v];
+            }
+          }
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj) {
+            const int ch = cg0 + cj;
+            if (ch < cc) {
+              const float* Tc = T + (size_t)ch * g.G;
+              if (MODE == QM_GATHER) {
+                float acc = Tc[c.cell[0]] * c.w[0];
+#pragma unroll
+                for (int v = 1; v < V; ++v) acc += Tc[c.cell[v]] * c.w[v];
+                fv[cj][i] = has_pad ? acc * pv[i] : acc;
+              } else if (MODE == QM_GATHER_GW) {
+                const float sgn = has_pad ? fv[cj][i] * pv[i] : fv[cj][i];
+#pragma unroll
+                for (int v = 0; v < V; ++v) gw[i][v] += Tc[c.cell[v]] * sgn;
+              } else {
+                const float f = has_pad ? fv[cj][i] * pv[i] : fv[cj][i];
+                unsigned* Zc = (unsigned*)T + (size_t)ch * g.G;
+                const float* Gc = T2 + (size_t)ch * g.G;
+                // only positive products can be winners (zero floor): lanes with f <= 0 skip
+                // every LDS access, which also thins out the bank conflicts of the others
+                unsigned zb[V], bits[V], old[V];
+                bool m[V];
+                const bool pos = f > 0.0f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) zb[v] = pos ? Zc[c.cell[v]] : 0u;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                  const float prod = f * c.w[v];
+                  bits[v] = __float_as_uint(prod);
+                  m[v] = pos && prod > 0.0f && zb[v] == bits[v];
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) old[v] = m[v] ? atomicCAS(&Zc[c.cell[v]], bits[v], 0u) : 0u;
+                float gf = 0.0f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                  if (m[v] && old[v] == bits[v]) {
+                    const float gzw = Gc[c.cell[v]];     // winners only (~6% of the lanes)
+                    gf += gzw * c.w[v];
+                    gw[i][v] += gzw * f;
+                  }
+                }
+                fv[cj][i] = has_pad ? gf * pv[i] : gf;
+              }
+            }
+          }
+        }
+        if (kDst) {
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj)
+            if (cg0 + cj < cc)
+              *(float4*)(dst + (size_t)(cg0 + cj) * a.N + n0) = make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]);
+        }
+      }
+      if (kGw) {
+        float gs[4][DIM];
+        {
+          float kk[DIM][4];
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) {
+            const float4 t = *(const float4*)(a.pos.keys + (bh * DIM + j) * a.N + n0);
+            kk[j][0] = t.x; kk[j][1] = t.y; kk[j][2] = t.z; kk[j][3] = t.w;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float w0[DIM], w1[DIM];
+            int f[DIM];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) ct_axis(kk[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+            ct_corner_grad<DIM>(w0, w1, gw[i], gs[i]);
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) gs[i][j] = gs[i][j] * ct_key_mask(kk[j][i]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          float* pk = a.g_pos + (bh * DIM + j) * a.N + n0;
+          if (atomic) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(pk + i, gs[i][j]);
+          } else {
+            float4 o = make_float4(gs[0][j], gs[1][j], gs[2][j], gs[3][j]);
+            if (!first) {
+              const float4 prev = *(const float4*)pk;
+              o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+            }
+            *(float4*)pk = o;
+          }
+        }
+      }
+    }
+    first = false;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
 // ---------------------------------------------------------------------------
 template <int DIM>
@@ -728,7 +954,7 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
           a.nchunks = (a.C + kRegCh - 1) / kRegCh;
         }
         dim3 rgrid(a.nchunks, a.H, a.B);
-        CT_LAUNCH((scatter_add_fx_reg_kernel<DIM, 4, kRegCh>), rgrid, round_threads(a.N / 4),
+        CT_LAUNCH((scatter_add_fx_reg_kernel<DIM, 4, kRegCh, CT_FXREG_CG>), rgrid, round_threads(a.N / 4),
                   (size_t)a.CC * g.G * 4, st, a, g);
       } else {
         CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
@@ -742,6 +968,21 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
     else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
   }
   return CT_OK;
+}
+
+
+// quad (4 points per thread, dwordx4) kernels need 16-byte aligned rows
+bool quad_ok(const RasterArgs& a, bool from_keys, bool lds_tile) {
+  if (!from_keys || !lds_tile || (a.N & 3) != 0) return false;
+  uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
+                   (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
+  return (bits & 15) == 0;
+}
+
+int quad_threads(int N, int nsplit) {
+  int nq = ((N >> 2) + nsplit - 1) / nsplit;
+  int t = round_threads(nq);
+  return t > CT_QUAD_THREADS ? CT_QUAD_THREADS : t;
 }
 
 int pick_nsplit(int B, int H, int nchunks, int N) {
@@ -760,6 +1001,13 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N);
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(p.nchunks * a.nsplit, a.H, a.B);
+  if constexpr (DIM == 2) {   // 3D exceeds the register budget of the quad form: generic kernel
+    if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
+      a.ncg = p.nchunks;   // one chunk per workgroup
+      CT_LAUNCH((quad_kernel<2, QM_GATHER, CT_QUAD_CG>), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
+      return CT_OK;
+    }
+  }
   if (p.lds_tile) CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
   else CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
   return CT_OK;
@@ -783,6 +1031,10 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
   if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(a.ncg * a.nsplit, a.H, a.B);
+  if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
+    CT_LAUNCH((quad_kernel<DIM, QM_GATHER_GW, (DIM == 2 ? CT_QUAD_CG : 2)>), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
+    return CT_OK;
+  }
   if (p.lds_tile) CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
   else CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
   return CT_OK;
@@ -803,6 +1055,14 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
   dim3 grid(a.ncg, a.H, a.B);
   if (p.lds_tile) {
+    bool done = false;
+    if constexpr (DIM == 2) {
+      if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
+        CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG>), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
+        done = true;
+      }
+    }
+    if (done) return CT_OK;
     if (two) CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
     else CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, p.lds_bytes, st, a, g);
   } else {
