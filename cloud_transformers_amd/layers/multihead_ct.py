@@ -1,0 +1,261 @@
+"""Multi-Headed Cloud Transform blocks on MI355X.
+
+Counterparts of the reference's `layers/multihead_ct.py` (`MultiHead` :9-118,
+`MultiHeadUnion` :121-198), `layers/multihead_ct_adain.py` (`forward_style`
+:8-16, `MultiHeadAdaIn` :19-136, `MultiHeadUnionAdaIn` :139-218) and
+`layers/multihead_ct_pool.py` (`MultiHeadPool` :9-86): same constructor
+arguments, forward signatures, return contract `(result, stats)` and the same
+sub-module / parameter / buffer NAMES, so reference checkpoints load with
+strict=True and reference-style model_zoo files can use these classes unchanged.
+
+What differs is what happens between the pointwise convolutions: the
+rasterize -> grouped conv -> de-rasterize core runs on the fused HIP path
+(`Splat.forward_keys` / `Slice.forward_keys`): corner weights and cell indices
+are recomputed in-kernel from the lattice, so `local_coordinate`,
+`flattened_index` and the reference's (B,H,C,V,N) intermediates never exist in
+HBM, there are no host synchronisations (the reference's four `.all()` asserts
+per block, cloud_transform.py:101-111), and the occupancy statistic is one small
+device reduction.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .cloud_transform import DifferentiablePositions, Slice, Splat
+from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer
+
+
+def forward_style(module_list, input, z):
+    """Apply a Sequential in which AdaIN layers also take the style vector `z`.
+    Dispatch is by class name, like the reference (multihead_ct_adain.py:11)."""
+    for layer in module_list:
+        if "AdaIn1dUpd" in str(type(layer)):
+            input = layer(input, z)
+        else:
+            input = layer(input)
+    return input
+
+
+def _grouped_conv(tensor_dim, channels, heads):
+    conv = nn.Conv3d if tensor_dim == 3 else nn.Conv2d
+    return nn.Sequential(conv(channels, channels, kernel_size=3, stride=1, padding=1, groups=heads, bias=True))
+
+
+class _MHCTCore(nn.Module):
+    """Shared plumbing of the three MHCT flavours: key/value prediction, per-head
+    rigid transform, lattice, fused Splat / Slice and the lattice statistics."""
+
+    def _build_core(self, model_dim, in_feature_dim, tensor_size, tensor_dim, heads, with_slice):
+        assert tensor_dim == 3 or tensor_dim == 2
+        self.in_feature_dim = in_feature_dim
+        self.model_dim = model_dim
+        self.tensor_size = tensor_size
+        self.tensor_dim = tensor_dim
+        self.heads = heads
+        self.keys_values_pred = nn.Sequential(
+            nn.Conv1d(model_dim, heads * (in_feature_dim + 3), kernel_size=1, bias=False))
+
+    def _build_grid_modules(self, with_slice):
+        kw = dict(tensor_size=self.tensor_size, dim=self.tensor_dim, heads=self.heads)
+        self.diff_poss = DifferentiablePositions(**kw)
+        self.splat = Splat(**kw)
+        if with_slice:
+            self.slice = Slice(**kw)
+
+    def _build_transform(self, scales):
+        cls = VolTransformer if self.tensor_dim == 3 else PlaneTransformer
+        self.transform = cls(self.heads, scales=scales)
+
+    def _lattice(self, orig_pcd, keys_res):
+        """keys = transform(xyz + residual) per head; lattice = tanh(keys)."""
+        B, _, N = keys_res.shape
+        keys = self.transform(orig_pcd[:, None] + keys_res.reshape(B, self.heads, 3, N))
+        keys = keys.reshape(B, self.heads * self.tensor_dim, N)
+        return keys, torch.tanh(keys)
+
+    def _occupancy(self, z, batch):
+        with torch.no_grad():
+            return ops.grid_occupancy_count(z).float() / (batch * self.in_feature_dim * self.heads)
+
+
+class MultiHead(_MHCTCore):
+    def __init__(self, model_dim, in_feature_dim, out_model_dim, tensor_size, tensor_dim, heads, scales=False):
+        super().__init__()
+        self.out_model_dim = out_model_dim       # accepted, unused — as in the reference
+        self._build_core(model_dim, in_feature_dim, tensor_size, tensor_dim, heads, True)
+        self.values_bn = nn.BatchNorm1d(heads * in_feature_dim)
+        self.key_bn = nn.BatchNorm1d(heads * 3)
+        self._build_grid_modules(True)
+        self.conv = _grouped_conv(tensor_dim, heads * in_feature_dim, heads)
+        self.after = nn.Sequential(nn.BatchNorm1d(heads * in_feature_dim), nn.ReLU(inplace=True))
+        self._build_transform(scales)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # keys start as the pure rigid transform of xyz (multihead_ct.py:79-80)
+        nn.init.zeros_(self.key_bn.weight)
+
+    def forward(self, input, orig_pcd, return_lattice=False):
+        pts_padd = None
+        if isinstance(orig_pcd, tuple):
+            orig_pcd, pts_padd = orig_pcd
+        H = self.heads
+        key_values = self.keys_values_pred(input)
+        keys_res = self.key_bn(key_values[:, :H * 3])
+        values = self.values_bn(key_values[:, H * 3:])
+        keys, lattice = self._lattice(orig_pcd, keys_res)
+        z = self.splat.forward_keys(lattice, values, pts_padd)
+        occ = self._occupancy(z, keys.size(0))
+        result = self.after(self.slice.forward_keys(lattice, self.conv(z), pts_padd))
+        with torch.no_grad():
+            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), None)
+        if return_lattice:
+            result = result, lattice
+        return result, stats
+
+
+class MultiHeadPool(_MHCTCore):
+    """Splat-only MHCT: a learned pooling of the cloud into 2D/3D grids."""
+
+    def __init__(self, model_dim, in_feature_dim, tensor_size, tensor_dim, heads, scales=False):
+        super().__init__()
+        self._build_core(model_dim, in_feature_dim, tensor_size, tensor_dim, heads, False)
+        self.values_bn = nn.BatchNorm1d(heads * in_feature_dim)
+        self.key_bn = nn.BatchNorm1d(heads * 3)
+        self._build_grid_modules(False)
+        self._build_transform(scales)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        nn.init.zeros_(self.key_bn.weight)
+
+    def forward(self, input, orig_pcd, return_lattice=False):
+        H = self.heads
+        key_values = self.keys_values_pred(input)
+        keys_res = self.key_bn(key_values[:, :H * 3])
+        values = self.values_bn(key_values[:, H * 3:])
+        keys, lattice = self._lattice(orig_pcd, keys_res)
+        z = self.splat.forward_keys(lattice, values)
+        occ = self._occupancy(z, keys.size(0))
+        with torch.no_grad():
+            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), None)
+        result = z
+        if return_lattice:
+            result = result, lattice
+        return result, stats
+
+
+class MultiHeadAdaIn(_MHCTCore):
+    """Style-conditioned MHCT: AdaIN instead of BatchNorm, learnable scalar `scale`
+    (init 0) on the key residual, no pts_padding."""
+
+    def __init__(self, model_dim, in_feature_dim, out_model_dim, tensor_size, tensor_dim, heads,
+                 n_latent=256, unet=False, scales=False):
+        super().__init__()
+        self.out_model_dim = out_model_dim
+        self.num_latent = n_latent
+        self._build_core(model_dim, in_feature_dim, tensor_size, tensor_dim, heads, True)
+        self.values_bn = nn.Sequential(AdaIn1dUpd(heads * in_feature_dim, num_latent=n_latent))
+        self.keys_bn = nn.Sequential(AdaIn1dUpd(heads * 3, num_latent=n_latent))
+        self._build_grid_modules(True)
+        self.conv = _grouped_conv(tensor_dim, heads * in_feature_dim, heads)
+        self.after = nn.Sequential(AdaIn1dUpd(heads * in_feature_dim, num_latent=n_latent), nn.ReLU(inplace=True))
+        self.scale = nn.Parameter(torch.tensor(0, dtype=torch.float32))
+        self._build_transform(scales)
+
+    def forward(self, input, style, orig_pcd, return_lattice=False):
+        H = self.heads
+        key_values = forward_style(self.keys_values_pred, input, style)
+        keys_res = forward_style(self.keys_bn, key_values[:, :H * 3], style)
+        values = forward_style(self.values_bn, key_values[:, H * 3:], style)
+        keys, lattice = self._lattice(orig_pcd, self.scale * keys_res)
+        z = self.splat.forward_keys(lattice, values)
+        occ = self._occupancy(z, keys.size(0))
+        result = forward_style(self.after, self.slice.forward_keys(lattice, self.conv(z)), style)
+        with torch.no_grad():
+            # the reference moves these to the host and copies ALL keys to numpy on every
+            # forward (multihead_ct_adain.py:127-131); here they stay on the device (no sync)
+            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), keys.detach())
+        if return_lattice:
+            result = result, lattice
+        return result, stats
+
+
+class _UnionBase(nn.Module):
+    """K MHCT blocks on the same input, concatenated on channels, projected back to
+    the model width and added to a (possibly projected) residual."""
+
+    def _check(self, features_dims, tensor_sizes, tensor_dims, heads):
+        assert len(features_dims) == len(tensor_sizes)
+        assert len(features_dims) == len(tensor_dims)
+        assert len(features_dims) == len(heads)
+
+    def _common(self, model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out):
+        self._check(features_dims, tensor_sizes, tensor_dims, heads)
+        self.model_dim = model_dim
+        self.features_dims = features_dims
+        self.tensor_sizes = tensor_sizes
+        self.tensor_dims = tensor_dims
+        self.heads = heads
+        self.model_dim_out = model_dim if model_dim_out is None else model_dim_out
+        self.prenorm = nn.Sequential()
+        return sum(h * f for h, f in zip(heads, features_dims))
+
+
+class MultiHeadUnion(_UnionBase):
+    def __init__(self, model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out=None, scales=False):
+        super().__init__()
+        cat_dim = self._common(model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out)
+        self.after = nn.Sequential(
+            nn.Conv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.BatchNorm1d(self.model_dim_out),
+            nn.ReLU(inplace=True))
+        self.shortcut = nn.Sequential()
+        if self.model_dim != self.model_dim_out:
+            self.shortcut.add_module("shortcut_conv", nn.Conv1d(self.model_dim, self.model_dim_out, kernel_size=1,
+                                                                stride=1, padding=0, bias=False))
+            self.shortcut.add_module("shortcut_bn", nn.BatchNorm1d(self.model_dim_out))
+        self.attentions = nn.ModuleList([
+            MultiHead(model_dim=self.model_dim, in_feature_dim=f, out_model_dim=self.model_dim_out,
+                      tensor_size=w, tensor_dim=d, heads=h, scales=scales)
+            for f, w, d, h in zip(features_dims, tensor_sizes, tensor_dims, heads)])
+
+    def forward(self, x, orig_pcd):
+        x = self.prenorm(x)
+        residual = self.shortcut(x)
+        results, stats = [], []
+        for attention in self.attentions:
+            r, s = attention(x, orig_pcd)
+            results.append(r)
+            stats.append(s)
+        return residual + self.after(torch.cat(results, dim=1)), stats
+
+
+class MultiHeadUnionAdaIn(_UnionBase):
+    def __init__(self, model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out=None,
+                 n_latent=256, unet=False, scales=False):
+        super().__init__()
+        cat_dim = self._common(model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out)
+        self.after = nn.Sequential(
+            nn.Conv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
+            AdaIn1dUpd(self.model_dim_out, num_latent=n_latent),
+            nn.ReLU(inplace=True))
+        self.shortcut = nn.Sequential()
+        if self.model_dim != self.model_dim_out:
+            self.shortcut.add_module("shortcut_conv", nn.Conv1d(self.model_dim, self.model_dim_out, kernel_size=1,
+                                                                stride=1, padding=0, bias=False))
+            self.shortcut.add_module("shortcut_bn", AdaIn1dUpd(self.model_dim_out, num_latent=n_latent))
+        self.attentions = nn.ModuleList([
+            MultiHeadAdaIn(model_dim=self.model_dim, in_feature_dim=f, out_model_dim=self.model_dim_out,
+                           tensor_size=w, tensor_dim=d, n_latent=n_latent, heads=h, unet=unet, scales=scales)
+            for f, w, d, h in zip(features_dims, tensor_sizes, tensor_dims, heads)])
+
+    def forward(self, x, style, orig_pcd):
+        x = self.prenorm(x)
+        residual = forward_style(self.shortcut, x, style)
+        results, stats = [], []
+        for attention in self.attentions:
+            r, s = attention(x, style, orig_pcd)
+            results.append(r)
+            stats.append(s)
+        return residual + forward_style(self.after, torch.cat(results, dim=1), style), stats
