@@ -83,6 +83,9 @@ SIGNATURES = {
     "ct_grid_occupancy": (_i, [_vp, ctypes.c_int64, _vp, _vp]),
     "ct_chamfer_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ct_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ct_emd_workspace_bytes": (_sz, [_i, _i]),
+    "ct_emd_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _f, _i, _vp]),
+    "ct_emd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 
 

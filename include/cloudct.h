@@ -136,6 +136,22 @@ int ct_chamfer_bwd(const float* xyz1, const float* xyz2, const float* g_dist1, c
                    const int32_t* idx1, const int32_t* idx2, float* g_xyz1, float* g_xyz2,
                    int B, int n, int m, ct_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * Approximate EMD by auction (emd_linear/emd.cpp:28-31 `forward`, `backward`;
+ * kernels emd_cuda.cu:23-316).  xyz1, xyz2 f32[B,n,3] in [0,1]^3; outputs
+ * dist f32[B,n] (squared distance to the assigned target) and assignment
+ * i32[B,n].  Preconditions as the reference (emd_cuda.cu:236-249): n % 1024 == 0,
+ * B <= 512 -> CT_EPRECOND otherwise; iters >= 1.  The reference's 12 caller-allocated
+ * scratch tensors (emd_module.py:41-54) become one opaque workspace.
+ * ---------------------------------------------------------------------- */
+size_t ct_emd_workspace_bytes(int B, int n);
+int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assignment,
+               void* workspace, size_t workspace_bytes, int B, int n, float eps, int iters,
+               ct_stream_t s);
+/* g_xyz1 = 2 g_dist (x1 - x2[assignment]); no gradient to xyz2 (emd_module.py:66-70). */
+int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const int32_t* assignment,
+               float* g_xyz1, int B, int n, ct_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+/*
+ * CPU oracle for the auction-based EMD approximation — TEST INFRASTRUCTURE ONLY
+ * (never linked into or called by the product; see oracle/ref_cpu.py header).
+ *
+ * A sequential restatement of the reference's CUDA extension
+ * emd_linear/emd_cuda.cu, kernel by kernel:
+ *   unassigned list      calc_unass_cnt / calc_unass_cnt_sum / calc_unass_idx  (:30-93)
+ *   Bid                  :95-179   value = 3.0 - sqrt(|x1-x2|^2) - price, best and
+ *                                  second best over ALL targets; ties -> lowest index
+ *                                  (strict '>' while scanning ascending, :150-157,:170-176);
+ *                                  bid increment = best - better + eps; per-target max
+ *   GetMax               :181-194  the bidder whose increment equals the max (+-1e-6)
+ *   Assign               :196-215  winner takes the target, previous owner is evicted,
+ *                                  price += increment; on the LAST iteration every
+ *                                  bidder is force-assigned to its bid (:201)
+ *   CalcDist             :217-226  squared distance to the assigned target
+ *   backward             :284-300  grad_xyz1 = 2 * grad_dist * (x1 - x2[assignment])
+ * Preconditions as the reference (:236-249): n % 1024 == 0, B <= 512 -> returns -1.
+ *
+ * Where the reference is nondeterministic the oracle fixes one legal outcome and the
+ * HIP implementation is made to agree with it: GetMax ties (several bidders within
+ * 1e-6 of the max) -> the highest bidder index (the reference: last writer);
+ * the forced assignment of the last iteration is applied in ascending bidder order.
+ * The arithmetic follows the reference expression by expression: the value is
+ * evaluated in double (the literal 3.0 is a double, :149) and rounded to float.
+ *
+ * Parity pin: the reference ships no known-answer vectors for EMD (its only check,
+ * emd_module.py:79-93, recomputes the distance from the returned assignment);
+ * tests/test_emd_*.py apply that same self-check to this oracle and to the HIP path.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+int emd_ref_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment,
+                    int B, int n, float eps, int iters) {
+  if (n % 1024 != 0 || B > 512 || B <= 0 || n <= 0) return -1;
+  float* price = (float*)calloc((size_t)n, sizeof(float));
+  float* bid_inc = (float*)calloc((size_t)n, sizeof(float));
+  float* max_inc = (float*)calloc((size_t)n, sizeof(float));
+  int* ass_inv = (int*)malloc((size_t)n * sizeof(int));
+  int* bid = (int*)calloc((size_t)n, sizeof(int));
+  int* max_idx = (int*)calloc((size_t)n, sizeof(int));
+  int* unass = (int*)malloc((size_t)n * sizeof(int));
+  for (int b = 0; b < B; ++b) {
+    const float* p1 = xyz1 + (size_t)b * n * 3;
+    const float* p2 = xyz2 + (size_t)b * n * 3;
+    int* ass = assignment + (size_t)b * n;
+    for (int j = 0; j < n; ++j) { ass[j] = -1; ass_inv[j] = -1; price[j] = 0.f; max_inc[j] = 0.f; max_idx[j] = 0; }
+    for (int it = 0; it < iters; ++it) {
+      const int last = (it == iters - 1);
+      int U = 0;
+      for (int j = 0; j < n; ++j) if (ass[j] == -1) unass[U++] = j;
+      /* Bid */
+      for (int u = 0; u < U; ++u) {
+        const int j = unass[u];
+        const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
+        float best = -1e9f, better = -1e9f;
+        int best_i = -1;
+        for (int k = 0; k < n; ++k) {
+          const float x2 = p2[k * 3 + 0] - x1, y2 = p2[k * 3 + 1] - y1, z2 = p2[k * 3 + 2] - z1;
+          const float d2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+          const float d = (float)(3.0 - (double)sqrtf(d2) - (double)price[k]);
+          if (d > best) { better = best; best = d; best_i = k; }
+          else if (d > better) better = d;
+        }
+        bid[j] = best_i;
+        bid_inc[j] = best - better + eps;
+        if (bid_inc[j] > max_inc[best_i]) max_inc[best_i] = bid_inc[j];
+      }
+      /* GetMax */
+      for (int u = 0; u < U; ++u) {
+        const int j = unass[u];
+        const int t = bid[j];
+        const float bi = bid_inc[j], mi = max_inc[t];
+        if (bi - 1e-6 <= mi && mi <= bi + 1e-6) max_idx[t] = j;   /* ascending j: the highest wins */
+      }
+      /* Assign */
+      for (int u = 0; u < U; ++u) {
+        const int j = unass[u];
+        const int t = bid[j];
+        if (last || max_idx[t] == j) {
+          const int prev = ass_inv[t];
+          if (!last && prev != -1) ass[prev] = -1;
+          ass_inv[t] = j;
+          ass[j] = t;
+          price[t] += bid_inc[j];
+          max_inc[t] = -1e9f;
+        }
+      }
+    }
+    for (int j = 0; j < n; ++j) {
+      const int k = ass[j];
+      const float dx = p1[j * 3 + 0] - p2[k * 3 + 0], dy = p1[j * 3 + 1] - p2[k * 3 + 1], dz = p1[j * 3 + 2] - p2[k * 3 + 2];
+      dist[(size_t)b * n + j] = dx * dx + dy * dy + dz * dz;
+    }
+  }
+  free(price); free(bid_inc); free(max_inc); free(ass_inv); free(bid); free(max_idx); free(unass);
+  return 1;
+}
+
+void emd_ref_backward(const float* xyz1, const float* xyz2, const float* grad_dist, const int* assignment,
+                      float* grad_xyz1, int B, int n) {
+  for (size_t i = 0; i < (size_t)B * n; ++i) {
+    const size_t b = i / n;
+    const int k = assignment[i];
+    const float g = grad_dist[i] * 2;
+    for (int c = 0; c < 3; ++c)
+      grad_xyz1[i * 3 + c] = g * (xyz1[i * 3 + c] - xyz2[(b * n + k) * 3 + c]);
+  }
+}

@@ -107,8 +107,8 @@ def test_block_state_dict_keys_match_reference_checkpoints():
         for k, v in sd.items():
             assert tuple(v.shape) == tuple(g[case]["sd/" + k].shape), (case, k)
     # key_bn starts at zero: keys are initially the pure rigid transform of xyz
-    assert float(built["mh2d"].key_bn.weight.abs().max()) == 0.0
-    assert float(built["adain"].scale) == 0.0
+    assert float(built["mh2d"].key_bn.weight.detach().abs().max()) == 0.0
+    assert float(built["adain"].scale.detach()) == 0.0
 
 
 def test_reference_import_paths_resolve():

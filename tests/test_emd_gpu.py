@@ -1,0 +1,70 @@
+"""GPU parity of the HIP auction EMD against oracle/emd_ref.c (same arithmetic,
+same tie rules -> identical assignments expected) and the reference's own
+self-check recipe (emd_linear/emd_module.py:79-93)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import emd_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(B, n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((B, n, 3), dtype=np.float32), rng.random((B, n, 3), dtype=np.float32)
+
+
+@pytest.mark.parametrize("B,n,eps,iters", [(2, 1024, 0.005, 50), (3, 2048, 0.005, 20), (1, 1024, 0.004, 300),
+                                           (2, 1024, 0.005, 1)])
+def test_matches_oracle(B, n, eps, iters):
+    from cloud_transformers_amd.emd import emdModule
+    a, b = _clouds(B, n, 10 * B + iters)
+    st, d_ref, ass_ref = emd_ref.forward(a, b, eps, iters)
+    assert st == 1
+    ac = torch.from_numpy(a).cuda().requires_grad_(True)
+    bc = torch.from_numpy(b).cuda()
+    dist, ass = emdModule()(ac, bc, eps, iters)
+    assert ass.dtype == torch.int32 and ass.shape == (B, n)
+    ass_np, d_np = ass.cpu().numpy(), dist.detach().cpu().numpy()
+    assert ass_np.min() >= 0 and ass_np.max() < n
+    # reference self-check: distance recomputed from the assignment
+    sel = np.take_along_axis(b, ass_np[..., None].astype(np.int64), axis=1)
+    np.testing.assert_allclose(((a - sel) ** 2).sum(-1), d_np, atol=1e-6)
+    # parity with the oracle: the loss value the training scripts use
+    # (train_inpainter.py:189: sqrt(dist).mean(1).mean())
+    np.testing.assert_allclose(np.sqrt(d_np).mean(), np.sqrt(d_ref).mean(), rtol=2e-3)
+    # and (same arithmetic, same tie rules) the assignments themselves
+    agree = (ass_np == ass_ref).mean()
+    assert agree > 0.98, agree
+    # backward
+    g = torch.rand(B, n, device="cuda")
+    (dist * g).sum().backward()
+    ga = emd_ref.backward(a, b, g.cpu().numpy(), ass_np)
+    np.testing.assert_allclose(ac.grad.cpu().numpy(), ga, atol=1e-6)
+
+
+def test_preconditions_raise():
+    from cloud_transformers_amd.emd import emdModule
+    from cloud_transformers_amd import _lib
+    x = torch.rand(1, 1000, 3, device="cuda")
+    with pytest.raises(AssertionError):
+        emdModule()(x, x, 0.005, 5)
+    lib = _lib.load()
+    buf = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
+    p = buf.data_ptr()
+    assert lib.ct_emd_fwd(p, p, p, p, p, 1 << 20, 1, 1000, 0.005, 5, None) == -4      # CT_EPRECOND
+    assert lib.ct_emd_fwd(p, p, p, p, p, 16, 1, 1024, 0.005, 5, None) == -3           # CT_EWORKSPACE
+
+
+def test_large_cloud_validity():
+    """Completion-config size (B2, n=16384): validity + the reference self-check."""
+    from cloud_transformers_amd.emd import emdModule
+    torch.manual_seed(0)
+    a = torch.rand(2, 16384, 3, device="cuda")
+    b = torch.rand(2, 16384, 3, device="cuda")
+    dist, ass = emdModule()(a, b, 0.005, 50)
+    sel = torch.gather(b, 1, ass.long()[..., None].expand(-1, -1, 3))
+    assert torch.allclose(((a - sel) ** 2).sum(-1), dist, atol=1e-6)
+    assert all(ass[i].unique().numel() > 0.9 * 16384 for i in range(2))
+    assert float(dist.sqrt().mean()) < 0.05
