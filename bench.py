@@ -69,6 +69,23 @@ def time_passes(step, iters=30):
     return res
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, with the gfx950
+    correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide read)."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for name, rec in table.get("kernels", {}).items():
+        if kernel in name:
+            return rec.get("hbm_bytes_per_launch")
+    return None
+
+
 def cpu_baseline(args):
     """The oracle (a pure-PyTorch port of the reference op sequence, materialised
     intermediates included) on a bounded sample: the same workload at batch 1."""
@@ -145,8 +162,10 @@ def main():
     if rank == 0:
         alg = step.algorithmic_bytes()
         passes = time_passes(step)
-        dom = max(passes, key=passes.get)
-        achieved = alg[dom] / (passes[dom] * 1e-3) / 1e9
+        dom = max(passes, key=passes.get)            # every pass is one kernel launch
+        dom_bytes = alg.get(dom + "_launch", alg[dom])
+        achieved = dom_bytes / (passes[dom] * 1e-3) / 1e9
+        traffic = measured_traffic(step.KERNELS.get(dom, dom)) if args.reduce == "max" else None
         out = {
             "metric": "points/sec fwd+bwd MHCT (positions->Splat->Slice), 4096-pt batch",
             "value": world * B * N / (dt / args.steps),
@@ -163,9 +182,10 @@ def main():
                                    % (B, N, H, C, dim, W, args.reduce),
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
                        "hip_graph": graph is not None},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": passes[dom]},
+            "roofline": {"bound": "hbm", "kernel": step.KERNELS.get(dom, dom) if args.reduce == "max" else dom,
+                         "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": passes[dom]},
             "passes_ms": passes,
             "step_roofline": {"algorithmic_bytes_per_step": alg["total"],
                               "achieved_GBs": alg["total"] / (ms * 1e-3) / 1e9,

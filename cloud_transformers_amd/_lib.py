@@ -76,6 +76,8 @@ SIGNATURES = {
     "ct_splat_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_slice_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_bwd_keys": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_splat_lc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_slice_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),

@@ -1225,6 +1225,21 @@ int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_
   return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s);
 }
 
+int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out, float* g_grid,
+                      int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  // a scatter-add of g_out: the same pass as Splat(sum) forward
+  return ct_splat_fwd(keys, g_out, pad, pad_dtype, g_grid, B, H, C, N, dim, W, CT_REDUCE_SUM, s);
+}
+
+int ct_slice_bwd_keys(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                      float* g_keys, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys || !valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_keys || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+  a.pos = PosSrc{keys, nullptr, nullptr};
+  a.src = g_out; a.tile_in = grid; a.g_pos = g_keys;
+  return dim == 2 ? run_gather_gw<2, true>(a, W, (hipStream_t)s) : run_gather_gw<3, true>(a, W, (hipStream_t)s);
+}
+
 int ct_splat_lc_fwd(const float* lc, const int64_t* idx, const float* feat, const void* pad, int pad_dtype,
                     float* grid, int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
   if (!lc || !idx) return CT_EINVAL;

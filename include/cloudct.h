@@ -97,6 +97,13 @@ int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_
 int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_dtype,
                  const float* g_out, float* g_grid, float* g_keys,
                  int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+/* The two halves of ct_slice_bwd, for callers that need only one cotangent
+ * (autograd's needs_input_grad) and for per-kernel timing: each is one launch. */
+int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out,
+                      float* g_grid, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+int ct_slice_bwd_keys(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                      const float* g_out, float* g_keys,
+                      int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
  * The same four passes with EXPLICIT local_coord / flat_idx tensors — the
