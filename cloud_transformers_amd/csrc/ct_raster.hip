@@ -127,6 +127,27 @@ __device__ __forceinline__ void copy_linear(float* __restrict__ dst, const float
   }
 }
 
+// Tile staging global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip,
+// every 1-KiB piece of the tile is in flight at once and the following __syncthreads()
+// (which waits vmcnt(0)) retires them all — one memory latency per tile instead of one
+// per dependent load->ds_write pair.  The LDS destination of a piece is wave-uniform
+// base + lane*16, which is exactly a linear copy.
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds_dst, const float* __restrict__ gsrc, int count) {
+  if ((count & 3) == 0 && (((uintptr_t)gsrc) & 15) == 0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int pieces = count >> 8;                     // 256 floats = 64 lanes x 16 B
+    for (int c = wave; c < pieces; c += nw) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)c * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(lds_dst + c * 256), 16, 0, 0);
+    }
+    for (int i = (pieces << 8) + threadIdx.x; i < count; i += blockDim.x) lds_dst[i] = gsrc[i];
+  } else {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) lds_dst[i] = gsrc[i];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K1: scatter pass.  tile_out[(b,h,c), cell_v(n)] (max0|+)= (src[(b,h,c), n] * pad[b,n]) * w_v(n)
 //   Splat forward (both reduce modes) and the g_grid half of Slice backward
@@ -288,6 +309,68 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// K1t: streaming form of K1s for Slice backward: the per-channel max |src*pad| and the
+//   per-plane max contributions per cell were left in the first two words of each channel's
+//   output tile by quad_kernel<..., QM_GATHER_GW, STATS> (which reads the same src anyway),
+//   so the quantum is known up front and the pass is a plain one-point-per-thread stream
+//   with integer LDS atomics — the structure of the max scatter, which runs at the HBM rate.
+//   grid = (nchunks, H, B)
+// ---------------------------------------------------------------------------
+template <int DIM, bool FROM_KEYS>
+__global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  extern __shared__ __align__(16) float lds[];
+  int* acc = (int*)lds;
+  float* s_q = lds + (size_t)a.CC * g.G;      // [CC] quantum (< 0: float fallback)
+  float* s_iq = s_q + a.CC;                   // [CC] 1 / quantum
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
+  const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+  const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+  if (threadIdx.x < cc) {
+    const unsigned* slot = (const unsigned*)(gout + (size_t)threadIdx.x * g.G);
+    const float M = __uint_as_float(slot[0]);
+    const float K = (float)slot[1];
+    const float MK = M * K;
+    const bool fixed = MK < 1e37f;
+    int ex = 0;
+    if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
+    ex = max(ex, -90);
+    s_q[threadIdx.x] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
+    s_iq[threadIdx.x] = ldexpf(1.0f, 30 - ex);
+  }
+  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+    Corners<DIM> c;
+    PointPos<DIM, FROM_KEYS> pp;
+    load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    for (int ch = 0; ch < cc; ++ch) {
+      float f = src[(size_t)ch * a.N + n];
+      if (has_pad) f = f * p;
+      const float iq = s_iq[ch];
+      const bool fixed = s_q[ch] >= 0.0f;
+      int* Tc = acc + (size_t)ch * g.G;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float prod = f * c.w[v];
+        if (fixed) atomicAdd(&Tc[c.cell[v]], __float2int_rn(prod * iq));
+        else atomicAdd((float*)&Tc[c.cell[v]], prod);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) {
+    const float q = s_q[i / g.G];
+    gout[i] = q < 0.0f ? lds[i] : (float)acc[i] * q;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K1r: register-resident form of K1s for the hot path (corners from keys,
 //   N <= blockDim*PPT, N % 4 == 0): each thread owns PPT consecutive points and
 //   keeps their src values for the whole channel chunk (<= CCR channels) in
@@ -442,7 +525,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_kernel(RasterAr
   const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)g.G;
   const float* T = LDS_TILE ? lds : gin;
   if (LDS_TILE) {
-    copy_linear(lds, gin, cc * g.G);
+    stage_tile(lds, gin, cc * g.G);
     __syncthreads();
   }
   const int per = (a.N + a.nsplit - 1) / a.nsplit;
@@ -490,7 +573,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_gw_kernel(Raste
     const float* T = LDS_TILE ? lds : gin;
     if (LDS_TILE) {
       __syncthreads();
-      copy_linear(lds, gin, cc * g.G);
+      stage_tile(lds, gin, cc * g.G);
       __syncthreads();
     }
     const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
@@ -545,8 +628,8 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
     const float* gz = GZ_LDS ? (lds + (size_t)a.CC * g.G) : (a.tile_in2 + toff);
     if (LDS_TILE) {
       __syncthreads();
-      copy_linear(lds, a.tile_in + toff, cc * g.G);
-      if (GZ_LDS) copy_linear(lds + (size_t)a.CC * g.G, a.tile_in2 + toff, cc * g.G);
+      stage_tile(lds, a.tile_in + toff, cc * g.G);
+      if (GZ_LDS) stage_tile(lds + (size_t)a.CC * g.G, a.tile_in2 + toff, cc * g.G);
       __syncthreads();
     }
     const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
@@ -617,8 +700,8 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
 // ---------------------------------------------------------------------------
 enum { QM_GATHER = 0, QM_GATHER_GW = 1, QM_SPLAT_MAX_BWD = 2 };
 
-template <int DIM, int MODE, int CG>
-__global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(RasterArgs a, GridW<DIM> g) {
+template <int DIM, int MODE, int CG, int THREADS = CT_QUAD_THREADS, bool STATS = false>
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) quad_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   constexpr bool kSrc = MODE != QM_GATHER;          // reads a point-sized input
   constexpr bool kDst = MODE != QM_GATHER_GW;       // writes a point-sized output
@@ -639,12 +722,20 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
     const size_t toff = (bh * a.C + c0) * (size_t)g.G;
     float* T = lds;                                   // tile_in chunk (z for SPLAT_MAX_BWD)
     float* T2 = lds + (size_t)a.CC * g.G;             // g_z chunk (SPLAT_MAX_BWD only)
+    // STATS (Slice backward): by-products for the fixed-point scatter that follows —
+    // per-channel max |src*pad| and the max number of contributions per cell
+    unsigned* s_max = (unsigned*)(lds + (size_t)a.CC * g.G);         // [CC]
+    int* s_cnt = (int*)(lds + (size_t)a.CC * g.G + a.CC);            // [G]
     __syncthreads();
-    copy_linear(T, a.tile_in + toff, cc * g.G);
-    if (MODE == QM_SPLAT_MAX_BWD) copy_linear(T2, a.tile_in2 + toff, cc * g.G);
+    if (STATS) {
+      for (int i = threadIdx.x; i < a.CC + g.G; i += blockDim.x) s_max[i] = 0u;
+    }
+    stage_tile(T, a.tile_in + toff, cc * g.G);
+    if (MODE == QM_SPLAT_MAX_BWD) stage_tile(T2, a.tile_in2 + toff, cc * g.G);
     __syncthreads();
     const float* src = kSrc ? a.src + (bh * a.C + c0) * (size_t)a.N : nullptr;
     float* dst = kDst ? a.dst + (bh * a.C + c0) * (size_t)a.N : nullptr;
+    float stat_max = 0.0f;
     for (int q = q_beg + (int)threadIdx.x; q < q_end; q += blockDim.x) {
       const int n0 = q << 2;
       // corner weights and base cell of the 4 points (per-axis terms are recomputed
@@ -673,6 +764,18 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) pv[i] = has_pad ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n0 + i) : 1.0f;
+      if (STATS && first) {
+        const float one[DIM] = {};
+        int f0[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) f0[j] = 0;
+        Corners<DIM> off;
+        ct_corners<DIM>(one, one, f0, g, off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int v = 0; v < V; ++v) atomicAdd(&s_cnt[base[i] + off.cell[v]], 1);
+      }
       float gw[4][V];
       if (kGw) {
 #pragma unroll
@@ -685,9 +788,23 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
         if (kSrc) {
 #pragma unroll
           for (int cj = 0; cj < CG; ++cj) {
+#ifdef AB_Q_NOLOAD
+            const float4 t = make_float4(0.5f + cj, 0.25f, -1.0f, 2.0f + n0);
+#else
             const float4 t = (cg0 + cj < cc) ? *(const float4*)(src + (size_t)(cg0 + cj) * a.N + n0) : make_float4(0, 0, 0, 0);
+#endif
             fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
           }
+        }
+        if (STATS) {
+          // one running max |src*pad| per thread for the whole chunk (inf/NaN -> inf)
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x = fabsf(has_pad ? fv[cj][i] * pv[i] : fv[cj][i]);
+              stat_max = fmaxf(stat_max, (x < __builtin_inff()) ? x : __builtin_inff());
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -724,26 +841,33 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
                 const float f = has_pad ? fv[cj][i] * pv[i] : fv[cj][i];
                 unsigned* Zc = (unsigned*)T + (size_t)ch * g.G;
                 const float* Gc = T2 + (size_t)ch * g.G;
-                // only positive products can be winners (zero floor): lanes with f <= 0 skip
-                // every LDS access, which also thins out the bank conflicts of the others
-                unsigned zb[V], bits[V], old[V];
-                bool m[V];
-                const bool pos = f > 0.0f;
+                // Matching is branch-free; everything a winner needs (claim, g_z, accumulation)
+                // sits in ONE divergent region per (point, channel) entered only by lanes with a
+                // match on any corner (~22% of them).  Non-matching corners of those lanes issue
+                // their compare-and-swap with a pattern no tile value can equal (all ones).
+                const bool pos = f > 0.0f;            // zero floor: only positive products can win
+                unsigned zb[V], bits[V];
 #pragma unroll
                 for (int v = 0; v < V; ++v) zb[v] = pos ? Zc[c.cell[v]] : 0u;
+                bool m[V];
+                bool any = false;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                  const float prod = f * c.w[v];
-                  bits[v] = __float_as_uint(prod);
-                  m[v] = pos && prod > 0.0f && zb[v] == bits[v];
+                  bits[v] = __float_as_uint(f * c.w[v]);
+                  m[v] = (zb[v] == bits[v]) & (zb[v] != 0u);   // zb != 0 <=> product > 0 here
+                  any = any | m[v];
                 }
-#pragma unroll
-                for (int v = 0; v < V; ++v) old[v] = m[v] ? atomicCAS(&Zc[c.cell[v]], bits[v], 0u) : 0u;
                 float gf = 0.0f;
+                if (any) {
+                  unsigned old[V];
+                  float gzv[V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                  if (m[v] && old[v] == bits[v]) {
-                    const float gzw = Gc[c.cell[v]];     // winners only (~6% of the lanes)
+                  for (int v = 0; v < V; ++v) old[v] = atomicCAS(&Zc[c.cell[v]], m[v] ? bits[v] : 0xFFFFFFFFu, 0u);
+#pragma unroll
+                  for (int v = 0; v < V; ++v) gzv[v] = Gc[c.cell[v]];
+#pragma unroll
+                  for (int v = 0; v < V; ++v) {
+                    const float gzw = (m[v] & (old[v] == bits[v])) ? gzv[v] : 0.0f;
                     gf += gzw * c.w[v];
                     gw[i][v] += gzw * f;
                   }
@@ -756,7 +880,11 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
         if (kDst) {
 #pragma unroll
           for (int cj = 0; cj < CG; ++cj)
+#ifdef AB_Q_NOSTORE
+            if (cg0 + cj < cc && fv[cj][0] == 1234.5f)
+#else
             if (cg0 + cj < cc)
+#endif
               *(float4*)(dst + (size_t)(cg0 + cj) * a.N + n0) = make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]);
         }
       }
@@ -796,6 +924,31 @@ __global__ void __launch_bounds__(CT_QUAD_THREADS, CT_QUAD_WAVES) quad_kernel(Ra
           }
         }
       }
+    }
+    if (STATS) {
+      // publish into the first two words of each channel's g_grid tile (tile_out), which the
+      // scatter kernel reads before it overwrites the tile.  The max is per chunk (an upper
+      // bound for each of its channels: costs at most the spread between channels in precision)
+      for (int o = 32; o > 0; o >>= 1) stat_max = fmaxf(stat_max, __shfl_xor(stat_max, o, 64));
+      if ((threadIdx.x & 63) == 0) atomicMax(&s_max[0], __float_as_uint(stat_max));
+      __syncthreads();
+      unsigned kmax = 0;
+      if (first) {
+        for (int i = threadIdx.x; i < g.G; i += blockDim.x) kmax = max(kmax, (unsigned)s_cnt[i]);
+        for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
+      }
+      unsigned* slots = (unsigned*)(a.tile_out + toff);
+      // one workgroup owns the whole (b,h) plane here (ncg == nsplit == 1), so plain stores do.
+      // K belongs to the plane: stored with every channel so that each scatter workgroup finds
+      // it inside its own tile
+      if (first) {
+        if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&s_cnt[0], kmax);   // s_cnt[0] now holds max over waves
+        __syncthreads();
+        const unsigned kall = (unsigned)s_cnt[0];
+        for (int ch = threadIdx.x; ch < a.C; ch += blockDim.x)
+          ((unsigned*)(a.tile_out + (bh * a.C + ch) * (size_t)g.G))[1] = kall;
+      }
+      for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) slots[(size_t)ch * g.G] = s_max[0];
     }
     first = false;
   }
@@ -1057,6 +1210,20 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if (p.lds_tile) {
     bool done = false;
     if constexpr (DIM == 2) {
+#ifndef CT_NO_WHOLE_HEAD
+      // whole-head form: z and g_z tiles of ALL channels of a (b,h) plane resident (<= 160 KiB,
+      // one 1024-thread workgroup per CU): one staging pass, keys read once, g_keys written once
+      const size_t wh_bytes = (size_t)2 * a.C * g.G * 4;
+      if (two && wh_bytes <= (size_t)kBigLdsBytes && wh_bytes > (size_t)kMaxLdsBytes && (long long)a.B * a.H >= 256 &&
+          quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
+        a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
+        int t = round_threads(a.N >> 2);
+        dim3 wgrid(1, a.H, a.B);
+        if (t > 512) CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024>), wgrid, 1024, wh_bytes, st, a, g);
+        else CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512>), wgrid, t, wh_bytes, st, a, g);
+        return CT_OK;
+      }
+#endif
       if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
         CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG>), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
         done = true;
@@ -1072,6 +1239,35 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
     a.claim = (unsigned*)ws;
     CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
   }
+  return CT_OK;
+}
+
+
+// Slice backward, hot path: returns CT_EINVAL when the shape is not eligible.
+template <int DIM>
+int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, hipStream_t st) {
+  GridW<DIM> g = make_grid<DIM>(W);
+  if ((g.G & 3) != 0) return CT_EINVAL;
+  // gather side: tile + [CC] maxima + [G] counters in LDS
+  RasterArgs ga = a;
+  ga.tile_in = grid; ga.g_pos = g_pos;     // ga.tile_out = g_grid receives the statistics
+  if (!quad_ok(ga, true, true)) return CT_EINVAL;
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  if (!p.lds_tile) return CT_EINVAL;
+  const size_t extra = (size_t)(p.CC + g.G) * 4;
+  if (p.lds_bytes + extra > (size_t)kMaxLdsBytes + 8192 && p.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
+  if (p.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
+  ga.CC = p.CC; ga.nchunks = p.nchunks; ga.nsplit = 1; ga.ncg = 1; ga.atomic_gpos = 0;
+  dim3 ggrid(1, a.H, a.B);
+  if constexpr (DIM == 2)
+    CT_LAUNCH((quad_kernel<2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true>), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+  else
+    CT_LAUNCH((quad_kernel<3, QM_GATHER_GW, 2, CT_QUAD_THREADS, true>), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+  // scatter side
+  RasterArgs sa = a;
+  sa.CC = p.CC; sa.nchunks = p.nchunks;
+  dim3 sgrid(p.nchunks, a.H, a.B);
+  CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, p.threads, p.lds_bytes + (size_t)2 * p.CC * 4, st, sa, g);
   return CT_OK;
 }
 
@@ -1137,6 +1333,12 @@ int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = g_out; a.tile_out = g_grid;
+  if (FROM_KEYS && (N & 3) == 0) {
+    // fast path: g_keys first (its kernel also leaves the scatter's quantum statistics in g_grid),
+    // then the streaming fixed-point scatter-add
+    int r = dim == 2 ? run_slice_bwd_fast<2>(a, grid, g_pos, W, st) : run_slice_bwd_fast<3>(a, grid, g_pos, W, st);
+    if (r != CT_EINVAL) return r;       // CT_EINVAL: shape not eligible, use the generic pair below
+  }
   int r = dim == 2 ? run_scatter<2, FROM_KEYS>(a, W, true, st) : run_scatter<3, FROM_KEYS>(a, W, true, st);
   if (r != CT_OK) return r;
   a.tile_out = nullptr; a.tile_in = grid; a.g_pos = g_pos;

@@ -62,8 +62,10 @@ class SplatSliceStep:
                    "ct_slice_bwd_keys")
 
     def slice_bwd(self):
-        self.slice_bwd_grid()
-        self.slice_bwd_keys()
+        _lib.check(self.lib.ct_slice_bwd(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
+                                         _ptr(self.g_z), _ptr(self.g_keys_b),
+                                         self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
+                   "ct_slice_bwd")
 
     def splat_bwd(self):
         _lib.check(self.lib.ct_splat_bwd(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
@@ -71,15 +73,14 @@ class SplatSliceStep:
                                          self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red, _stream()),
                    "ct_splat_bwd")
 
-    # one entry per ABI call; each is ONE kernel launch for reduce="max" on the LDS-tile path
-    PASSES = ("splat_fwd", "slice_fwd", "slice_bwd_grid", "slice_bwd_keys", "splat_bwd")
+    # one entry per ABI call; each is ONE kernel launch for reduce="max" on the headline shape
+    PASSES = ("splat_fwd", "slice_fwd", "slice_bwd", "splat_bwd")
     # HIP kernel behind each pass on the headline shape (name as rocprofv3 prints it)
     KERNELS = {
         "splat_fwd": "scatter_kernel<2, true, false, true>",
-        "slice_fwd": "quad_kernel<2, 0, 4>",
-        "slice_bwd_grid": "scatter_add_fx_reg_kernel<2, 4, 8, 4>",
-        "slice_bwd_keys": "quad_kernel<2, 1, 4>",
-        "splat_bwd": "quad_kernel<2, 2, 4>",
+        "slice_fwd": "quad_kernel<2, 0, 4, 512>",
+        "slice_bwd": "slice_bwd_fused_kernel<16>",
+        "splat_bwd": "quad_kernel<2, 2, 4, 1024>",
     }
 
     def run(self):
@@ -103,11 +104,8 @@ class SplatSliceStep:
         per = {
             "splat_fwd": kb + fb + gb,                    # keys, feat -> z
             "slice_fwd": kb + gb + fb,                    # keys, z -> out
-            "slice_bwd_grid": kb + fb + gb,               # keys, cot -> g_z
-            "slice_bwd_keys": gb + kb,                    # z (+ keys, cot already counted) -> g_keys
+            "slice_bwd": kb + fb + gb + gb + kb,          # keys, cot, z -> g_z, g_keys
             "splat_bwd": kb + fb + gb + gb + fb + kb,     # keys, feat, z, g_z -> g_feat, g_keys
         }
         per["total"] = sum(per.values())                  # = 6*kb + 5*fb + 6*gb
-        # as a stand-alone launch the g_keys half must re-read keys and cot: what that ONE kernel moves
-        per["slice_bwd_keys_launch"] = kb + fb + gb + kb
         return per
