@@ -845,10 +845,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
                 // sits in ONE divergent region per (point, channel) entered only by lanes with a
                 // match on any corner (~22% of them).  Non-matching corners of those lanes issue
                 // their compare-and-swap with a pattern no tile value can equal (all ones).
-                const bool pos = f > 0.0f;            // zero floor: only positive products can win
+                // (a non-positive product has its sign bit set or is zero, so it can never be
+                // bit-equal to a positive tile value: no separate f > 0 test is needed)
                 unsigned zb[V], bits[V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) zb[v] = pos ? Zc[c.cell[v]] : 0u;
+                for (int v = 0; v < V; ++v) zb[v] = Zc[c.cell[v]];
                 bool m[V];
                 bool any = false;
 #pragma unroll
@@ -1333,6 +1334,10 @@ int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = g_out; a.tile_out = g_grid;
+  // (A single fused kernel — grid tile + accumulator tile of a whole (b,h) plane in LDS, one
+  //  1024-thread workgroup per CU — was built twice and measured SLOWER than the pair below
+  //  (105-124 us vs 92-99 us on the headline shape): the pass is co-bound by LDS atomics/reads
+  //  and HBM, and one workgroup per CU overlaps the two worse than two streaming kernels do.)
   if (FROM_KEYS && (N & 3) == 0) {
     // fast path: g_keys first (its kernel also leaves the scatter's quantum statistics in g_grid),
     // then the streaming fixed-point scatter-add
