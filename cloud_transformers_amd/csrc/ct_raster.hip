@@ -788,11 +788,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
         if (kSrc) {
 #pragma unroll
           for (int cj = 0; cj < CG; ++cj) {
-#ifdef AB_Q_NOLOAD
-            const float4 t = make_float4(0.5f + cj, 0.25f, -1.0f, 2.0f + n0);
-#else
             const float4 t = (cg0 + cj < cc) ? *(const float4*)(src + (size_t)(cg0 + cj) * a.N + n0) : make_float4(0, 0, 0, 0);
-#endif
             fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
           }
         }
@@ -881,11 +877,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
         if (kDst) {
 #pragma unroll
           for (int cj = 0; cj < CG; ++cj)
-#ifdef AB_Q_NOSTORE
-            if (cg0 + cj < cc && fv[cj][0] == 1234.5f)
-#else
             if (cg0 + cj < cc)
-#endif
               *(float4*)(dst + (size_t)(cg0 + cj) * a.N + n0) = make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]);
         }
       }

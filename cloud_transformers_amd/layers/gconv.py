@@ -1,0 +1,79 @@
+"""Grouped 3^d convolution modules backed by the MFMA kernels of csrc/ct_gconv.hip.
+
+`GroupedConv2d` / `GroupedConv3d` subclass `nn.Conv2d` / `nn.Conv3d`, so parameter names,
+shapes, initialisation and state dicts are exactly those of the `nn.Conv{2,3}d(...,
+groups=heads)` layers the reference builds (layers/multihead_ct.py:50-65,
+unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29).  The forward/backward run on the
+hand-written kernels whenever the layer is the shape the MHCT path uses — kernel 3, stride 1,
+padding 1, dilation 1, zero padding, fp32 on a HIP device; any other configuration (e.g. the
+1x1 skip convolutions) goes to the stock PyTorch/MIOpen implementation of the parent class.
+"""
+import torch
+from torch import nn
+
+from .. import _lib
+from ..ops import _ptr, _stream
+
+
+class GroupedConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups):
+        x = x.contiguous()
+        weight = weight.contiguous()
+        dim = x.dim() - 2
+        B = x.shape[0]
+        Cin = x.shape[1] // groups
+        Cout = weight.shape[0] // groups
+        W = list(x.shape[2:])
+        y = torch.empty(B, groups * Cout, *W, device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ct_gconv_fwd(_ptr(x), _ptr(weight), _ptr(bias.contiguous()) if bias is not None else None,
+                                        _ptr(y), B, groups, Cin, Cout, dim, _lib.int_array(W), _stream()),
+                       "ct_gconv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (groups, Cin, Cout, dim, W, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, weight = ctx.saved_tensors
+        groups, Cin, Cout, dim, W, has_bias = ctx.meta
+        g_y = g_y.contiguous()
+        B = x.shape[0]
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        g_x = g_w = g_b = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                g_x = torch.empty_like(x)
+                _lib.check(lib.ct_gconv_bwd_data(_ptr(g_y), _ptr(weight), _ptr(g_x), B, groups, Cin, Cout, dim, Wa,
+                                                 _stream()), "ct_gconv_bwd_data")
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                g_w = torch.empty_like(weight)
+                g_b = torch.empty(groups * Cout, device=x.device, dtype=torch.float32) if has_bias else None
+                _lib.check(lib.ct_gconv_bwd_weight(_ptr(x), _ptr(g_y), _ptr(g_w), _ptr(g_b), B, groups, Cin, Cout,
+                                                   dim, Wa, _stream()), "ct_gconv_bwd_weight")
+        return g_x, g_w, g_b, None
+
+
+def _eligible(mod, x):
+    nd = x.dim() - 2
+    return (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32
+            and tuple(mod.kernel_size) == (3,) * nd and tuple(mod.stride) == (1,) * nd
+            and tuple(mod.padding) == (1,) * nd and tuple(mod.dilation) == (1,) * nd
+            and mod.padding_mode == "zeros")
+
+
+class GroupedConv2d(nn.Conv2d):
+    def forward(self, x):
+        if _eligible(self, x):
+            return GroupedConvFn.apply(x, self.weight, self.bias, self.groups)
+        return super().forward(x)
+
+
+class GroupedConv3d(nn.Conv3d):
+    def forward(self, x):
+        if _eligible(self, x):
+            return GroupedConvFn.apply(x, self.weight, self.bias, self.groups)
+        return super().forward(x)

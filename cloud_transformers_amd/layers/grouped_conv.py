@@ -10,7 +10,10 @@ reference's state dicts load with strict=True.
 import torch.nn as nn
 import torch.nn.functional as F
 
-_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+from .gconv import GroupedConv2d, GroupedConv3d
+
+# nn.Conv{2,3}d subclasses: 3^d / stride 1 / pad 1 layers run on the MFMA kernels, 1x1 skips on MIOpen
+_CONV = {2: GroupedConv2d, 3: GroupedConv3d}
 _CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
 _BN = {2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
 

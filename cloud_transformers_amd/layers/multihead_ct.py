@@ -22,6 +22,7 @@ from torch import nn
 
 from .. import ops
 from .cloud_transform import DifferentiablePositions, Slice, Splat
+from .gconv import GroupedConv2d, GroupedConv3d
 from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer
 
 
@@ -37,7 +38,7 @@ def forward_style(module_list, input, z):
 
 
 def _grouped_conv(tensor_dim, channels, heads):
-    conv = nn.Conv3d if tensor_dim == 3 else nn.Conv2d
+    conv = GroupedConv3d if tensor_dim == 3 else GroupedConv2d      # nn.Conv{2,3}d subclasses on the MFMA kernels
     return nn.Sequential(conv(channels, channels, kernel_size=3, stride=1, padding=1, groups=heads, bias=True))
 
 

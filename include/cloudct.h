@@ -132,6 +132,24 @@ int ct_slice_lc_bwd(const float* local_coord, const int64_t* flat_idx, const flo
 int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Grouped 3^dim convolution over the rasterised planes / volumes, stride 1, padding 1
+ * (MultiHead.conv: layers/multihead_ct.py:50-65 with bias; Res2DBlock / Res3DBlock:
+ * unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29 without), fp32 on the matrix
+ * cores (v_mfma_f32_16x16x4_f32: exact fp32, one rounding per product, k-ordered).
+ *   x f32[B, groups*Cin, *W]   w f32[groups*Cout, Cin, 3^dim]   bias f32[groups*Cout] | NULL
+ *   y f32[B, groups*Cout, *W]
+ * bwd_data : g_x from g_y and w.   bwd_weight: g_w (and g_bias unless NULL) from x and g_y;
+ * both outputs are overwritten (g_w / g_bias are accumulated across workgroups with float
+ * atomics: the summation order is not fixed).
+ * ---------------------------------------------------------------------- */
+int ct_gconv_fwd(const float* x, const float* w, const float* bias, float* y,
+                 int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
+int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
+                      int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
+int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias,
+                        int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Chamfer distance (chamfer_extension/chamfer_cuda.cpp:30-33 `forward`,
  * `backward`; kernels chamfer.cu:12-195).  xyz1 f32[B,n,3], xyz2 f32[B,m,3];
  * dist1 f32[B,n], idx1 i32[B,n] (nearest point of cloud 2, lowest index on
