@@ -1,0 +1,51 @@
+"""The reference's data-parallel recipe (train_segmentation.py:58-61,128-130:
+init_process_group('nccl') + DistributedDataParallel(SyncBatchNorm.convert_sync_batchnorm(model)))
+on the HIP modules: RCCL process group of one rank on the test box — checks that DDP's
+autograd hooks fire through the ctypes-backed autograd Functions and that gradients equal the
+plain run (multi-rank logic is covered on gloo in tests/test_parallel_gloo.py)."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_ddp_syncbn_single_rank_matches_plain():
+    from cloud_transformers_amd.layers.multihead_ct import MultiHeadUnion
+    from cloud_transformers_amd import parallel as P
+    torch.manual_seed(0)
+    model = MultiHeadUnion(32, [4, 4], [16, 8], [2, 3], [4, 2]).cuda()
+    x = torch.randn(2, 32, 256, device="cuda")
+    pcd = torch.rand(2, 3, 256, device="cuda") * 2 - 1
+    out, _ = model(x, pcd)
+    out.square().mean().backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(
+            torch.nn.SyncBatchNorm.convert_sync_batchnorm(model), device_ids=[0])
+        out, stats = ddp(x, pcd)
+        loss = out.square().mean()
+        loss.backward()
+        for n, p in ddp.module.named_parameters():
+            assert p.grad is not None, n
+            assert torch.allclose(p.grad, ref[n], atol=2e-5, rtol=1e-4), n
+        red = P.reduce_loss_dict(dist, {"loss": loss.detach()})
+        assert torch.allclose(red["loss"], loss.detach())
+        assert P.max_over_ranks(dist, 1.5) == 1.5
+        P.barrier(dist)
+    finally:
+        dist.destroy_process_group()
