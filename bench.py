@@ -162,7 +162,9 @@ def main():
     if rank == 0:
         alg = step.algorithmic_bytes()
         passes = time_passes(step)
-        dom = max(passes, key=passes.get)            # every pass is one kernel launch
+        # dominant KERNEL: the longest pass that is a single launch (slice_bwd is two shorter kernels;
+        # profiles/*_kernel_stats.csv lists every kernel's average for cross-checking)
+        dom = max(step.SINGLE_KERNEL, key=lambda k: passes[k])
         dom_bytes = alg.get(dom + "_launch", alg[dom])
         achieved = dom_bytes / (passes[dom] * 1e-3) / 1e9
         traffic = measured_traffic(step.KERNELS.get(dom, dom)) if args.reduce == "max" else None

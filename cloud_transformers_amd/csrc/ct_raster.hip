@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
 // ---------------------------------------------------------------------------
 enum { QM_GATHER = 0, QM_GATHER_GW = 1, QM_SPLAT_MAX_BWD = 2 };
 
-template <int DIM, int MODE, int CG, int THREADS = CT_QUAD_THREADS, bool STATS = false>
+template <int DIM, int MODE, int CG, int THREADS, bool STATS, bool HAS_PAD>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) quad_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   constexpr bool kSrc = MODE != QM_GATHER;          // reads a point-sized input
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
   const int cgi = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
   const int h = blockIdx.y, b = blockIdx.z;
   const size_t bh = (size_t)b * a.H + h;
-  const bool has_pad = a.pad_dtype != CT_PAD_NONE;
+  constexpr bool has_pad = HAS_PAD;            // compile-time: no per-element select on the no-padding path
   const bool atomic = a.atomic_gpos != 0;
   const int nq = a.N >> 2;
   const int per = (nq + a.nsplit - 1) / a.nsplit;
@@ -1082,6 +1082,20 @@ int set_lds(K kernel, size_t bytes) {
     CT_CHECK_LAUNCH();                                                      \
   } while (0)
 
+
+// quad kernels are specialised on "has a padding mask" (compile-time: no per-element select
+// on the common no-padding path); TARGS = (DIM, MODE, CG, THREADS, STATS)
+#define CT_QUAD_T(DIMV, MODE, CG, THREADS, STATS, PAD) quad_kernel<DIMV, MODE, CG, THREADS, STATS, PAD>
+#define CT_STRIP(...) __VA_ARGS__
+#define CT_LAUNCH_QUAD(TARGS, GRID, NT, LDS, STREAM, ARGS, GW)                                        \
+  do {                                                                                                \
+    if ((ARGS).pad_dtype != CT_PAD_NONE)                                                              \
+      CT_LAUNCH((CT_QUAD_T_APPLY_(CT_STRIP TARGS, true)), GRID, NT, LDS, STREAM, ARGS, GW);           \
+    else                                                                                              \
+      CT_LAUNCH((CT_QUAD_T_APPLY_(CT_STRIP TARGS, false)), GRID, NT, LDS, STREAM, ARGS, GW);          \
+  } while (0)
+#define CT_QUAD_T_APPLY_(...) CT_QUAD_T(__VA_ARGS__)
+
 // scatter: Splat fwd (max/sum) and Slice bwd g_grid
 template <int DIM, bool FROM_KEYS>
 int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
@@ -1150,7 +1164,7 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   if constexpr (DIM == 2) {   // 3D exceeds the register budget of the quad form: generic kernel
     if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
       a.ncg = p.nchunks;   // one chunk per workgroup
-      CT_LAUNCH((quad_kernel<2, QM_GATHER, CT_QUAD_CG>), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
+      CT_LAUNCH_QUAD((2, QM_GATHER, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
       return CT_OK;
     }
   }
@@ -1178,7 +1192,7 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(a.ncg * a.nsplit, a.H, a.B);
   if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
-    CT_LAUNCH((quad_kernel<DIM, QM_GATHER_GW, (DIM == 2 ? CT_QUAD_CG : 2)>), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
+    CT_LAUNCH_QUAD((DIM, QM_GATHER_GW, (DIM == 2 ? CT_QUAD_CG : 2), CT_QUAD_THREADS, false), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
     return CT_OK;
   }
   if (p.lds_tile) CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
@@ -1212,13 +1226,13 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
         a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
         int t = round_threads(a.N >> 2);
         dim3 wgrid(1, a.H, a.B);
-        if (t > 512) CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024>), wgrid, 1024, wh_bytes, st, a, g);
-        else CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512>), wgrid, t, wh_bytes, st, a, g);
+        if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
+        else CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512, false), wgrid, t, wh_bytes, st, a, g);
         return CT_OK;
       }
 #endif
       if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
-        CT_LAUNCH((quad_kernel<2, QM_SPLAT_MAX_BWD, CT_QUAD_CG>), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
+        CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
         done = true;
       }
     }
@@ -1253,9 +1267,9 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   ga.CC = p.CC; ga.nchunks = p.nchunks; ga.nsplit = 1; ga.ncg = 1; ga.atomic_gpos = 0;
   dim3 ggrid(1, a.H, a.B);
   if constexpr (DIM == 2)
-    CT_LAUNCH((quad_kernel<2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true>), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+    CT_LAUNCH_QUAD((2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
   else
-    CT_LAUNCH((quad_kernel<3, QM_GATHER_GW, 2, CT_QUAD_THREADS, true>), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+    CT_LAUNCH_QUAD((3, QM_GATHER_GW, 2, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
   // scatter side
   RasterArgs sa = a;
   sa.CC = p.CC; sa.nchunks = p.nchunks;

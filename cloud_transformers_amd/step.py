@@ -78,10 +78,12 @@ class SplatSliceStep:
     # HIP kernel behind each pass on the headline shape (name as rocprofv3 prints it)
     KERNELS = {
         "splat_fwd": "scatter_kernel<2, true, false, true>",
-        "slice_fwd": "quad_kernel<2, 0, 4, 512>",
-        "slice_bwd": "slice_bwd_fused_kernel<16>",
-        "splat_bwd": "quad_kernel<2, 2, 4, 1024>",
+        "slice_fwd": "quad_kernel<2, 0, 4, 512, false, false>",
+        "slice_bwd": "quad_kernel<2, 1, 4, 512, true, false> + scatter_add_fx_stream_kernel<2, true>",
+        "splat_bwd": "quad_kernel<2, 2, 4, 1024, false, false>",
     }
+    # passes that are exactly one kernel launch (slice_bwd is two: ~43 us + ~50 us on the headline shape)
+    SINGLE_KERNEL = ("splat_fwd", "slice_fwd", "splat_bwd")
 
     def run(self):
         self.splat_fwd()
