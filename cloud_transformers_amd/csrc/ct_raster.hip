@@ -931,17 +931,25 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
         for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
       }
       unsigned* slots = (unsigned*)(a.tile_out + toff);
-      // one workgroup owns the whole (b,h) plane here (ncg == nsplit == 1), so plain stores do.
-      // K belongs to the plane: stored with every channel so that each scatter workgroup finds
-      // it inside its own tile
+      // K belongs to the (b,h) plane: stored with every channel so that each scatter workgroup finds
+      // it inside its own tile.  With one workgroup per plane plain stores do; when N is split over
+      // workgroups the slots were zeroed and are combined atomically: max for M, and for K the SUM of
+      // the per-split maxima (an upper bound of the true per-cell maximum, which is all K has to be).
+      const bool split = a.nsplit > 1;
       if (first) {
         if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&s_cnt[0], kmax);   // s_cnt[0] now holds max over waves
         __syncthreads();
         const unsigned kall = (unsigned)s_cnt[0];
-        for (int ch = threadIdx.x; ch < a.C; ch += blockDim.x)
-          ((unsigned*)(a.tile_out + (bh * a.C + ch) * (size_t)g.G))[1] = kall;
+        for (int ch = threadIdx.x; ch < a.C; ch += blockDim.x) {
+          unsigned* kslot = (unsigned*)(a.tile_out + (bh * a.C + ch) * (size_t)g.G) + 1;
+          if (split) atomicAdd(kslot, kall);
+          else *kslot = kall;
+        }
       }
-      for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) slots[(size_t)ch * g.G] = s_max[0];
+      for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+        if (split) atomicMax(slots + (size_t)ch * g.G, s_max[0]);
+        else slots[(size_t)ch * g.G] = s_max[0];
+      }
     }
     first = false;
   }
@@ -1040,7 +1048,8 @@ int round_threads(int n) {
 
 // Choose channels-per-tile: the largest chunk that fits the LDS budget while
 // leaving at least ~2 workgroups per CU chip-wide when C allows it.
-Plan make_plan(int B, int H, int C, int N, int G, int tiles_per_wg /*1 or 2 tiles resident*/) {
+Plan make_plan(int B, int H, int C, int N, int G, int tiles_per_wg /*1 or 2 tiles resident*/,
+               long long want = 256 /*workgroups to aim for*/, int min_cc = 4 /*do not shrink chunks below this*/) {
   Plan p;
   size_t per_ch = (size_t)G * 4 * tiles_per_wg;
   p.lds_tile = true;
@@ -1053,11 +1062,15 @@ Plan make_plan(int B, int H, int C, int N, int G, int tiles_per_wg /*1 or 2 tile
     return p;
   }
   int cc_fit = (int)(kMaxLdsBytes / per_ch);
-  if (cc_fit < 1) cc_fit = 1;  // single channel between 64 KiB and 160 KiB: one WG per CU
+  // tiles that hold fewer than min_cc channels in 64 KiB take the whole CU instead (one workgroup
+  // per CU, up to 160 KiB): thin chunks recompute every point's corners once per chunk
+  if (cc_fit < min_cc) cc_fit = (int)((size_t)kBigLdsBytes / per_ch) < min_cc ? (int)((size_t)kBigLdsBytes / per_ch) : min_cc;
+  if (cc_fit < 1) cc_fit = 1;
   int cc = cc_fit < C ? cc_fit : C;
-  // enough workgroups to fill 256 CUs
-  const long long want = 512;
-  while (cc > 1 && (long long)B * H * ((C + cc - 1) / cc) < want) cc = (cc + 1) / 2;
+  // enough workgroups to fill the 256 CUs — but chunks thinner than min_cc channels recompute the
+  // corners of every point too often to be worth the extra parallelism
+  if (min_cc > cc) min_cc = cc;
+  while (cc > min_cc && (long long)B * H * ((C + cc - 1) / cc) < want) cc = (cc + 1) / 2 < min_cc ? min_cc : (cc + 1) / 2;
   p.CC = cc;
   p.nchunks = (C + cc - 1) / cc;
   p.lds_bytes = (size_t)cc * per_ch;
@@ -1259,22 +1272,31 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   RasterArgs ga = a;
   ga.tile_in = grid; ga.g_pos = g_pos;     // ga.tile_out = g_grid receives the statistics
   if (!quad_ok(ga, true, true)) return CT_EINVAL;
-  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
-  if (!p.lds_tile) return CT_EINVAL;
-  const size_t extra = (size_t)(p.CC + g.G) * 4;
-  if (p.lds_bytes + extra > (size_t)kMaxLdsBytes + 8192 && p.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
-  if (p.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
-  ga.CC = p.CC; ga.nchunks = p.nchunks; ga.nsplit = 1; ga.ncg = 1; ga.atomic_gpos = 0;
-  dim3 ggrid(1, a.H, a.B);
+  // gather side: the largest channel chunk that fits (parallelism comes from splitting N, which a
+  // gather may do freely); scatter side: its own chunking (it owns whole tiles)
+  Plan pg = make_plan(a.B, a.H, a.C, a.N, g.G, 1, /*want=*/1);
+  Plan ps = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  if (!pg.lds_tile || !ps.lds_tile) return CT_EINVAL;
+  const size_t extra = (size_t)(pg.CC + g.G) * 4;
+  if (pg.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
+  ga.CC = pg.CC; ga.nchunks = pg.nchunks; ga.ncg = 1; ga.atomic_gpos = 0;
+  ga.nsplit = 1;
+  while ((long long)a.B * a.H * ga.nsplit < 256 && (a.N >> 2) / (ga.nsplit * 2) >= 128) ga.nsplit *= 2;
+  if (ga.nsplit > 1) {
+    // statistics are combined across the splits with atomics: zero their slots (first two words of
+    // every channel tile of g_grid) first
+    if (hipMemset2DAsync(a.tile_out, (size_t)g.G * 4, 0, 8, (size_t)a.B * a.H * a.C, st) != hipSuccess) return CT_ELAUNCH;
+  }
+  dim3 ggrid(ga.nsplit, a.H, a.B);
   if constexpr (DIM == 2)
-    CT_LAUNCH_QUAD((2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+    CT_LAUNCH_QUAD((2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, ga.nsplit), pg.lds_bytes + extra, st, ga, g);
   else
-    CT_LAUNCH_QUAD((3, QM_GATHER_GW, 2, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, 1), p.lds_bytes + extra, st, ga, g);
+    CT_LAUNCH_QUAD((3, QM_GATHER_GW, 2, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, ga.nsplit), pg.lds_bytes + extra, st, ga, g);
   // scatter side
   RasterArgs sa = a;
-  sa.CC = p.CC; sa.nchunks = p.nchunks;
-  dim3 sgrid(p.nchunks, a.H, a.B);
-  CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, p.threads, p.lds_bytes + (size_t)2 * p.CC * 4, st, sa, g);
+  sa.CC = ps.CC; sa.nchunks = ps.nchunks;
+  dim3 sgrid(ps.nchunks, a.H, a.B);
+  CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, ps.threads, ps.lds_bytes + (size_t)2 * ps.CC * 4, st, sa, g);
   return CT_OK;
 }
 

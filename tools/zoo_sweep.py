@@ -1,0 +1,24 @@
+"""Secondary sweep: the six zoo head shapes at B8 H16, N in {2048, 4096}, plus N=16384 at B2:
+per-pass device time and fraction of the 8 TB/s roofline for the fwd+bwd step."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cloud_transformers_amd.step import SplatSliceStep
+from bench import time_passes
+
+SHAPES = [(4, 128, 2), (4, 32, 3), (16, 64, 2), (16, 16, 3), (16, 16, 2), (32, 8, 3)]
+print("C W dim | B N | us per pass ... | step us | algorithmic MB | frac of 8 TB/s")
+for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
+    for C, W, dim in SHAPES:
+        torch.manual_seed(0)
+        H = 16
+        keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
+        feat = torch.randn(B, H * C, N, device="cuda")
+        cot = torch.randn(B, H * C, N, device="cuda")
+        st = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
+        st.run(); torch.cuda.synchronize()
+        p = time_passes(st, iters=20)
+        tot = sum(p.values()) * 1e3
+        alg = st.algorithmic_bytes()["total"]
+        print(C, W, dim, "|", B, N, "|", {k: round(v * 1e3, 1) for k, v in p.items()}, "|", round(tot, 1), "|",
+              round(alg / 1e6, 1), "|", round(alg / (tot * 1e-6) / 8e12, 3), flush=True)
