@@ -21,7 +21,8 @@ namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;                // small tiles: several workgroups per CU
+constexpr int kThreadsBig = 1024;            // tiles that leave room for one or two workgroups per CU
 constexpr int kP = 4;                      // position groups per wave sharing one A read
 #ifndef CT_GCONV_LDS
 #define CT_GCONV_LDS (32 * 1024)
@@ -103,7 +104,7 @@ __device__ __forceinline__ void stage_halo_tile(float* xs, const float* xg, cons
 
 // grid = (nD*nH, groups, B)
 template <int DIM>
-__global__ void __launch_bounds__(kThreads) gconv_fwd_kernel(GconvArgs a) {
+__global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
   const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
@@ -180,99 +181,124 @@ __global__ void __launch_bounds__(kThreads) gconv_fwd_kernel(GconvArgs a) {
 // ---------------------------------------------------------------------------
 // backward wrt the filter bank (and bias):
 //   g_w[co, ci, tap] = sum_{b, pos} g_y[b, co, pos] * x[b, ci, pos + tap]
-// implicit GEMM with K = positions: A (16x4) = g_y[co 0..15][4 positions], B (4x16) =
-// x[ci 0..15][the same 4 positions + tap].  One workgroup per (tile, group, batch) with both
-// tiles in LDS.  The tile's positions are split over the waves; a wave keeps the 9 accumulators
-// of one z-slab of taps, so one A read feeds 9 MFMAs.  Wave partials are summed through LDS and
-// added to g_w with one float atomic per filter element per workgroup (g_w is zeroed first; the
-// summation order across workgroups is not fixed: last bits may differ from run to run).
+// implicit GEMM with K = (batch, positions): A (16x4) = g_y[co 0..15][4 positions], B (4x16) =
+// x[ci 0..15][the same 4 positions + tap].  A workgroup owns one group and a CHUNK of the
+// (batch, tile) units: it walks its units one after the other (tiles of x with halo and of g_y
+// staged in LDS), keeping all 3^d accumulators of one 16x16 filter block in registers — so one
+// A read feeds 9 MFMAs and the cross-wave reduction + the float atomics on g_w happen once per
+// workgroup, not once per tile.  (g_w is zeroed first; the summation order across workgroups is
+// not fixed: last bits may differ from run to run.)
+// grid = (unit chunks, groups)
 // ---------------------------------------------------------------------------
 template <int DIM>
-__global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a, const float* gy, float* gw, float* gbias) {
+__global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a, const float* gy, float* gw, int units_per_wg) {
+  constexpr int NZ = DIM == 3 ? 3 : 1;                  // z-slabs of 9 taps
   extern __shared__ __align__(16) float lds[];
-  const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
-  const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
-  const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
+  const int grp = blockIdx.y;
+  const int ntiles = a.nD * a.nH;
+  const int U = a.B * ntiles;
+  const int u_beg = blockIdx.x * units_per_wg, u_end = min(U, u_beg + units_per_wg);
   const int CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
   const size_t vol = (size_t)a.D * a.H * a.W;
-  const int npos = td * th * a.W;
-  const int nk = (npos + 3) & ~3;                       // positions walked, 4 per MFMA
-  const int gstride = nk | 1;                           // odd row stride: the 16 rows of an A read hit 16 banks
-  float* xs = lds;                                      // [CiB*16][plane]  (zero beyond Cin)
-  float* gs = lds + (size_t)CiB * 16 * a.plane;         // [CoB*16][gstride] (zero beyond Cout / npos)
+  const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
+  float* xs = lds;                                      // [16][plane]      input block (zero beyond Cin)
+  float* gs = lds + (size_t)16 * a.plane;               // [16][gstride]    g_y block (zero beyond Cout / npos)
+  float* red = gs + (size_t)16 * gstride_max;           // [nwaves][3][256] partials of 3 taps at a time
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  stage_halo_tile<DIM>(xs, a.x + ((size_t)b * a.groups + grp) * a.Cin * vol, a, CiB * 16, td0, th0, lane, wave, nwaves);
-  {
-    // g_y tile: the th rows of a depth slice are contiguous in memory (full-width tile)
-    const float* gg = gy + ((size_t)b * a.groups + grp) * a.Cout * vol;
-    const int slab = th * a.W;
-    for (int row = wave; row < CoB * 16 * td; row += nwaves) {
-      const int c = row / td, z = row % td;
-      float* dst = gs + (size_t)c * gstride + z * slab;
-      const float* src = gg + (size_t)c * vol + ((size_t)(td0 + z) * a.H + th0) * a.W;
-      for (int i = lane; i < slab; i += 64) dst[i] = c < a.Cout ? src[i] : 0.0f;
-    }
-    for (int c = threadIdx.x; c < CoB * 16; c += blockDim.x)
-      for (int i = npos; i < gstride; ++i) gs[(size_t)c * gstride + i] = 0.0f;
-  }
-  __syncthreads();
   const int col = lane & 15, kq = lane >> 4;
-  // bias gradient: sum of g_y over the tile
-  if (gbias != nullptr) {
-    for (int c = wave; c < a.Cout; c += nwaves) {
-      float s = 0.0f;
-      for (int pos = lane; pos < npos; pos += 64) s += gs[(size_t)c * gstride + pos];
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (lane == 0) atomicAdd(&gbias[grp * a.Cout + c], s);
-    }
-  }
-  // this wave's share of the positions (multiple of 4)
-  const int per = (((nk >> 2) + nwaves - 1) / nwaves) << 2;
-  const int p_beg = min(nk, wave * per), p_end = min(nk, p_beg + per);
-  float* red = gs + (size_t)CoB * 16 * gstride;          // [nwaves][3][256] partials of 3 taps at a time
+
   for (int cob = 0; cob < CoB; ++cob) {
     for (int cib = 0; cib < CiB; ++cib) {
-      for (int tz = 0; tz < (DIM == 3 ? 3 : 1); ++tz) {
-        floatx4 acc[9];
+      floatx4 acc[NZ * 9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* ga = gs + (size_t)(cob * 16 + col) * gstride;             // A: row = co, k = position
-        const float* xb = xs + (size_t)(cib * 16 + col) * a.plane + tz * a.Hs * a.Ws;   // B: col = ci
-        // (x, y, z) of this lane's position p_beg + kq, advanced by 4 per step
+      for (int t = 0; t < NZ * 9; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u = u_beg; u < u_end; ++u) {
+        const int b = u / ntiles, tile = u % ntiles;
+        const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
+        const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
+        const int npos = td * th * a.W;
+        const int nk = (npos + 3) & ~3;                   // positions walked, 4 per MFMA
+        const int gstride = nk | 1;                       // odd: the 16 rows of an A read hit 16 banks
+        __syncthreads();                                  // previous unit fully consumed
+        // input block cib (16 channels) with halo
+        {
+          GconvArgs sub = a;
+          sub.Cin = min(16, a.Cin - cib * 16);
+          stage_halo_tile<DIM>(xs, a.x + (((size_t)b * a.groups + grp) * a.Cin + cib * 16) * vol, sub, 16, td0, th0, lane,
+                               wave, nwaves);
+        }
+        // g_y block cob: the th rows of a depth slice are contiguous in memory (full-width tile)
+        {
+          const float* gg = gy + (((size_t)b * a.groups + grp) * a.Cout + cob * 16) * vol;
+          const int slab = th * a.W;
+          for (int row = wave; row < 16 * td; row += nwaves) {
+            const int c = row / td, z = row % td;
+            float* dst = gs + (size_t)c * gstride + z * slab;
+            const float* src = gg + (size_t)c * vol + ((size_t)(td0 + z) * a.H + th0) * a.W;
+            const bool ok = cob * 16 + c < a.Cout;
+            for (int i = lane; i < slab; i += 64) dst[i] = ok ? src[i] : 0.0f;
+          }
+          for (int c = threadIdx.x; c < 16; c += blockDim.x)
+            for (int i = npos; i < gstride; ++i) gs[(size_t)c * gstride + i] = 0.0f;
+        }
+        __syncthreads();
+        // this wave's share of the unit's positions (multiple of 4)
+        const int per = (((nk >> 2) + nwaves - 1) / nwaves) << 2;
+        const int p_beg = min(nk, wave * per), p_end = min(nk, p_beg + per);
+        const float* ga = gs + (size_t)col * gstride;                         // A: row = co, k = position
+        const float* xb = xs + (size_t)col * a.plane;                          // B: col = ci
         int pos = min(p_beg + kq, npos - 1);
         int x = pos % a.W, y = (pos / a.W) % th, z = pos / (a.W * th);
         for (int p0 = p_beg; p0 < p_end; p0 += 4) {
-          const float av = ga[p0 + kq];                   // positions >= npos carry g_y = 0
+          const float av = ga[p0 + kq];                    // positions >= npos carry g_y = 0
           const float* xp = xb + (z * a.Hs + y) * a.Ws + x;
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[(t / 3) * a.Ws + (t % 3)], acc[t], 0, 0, 0);
+          for (int tz = 0; tz < NZ; ++tz)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+              acc[tz * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  av, xp[(tz * a.Hs + t / 3) * a.Ws + (t % 3)], acc[tz * 9 + t], 0, 0, 0);
           x += 4;
           while (x >= a.W) { x -= a.W; ++y; }
           while (y >= th) { y -= th; ++z; }
-          if (z >= td) { z = td - 1; y = th - 1; x = a.W - 1; }      // padded tail: stay in bounds (g_y is 0 there)
+          if (z >= td) { z = td - 1; y = th - 1; x = a.W - 1; }     // padded tail: stay in bounds (g_y is 0 there)
         }
-        // sum the wave partials through LDS, three taps per round; D: row (co) = kq*4 + r, column (ci) = col
+      }
+      // sum the wave partials through LDS, three taps per round; D: row (co) = kq*4 + r, column (ci) = col
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-          __syncthreads();
+      for (int t3 = 0; t3 < NZ * 3; ++t3) {
+        __syncthreads();
 #pragma unroll
-          for (int tt = 0; tt < 3; ++tt)
+        for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * 3 + tt) * 256 + (kq * 4 + r) * 16 + col] = acc[t3 * 3 + tt][r];
-          __syncthreads();
-          for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
-            float sum = 0.0f;
-            for (int w2 = 0; w2 < nwaves; ++w2) sum += red[w2 * 3 * 256 + i];
-            const int t = t3 * 3 + (i >> 8), co = cob * 16 + ((i >> 4) & 15), ci = cib * 16 + (i & 15);
-            if (co < a.Cout && ci < a.Cin)
-              atomicAdd(&gw[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + tz * 9 + t], sum);
-          }
+          for (int r = 0; r < 4; ++r) red[(wave * 3 + tt) * 256 + (kq * 4 + r) * 16 + col] = acc[t3 * 3 + tt][r];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+          float sum = 0.0f;
+          for (int w2 = 0; w2 < nwaves; ++w2) sum += red[w2 * 3 * 256 + i];
+          const int t = t3 * 3 + (i >> 8), co = cob * 16 + ((i >> 4) & 15), ci = cib * 16 + (i & 15);
+          if (co < a.Cout && ci < a.Cin)
+            atomicAdd(&gw[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + t], sum);
         }
       }
     }
   }
+}
+
+// bias gradient: g_bias[c] = sum over batch and positions of g_y (one wave per channel row chunk)
+__global__ void gconv_bias_grad_kernel(const float* gy, float* gbias, int B, int C, size_t vol) {
+  const int c = blockIdx.x;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = gy + ((size_t)b * C + c) * vol;
+    for (size_t i = threadIdx.x; i < vol; i += blockDim.x) s += p[i];
+  }
+  __shared__ float red[4];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) gbias[c] = red[0] + red[1] + red[2] + red[3];
 }
 
 bool plan_tiles_budget(GconvArgs& a, int dim, size_t extra_per_pos_bytes, size_t fixed_bytes, int cin_planes,
@@ -327,13 +353,14 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   if (!plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16)) return CT_EINVAL;
   const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes;
   dim3 grid(a.nD * a.nH, a.groups, a.B);
+  const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
   CT_CLEAR_ERROR();
   if (dim == 2) {
     if (set_lds_attr(gconv_fwd_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_fwd_kernel<2>, grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(gconv_fwd_kernel<2>, grid, dim3(threads), lds, st, a);
   } else {
     if (set_lds_attr(gconv_fwd_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_fwd_kernel<3>, grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(gconv_fwd_kernel<3>, grid, dim3(threads), lds, st, a);
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
@@ -372,22 +399,30 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   if (r != CT_OK) return r;
   a.x = x; a.transposed = 0;
   hipStream_t st = (hipStream_t)s;
-  const int CiB = (Cin + 15) / 16, CoB = (Cout + 15) / 16;
-  if (!plan_tiles(a, dim, (size_t)CoB * 16 * 4, 1024 + (size_t)CoB * 16 * 8 * 4 + (size_t)(kThreads / 64) * 3 * 256 * 4, CiB * 16, 1,
-                  kLdsBudgetWrw)) return CT_EINVAL;
-  const int npos4 = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
+  // LDS: 16 input planes with halo + 16 rows of g_y + the cross-wave reduction buffer
   const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
-  const size_t lds = ((size_t)CiB * 16 * a.plane + (size_t)CoB * 16 * npos4) * 4 + red_bytes;
+  if (!plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, 1, kLdsBudgetWrw)) return CT_EINVAL;
+  const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
+  const size_t lds = ((size_t)16 * a.plane + (size_t)16 * gstride_max) * 4 + red_bytes;
   if (hipMemsetAsync(g_w, 0, (size_t)groups * Cout * Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
-  if (g_bias && hipMemsetAsync(g_bias, 0, (size_t)groups * Cout * 4, st) != hipSuccess) return CT_ELAUNCH;
-  dim3 grid(a.nD * a.nH, groups, B);
+  const int U = B * a.nD * a.nH;
+  int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight
+  if (chunks > U) chunks = U;
+  if (chunks < 1) chunks = 1;
+  const int units_per_wg = (U + chunks - 1) / chunks;
+  chunks = (U + units_per_wg - 1) / units_per_wg;
+  dim3 grid(chunks, groups);
   CT_CLEAR_ERROR();
   if (dim == 2) {
     if (set_lds_attr(gconv_bwd_weight_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_bwd_weight_kernel<2>, grid, dim3(kThreads), lds, st, a, g_y, g_w, g_bias);
+    hipLaunchKernelGGL(gconv_bwd_weight_kernel<2>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
   } else {
     if (set_lds_attr(gconv_bwd_weight_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_bwd_weight_kernel<3>, grid, dim3(kThreads), lds, st, a, g_y, g_w, g_bias);
+    hipLaunchKernelGGL(gconv_bwd_weight_kernel<3>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
+  }
+  if (g_bias) {
+    const size_t vol = (size_t)a.D * a.H * a.W;
+    hipLaunchKernelGGL(gconv_bias_grad_kernel, dim3(groups * Cout), dim3(256), 0, st, g_y, g_bias, B, groups * Cout, vol);
   }
   CT_CHECK_LAUNCH();
   return CT_OK;

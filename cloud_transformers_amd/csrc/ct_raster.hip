@@ -349,17 +349,26 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
     PointPos<DIM, FROM_KEYS> pp;
     load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
     const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
-    for (int ch = 0; ch < cc; ++ch) {
-      float f = src[(size_t)ch * a.N + n];
-      if (has_pad) f = f * p;
-      const float iq = s_iq[ch];
-      const bool fixed = s_q[ch] >= 0.0f;
-      int* Tc = acc + (size_t)ch * g.G;
+    // channels in groups of 4: the group's loads are issued together, then its 16/32 atomics
+    for (int c4 = 0; c4 < cc; c4 += 4) {
+      float f[4];
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const float prod = f * c.w[v];
-        if (fixed) atomicAdd(&Tc[c.cell[v]], __float2int_rn(prod * iq));
-        else atomicAdd((float*)&Tc[c.cell[v]], prod);
+      for (int u = 0; u < 4; ++u) f[u] = (c4 + u < cc) ? src[(size_t)(c4 + u) * a.N + n] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ch = c4 + u;
+        if (ch < cc) {
+          const float fu = has_pad ? f[u] * p : f[u];
+          const float iq = s_iq[ch];
+          int* Tc = acc + (size_t)ch * g.G;
+          if (s_q[ch] >= 0.0f) {            // block-uniform
+#pragma unroll
+            for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn((fu * c.w[v]) * iq));
+          } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) atomicAdd((float*)&Tc[c.cell[v]], fu * c.w[v]);
+          }
+        }
       }
     }
   }
