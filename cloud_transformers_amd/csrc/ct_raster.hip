@@ -1009,12 +1009,32 @@ __global__ void positions_bwd_kernel(const float* keys, const float* g_lc, float
   for (int j = 0; j < DIM; ++j) g_keys[(bh * DIM + j) * N + n] = gs[j] * mask[j];
 }
 
-__global__ void occupancy_kernel(const float* grid, long long n, unsigned long long* count) {
-  unsigned long long local = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    local += fabsf(grid[i]) > 1e-9f ? 1ull : 0ull;
+__global__ void __launch_bounds__(256) occupancy_kernel(const float* grid, long long n, unsigned long long* count) {
+  // dwordx4 stream, wave + block reduction, ONE atomic per workgroup (thousands of atomics on a
+  // single address serialise at ~12 ns each and used to dominate this kernel)
+  __shared__ unsigned s_part[4];
+  unsigned local = 0;
+  const long long n4 = n >> 2;
+  const float4* g4 = (const float4*)grid;
+  const bool aligned = (((uintptr_t)grid) & 15) == 0;
+  if (aligned) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      const float4 v = g4[i];
+      local += (fabsf(v.x) > 1e-9f) + (fabsf(v.y) > 1e-9f) + (fabsf(v.z) > 1e-9f) + (fabsf(v.w) > 1e-9f);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      local += fabsf(grid[i]) > 1e-9f;
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      local += fabsf(grid[i]) > 1e-9f;
+  }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (t) atomicAdd(count, t);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1521,8 +1541,9 @@ int ct_grid_occupancy(const float* grid, int64_t n, int64_t* count, ct_stream_t 
   if (hipMemsetAsync(count, 0, sizeof(int64_t), st) != hipSuccess) return CT_ELAUNCH;
   if (n == 0) return CT_OK;
   CT_CLEAR_ERROR();
-  int blocks = (int)((n + 1023) / 1024);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((n + 4095) / 4096);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(256), 0, st, grid, (long long)n, (unsigned long long*)count);
   CT_CHECK_LAUNCH();
   return CT_OK;

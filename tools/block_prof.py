@@ -1,0 +1,11 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cloud_transformers_amd.layers import multihead_ct as M
+torch.manual_seed(0)
+m = M.MultiHeadUnion(512, [16, 16], [64, 16], [2, 3], [16, 16]).cuda()
+x = torch.randn(8, 512, 4096, device="cuda", requires_grad=True)
+pcd = torch.rand(8, 3, 4096, device="cuda") * 2 - 1
+for _ in range(12):
+    out, _ = m(x, pcd); out.square().mean().backward()
+torch.cuda.synchronize()
