@@ -169,7 +169,7 @@ def main():
         achieved = dom_bytes / (passes[dom] * 1e-3) / 1e9
         traffic = measured_traffic(step.KERNELS.get(dom, dom)) if args.reduce == "max" else None
         out = {
-            "metric": "points/sec fwd+bwd MHCT (positions->Splat->Slice), 4096-pt batch",
+            "metric": "points/sec fwd+bwd MHCT, 4096-pt batch, 1/2/4/8 MI355X; % HBM roofline",   # BASELINE.json
             "value": world * B * N / (dt / args.steps),
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
