@@ -1,0 +1,152 @@
+// Per-head rigid transform + tanh ("lattice") for the MHCT blocks, forward and backward, fused:
+//   p      = xyz + kscale * residual + shift_h                       (3-vector per point and head)
+//   keys_n = (sum_c p_c * R_h[c][n]) * scales_h[n]    n < dim        (row vector times R; planes keep n < 2)
+//   lattice = tanh(keys)
+// replaces the reference's chain  add -> einsum('bhcp,hcn->bhnp') -> slice -> mul -> reshape -> tanh
+// (layers/utils.py:25-34,53-61, layers/multihead_ct.py:93-97) and its autograd: ~15 elementwise /
+// reduction launches per block become two.  R_h = so3_exponential_map(log_R_h) stays a tiny host-side
+// torch op (H 3x3 matrices) so that its own autograd produces g_log_R from g_R.
+//
+// Layouts: xyz (B,3,N); residual (B,H*3,N); keys / lattice (B,H*dim,N); R (H,3,3); shift (H,3);
+// scales (H,dim) or null; kscale: device scalar or null (= 1).
+#include "ct_common.h"
+
+namespace {
+
+struct LatticeArgs {
+  const float* xyz;
+  const float* res;
+  const float* R;
+  const float* shift;
+  const float* scales;   // nullable
+  const float* kscale;   // nullable
+  int B, H, N, dim;
+};
+
+__global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* keys, float* lattice) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (n >= a.N) return;
+  const float ks = a.kscale ? a.kscale[0] : 1.0f;
+  float p[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] + a.shift[h * 3 + c];
+  const float* R = a.R + h * 9;
+  for (int j = 0; j < a.dim; ++j) {
+    float k = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
+    if (a.scales) k *= a.scales[h * a.dim + j];
+    const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
+    keys[o] = k;
+    lattice[o] = tanhf(k);
+  }
+}
+
+// grid = (ceil(N/256), H, B).  Point-wise outputs: g_res; g_xyz accumulated over heads with atomics
+// (zeroed first).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
+// reduced per workgroup and added with one atomic each.
+__global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const float* lattice, const float* g_lattice,
+                                                          const float* g_keys, float* g_xyz, float* g_res, float* g_R, float* g_shift,
+                                                          float* g_scales, float* g_kscale) {
+  __shared__ float red[4][16];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool ok = n < a.N;
+  const float ks = a.kscale ? a.kscale[0] : 1.0f;
+  const float* R = a.R + h * 9;
+  float p[3] = {0, 0, 0}, r[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, gsc[3] = {0, 0, 0};
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      r[c] = a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n];
+      p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * r[c] + a.shift[h * 3 + c];
+    }
+    for (int j = 0; j < a.dim; ++j) {
+      const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
+      const float t = lattice[o];
+      float gk = g_lattice ? g_lattice[o] * (1.0f - t * t) : 0.0f;     // d tanh
+      if (g_keys) gk += g_keys[o];                                    // direct cotangent of the pre-tanh keys
+      const float rot = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
+      const float sc = a.scales ? a.scales[h * a.dim + j] : 1.0f;
+      gsc[j] = gk * rot;                                              // d / d scales_j
+      gq[j] = gk * sc;                                                // cotangent of the rotated coordinate
+    }
+  }
+  float gp[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gp[c] = R[c * 3 + 0] * gq[0] + R[c * 3 + 1] * gq[1] + R[c * 3 + 2] * gq[2];
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = ks * gp[c];
+      atomicAdd(&g_xyz[((size_t)b * 3 + c) * a.N + n], gp[c]);
+    }
+  }
+  // 16 per-head parameter partials: g_R[c][j] = p_c * gq_j (9), g_shift[c] = gp_c (3), g_scales[j] (3), g_kscale (1)
+  float part[16];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) part[c * 3 + j] = p[c] * gq[j];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) part[9 + c] = gp[c];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) part[12 + j] = gsc[j];
+  part[15] = gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float v = part[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int i = threadIdx.x;
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < 9) atomicAdd(&g_R[h * 9 + i], v);
+    else if (i < 12) atomicAdd(&g_shift[h * 3 + (i - 9)], v);
+    else if (i < 15) { if (g_scales && (i - 12) < a.dim) atomicAdd(&g_scales[h * a.dim + (i - 12)], v); }
+    else if (g_kscale) atomicAdd(g_kscale, v);
+  }
+}
+
+bool valid(const LatticeArgs& a) {
+  return a.xyz && a.res && a.R && a.shift && a.B > 0 && a.H > 0 && a.N > 0 && (a.dim == 2 || a.dim == 3) &&
+         a.B <= 65535 && a.H <= 65535;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
+                   const float* kscale, float* keys, float* lattice, int B, int H, int N, int dim, ct_stream_t s) {
+  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
+  if (!valid(a) || !keys || !lattice) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(lattice_fwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
+                   const float* kscale, const float* lattice, const float* g_lattice, const float* g_keys, float* g_xyz,
+                   float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, int B, int H, int N, int dim,
+                   ct_stream_t s) {
+  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
+  if (!valid(a) || !lattice || (!g_lattice && !g_keys) || !g_xyz || !g_residual || !g_R || !g_shift) return CT_EINVAL;
+  if ((scales != nullptr) != (g_scales != nullptr) || (kscale != nullptr) != (g_kscale != nullptr)) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(g_xyz, 0, (size_t)B * 3 * N * 4, st) != hipSuccess) return CT_ELAUNCH;
+  if (hipMemsetAsync(g_R, 0, (size_t)H * 9 * 4, st) != hipSuccess) return CT_ELAUNCH;
+  if (hipMemsetAsync(g_shift, 0, (size_t)H * 3 * 4, st) != hipSuccess) return CT_ELAUNCH;
+  if (g_scales && hipMemsetAsync(g_scales, 0, (size_t)H * dim * 4, st) != hipSuccess) return CT_ELAUNCH;
+  if (g_kscale && hipMemsetAsync(g_kscale, 0, 4, st) != hipSuccess) return CT_ELAUNCH;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(lattice_bwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
+                     g_residual, g_R, g_shift, g_scales, g_kscale);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+}  // extern "C"

@@ -23,7 +23,7 @@ from torch import nn
 from .. import ops
 from .cloud_transform import DifferentiablePositions, Slice, Splat
 from .gconv import GroupedConv2d, GroupedConv3d
-from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer
+from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer, so3_exponential_map
 
 
 def forward_style(module_list, input, z):
@@ -67,12 +67,12 @@ class _MHCTCore(nn.Module):
         cls = VolTransformer if self.tensor_dim == 3 else PlaneTransformer
         self.transform = cls(self.heads, scales=scales)
 
-    def _lattice(self, orig_pcd, keys_res):
-        """keys = transform(xyz + residual) per head; lattice = tanh(keys)."""
-        B, _, N = keys_res.shape
-        keys = self.transform(orig_pcd[:, None] + keys_res.reshape(B, self.heads, 3, N))
-        keys = keys.reshape(B, self.heads * self.tensor_dim, N)
-        return keys, torch.tanh(keys)
+    def _lattice(self, orig_pcd, keys_res, kscale=None):
+        """keys = transform(xyz + kscale * residual) per head; lattice = tanh(keys) — one fused HIP
+        kernel each way (ct_lattice_fwd / _bwd); only the H 3x3 rotations are built by torch."""
+        t = self.transform
+        R = so3_exponential_map(t.log_R)
+        return ops.lattice(orig_pcd, keys_res, R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim)
 
     def _occupancy(self, z, batch):
         with torch.no_grad():
@@ -169,7 +169,7 @@ class MultiHeadAdaIn(_MHCTCore):
         key_values = forward_style(self.keys_values_pred, input, style)
         keys_res = forward_style(self.keys_bn, key_values[:, :H * 3], style)
         values = forward_style(self.values_bn, key_values[:, H * 3:], style)
-        keys, lattice = self._lattice(orig_pcd, self.scale * keys_res)
+        keys, lattice = self._lattice(orig_pcd, keys_res, self.scale)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
         result = forward_style(self.after, self.slice.forward_keys(lattice, self.conv(z)), style)

@@ -261,6 +261,53 @@ class SliceLcFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
+# lattice: per-head rigid transform of (xyz + residual) and tanh, fused
+# ---------------------------------------------------------------------------
+class LatticeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, residual, R, shift, scales, kscale, dim):
+        _dev(xyz, residual, R, shift, scales, kscale)
+        xyz, residual, R, shift = _f32c(xyz), _f32c(residual), _f32c(R), _f32c(shift)
+        scales = _f32c(scales) if scales is not None else None
+        ks = _f32c(kscale).reshape(1) if kscale is not None else None
+        B, _, N = xyz.shape
+        H = R.shape[0]
+        assert xyz.shape[1] == 3 and residual.shape == (B, H * 3, N) and R.shape == (H, 3, 3) and shift.shape == (H, 3)
+        keys = torch.empty(B, H * dim, N, device=xyz.device, dtype=torch.float32)
+        lattice = torch.empty_like(keys)
+        lib = _lib.load()
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.ct_lattice_fwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
+                                          _ptr(keys), _ptr(lattice), B, H, N, dim, _stream()), "ct_lattice_fwd")
+        ctx.save_for_backward(xyz, residual, R, shift, scales, ks, lattice)
+        ctx.meta = (B, H, N, dim, kscale.shape if kscale is not None else None)
+        return keys, lattice
+
+    @staticmethod
+    def backward(ctx, g_keys, g_lattice):
+        xyz, residual, R, shift, scales, ks, lattice = ctx.saved_tensors
+        B, H, N, dim, ks_shape = ctx.meta
+        g_keys = _f32c(g_keys) if g_keys is not None else None
+        g_lattice = _f32c(g_lattice) if g_lattice is not None else None
+        g_xyz, g_res = torch.empty_like(xyz), torch.empty_like(residual)
+        g_R, g_shift = torch.empty_like(R), torch.empty_like(shift)
+        g_scales = torch.empty_like(scales) if scales is not None else None
+        g_ks = torch.empty_like(ks) if ks is not None else None
+        lib = _lib.load()
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.ct_lattice_bwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
+                                          _ptr(lattice), _ptr(g_lattice), _ptr(g_keys), _ptr(g_xyz), _ptr(g_res),
+                                          _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), B, H, N, dim, _stream()),
+                       "ct_lattice_bwd")
+        return g_xyz, g_res, g_R, g_shift, g_scales, (g_ks.reshape(ks_shape) if g_ks is not None else None), None
+
+
+def lattice(xyz, residual, R, shift, scales, kscale, dim):
+    """(keys, tanh(keys)) of an MHCT block; R = so3_exponential_map(log_R) [H,3,3]."""
+    return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim)
+
+
+# ---------------------------------------------------------------------------
 # functional entry points
 # ---------------------------------------------------------------------------
 def positions(keys, tensor_size, heads, dim):

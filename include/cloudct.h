@@ -132,6 +132,25 @@ int ct_slice_lc_bwd(const float* local_coord, const int64_t* flat_idx, const flo
 int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Lattice of an MHCT block: per-head rigid transform of (xyz + key residual) followed by tanh
+ * (VolTransformer / PlaneTransformer: layers/utils.py:9-61; layers/multihead_ct.py:93-97,
+ *  layers/multihead_ct_adain.py:112-116 with its learnable scalar on the residual):
+ *   p = xyz + kscale*residual + shift_h;  keys_n = (sum_c p_c R_h[c][n]) * scales_h[n], n < dim;
+ *   lattice = tanh(keys)
+ * xyz f32[B,3,N], residual f32[B,H*3,N], R f32[H,3,3] (= so3_exponential_map(log_R), computed by the
+ * caller), shift f32[H,3], scales f32[H,dim] | NULL, kscale device f32[1] | NULL (= 1).
+ * Forward writes keys and lattice f32[B,H*dim,N].  Backward takes the cotangents of the lattice and /
+ * or of the pre-tanh keys (either may be NULL, not both) and overwrites g_xyz, g_residual, g_R, g_shift (and g_scales / g_kscale iff scales / kscale given).
+ * ---------------------------------------------------------------------- */
+int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift,
+                   const float* scales, const float* kscale, float* keys, float* lattice,
+                   int B, int H, int N, int dim, ct_stream_t s);
+int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift,
+                   const float* scales, const float* kscale, const float* lattice, const float* g_lattice,
+                   const float* g_keys, float* g_xyz, float* g_residual, float* g_R, float* g_shift, float* g_scales,
+                   float* g_kscale, int B, int H, int N, int dim, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Grouped 3^dim convolution over the rasterised planes / volumes, stride 1, padding 1
  * (MultiHead.conv: layers/multihead_ct.py:50-65 with bias; Res2DBlock / Res3DBlock:
  * unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29 without), fp32 on the matrix
