@@ -46,7 +46,7 @@ struct GconvArgs {
   int taps;            // 9 or 27
   int transposed;      // backward-data: w is indexed [ci_of_this_conv][co_of_this_conv] swapped + flipped taps
   int plane;           // LDS stride between input channels (== 16 mod 32: conflict-free B reads)
-  int Hs, Ws;          // halo tile extents (TH+2, W+2); depth extent is TD+2 (3D) or 1 (2D)
+  int Hs, Ws;          // tile rows (TH+2) and row length (= W: no x halo); depth extent is TD+2 (3D) or 1 (2D)
   int KB;              // ceil(Cin / 4)
 };
 
@@ -77,27 +77,47 @@ __device__ __forceinline__ void stage_weights(float* ws, const GconvArgs& a, int
   }
 }
 
-// Zero-padded halo tile of `planes` input channels (channels >= a.Cin stay zero).
+// Zero-padded halo tile of `planes` input channels (channels >= a.Cin stay zero).  The tile has a
+// halo in depth and height only: rows keep the tensor's own width W, so the interior rows of a depth
+// slice are CONTIGUOUS both in HBM and in LDS and move as whole 1-KiB LDS-DMA pieces
+// (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16).  The left/right neighbours
+// that fall outside a row are masked at the consumer (an out-of-row read lands on the neighbouring
+// row — in bounds thanks to kSlack floats of slack in front of the tile — and is replaced by zero).
+constexpr int kSlack = 4;
+
 template <int DIM>
 __device__ __forceinline__ void stage_halo_tile(float* xs, const float* xg, const GconvArgs& a, int planes,
                                                 int td0, int th0, int lane, int wave, int nwaves) {
   const int Dz = DIM == 3 ? a.TD + 2 : 1;
   const size_t vol = (size_t)a.D * a.H * a.W;
-  const int total4 = (planes * a.plane) >> 2;           // plane is a multiple of 4? not necessarily: handle tail
-  for (int i = threadIdx.x; i < total4; i += blockDim.x) ((float4*)xs)[i] = make_float4(0, 0, 0, 0);
-  for (int i = (total4 << 2) + threadIdx.x; i < planes * a.plane; i += blockDim.x) xs[i] = 0.0f;
+  const int total = planes * a.plane;
+  for (int i = threadIdx.x; i < (total >> 2); i += blockDim.x) ((float4*)xs)[i] = make_float4(0, 0, 0, 0);
+  for (int i = ((total >> 2) << 2) + threadIdx.x; i < total; i += blockDim.x) xs[i] = 0.0f;
   __syncthreads();
-  const int nrows = min(planes, a.Cin) * Dz * a.Hs;
-  for (int row = wave; row < nrows; row += nwaves) {
-    const int c = row / (Dz * a.Hs), zz = (row / a.Hs) % Dz, yy = row % a.Hs;
-    const int gz = DIM == 3 ? td0 + zz - 1 : 0, gy = th0 + yy - 1;
-    if (gz < 0 || gz >= a.D || gy < 0 || gy >= a.H) continue;          // wave-uniform
-    const float* src = xg + (size_t)c * vol + ((size_t)gz * a.H + gy) * a.W;
-    float* dst = xs + (size_t)c * a.plane + (zz * a.Hs + yy) * a.Ws + 1;  // x halo: column 0 stays zero
-    for (int x0 = 0; x0 < a.W; x0 += 64) {
-      if (x0 + lane < a.W)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + x0 + lane),
-                                         (__attribute__((address_space(3))) void*)(dst + x0), 4, 0, 0);
+  // interior rows of this tile: tensor rows [gy_lo, gy_hi) -> tile rows [gy_lo - th0 + 1, ...)
+  const int gy_lo = max(th0 - 1, 0), gy_hi = min(th0 + a.TH + 1, a.H);
+  const int cnt = (gy_hi - gy_lo) * a.W;                       // contiguous floats per (channel, depth slice)
+  const int nslabs = min(planes, a.Cin) * Dz;
+  const bool vec = ((a.W & 3) == 0) && ((((uintptr_t)xg) & 15) == 0);
+  for (int sl = wave; sl < nslabs; sl += nwaves) {
+    const int c = sl / Dz, zz = sl % Dz;
+    const int gz = DIM == 3 ? td0 + zz - 1 : 0;
+    if (gz < 0 || gz >= a.D) continue;                          // wave-uniform
+    const float* src = xg + (size_t)c * vol + ((size_t)gz * a.H + gy_lo) * a.W;
+    float* dst = xs + (size_t)c * a.plane + (zz * a.Hs + (gy_lo - th0 + 1)) * a.W;
+    if (vec) {
+      const int n16 = cnt >> 2;                                 // 16-byte units
+      for (int p0 = 0; p0 < n16; p0 += 64) {
+        if (p0 + lane < n16)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(p0 + lane) * 4),
+                                           (__attribute__((address_space(3))) void*)(dst + p0 * 4), 16, 0, 0);
+      }
+    } else {
+      for (int p0 = 0; p0 < cnt; p0 += 64) {
+        if (p0 + lane < cnt)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p0 + lane),
+                                           (__attribute__((address_space(3))) void*)(dst + p0), 4, 0, 0);
+      }
     }
   }
 }
@@ -111,8 +131,8 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
   const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
   const int Dz = DIM == 3 ? a.TD + 2 : 1;
   const int KB = a.KB;
-  float* xs = lds;                                   // [KB*4][plane]
-  float* ws = lds + (size_t)KB * 4 * a.plane;        // [taps][KB][4][16]
+  float* xs = lds + kSlack;                          // [KB*4][plane], kSlack floats of slack in front
+  float* ws = lds + kSlack + (size_t)KB * 4 * a.plane + kSlack;   // [taps][KB][4][16]
   const size_t vol = (size_t)a.D * a.H * a.W;
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
@@ -138,25 +158,32 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
     for (int pg0 = wave * kP; pg0 < ngroups16; pg0 += nwaves * kP) {
       // window origin of this lane's position in each of the kP groups
       int off[kP];
+      bool xl[kP], xr[kP];                                           // position sits on the left / right border
       floatx4 acc[kP];
 #pragma unroll
       for (int p = 0; p < kP; ++p) {
         const int pos = min((pg0 + p) * 16 + col, npos - 1);      // clamped: inactive lanes read valid LDS
         const int x = pos % a.W, y = (pos / a.W) % th, z = pos / (a.W * th);
-        off[p] = (z * a.Hs + y) * a.Ws + x;
+        off[p] = (z * a.Hs + y) * a.W + x;
+        xl[p] = x == 0;
+        xr[p] = x == a.W - 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[p][r] = bias_r[r];
       }
 #pragma unroll 9
       for (int tap = 0; tap < (DIM == 3 ? 27 : 9); ++tap) {
         const int dx = tap % 3, dy = (tap / 3) % 3, dz = tap / 9;
-        const int toff = (dz * a.Hs + dy) * a.Ws + dx;
+        const int toff = (dz * a.Hs + dy) * a.W + dx - 1;
         for (int kb = 0; kb < KB; ++kb) {
           const float av = ws[((tap * KB + kb) * 4 + kq) * 16 + col];
           const float* xb = xs + (size_t)(kb * 4 + kq) * a.plane + toff;
 #pragma unroll
-          for (int p = 0; p < kP; ++p)
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[off[p]], acc[p], 0, 0, 0);
+          for (int p = 0; p < kP; ++p) {
+            float bv = xb[off[p]];
+            if (dx == 0) bv = xl[p] ? 0.0f : bv;                   // left neighbour outside the row
+            if (dx == 2) bv = xr[p] ? 0.0f : bv;                   // right neighbour outside the row
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[p], 0, 0, 0);
+          }
         }
       }
       // D: row (output channel) = kq*4 + r, column (position) = col
@@ -201,8 +228,8 @@ __global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a,
   const int CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
   const size_t vol = (size_t)a.D * a.H * a.W;
   const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
-  float* xs = lds;                                      // [16][plane]      input block (zero beyond Cin)
-  float* gs = lds + (size_t)16 * a.plane;               // [16][gstride]    g_y block (zero beyond Cout / npos)
+  float* xs = lds + kSlack;                             // [16][plane]      input block (zero beyond Cin)
+  float* gs = lds + kSlack + (size_t)16 * a.plane + kSlack;   // [16][gstride]    g_y block (zero beyond Cout / npos)
   float* red = gs + (size_t)16 * gstride_max;           // [nwaves][3][256] partials of 3 taps at a time
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
@@ -252,13 +279,17 @@ __global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a,
         int x = pos % a.W, y = (pos / a.W) % th, z = pos / (a.W * th);
         for (int p0 = p_beg; p0 < p_end; p0 += 4) {
           const float av = ga[p0 + kq];                    // positions >= npos carry g_y = 0
-          const float* xp = xb + (z * a.Hs + y) * a.Ws + x;
+          const float* xp = xb + (z * a.Hs + y) * a.W + x - 1;
+          const bool bl = x == 0, br = x == a.W - 1;
 #pragma unroll
           for (int tz = 0; tz < NZ; ++tz)
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-              acc[tz * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  av, xp[(tz * a.Hs + t / 3) * a.Ws + (t % 3)], acc[tz * 9 + t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) {
+              float bv = xp[(tz * a.Hs + t / 3) * a.W + (t % 3)];
+              if (t % 3 == 0) bv = bl ? 0.0f : bv;
+              if (t % 3 == 2) bv = br ? 0.0f : bv;
+              acc[tz * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tz * 9 + t], 0, 0, 0);
+            }
           x += 4;
           while (x >= a.W) { x -= a.W; ++y; }
           while (y >= th) { y -= th; ++z; }
@@ -304,14 +335,14 @@ __global__ void gconv_bias_grad_kernel(const float* gy, float* gbias, int B, int
 bool plan_tiles_budget(GconvArgs& a, int dim, size_t extra_per_pos_bytes, size_t fixed_bytes, int cin_planes,
                        int plane_mod, size_t budget) {
   // LDS per workgroup = cin_planes*plane*4 + fixed + extra_per_pos*TD*TH*W  <= budget
-  a.Ws = a.W + 2;
+  a.Ws = a.W;                                     // rows keep the tensor width (no x halo)
   const int dzh = dim == 3 ? 2 : 0;
   for (int TD = dim == 3 ? a.D : 1; TD >= 1; --TD) {
     for (int TH = a.H; TH >= 1; --TH) {
       const int Hs = TH + 2;
       int plane = (TD + dzh) * Hs * a.Ws;
       plane += (plane_mod - (plane & 31) + 32) & 31;   // plane == plane_mod (mod 32): conflict-free operand reads
-      const size_t bytes = (size_t)cin_planes * plane * 4 + fixed_bytes + extra_per_pos_bytes * TD * TH * a.W;
+      const size_t bytes = (size_t)cin_planes * plane * 4 + fixed_bytes + extra_per_pos_bytes * TD * TH * a.W + 64;
       if (bytes <= budget) {
         a.TD = TD; a.TH = TH; a.Hs = Hs; a.plane = plane;
         a.nD = (a.D + TD - 1) / TD; a.nH = (a.H + TH - 1) / TH;
@@ -351,7 +382,7 @@ int set_lds_attr(K kernel, size_t bytes) {
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;
   if (!plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16)) return CT_EINVAL;
-  const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes;
+  const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes + 2 * kSlack * 4;
   dim3 grid(a.nD * a.nH, a.groups, a.B);
   const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
   CT_CLEAR_ERROR();
@@ -401,9 +432,10 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   hipStream_t st = (hipStream_t)s;
   // LDS: 16 input planes with halo + 16 rows of g_y + the cross-wave reduction buffer
   const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
-  if (!plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, 1, kLdsBudgetWrw)) return CT_EINVAL;
+  if (!plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, /*plane == 4 (mod 32): 16-byte aligned for the DMA*/ 4,
+                  kLdsBudgetWrw)) return CT_EINVAL;
   const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
-  const size_t lds = ((size_t)16 * a.plane + (size_t)16 * gstride_max) * 4 + red_bytes;
+  const size_t lds = ((size_t)16 * a.plane + (size_t)16 * gstride_max) * 4 + red_bytes + 2 * kSlack * 4;
   if (hipMemsetAsync(g_w, 0, (size_t)groups * Cout * Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
   const int U = B * a.nD * a.nH;
   int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight

@@ -6,6 +6,6 @@ torch.manual_seed(0)
 m = M.MultiHeadUnion(512, [16, 16], [64, 16], [2, 3], [16, 16]).cuda()
 x = torch.randn(8, 512, 4096, device="cuda", requires_grad=True)
 pcd = torch.rand(8, 3, 4096, device="cuda") * 2 - 1
-for _ in range(12):
+for _ in range(40):
     out, _ = m(x, pcd); out.square().mean().backward()
 torch.cuda.synchronize()
