@@ -1037,6 +1037,15 @@ __global__ void __launch_bounds__(256) occupancy_kernel(const float* grid, long 
   }
 }
 
+// zero the two statistics words at the head of every channel tile
+__global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) {
+    tiles[r * stride] = 0.0f;
+    tiles[r * stride + 1] = 0.0f;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side planning
 // ---------------------------------------------------------------------------
@@ -1314,7 +1323,11 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   if (ga.nsplit > 1) {
     // statistics are combined across the splits with atomics: zero their slots (first two words of
     // every channel tile of g_grid) first
-    if (hipMemset2DAsync(a.tile_out, (size_t)g.G * 4, 0, 8, (size_t)a.B * a.H * a.C, st) != hipSuccess) return CT_ELAUNCH;
+    // (a kernel rather than hipMemset2DAsync: the 2-D memset node crashed HIP-graph capture on ROCm 7.0/7.2)
+    const size_t rows = (size_t)a.B * a.H * a.C;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(zero_slots_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a.tile_out, (size_t)g.G, rows);
+    CT_CHECK_LAUNCH();
   }
   dim3 ggrid(ga.nsplit, a.H, a.B);
   if constexpr (DIM == 2)

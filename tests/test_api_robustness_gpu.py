@@ -80,3 +80,4 @@ def test_modules_move_with_to_and_eval():
         (res, lattice), stats = m(x, pcd, return_lattice=True)
     assert res.shape == (1, 8, 64) and lattice.shape == (1, 4, 64) and len(stats) == 4 and stats[3] is None
     assert m.splat.tensor_mod.device.type == "cuda"
+

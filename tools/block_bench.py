@@ -101,3 +101,4 @@ ours, mem_o = run(make(False), x, pcd)
 eager, mem_e = run(make(True), x, pcd)
 print("MultiHeadUnion fwd+bwd B8 N4096: ours %.2f ms (%.0f k points/s, peak %.2f GiB) | eager PyTorch-ROCm formulation %.2f ms (%.0f k points/s, peak %.2f GiB) | speed-up %.1fx"
       % (ours, B * N / ours, mem_o, eager, B * N / eager, mem_e, eager / ours))
+
