@@ -141,9 +141,14 @@ def main():
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step.run()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step.run()
+        except Exception as ex:          # noqa: BLE001 — capture unavailable: time eager launches instead
+            print("bench: HIP graph capture failed (%r), timing eager launches" % (ex,), file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else step.run
 
     for _ in range(args.warmup):
