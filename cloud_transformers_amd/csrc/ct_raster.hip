@@ -658,30 +658,31 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
         if (has_pad) f = f * p;
         unsigned* Tc = T + (size_t)ch * g.G;
         const float* Gc = gz + (size_t)ch * g.G;
-        // all LDS reads of this channel are issued back to back (one wait), then the
-        // rare claims, instead of one dependent read->CAS->read chain per corner
-        unsigned zb[V], bits[V], old[V];
-        float gzv[V];
+        // Branch-free matching; one divergent region per (point, channel) for the rare winners
+        // (see quad_kernel<QM_SPLAT_MAX_BWD>): a non-positive product can never be bit-equal to a
+        // positive tile value, non-matching corners compare-and-swap against all ones.
+        unsigned zb[V], bits[V];
         bool m[V];
+        bool any = false;
 #pragma unroll
         for (int v = 0; v < V; ++v) zb[v] = Tc[c.cell[v]];
-        if (GZ_LDS) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) gzv[v] = Gc[c.cell[v]];
-        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          float prod = f * c.w[v];
-          bits[v] = __float_as_uint(prod);
-          m[v] = prod > 0.0f && zb[v] == bits[v];
+          bits[v] = __float_as_uint(f * c.w[v]);
+          m[v] = (zb[v] == bits[v]) & (zb[v] != 0u);
+          any = any | m[v];
         }
-#pragma unroll
-        for (int v = 0; v < V; ++v) old[v] = m[v] ? atomicCAS(&Tc[c.cell[v]], bits[v], 0u) : 0u;
         float gf = 0.0f;
+        if (any) {
+          unsigned old[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          if (m[v] && old[v] == bits[v]) {
-            float gzw = GZ_LDS ? gzv[v] : Gc[c.cell[v]];
+          for (int v = 0; v < V; ++v) old[v] = atomicCAS(&Tc[c.cell[v]], m[v] ? bits[v] : 0xFFFFFFFFu, 0u);
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const bool win = m[v] & (old[v] == bits[v]);
+            float gzw = 0.0f;
+            if (GZ_LDS) gzw = win ? Gc[c.cell[v]] : 0.0f;
+            else if (win) gzw = Gc[c.cell[v]];
             gf += gzw * c.w[v];
             gw[v] += gzw * f;
           }
