@@ -1338,8 +1338,9 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   // scatter side
   RasterArgs sa = a;
   sa.CC = ps.CC; sa.nchunks = ps.nchunks;
-  dim3 sgrid(ps.nchunks, a.H, a.B);
-  CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, ps.threads, ps.lds_bytes + (size_t)2 * ps.CC * 4, st, sa, g);
+  const int sthreads = ps.threads;   // (finer chunks / smaller workgroups were measured: no gain)
+  dim3 sgrid(sa.nchunks, a.H, a.B);
+  CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, sthreads, (size_t)sa.CC * g.G * 4 + (size_t)2 * sa.CC * 4, st, sa, g);
   return CT_OK;
 }
 
