@@ -311,23 +311,65 @@ def lattice(xyz, residual, R, shift, scales, kscale, dim):
 # functional entry points
 # ---------------------------------------------------------------------------
 def positions(keys, tensor_size, heads, dim):
+    if keys.numel() == 0:
+        _dev(keys)
+        B, _, N = keys.shape
+        V = 1 << dim
+        lc = torch.zeros(B, heads, V, N, device=keys.device, dtype=torch.float32)
+        e = _empty(keys)
+        return (lc if e is None else lc + e), torch.zeros(B, heads, V, N, device=keys.device, dtype=torch.int64)
     return PositionsFn.apply(keys, sizes_of(tensor_size, dim), heads)
 
 
+def _empty(*tensors):
+    """Empty batches / empty clouds never reach the kernels (the ABI rejects zero sizes): their result is
+    defined by the op itself — an empty cloud rasterises to the zero floor, slices to an empty tensor —
+    and stays connected to the autograd graph with zero cotangents."""
+    z = None
+    for t in tensors:
+        if t is not None and t.requires_grad:
+            z = t.sum() * 0 if z is None else z + t.sum() * 0
+    return z
+
+
 def splat_keys(keys, features, pts_padding, tensor_size, heads, dim, reduce="max"):
-    return SplatKeysFn.apply(keys, features, pts_padding, sizes_of(tensor_size, dim), heads, reduce)
+    W = sizes_of(tensor_size, dim)
+    if features.numel() == 0:
+        _dev(keys, features)
+        out = torch.zeros(features.shape[0], features.shape[1], *W, device=features.device, dtype=torch.float32)
+        e = _empty(keys, features)
+        return out if e is None else out + e
+    return SplatKeysFn.apply(keys, features, pts_padding, W, heads, reduce)
 
 
 def slice_keys(keys, grid, pts_padding, tensor_size, heads, dim):
-    return SliceKeysFn.apply(keys, grid, pts_padding, sizes_of(tensor_size, dim), heads)
+    W = sizes_of(tensor_size, dim)
+    if keys.numel() == 0 or grid.numel() == 0:
+        _dev(keys, grid)
+        out = torch.zeros(grid.shape[0], grid.shape[1], keys.shape[-1], device=grid.device, dtype=torch.float32)
+        e = _empty(keys, grid)
+        return out if e is None else out + e
+    return SliceKeysFn.apply(keys, grid, pts_padding, W, heads)
 
 
 def splat_lc(lc, idx, features, pts_padding, tensor_size, heads, dim, reduce="max"):
-    return SplatLcFn.apply(lc, idx, features, pts_padding, sizes_of(tensor_size, dim), heads, reduce)
+    W = sizes_of(tensor_size, dim)
+    if features.numel() == 0:
+        _dev(lc, features)
+        out = torch.zeros(features.shape[0], features.shape[1], *W, device=features.device, dtype=torch.float32)
+        e = _empty(lc, features)
+        return out if e is None else out + e
+    return SplatLcFn.apply(lc, idx, features, pts_padding, W, heads, reduce)
 
 
 def slice_lc(lc, idx, grid, pts_padding, tensor_size, heads, dim):
-    return SliceLcFn.apply(lc, idx, grid, pts_padding, sizes_of(tensor_size, dim), heads)
+    W = sizes_of(tensor_size, dim)
+    if lc.numel() == 0 or grid.numel() == 0:
+        _dev(lc, grid)
+        out = torch.zeros(grid.shape[0], grid.shape[1], lc.shape[-1], device=grid.device, dtype=torch.float32)
+        e = _empty(lc, grid)
+        return out if e is None else out + e
+    return SliceLcFn.apply(lc, idx, grid, pts_padding, W, heads)
 
 
 def grid_occupancy_count(grid):

@@ -81,3 +81,23 @@ def test_modules_move_with_to_and_eval():
     assert res.shape == (1, 8, 64) and lattice.shape == (1, 4, 64) and len(stats) == 4 and stats[3] is None
     assert m.splat.tensor_mod.device.type == "cuda"
 
+
+
+def test_empty_clouds_and_batches():
+    """Empty inputs: an empty cloud rasterises to the zero floor and slices to an empty tensor; gradients
+    are zeros of the right shapes."""
+    from cloud_transformers_amd import ops
+    dev = "cuda"
+    keys = torch.zeros(2, 3 * 2, 0, device=dev, requires_grad=True)
+    feat = torch.zeros(2, 3 * 4, 0, device=dev, requires_grad=True)
+    z = ops.splat_keys(keys, feat, None, [8, 8], 3, 2)
+    assert z.shape == (2, 12, 8, 8) and float(z.abs().max()) == 0.0
+    grid = torch.randn(2, 12, 8, 8, device=dev, requires_grad=True)
+    o = ops.slice_keys(keys, grid, None, [8, 8], 3, 2)
+    assert o.shape == (2, 12, 0)
+    (z.sum() + o.sum()).backward()
+    assert feat.grad.shape == feat.shape and keys.grad.shape == keys.shape and float(grid.grad.abs().max()) == 0.0
+    lc, idx = ops.positions(keys, 8, 3, 2)
+    assert lc.shape == (2, 3, 4, 0) and idx.dtype == torch.int64
+    zb = ops.splat_keys(torch.zeros(0, 6, 5, device=dev), torch.zeros(0, 12, 5, device=dev), None, [8, 8], 3, 2)
+    assert zb.shape == (0, 12, 8, 8)
