@@ -1,7 +1,7 @@
 // Chamfer distance for gfx950: brute-force bidirectional nearest neighbour and
 // its gradient (replaces chamfer_extension/chamfer.cu:12-195 of the reference).
 //
-// Forward is O(n*m) fp32 VALU work.  One 256-thread workgroup owns 64*Q query
+// Forward is O(n*m) fp32 VALU work.  One 1024-thread workgroup owns 64*Q query
 // points (Q per lane, in registers); each of its 4 waves scans one quarter of
 // the target cloud.  Target coordinates are wave-uniform, so they are fetched
 // with scalar loads (s_load_dwordx*) straight into SGPRs — no LDS staging and
@@ -15,9 +15,10 @@ namespace {
 
 constexpr int kQ = 4;          // queries per lane
 constexpr int kUnroll = 8;     // targets per scalar-load batch
-constexpr int kWaves = 4;
+constexpr int kWaves = 16;     // waves per workgroup = target slices (B*n/256 query groups alone would
+                               // leave most of the 256 CUs idle: 16 slices give ~2k waves at n = 16k)
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kWaves)
 nn_kernel(const float* __restrict__ q, const float* __restrict__ t, float* __restrict__ dist,
           int* __restrict__ idx, int n, int m) {
   __shared__ float s_best[kWaves][64 * kQ];
@@ -121,8 +122,8 @@ int ct_chamfer_fwd(const float* xyz1, const float* xyz2, float* dist1, float* di
   hipStream_t st = (hipStream_t)s;
   const int per = 64 * kQ;
   CT_CLEAR_ERROR();
-  hipLaunchKernelGGL(nn_kernel, dim3((n + per - 1) / per, B), dim3(256), 0, st, xyz1, xyz2, dist1, idx1, n, m);
-  hipLaunchKernelGGL(nn_kernel, dim3((m + per - 1) / per, B), dim3(256), 0, st, xyz2, xyz1, dist2, idx2, m, n);
+  hipLaunchKernelGGL(nn_kernel, dim3((n + per - 1) / per, B), dim3(64 * kWaves), 0, st, xyz1, xyz2, dist1, idx1, n, m);
+  hipLaunchKernelGGL(nn_kernel, dim3((m + per - 1) / per, B), dim3(64 * kWaves), 0, st, xyz2, xyz1, dist2, idx2, m, n);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
