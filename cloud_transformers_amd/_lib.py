@@ -20,7 +20,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("CLOUDCT_LIB") or os.path.join(LIB_DIR, "libcloudct.so")   # override: A/B builds
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-HIP_SOURCES = ["ct_raster.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip"]
+HIP_SOURCES = ["ct_raster.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip",
+               "ct_adain.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # index/weight math must round exactly like the reference's fp32 op sequence
                "-ffp-contract=off"]
@@ -85,6 +86,8 @@ SIGNATURES = {
     "ct_grid_occupancy": (_i, [_vp, ctypes.c_int64, _vp, _vp]),
     "ct_lattice_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_lattice_bwd": (_i, [_vp] * 15 + [_i, _i, _i, _i, _vp]),
+    "ct_adain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "ct_adain_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_gconv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),

@@ -1,0 +1,292 @@
+// Adaptive instance normalisation for the AdaIN MHCT blocks, forward and backward, one launch each:
+//   xhat = (x - mean_n x) * rsqrt(var_n x + eps)           per (b, c) row of N points, biased variance
+//   y    = xhat * (gamma[b,c] + 1) + beta[b,c]             (optionally followed by ReLU)
+// replaces the reference's  InstanceNorm1d(affine=False) -> mul -> add (-> ReLU)  chain
+// (layers/utils.py:82-97, used at layers/multihead_ct_adain.py:57-66,176-187) and its autograd.
+// The reference's chain moves the row 4x forward (norm read+write, mul, add as separate kernels, more
+// with ReLU) and again in backward; here a row is read once and written once (8 B/element forward,
+// 12 B/element backward), so the kernel is HBM-bound by construction.
+//
+// Layouts: x, y, gy, gx (B, C, N) contiguous; gamma_beta (B, 2, C) = the Linear(style) output viewed
+// as the reference views it (utils.py:94-96): [:,0] scale, [:,1] bias; mean, rstd (B*C).
+//
+// One workgroup of 256 threads owns one row.  Rows with N % 4 == 0 and N <= 16384 are held in
+// registers as float4 (NV per thread) between the statistics and the normalisation, so nothing is
+// re-read; other rows take the strided kernel, which re-reads the row (from L2) for each pass.
+#include "ct_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / CT_WAVE;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = CT_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CT_WAVE);
+  return v;
+}
+
+// sum of up to two values over the workgroup; every thread gets the result
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float (*red)[kWaves]) {
+  const int lane = threadIdx.x & (CT_WAVE - 1), wave = threadIdx.x / CT_WAVE;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) red[k][wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += red[k][w];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+struct AdainArgs {
+  const float* x;
+  const float* gamma_beta;
+  float* mean;
+  float* rstd;
+  int B, C, N;
+  float eps;
+  int relu;
+};
+
+template <int NV>
+__global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, float* __restrict__ y) {
+  __shared__ float red[2][kWaves];
+  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int nq = a.N >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)row * a.N);
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    v[k] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s[0] += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  block_sum<1>(s, red);
+  const float inv_n = 1.0f / (float)a.N;
+  const float mu = s[0] * inv_n;
+  float ss[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < nq) {
+      const float dx = v[k].x - mu, dy = v[k].y - mu, dz = v[k].z - mu, dw = v[k].w - mu;
+      ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  block_sum<1>(ss, red);
+  const float rs = rsqrtf(ss[0] * inv_n + a.eps);
+  if (threadIdx.x == 0) {
+    a.mean[row] = mu;
+    a.rstd[row] = rs;
+  }
+  const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
+  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float lo = a.relu ? 0.0f : -INFINITY;
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * a.N);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < nq) {
+      float4 o;
+      o.x = fmaxf((v[k].x - mu) * g + be, lo);
+      o.y = fmaxf((v[k].y - mu) * g + be, lo);
+      o.z = fmaxf((v[k].z - mu) * g + be, lo);
+      o.w = fmaxf((v[k].w - mu) * g + be, lo);
+      yr[q] = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainArgs a, float* __restrict__ y) {
+  __shared__ float red[2][kWaves];
+  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const float* xr = a.x + (size_t)row * a.N;
+  float s[1] = {0.f};
+  for (int n = threadIdx.x; n < a.N; n += kThreads) s[0] += xr[n];
+  block_sum<1>(s, red);
+  const float inv_n = 1.0f / (float)a.N;
+  const float mu = s[0] * inv_n;
+  float ss[1] = {0.f};
+  for (int n = threadIdx.x; n < a.N; n += kThreads) {
+    const float d = xr[n] - mu;
+    ss[0] += d * d;
+  }
+  block_sum<1>(ss, red);
+  const float rs = rsqrtf(ss[0] * inv_n + a.eps);
+  if (threadIdx.x == 0) {
+    a.mean[row] = mu;
+    a.rstd[row] = rs;
+  }
+  const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
+  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float lo = a.relu ? 0.0f : -INFINITY;
+  float* yr = y + (size_t)row * a.N;
+  for (int n = threadIdx.x; n < a.N; n += kThreads) yr[n] = fmaxf((xr[n] - mu) * g + be, lo);
+}
+
+// Backward of y = relu?(xhat * (gamma + 1) + beta) wrt x, gamma, beta.  With g' = gy masked by the ReLU:
+//   g_beta = sum g',  g_gamma = sum g' * xhat,
+//   gx = rstd * (gamma + 1) * (g' - mean(g') - xhat * mean(g' * xhat))
+struct AdainBwdArgs {
+  const float* x;
+  const float* gamma_beta;
+  const float* mean;
+  const float* rstd;
+  const float* gy;
+  float* gx;
+  float* g_gamma_beta;
+  int B, C, N;
+  int relu;
+};
+
+__device__ __forceinline__ float masked(float gy, float xh, float g1, float be, int relu) {
+  return (relu && !(xh * g1 + be > 0.0f)) ? 0.0f : gy;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a) {
+  __shared__ float red[2][kWaves];
+  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int nq = a.N >> 2;
+  const float mu = a.mean[row], rs = a.rstd[row];
+  const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)row * a.N);
+  const float4* gr = reinterpret_cast<const float4*>(a.gy + (size_t)row * a.N);
+  float4 xh[NV], g[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    const bool ok = q < nq;
+    const float4 xv = ok ? xr[q] : make_float4(mu, mu, mu, mu);
+    const float4 gv = ok ? gr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    g[k] = make_float4(masked(gv.x, xh[k].x, g1, be, a.relu), masked(gv.y, xh[k].y, g1, be, a.relu),
+                       masked(gv.z, xh[k].z, g1, be, a.relu), masked(gv.w, xh[k].w, g1, be, a.relu));
+  }
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    s[0] += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+    s[1] += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    a.g_gamma_beta[((size_t)b * 2 + 0) * a.C + c] = s[1];
+    a.g_gamma_beta[((size_t)b * 2 + 1) * a.C + c] = s[0];
+  }
+  const float inv_n = 1.0f / (float)a.N;
+  const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
+  float4* or_ = reinterpret_cast<float4*>(a.gx + (size_t)row * a.N);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < nq)
+      or_[q] = make_float4(sc * (g[k].x - m0 - xh[k].x * m1), sc * (g[k].y - m0 - xh[k].y * m1),
+                           sc * (g[k].z - m0 - xh[k].z * m1), sc * (g[k].w - m0 - xh[k].w * m1));
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArgs a) {
+  __shared__ float red[2][kWaves];
+  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const float mu = a.mean[row], rs = a.rstd[row];
+  const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float* xr = a.x + (size_t)row * a.N;
+  const float* gr = a.gy + (size_t)row * a.N;
+  float s[2] = {0.f, 0.f};
+  for (int n = threadIdx.x; n < a.N; n += kThreads) {
+    const float xh = (xr[n] - mu) * rs;
+    const float g = masked(gr[n], xh, g1, be, a.relu);
+    s[0] += g;
+    s[1] += g * xh;
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    a.g_gamma_beta[((size_t)b * 2 + 0) * a.C + c] = s[1];
+    a.g_gamma_beta[((size_t)b * 2 + 1) * a.C + c] = s[0];
+  }
+  const float inv_n = 1.0f / (float)a.N;
+  const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
+  float* or_ = a.gx + (size_t)row * a.N;
+  for (int n = threadIdx.x; n < a.N; n += kThreads) {
+    const float xh = (xr[n] - mu) * rs;
+    const float g = masked(gr[n], xh, g1, be, a.relu);
+    or_[n] = sc * (g - m0 - xh * m1);
+  }
+}
+
+bool vec_ok(int N, const void* p0, const void* p1, const void* p2) {
+  const uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
+  return (N & 3) == 0 && N <= 4 * kThreads * 16 && (bits & 15) == 0;
+}
+
+int nv_for(int N) {
+  const int per = ((N >> 2) + kThreads - 1) / kThreads;
+  int nv = 1;
+  while (nv < per) nv <<= 1;
+  return nv;
+}
+
+}  // namespace
+
+#define CT_ADAIN_DISPATCH(NVV, KERNEL, ...)                                                       \
+  switch (NVV) {                                                                                  \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break;   \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break;   \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break;   \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break;   \
+    default: hipLaunchKernelGGL((KERNEL<16>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break; \
+  }
+
+extern "C" int ct_adain_fwd(const float* x, const float* gamma_beta, float* y, float* mean, float* rstd, int B, int C,
+                            int N, float eps, int relu, ct_stream_t s) {
+  hipStream_t stream = (hipStream_t)s;
+  if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
+  if ((size_t)B * C == 0 || N == 0) return CT_OK;
+  if (!x || !gamma_beta || !y || !mean || !rstd) return CT_EINVAL;
+  if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
+  const int rows = B * C;
+  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu};
+  CT_CLEAR_ERROR();
+  if (vec_ok(N, x, y, nullptr)) {
+    CT_ADAIN_DISPATCH(nv_for(N), adain_fwd_reg_kernel, a, y)
+  } else {
+    hipLaunchKernelGGL(adain_fwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a, y);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+extern "C" int ct_adain_bwd(const float* x, const float* gamma_beta, const float* mean, const float* rstd,
+                            const float* gy, float* gx, float* g_gamma_beta, int B, int C, int N, int relu,
+                            ct_stream_t s) {
+  hipStream_t stream = (hipStream_t)s;
+  if (B < 0 || C < 0 || N < 0) return CT_EINVAL;
+  if ((size_t)B * C == 0) return CT_OK;
+  if (!gamma_beta || !mean || !rstd || !g_gamma_beta) return CT_EINVAL;
+  if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
+  if (N == 0) return hipMemsetAsync(g_gamma_beta, 0, (size_t)B * 2 * C * sizeof(float), stream) == hipSuccess ? CT_OK : CT_ELAUNCH;
+  if (!x || !gy || !gx) return CT_EINVAL;
+  const int rows = B * C;
+  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu};
+  CT_CLEAR_ERROR();
+  if (vec_ok(N, x, gy, gx)) {
+    CT_ADAIN_DISPATCH(nv_for(N), adain_bwd_reg_kernel, a)
+  } else {
+    hipLaunchKernelGGL(adain_bwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}

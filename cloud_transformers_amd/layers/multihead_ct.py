@@ -29,11 +29,17 @@ from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer, so3_exponential
 def forward_style(module_list, input, z):
     """Apply a Sequential in which AdaIN layers also take the style vector `z`.
     Dispatch is by class name, like the reference (multihead_ct_adain.py:11)."""
-    for layer in module_list:
+    layers = list(module_list)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
         if "AdaIn1dUpd" in str(type(layer)):
-            input = layer(input, z)
+            fuse = i + 1 < len(layers) and type(layers[i + 1]) is nn.ReLU and isinstance(layer, AdaIn1dUpd)
+            input = layer(input, z, relu=True) if fuse else layer(input, z)
+            i += 2 if fuse else 1
         else:
             input = layer(input)
+            i += 1
     return input
 
 

@@ -307,6 +307,45 @@ def lattice(xyz, residual, R, shift, scales, kscale, dim):
     return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim)
 
 
+class AdaInFn(torch.autograd.Function):
+    """relu?(instance_norm(x) * (gamma + 1) + beta), gamma_beta [B,2,C] (layers/utils.py:88-97)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma_beta, eps, relu):
+        _dev(x, gamma_beta)
+        x, gamma_beta = _f32c(x), _f32c(gamma_beta)
+        B, C, N = x.shape
+        assert gamma_beta.shape == (B, 2, C)
+        y = torch.empty_like(x)
+        mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ct_adain_fwd(_ptr(x), _ptr(gamma_beta), _ptr(y), _ptr(mean), _ptr(rstd), B, C, N,
+                                        float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
+        ctx.save_for_backward(x, gamma_beta, mean, rstd)
+        ctx.relu = int(bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma_beta, mean, rstd = ctx.saved_tensors
+        B, C, N = x.shape
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        g_gb = torch.empty_like(gamma_beta)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ct_adain_bwd(_ptr(x), _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), _ptr(gx), _ptr(g_gb),
+                                        B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
+        return gx, g_gb, None, None
+
+
+def adain(x, gamma_beta, eps=1e-5, relu=False):
+    """Adaptive instance norm of x [B,C,N] with per-(b,c) scale (+1) and bias gamma_beta [B,2,C]."""
+    return AdaInFn.apply(x, gamma_beta, eps, relu)
+
+
 # ---------------------------------------------------------------------------
 # functional entry points
 # ---------------------------------------------------------------------------

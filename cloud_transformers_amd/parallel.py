@@ -68,3 +68,43 @@ def all_gather_tensor(dist, t):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t.contiguous())
     return out
+
+
+def all_gather(dist, data):
+    """Gather one picklable object per rank -> list ordered by rank
+    (utils/train_util_distributed.py:37-77; the reference pads pickled byte tensors by hand,
+    torch.distributed.all_gather_object does the same exchange)."""
+    if world_size(dist) < 2:
+        return [data]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, data)
+    return out
+
+
+def _plain_module(obj):
+    return obj.module if isinstance(obj, torch.nn.parallel.DistributedDataParallel) else obj
+
+
+def save_exp_parallel(objects, names, exp_path, epoch, epoch_name="epoch"):
+    """`<exp_path>/<name>_<epoch_name>_<epoch>.t7` per object; DDP wrappers are saved unwrapped so the
+    files load into a bare module (utils/train_util_distributed.py:80-88)."""
+    assert len(objects) == len(names)
+    for obj, name in zip(objects, names):
+        with open("{}/{}_{}_{}.t7".format(str(exp_path), name, epoch_name, epoch), "wb") as f:
+            torch.save(_plain_module(obj).state_dict(), f)
+
+
+def restore_exp(dist, objects, names, device=None, verbose=True):
+    """Load state dicts from the given paths on every rank, then barrier
+    (utils/train_util_distributed.py:91-103)."""
+    from pathlib import Path
+    assert len(objects) == len(names)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    for obj, name in zip(objects, names):
+        assert Path(name).exists()
+        if verbose:
+            print("restoring form {}".format(name))
+        with open(name, "rb") as f:
+            obj.load_state_dict(torch.load(f, map_location=device))
+    barrier(dist)

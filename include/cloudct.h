@@ -151,6 +151,20 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
                    float* g_kscale, int B, int H, int N, int dim, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Adaptive instance normalisation of the AdaIN blocks (AdaIn1dUpd: layers/utils.py:82-97 =
+ * InstanceNorm1d(affine=False, eps) -> * (gamma + 1) -> + beta; followed by ReLU in `after`,
+ * layers/multihead_ct_adain.py:64-66,183-187), one launch forward and one backward:
+ *   y[b,c,n] = relu?( (x - mean_n x) * rsqrt(var_n x + eps) * (gamma[b,c] + 1) + beta[b,c] )
+ * x, y, gy, gx f32[B,C,N]; gamma_beta f32[B,2,C] (the Linear(style) output: [:,0] scale, [:,1] bias);
+ * mean, rstd f32[B*C] are written by the forward and read by the backward (biased variance).
+ * Backward overwrites gx and g_gamma_beta f32[B,2,C]; with relu != 0 the mask is recomputed from x.
+ * ---------------------------------------------------------------------- */
+int ct_adain_fwd(const float* x, const float* gamma_beta, float* y, float* mean, float* rstd,
+                 int B, int C, int N, float eps, int relu, ct_stream_t s);
+int ct_adain_bwd(const float* x, const float* gamma_beta, const float* mean, const float* rstd,
+                 const float* gy, float* gx, float* g_gamma_beta, int B, int C, int N, int relu, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Grouped 3^dim convolution over the rasterised planes / volumes, stride 1, padding 1
  * (MultiHead.conv: layers/multihead_ct.py:50-65 with bias; Res2DBlock / Res3DBlock:
  * unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29 without), fp32 on the matrix

@@ -276,3 +276,22 @@ def chamfer_bwd(xyz1, xyz2, g1, g2, i1, i2):
         gb[b] += t
         ga[b].index_add_(0, i2[b].long(), -t)
     return ga, gb
+
+
+def fscore(gt, pr, th=0.01):
+    """(fscore, precision, recall) of utils/f1_metric.py:9-30 for one pair of clouds gt [n,3], pr [m,3].
+    Nearest-neighbour distances come from a float64 KD-tree (scipy), as open3d's
+    compute_point_cloud_distance does in the reference (:13-14): d1 = gt->pr, d2 = pr->gt,
+    recall = |d2 < th| / |d2|, precision = |d1 < th| / |d1| (:17-18)."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    gt = np.asarray(gt, dtype=np.float64)
+    pr = np.asarray(pr, dtype=np.float64)
+    if len(gt) == 0 or len(pr) == 0:
+        return 0.0, 0.0, 0.0
+    d1 = cKDTree(pr).query(gt)[0]
+    d2 = cKDTree(gt).query(pr)[0]
+    recall = float((d2 < th).sum()) / len(d2)
+    precision = float((d1 < th).sum()) / len(d1)
+    f = 2 * recall * precision / (recall + precision) if recall + precision > 0 else 0.0
+    return f, precision, recall

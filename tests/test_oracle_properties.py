@@ -91,3 +91,15 @@ def test_chamfer_symmetry_and_selfdistance(B, n, m, seed):
     assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
     s1, s2, k1, _ = R.chamfer_fwd(a, a.clone())
     assert float(s1.max()) == 0.0 and float(s2.max()) == 0.0
+
+
+def test_fscore_oracle_known_answers():
+    """oracle fscore (utils/f1_metric.py:9-30): hand-computed precision / recall, and the zero branches."""
+    import numpy as np
+    gt = np.array([[0., 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    pr = np.array([[0., 0, 0.005], [1, 0, 0.02], [5, 5, 5]])
+    f, p, r = R.fscore(gt, pr, 0.01)
+    assert (p, r) == (0.25, 1 / 3) and abs(f - 2 / 7) < 1e-12
+    assert R.fscore(gt, gt, 0.01) == (1.0, 1.0, 1.0)
+    assert R.fscore(gt, gt + 10, 0.01) == (0.0, 0.0, 0.0)
+    assert R.fscore(gt, gt[:0], 0.01) == (0.0, 0.0, 0.0)
