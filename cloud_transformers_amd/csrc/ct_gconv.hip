@@ -28,7 +28,7 @@ constexpr int kP = 4;                      // position groups per wave sharing o
 #define CT_GCONV_LDS (32 * 1024)
 #endif
 #ifndef CT_GCONV_LDS_WRW
-#define CT_GCONV_LDS_WRW (64 * 1024)
+#define CT_GCONV_LDS_WRW (80 * 1024 - 512)
 #endif
 constexpr int kLdsBudget = CT_GCONV_LDS;         // forward / backward-data tile budget: ~4 workgroups per CU (measured best)
 constexpr int kLdsBudgetWrw = CT_GCONV_LDS_WRW;  // backward-weight tile budget
@@ -48,6 +48,8 @@ struct GconvArgs {
   int plane;           // LDS stride between input channels (== 16 mod 32: conflict-free B reads)
   int Hs, Ws;          // tile rows (TH+2) and row length (= W: no x halo); depth extent is TD+2 (3D) or 1 (2D)
   int KB;              // ceil(Cin / 4)
+  int gstride;         // ring kernel: LDS stride between g_y channels
+  int TZ;              // ring kernel: depth slices per unit (3D)
 };
 
 // A-operand tile of one group and one 16-row block of output channels, laid out so that the 64
@@ -317,6 +319,308 @@ __global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------
+// backward wrt the filter bank, ring form.  Same implicit GEMM as above, but the operands stream
+// through LDS rings filled by LDS-DMA one phase ahead of the MFMAs, so loads overlap the matrix work
+// and nothing is staged twice along the walking axis:
+//   3D: a unit is (batch, row tile, depth chunk); the workgroup walks the depth slices z of the chunk.
+//       Phase z multiplies g_y slice z (ring of 2) with x slices z-1, z, z+1 (ring of 4: the slice for
+//       phase z+1 lands while phase z computes).  Out-of-range slices are not loaded — their 9 taps are
+//       skipped (wave-uniform) instead of multiplying zeros.
+//   2D: a unit is (batch, row tile); the x / g_y tiles of unit u+1 land while unit u computes (rings of 2).
+// Tile rows keep the tensor width (no x halo; left/right neighbours masked at the consumer), the row
+// halo is one row above and below; rows outside the image are zero-filled by the loading wave.
+// grid = (unit chunks, groups); the 3^d accumulators live in registers across all units of the
+// workgroup; one cross-wave reduction + float atomics on g_w at the end (g_w zeroed first).
+// ---------------------------------------------------------------------------
+// LDS-DMA issued through inline asm so that it stays OUT of the compiler's wait-count bookkeeping: with the
+// builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the next LDS read (it cannot tell the ring slots
+// apart), which drains the prefetch before the phase it was meant to overlap.  The issuing wave waits
+// itself (dma_wait_all) before the barrier that publishes the slot.
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// `count` contiguous floats -> LDS at dst (wave-uniform); 16-byte pieces when src / dst / count allow
+__device__ __forceinline__ void dma_run(float* dst, const float* src, int count, int lane, bool vec) {
+#ifdef CT_WRW_NO_DMA
+  return;
+#endif
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(dst));
+  if (vec) {
+    const int n16 = count >> 2;
+    for (int p0 = 0; p0 < n16; p0 += 64)
+      if (p0 + lane < n16) glds16(src + (size_t)(p0 + lane) * 4, base + p0 * 16);
+  } else {
+    for (int p0 = 0; p0 < count; p0 += 64)
+      if (p0 + lane < count) glds4(src + p0 + lane, base + p0 * 4);
+  }
+}
+
+// The MFMAs of one K group (16 positions) of the ring kernel for the slices in ZMASK.  Rows are
+// fetched one ahead of the row being multiplied (two 6-float register sets).
+template <int NZ, int ZMASK>
+__device__ __forceinline__ void wrw_group(floatx4 (&acc)[NZ * 9], float& gsum, const float* const (&xb)[NZ], const float* ga, int o,
+                                          int W, bool bl, bool br) {
+  constexpr int NR = NZ * 3;
+  const float4 a4 = *(const float4*)__builtin_assume_aligned(ga, 16);      // zero beyond the tile's positions
+  const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+  gsum += (a4.x + a4.y) + (a4.z + a4.w);                 // bias gradient rides along: sum of g_y over positions
+  float w[NR][6];
+  auto fetch = [&](int r) {
+    const float* rp = xb[r / 3] + o + (r % 3) * W;
+    const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);     // one ds_read_b128
+    const float l = rp[-1], rt = rp[4];
+    w[r][0] = l; w[r][1] = q4.x; w[r][2] = q4.y; w[r][3] = q4.z; w[r][4] = q4.w; w[r][5] = rt;
+  };
+  constexpr int first = (ZMASK & 1) ? 0 : 3;
+  constexpr int last = (NZ == 3 && (ZMASK & 4)) ? 8 : (NZ == 3 ? 5 : 2);
+  fetch(first);
+#pragma unroll
+  for (int r = first; r <= last; ++r) {
+    if (r < last) fetch(r + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float lf = bl ? 0.0f : w[r][0], rt = br ? 0.0f : w[r][5];
+    const float v[6] = {lf, w[r][1], w[r][2], w[r][3], w[r][4], rt};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        acc[r * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], v[j + dx], acc[r * 3 + dx], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, const float* gy, float* gw, float* ws, int units_per_wg) {
+  constexpr int NZ = DIM == 3 ? 3 : 1;
+  constexpr int R = DIM == 3 ? 4 : 2;                   // x ring slots
+  extern __shared__ __align__(16) float lds[];
+  const int grp = blockIdx.y;
+  const int U = a.B * a.nH * a.nD;
+  const int u_beg = blockIdx.x * units_per_wg, u_end = min(U, u_beg + units_per_wg);
+  const int CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
+  const size_t vol = (size_t)a.D * a.H * a.W;
+  const int cs = a.plane, gs = a.gstride;               // channel strides inside a slot
+  const int xslot = 16 * cs, gslot = 16 * gs;
+  float* xr = lds + kSlack;                              // [R][16][cs]
+  float* gr = xr + (size_t)R * xslot;                    // [2][16][gs]
+  float* red = lds;                                      // reduction buffer aliases the rings (after the last phase)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const bool vec = ((a.W & 3) == 0) && ((((uintptr_t)a.x | (uintptr_t)gy) & 15) == 0);
+  const int lds_floats = kSlack + R * xslot + 2 * gslot;
+
+  for (int cob = 0; cob < CoB; ++cob) {
+    for (int cib = 0; cib < CiB; ++cib) {
+      const int cin_here = min(16, a.Cin - cib * 16), cout_here = min(16, a.Cout - cob * 16);
+      floatx4 acc[NZ * 9];
+      float gsum = 0.0f;                                 // this lane's share of sum_pos g_y[co = col]
+#pragma unroll
+      for (int t = 0; t < NZ * 9; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+      __syncthreads();                                   // previous block's reduction has read `red`
+      for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;   // channels beyond Cin / Cout stay zero
+      __syncthreads();
+
+      // x slice z of one (batch, row tile) -> ring slot; rows outside the image are zero-filled
+      auto load_x = [&](int slot, int b, int z, int th0, int th) {
+        if (z < 0 || z >= a.D) {                         // depth padding: a slice of zeros
+          for (int c = wave; c < cin_here; c += nwaves) {
+            float* dst = xr + (size_t)slot * xslot + (size_t)c * cs;
+            for (int i = lane; i < (th + 2) * a.W; i += 64) dst[i] = 0.0f;
+          }
+          return;
+        }
+        const int r_lo = th0 == 0 ? 1 : 0, r_hi = min(th + 2, a.H - th0 + 1);
+        for (int c = wave; c < cin_here; c += nwaves) {
+          float* dst = xr + (size_t)slot * xslot + (size_t)c * cs;
+          const float* src = a.x + (((size_t)b * a.groups + grp) * a.Cin + cib * 16 + c) * vol +
+                             ((size_t)z * a.H + (th0 - 1 + r_lo)) * a.W;
+          dma_run(dst + r_lo * a.W, src, (r_hi - r_lo) * a.W, lane, vec);
+          if (r_lo) for (int i = lane; i < a.W; i += 64) dst[i] = 0.0f;
+          for (int i = r_hi * a.W + lane; i < (th + 2) * a.W; i += 64) dst[i] = 0.0f;
+        }
+      };
+      auto load_g = [&](int slot, int b, int z, int th0, int th) {
+        const int npos = th * a.W;
+        for (int c = wave; c < cout_here; c += nwaves) {
+          float* dst = gr + (size_t)slot * gslot + (size_t)c * gs;
+          const float* src = gy + (((size_t)b * a.groups + grp) * a.Cout + cob * 16 + c) * vol + ((size_t)z * a.H + th0) * a.W;
+          dma_run(dst, src, npos, lane, vec);
+          if (lane < ((16 - (npos & 15)) & 15)) dst[npos + lane] = 0.0f;   // padded K tail (groups of 16 positions)
+        }
+      };
+      // One phase: all positions of a (th x W) slice against the 9 taps of each present x slice.
+      // K runs over positions, 16 per group: lane (col, kq) owns the 4 CONSECUTIVE positions
+      // pq = p0 + 4*kq .. +3 (one row: W % 4 == 0) and MFMA j of a group takes element j of every lane —
+      // any assignment of positions to K slots is valid as long as A and B agree.  So one aligned
+      // ds_read_b128 of g_y feeds the A operand of all 108 (36 in 2D) MFMAs of the group, and per tile
+      // row one ds_read_b128 plus the two neighbours (ds_read_b32) feed the B operands of 12 MFMAs
+      // (3 horizontal taps x 4 elements): 28 LDS reads per 108 MFMAs instead of one per MFMA — on
+      // gfx950 a ds_read_b32 per MFMA, not the matrix pipe, sets the pace (tools/microbench/mfma_f32.hip).
+      auto compute = [&](const int (&xs_slot)[NZ], int zmask, int g_slot, int th) {
+        const int npos = th * a.W;                       // multiple of 4
+        const int ng = (npos + 15) >> 4;
+        const int per = (ng + nwaves - 1) / nwaves;
+        const int g_beg = min(ng, wave * per), g_end = min(ng, g_beg + per);
+        const float* ga = gr + (size_t)g_slot * gslot + (size_t)col * gs + 4 * kq;
+        const float* xb[NZ];
+#pragma unroll
+        for (int tz = 0; tz < NZ; ++tz) xb[tz] = xr + (size_t)xs_slot[tz] * xslot + (size_t)col * cs;
+        int pq = g_beg * 16 + 4 * kq;
+        {
+          const int pc = min(pq, npos - 4);
+          pq = pc;                                        // lanes past the end re-read the last quad (their g_y is 0)
+        }
+        int x0 = pq % a.W, y = pq / a.W;
+        for (int gi = g_beg; gi < g_end; ++gi) {
+          const bool bl = x0 == 0, br = x0 + 4 == a.W;
+          const int o = y * a.W + x0;
+#ifndef CT_WRW_NO_MFMA
+          wrw_group<NZ, NZ == 3 ? 7 : 1>(acc, gsum, xb, ga + gi * 16, o, a.W, bl, br);
+#endif
+          x0 += 16;
+          while (x0 >= a.W) { x0 -= a.W; ++y; }
+          if (y >= th) { y = th - 1; x0 = a.W - 4; }      // padded tail: stay in bounds (g_y is 0 there)
+        }
+      };
+      auto unit_of = [&](int u, int& b, int& th0, int& th, int& z0, int& z1) {
+        const int zc = u % a.nD, yt = (u / a.nD) % a.nH;
+        b = u / (a.nD * a.nH);
+        th0 = yt * a.TH;
+        th = min(a.TH, a.H - th0);
+        z0 = zc * a.TZ;
+        z1 = min(a.D, z0 + a.TZ);
+      };
+
+      if constexpr (DIM == 3) {
+        for (int u = u_beg; u < u_end; ++u) {
+          int b, th0, th, z0, z1;
+          unit_of(u, b, th0, th, z0, z1);
+          // entries e = 0 .. (z1-z0)+1 of this unit are the slices z0-1+e; entry e lives in slot e % 4
+          load_x(0, b, z0 - 1, th0, th);
+          load_x(1, b, z0, th0, th);
+          load_x(2, b, z0 + 1, th0, th);
+          load_g(0, b, z0, th0, th);
+          dma_wait_all();
+          __syncthreads();
+          for (int j = 0; j < z1 - z0; ++j) {
+            const int z = z0 + j;
+            if (j + 1 < z1 - z0) {
+              load_x((j + 3) & 3, b, z + 2, th0, th);
+              load_g((j + 1) & 1, b, z + 1, th0, th);
+            }
+            const int slots[NZ] = {j & 3, (j + 1) & 3, (j + 2) & 3};
+            compute(slots, 7, j & 1, th);
+            dma_wait_all();
+            __syncthreads();                             // phase done: its slots may be refilled, the prefetch has landed
+          }
+        }
+      } else {
+        int b, th0, th, z0, z1;
+        if (u_beg < u_end) {
+          unit_of(u_beg, b, th0, th, z0, z1);
+          load_x(0, b, 0, th0, th);
+          load_g(0, b, 0, th0, th);
+        }
+        dma_wait_all();
+        __syncthreads();
+        for (int u = u_beg; u < u_end; ++u) {
+          const int s = (u - u_beg) & 1;
+          if (u + 1 < u_end) {
+            unit_of(u + 1, b, th0, th, z0, z1);
+            load_x(s ^ 1, b, 0, th0, th);
+            load_g(s ^ 1, b, 0, th0, th);
+          }
+          unit_of(u, b, th0, th, z0, z1);
+          const int slots[NZ] = {s};
+          compute(slots, 1, s, th);
+          dma_wait_all();
+          __syncthreads();
+        }
+      }
+      // sum the wave partials through LDS, three taps per round; D: row (co) = kq*4 + r, column (ci) = col.
+      // With a workspace the workgroup's partial sums are STORED (slot = chunk, group, block) and a second small
+      // kernel adds the chunks in a fixed order; without one they go to g_w by float atomics (zeroed first).
+      // Thousands of device-scope atomics per workgroup on a few KiB of g_w were the kernel's whole run time.
+      float* wsp = ws ? ws + ((((size_t)blockIdx.x * a.groups + grp) * CoB + cob) * CiB + cib) * (NZ * 9 * 256) : nullptr;
+#pragma unroll
+      for (int t3 = 0; t3 < NZ * 3; ++t3) {
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(wave * 3 + tt) * 256 + (kq * 4 + r) * 16 + col] = acc[t3 * 3 + tt][r];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+          float sum = 0.0f;
+          for (int w2 = 0; w2 < nwaves; ++w2) sum += red[w2 * 3 * 256 + i];
+          if (wsp) {
+            wsp[t3 * 3 * 256 + i] = sum;
+          } else {
+            const int t = t3 * 3 + (i >> 8), co = cob * 16 + ((i >> 4) & 15), ci = cib * 16 + (i & 15);
+            if (co < a.Cout && ci < a.Cin)
+              atomicAdd(&gw[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + t], sum);
+          }
+        }
+      }
+      // bias partial of this chunk: lanes (col, kq = 0..3) and the waves hold disjoint positions of channel col
+      if (ws && cib == 0) {
+        gsum += __shfl_xor(gsum, 16, 64);
+        gsum += __shfl_xor(gsum, 32, 64);
+        __syncthreads();
+        if (lane < 16) red[wave * 16 + lane] = gsum;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+          float sum = 0.0f;
+          for (int w2 = 0; w2 < nwaves; ++w2) sum += red[w2 * 16 + threadIdx.x];
+          float* wb = ws + (size_t)gridDim.x * a.groups * CoB * CiB * (NZ * 9 * 256);       // after the filter partials
+          wb[(((size_t)blockIdx.x * a.groups + grp) * CoB + cob) * 16 + threadIdx.x] = sum;
+        }
+      }
+    }
+  }
+}
+
+// second stage of the ring kernel's reduction: g_w[grp, co, ci, t] = sum over chunks (ascending) of the stored partials
+__global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int Cin,
+                                                               int Cout, int taps) {
+  const int CiB = (Cin + 15) >> 4, CoB = (Cout + 15) >> 4;
+  const int per_blk = taps * 256;
+  const size_t per_chunk = (size_t)groups * CoB * CiB * per_blk;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // (grp, cob, cib, t, co16, ci16)
+  if (idx < per_chunk) {
+    float sum = 0.0f;
+    for (int c = 0; c < chunks; ++c) sum += ws[(size_t)c * per_chunk + idx];
+    const int i = (int)(idx % 256), t = (int)((idx / 256) % taps);
+    const int blk = (int)(idx / per_blk);
+    const int cib = blk % CiB, cob = (blk / CiB) % CoB, grp = blk / (CiB * CoB);
+    const int co = cob * 16 + (i >> 4), ci = cib * 16 + (i & 15);
+    if (co < Cout && ci < Cin) gw[((size_t)(grp * Cout + co) * Cin + ci) * taps + t] = sum;
+  }
+  // bias partials follow the filter partials: [chunk][grp][cob][16]
+  const size_t nb = (size_t)groups * CoB * 16;
+  if (gbias && idx < nb) {
+    const float* wb = ws + (size_t)chunks * per_chunk;
+    float sum = 0.0f;
+    for (int c = 0; c < chunks; ++c) sum += wb[(size_t)c * nb + idx];
+    const int co = (int)((idx / 16) % CoB) * 16 + (int)(idx % 16), grp = (int)(idx / (16 * CoB));
+    if (co < Cout) gbias[grp * Cout + co] = sum;
+  }
+}
+
 // bias gradient: g_bias[c] = sum over batch and positions of g_y (one wave per channel row chunk)
 __global__ void gconv_bias_grad_kernel(const float* gy, float* gbias, int B, int C, size_t vol) {
   const int c = blockIdx.x;
@@ -397,6 +701,104 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   return CT_OK;
 }
 
+// backward-weight, ring kernel (rows of W % 4 == 0 floats): the plan ...
+struct WrwRingPlan { size_t lds; int chunks, units_per_wg; };
+
+bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p) {
+  const int B = a.B, groups = a.groups;
+  // the tallest row tile whose rings fit the budget (64 KiB: two workgroups per CU, then whatever one CU
+  // holds), then depth chunks until ~512 workgroups exist
+  const int R = dim == 3 ? 4 : 2;
+  const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
+  auto pad4 = [](int n) { return n + ((4 - (n & 63) + 64) & 63); };      // == 4 (mod 64): conflict-free ds_read_b128 operand reads
+  auto ring_bytes = [&](int TH) {
+    const size_t b = ((size_t)R * 16 * pad4((TH + 2) * a.W) + (size_t)2 * 16 * pad4((TH * a.W + 15) & ~15) + 2 * kSlack) * 4;
+    return b > red_bytes ? b : red_bytes;
+  };
+  int TH = 0;
+  for (size_t budget : {(size_t)kLdsBudgetWrw, (size_t)kLdsBudgetMax}) {
+    for (int t = a.H; t >= 1 && !TH; --t)
+      if (ring_bytes(t) <= budget) TH = t;
+    if (TH) break;
+  }
+  if (!TH) return false;
+  a.TH = TH; a.nH = (a.H + TH - 1) / TH;
+  a.plane = pad4((TH + 2) * a.W); a.gstride = pad4((TH * a.W + 15) & ~15);
+  a.Hs = TH + 2; a.Ws = a.W; a.TD = 1;
+  a.nD = 1; a.TZ = a.D;
+  if (dim == 3) {
+    const int want = (512 + groups - 1) / groups;       // units wanted per group
+    int nD = (want + B * a.nH - 1) / (B * a.nH);
+    if (nD > a.D / 2) nD = a.D / 2 > 0 ? a.D / 2 : 1;    // at least two slices per chunk: each loads two extra x slices
+    if (nD < 1) nD = 1;
+    a.TZ = (a.D + nD - 1) / nD;
+    a.nD = (a.D + a.TZ - 1) / a.TZ;
+  }
+  p.lds = ring_bytes(TH);
+  const int U = B * a.nH * a.nD;
+  int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight
+  if (chunks > U) chunks = U;
+  if (chunks < 1) chunks = 1;
+  p.units_per_wg = (U + chunks - 1) / chunks;
+  p.chunks = (U + p.units_per_wg - 1) / p.units_per_wg;
+  return true;
+}
+
+size_t wrw_ring_workspace(const GconvArgs& a, const WrwRingPlan& p) {
+  const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
+  return ((size_t)p.chunks * a.groups * CoB * CiB * a.taps * 256 + (size_t)p.chunks * a.groups * CoB * 16) * sizeof(float);
+}
+
+// ... and the launch.  `ws` (>= wrw_ring_workspace bytes) selects the two-stage reduction; NULL the atomics.
+int launch_wrw_ring(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_bias, float* ws, size_t ws_bytes, hipStream_t st) {
+  WrwRingPlan p;
+  if (!plan_wrw_ring(a, dim, p)) return CT_EINVAL;
+  if (ws && ws_bytes < wrw_ring_workspace(a, p)) return CT_EWORKSPACE;
+  if (!ws && hipMemsetAsync(g_w, 0, (size_t)a.groups * a.Cout * a.Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
+  dim3 grid(p.chunks, a.groups);
+  if (dim == 2) {
+    if (set_lds_attr(gconv_wrw_ring_kernel<2>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_wrw_ring_kernel<2>, grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+  } else {
+    if (set_lds_attr(gconv_wrw_ring_kernel<3>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_wrw_ring_kernel<3>, grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+  }
+  if (ws) {
+    const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
+    const size_t n = (size_t)a.groups * CoB * CiB * a.taps * 256;
+    hipLaunchKernelGGL(gconv_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, g_w, g_bias, p.chunks,
+                       a.groups, a.Cin, a.Cout, a.taps);
+  }
+  return CT_OK;
+}
+
+// backward-weight, tile kernel (any row length): plan + launch
+int launch_wrw_tiles(GconvArgs a, int dim, const float* g_y, float* g_w, hipStream_t st) {
+  const int B = a.B, groups = a.groups;
+  if (hipMemsetAsync(g_w, 0, (size_t)groups * a.Cout * a.Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
+  // LDS: 16 input planes with halo + 16 rows of g_y + the cross-wave reduction buffer
+  const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
+  if (!plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, /*plane == 4 (mod 32): 16-byte aligned for the DMA*/ 4,
+                  kLdsBudgetWrw)) return CT_EINVAL;
+  const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
+  const size_t lds = ((size_t)16 * a.plane + (size_t)16 * gstride_max) * 4 + red_bytes + 2 * kSlack * 4;
+  const int U = B * a.nD * a.nH;
+  int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight
+  if (chunks > U) chunks = U;
+  if (chunks < 1) chunks = 1;
+  const int units_per_wg = (U + chunks - 1) / chunks;
+  chunks = (U + units_per_wg - 1) / units_per_wg;
+  dim3 grid(chunks, groups);
+  if (dim == 2) {
+    if (set_lds_attr(gconv_bwd_weight_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_bwd_weight_kernel<2>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
+  } else {
+    if (set_lds_attr(gconv_bwd_weight_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_bwd_weight_kernel<3>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
+  }
+  return CT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -422,7 +824,14 @@ int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
   return launch_fwd(a, dim, (hipStream_t)s);
 }
 
-int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias,
+size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout, int dim, const int* W) {
+  GconvArgs a = {};
+  if (gconv_common(a, B, groups, Cin, Cout, dim, W) != CT_OK || (a.W & 3) != 0) return 0;
+  WrwRingPlan p;
+  return plan_wrw_ring(a, dim, p) ? wrw_ring_workspace(a, p) : 0;
+}
+
+int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias, void* workspace, size_t workspace_bytes,
                         int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s) {
   if (!x || !g_y || !g_w) return CT_EINVAL;
   GconvArgs a = {};
@@ -430,29 +839,11 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   if (r != CT_OK) return r;
   a.x = x; a.transposed = 0;
   hipStream_t st = (hipStream_t)s;
-  // LDS: 16 input planes with halo + 16 rows of g_y + the cross-wave reduction buffer
-  const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
-  if (!plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, /*plane == 4 (mod 32): 16-byte aligned for the DMA*/ 4,
-                  kLdsBudgetWrw)) return CT_EINVAL;
-  const int gstride_max = ((a.TD * a.TH * a.W + 3) & ~3) | 1;
-  const size_t lds = ((size_t)16 * a.plane + (size_t)16 * gstride_max) * 4 + red_bytes + 2 * kSlack * 4;
-  if (hipMemsetAsync(g_w, 0, (size_t)groups * Cout * Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
-  const int U = B * a.nD * a.nH;
-  int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight
-  if (chunks > U) chunks = U;
-  if (chunks < 1) chunks = 1;
-  const int units_per_wg = (U + chunks - 1) / chunks;
-  chunks = (U + units_per_wg - 1) / units_per_wg;
-  dim3 grid(chunks, groups);
   CT_CLEAR_ERROR();
-  if (dim == 2) {
-    if (set_lds_attr(gconv_bwd_weight_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_bwd_weight_kernel<2>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
-  } else {
-    if (set_lds_attr(gconv_bwd_weight_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_bwd_weight_kernel<3>, grid, dim3(kThreads), lds, st, a, g_y, g_w, units_per_wg);
-  }
-  if (g_bias) {
+  r = (a.W & 3) == 0 ? launch_wrw_ring(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st)
+                     : launch_wrw_tiles(a, dim, g_y, g_w, st);
+  if (r != CT_OK) return r;
+  if (g_bias && !((a.W & 3) == 0 && workspace)) {       // the ring kernel's workspace path produces g_bias itself
     const size_t vol = (size_t)a.D * a.H * a.W;
     hipLaunchKernelGGL(gconv_bias_grad_kernel, dim3(groups * Cout), dim3(256), 0, st, g_y, g_bias, B, groups * Cout, vol);
   }

@@ -52,8 +52,10 @@ class GroupedConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 g_w = torch.empty_like(weight)
                 g_b = torch.empty(groups * Cout, device=x.device, dtype=torch.float32) if has_bias else None
-                _lib.check(lib.ct_gconv_bwd_weight(_ptr(x), _ptr(g_y), _ptr(g_w), _ptr(g_b), B, groups, Cin, Cout,
-                                                   dim, Wa, _stream()), "ct_gconv_bwd_weight")
+                ws_bytes = lib.ct_gconv_bwd_weight_workspace_bytes(B, groups, Cin, Cout, dim, Wa)
+                ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
+                _lib.check(lib.ct_gconv_bwd_weight(_ptr(x), _ptr(g_y), _ptr(g_w), _ptr(g_b), _ptr(ws), ws_bytes,
+                                                   B, groups, Cin, Cout, dim, Wa, _stream()), "ct_gconv_bwd_weight")
         return g_x, g_w, g_b, None
 
 

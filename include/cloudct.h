@@ -172,14 +172,18 @@ int ct_adain_bwd(const float* x, const float* gamma_beta, const float* mean, con
  *   x f32[B, groups*Cin, *W]   w f32[groups*Cout, Cin, 3^dim]   bias f32[groups*Cout] | NULL
  *   y f32[B, groups*Cout, *W]
  * bwd_data : g_x from g_y and w.   bwd_weight: g_w (and g_bias unless NULL) from x and g_y;
- * both outputs are overwritten (g_w / g_bias are accumulated across workgroups with float
- * atomics: the summation order is not fixed).
+ * both outputs are overwritten.  bwd_weight sums over (batch, positions) in workgroup-sized chunks:
+ * with a workspace of ct_gconv_bwd_weight_workspace_bytes (0 = the shape does not use one) the chunk
+ * sums are stored and added in a fixed order (bitwise reproducible); with workspace NULL they are
+ * accumulated into g_w with float atomics (order not fixed, and several times slower).
  * ---------------------------------------------------------------------- */
 int ct_gconv_fwd(const float* x, const float* w, const float* bias, float* y,
                  int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
 int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
                       int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
+size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout, int dim, const int* W);
 int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias,
+                        void* workspace, size_t workspace_bytes,
                         int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
