@@ -23,6 +23,7 @@ from torch import nn
 from .. import ops
 from .cloud_transform import DifferentiablePositions, Slice, Splat
 from .gconv import GroupedConv2d, GroupedConv3d
+from .pointwise import PointwiseConv1d
 from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer, so3_exponential_map
 
 
@@ -60,7 +61,7 @@ class _MHCTCore(nn.Module):
         self.tensor_dim = tensor_dim
         self.heads = heads
         self.keys_values_pred = nn.Sequential(
-            nn.Conv1d(model_dim, heads * (in_feature_dim + 3), kernel_size=1, bias=False))
+            PointwiseConv1d(model_dim, heads * (in_feature_dim + 3), kernel_size=1, bias=False))
 
     def _build_grid_modules(self, with_slice):
         kw = dict(tensor_size=self.tensor_size, dim=self.tensor_dim, heads=self.heads)
@@ -108,8 +109,9 @@ class MultiHead(_MHCTCore):
             orig_pcd, pts_padd = orig_pcd
         H = self.heads
         key_values = self.keys_values_pred(input)
-        keys_res = self.key_bn(key_values[:, :H * 3])
-        values = self.values_bn(key_values[:, H * 3:])
+        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
+        keys_res = self.key_bn(k_part)
+        values = self.values_bn(v_part)
         keys, lattice = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, keys.size(0))
@@ -139,8 +141,9 @@ class MultiHeadPool(_MHCTCore):
     def forward(self, input, orig_pcd, return_lattice=False):
         H = self.heads
         key_values = self.keys_values_pred(input)
-        keys_res = self.key_bn(key_values[:, :H * 3])
-        values = self.values_bn(key_values[:, H * 3:])
+        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
+        keys_res = self.key_bn(k_part)
+        values = self.values_bn(v_part)
         keys, lattice = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
@@ -173,8 +176,9 @@ class MultiHeadAdaIn(_MHCTCore):
     def forward(self, input, style, orig_pcd, return_lattice=False):
         H = self.heads
         key_values = forward_style(self.keys_values_pred, input, style)
-        keys_res = forward_style(self.keys_bn, key_values[:, :H * 3], style)
-        values = forward_style(self.values_bn, key_values[:, H * 3:], style)
+        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
+        keys_res = forward_style(self.keys_bn, k_part, style)
+        values = forward_style(self.values_bn, v_part, style)
         keys, lattice = self._lattice(orig_pcd, keys_res, self.scale)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
@@ -214,12 +218,12 @@ class MultiHeadUnion(_UnionBase):
         super().__init__()
         cat_dim = self._common(model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out)
         self.after = nn.Sequential(
-            nn.Conv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
+            PointwiseConv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
             nn.BatchNorm1d(self.model_dim_out),
             nn.ReLU(inplace=True))
         self.shortcut = nn.Sequential()
         if self.model_dim != self.model_dim_out:
-            self.shortcut.add_module("shortcut_conv", nn.Conv1d(self.model_dim, self.model_dim_out, kernel_size=1,
+            self.shortcut.add_module("shortcut_conv", PointwiseConv1d(self.model_dim, self.model_dim_out, kernel_size=1,
                                                                 stride=1, padding=0, bias=False))
             self.shortcut.add_module("shortcut_bn", nn.BatchNorm1d(self.model_dim_out))
         self.attentions = nn.ModuleList([
@@ -244,12 +248,12 @@ class MultiHeadUnionAdaIn(_UnionBase):
         super().__init__()
         cat_dim = self._common(model_dim, features_dims, tensor_sizes, tensor_dims, heads, model_dim_out)
         self.after = nn.Sequential(
-            nn.Conv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
+            PointwiseConv1d(cat_dim, self.model_dim_out, kernel_size=1, stride=1, padding=0, bias=False),
             AdaIn1dUpd(self.model_dim_out, num_latent=n_latent),
             nn.ReLU(inplace=True))
         self.shortcut = nn.Sequential()
         if self.model_dim != self.model_dim_out:
-            self.shortcut.add_module("shortcut_conv", nn.Conv1d(self.model_dim, self.model_dim_out, kernel_size=1,
+            self.shortcut.add_module("shortcut_conv", PointwiseConv1d(self.model_dim, self.model_dim_out, kernel_size=1,
                                                                 stride=1, padding=0, bias=False))
             self.shortcut.add_module("shortcut_bn", AdaIn1dUpd(self.model_dim_out, num_latent=n_latent))
         self.attentions = nn.ModuleList([

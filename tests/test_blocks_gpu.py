@@ -145,3 +145,30 @@ def test_reference_style_zoo_model_runs():
         losses.append(float(loss))
     assert len(stats) == 4 and all(torch.isfinite(s[0]) for s in stats)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_pointwise_conv1d_matches_conv1d():
+    """PointwiseConv1d (rocBLAS batched-GEMM weight gradient) against nn.Conv1d evaluated in float64 on the CPU;
+    same state-dict keys as the nn.Conv1d it replaces."""
+    from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
+    torch.manual_seed(11)
+    for cin, cout, bias in [(64, 48, False), (33, 17, True)]:
+        m = PointwiseConv1d(cin, cout, kernel_size=1, bias=bias)
+        assert sorted(m.state_dict()) == sorted(torch.nn.Conv1d(cin, cout, 1, bias=bias).state_dict())
+        x = torch.randn(3, cin, 257)
+        gy = torch.randn(3, cout, 257)
+        xr = x.double().requires_grad_(True)
+        wr = m.weight.detach().double().requires_grad_(True)
+        br = m.bias.detach().double().requires_grad_(True) if bias else None
+        torch.nn.functional.conv1d(xr, wr, br).backward(gy.double())
+        m = m.cuda()
+        xc = x.cuda().requires_grad_(True)
+        y = m(xc)
+        y.backward(gy.cuda())
+        np.testing.assert_allclose(xc.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(m.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-4)
+        if bias:
+            np.testing.assert_allclose(m.bias.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=2e-4)
+    # anything that is not a plain 1x1 projection falls through to nn.Conv1d
+    k3 = PointwiseConv1d(8, 8, kernel_size=3, padding=1).cuda()
+    assert k3(torch.randn(1, 8, 16, device="cuda")).shape == (1, 8, 16)
