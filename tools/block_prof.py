@@ -6,6 +6,8 @@ torch.manual_seed(0)
 m = M.MultiHeadUnion(512, [16, 16], [64, 16], [2, 3], [16, 16]).cuda()
 x = torch.randn(8, 512, 4096, device="cuda", requires_grad=True)
 pcd = torch.rand(8, 3, 4096, device="cuda") * 2 - 1
-for _ in range(40):
+ITERS = 100
+for _ in range(ITERS):
+    m.zero_grad(set_to_none=True); x.grad = None
     out, _ = m(x, pcd); out.square().mean().backward()
 torch.cuda.synchronize()
