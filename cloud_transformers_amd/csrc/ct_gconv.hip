@@ -208,6 +208,71 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Four-channel groups (the zoo's C=4 heads: 128^2 planes, 32^3 volumes) on the vector ALU.
+// A 16x16x4 MFMA carries 4 useful rows and 4 useful K slots out of 16 for these filters; the op is
+// HBM-bound (9-27 flop/B) once the padding work is gone.  Each lane computes 4 consecutive x positions x 4
+// output channels (16 accumulators): per (input channel, dz, dy) one aligned ds_read_b128 of the tile row
+// plus its two neighbours feed 48 FMAs, the 12 filter taps of that row are wave-uniform and come from SGPRs
+// (scalar loads of the group's 4x4x3^d bank).  Same halo tile, staging and border masking as the MFMA kernel;
+// backward-data reads the bank transposed + flipped.  grid = (nD*nH, groups, B)
+// ---------------------------------------------------------------------------
+template <int DIM, bool TRANSPOSED>
+__global__ void __launch_bounds__(kThreads) gconv_c4_kernel(GconvArgs a) {
+  constexpr int C = 4;
+  constexpr int NZ = DIM == 3 ? 3 : 1;
+  constexpr int TAPS = NZ * 9;
+  extern __shared__ __align__(16) float lds[];
+  const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
+  const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
+  float* xs = lds + kSlack;                          // [4][plane]
+  const size_t vol = (size_t)a.D * a.H * a.W;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  stage_halo_tile<DIM>(xs, a.x + ((size_t)b * a.groups + grp) * C * vol, a, C, td0, th0, lane, wave, nwaves);
+  __syncthreads();
+  const float* wg = a.w + (size_t)grp * C * C * TAPS;  // wave-uniform: scalar loads
+  const int wq = a.W >> 2;                            // quads per row
+  const int nquads = td * th * wq;
+  float* yg = a.y + ((size_t)b * a.groups + grp) * C * vol;
+  for (int q = threadIdx.x; q < nquads; q += blockDim.x) {
+    const int xq = q % wq, y = (q / wq) % th, z = q / (wq * th);
+    const int x0 = xq * 4;
+    const bool bl = x0 == 0, br = x0 + 4 == a.W;
+    float acc[C][4];
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+      const float bv = a.bias ? a.bias[grp * C + co] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[co][j] = bv;
+    }
+#pragma unroll 1
+    for (int ci = 0; ci < C; ++ci) {
+#pragma unroll 1
+      for (int r = 0; r < NZ * 3; ++r) {                // tile rows (dz, dy) of the window; 12 taps per row in SGPRs
+        const int dz = r / 3, dy = r % 3;
+        const float* rp = xs + (size_t)ci * a.plane + ((z + dz) * a.Hs + (y + dy)) * a.W + x0;
+        const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+        const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+        const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int tap = r * 3 + dx;
+            const float wv = TRANSPOSED ? wg[(ci * C + co) * TAPS + (TAPS - 1 - tap)] : wg[(co * C + ci) * TAPS + tap];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(wv, v[j + dx], acc[co][j]);
+          }
+        }
+      }
+    }
+    const size_t o = ((size_t)(td0 + z) * a.H + (th0 + y)) * a.W + x0;
+#pragma unroll
+    for (int co = 0; co < C; ++co) *(float4*)(yg + (size_t)co * vol + o) = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // backward wrt the filter bank (and bias):
 //   g_w[co, ci, tap] = sum_{b, pos} g_y[b, co, pos] * x[b, ci, pos + tap]
 // implicit GEMM with K = (batch, positions): A (16x4) = g_y[co 0..15][4 positions], B (4x16) =
@@ -402,18 +467,19 @@ __device__ __forceinline__ void wrw_group(floatx4 (&acc)[NZ * 9], float& gsum, c
   }
 }
 
-template <int DIM>
+template <int DIM, bool C4>
 __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, const float* gy, float* gw, float* ws, int units_per_wg) {
   constexpr int NZ = DIM == 3 ? 3 : 1;
   constexpr int R = DIM == 3 ? 4 : 2;                   // x ring slots
+  constexpr int NCH = C4 ? 4 : 16;                      // channels per block: 16 (MFMA engine) or the 4 of a C=4 group (vector ALU)
   extern __shared__ __align__(16) float lds[];
   const int grp = blockIdx.y;
   const int U = a.B * a.nH * a.nD;
   const int u_beg = blockIdx.x * units_per_wg, u_end = min(U, u_beg + units_per_wg);
-  const int CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
+  const int CiB = (a.Cin + NCH - 1) / NCH, CoB = (a.Cout + NCH - 1) / NCH;
   const size_t vol = (size_t)a.D * a.H * a.W;
   const int cs = a.plane, gs = a.gstride;               // channel strides inside a slot
-  const int xslot = 16 * cs, gslot = 16 * gs;
+  const int xslot = NCH * cs, gslot = NCH * gs;
   float* xr = lds + kSlack;                              // [R][16][cs]
   float* gr = xr + (size_t)R * xslot;                    // [2][16][gs]
   float* red = lds;                                      // reduction buffer aliases the rings (after the last phase)
@@ -425,11 +491,17 @@ __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, c
 
   for (int cob = 0; cob < CoB; ++cob) {
     for (int cib = 0; cib < CiB; ++cib) {
-      const int cin_here = min(16, a.Cin - cib * 16), cout_here = min(16, a.Cout - cob * 16);
-      floatx4 acc[NZ * 9];
+      const int cin_here = min(NCH, a.Cin - cib * NCH), cout_here = min(NCH, a.Cout - cob * NCH);
+      floatx4 acc[NZ * 9];                               // MFMA engine: one 16x16 block per tap
+      float acc4[C4 ? 4 : 1][C4 ? NZ * 9 : 1];           // vector-ALU engine: g_w[co 0..3][ci = wave][tap] of this lane's positions
       float gsum = 0.0f;                                 // this lane's share of sum_pos g_y[co = col]
+      float bsum4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int t = 0; t < NZ * 9; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int co = 0; co < (C4 ? 4 : 1); ++co)
+#pragma unroll
+        for (int t = 0; t < (C4 ? NZ * 9 : 1); ++t) acc4[co][t] = 0.0f;
       __syncthreads();                                   // previous block's reduction has read `red`
       for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;   // channels beyond Cin / Cout stay zero
       __syncthreads();
@@ -446,7 +518,7 @@ __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, c
         const int r_lo = th0 == 0 ? 1 : 0, r_hi = min(th + 2, a.H - th0 + 1);
         for (int c = wave; c < cin_here; c += nwaves) {
           float* dst = xr + (size_t)slot * xslot + (size_t)c * cs;
-          const float* src = a.x + (((size_t)b * a.groups + grp) * a.Cin + cib * 16 + c) * vol +
+          const float* src = a.x + (((size_t)b * a.groups + grp) * a.Cin + cib * NCH + c) * vol +
                              ((size_t)z * a.H + (th0 - 1 + r_lo)) * a.W;
           dma_run(dst + r_lo * a.W, src, (r_hi - r_lo) * a.W, lane, vec);
           if (r_lo) for (int i = lane; i < a.W; i += 64) dst[i] = 0.0f;
@@ -457,7 +529,7 @@ __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, c
         const int npos = th * a.W;
         for (int c = wave; c < cout_here; c += nwaves) {
           float* dst = gr + (size_t)slot * gslot + (size_t)c * gs;
-          const float* src = gy + (((size_t)b * a.groups + grp) * a.Cout + cob * 16 + c) * vol + ((size_t)z * a.H + th0) * a.W;
+          const float* src = gy + (((size_t)b * a.groups + grp) * a.Cout + cob * NCH + c) * vol + ((size_t)z * a.H + th0) * a.W;
           dma_run(dst, src, npos, lane, vec);
           if (lane < ((16 - (npos & 15)) & 15)) dst[npos + lane] = 0.0f;   // padded K tail (groups of 16 positions)
         }
@@ -471,6 +543,37 @@ __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, c
       // (3 horizontal taps x 4 elements): 28 LDS reads per 108 MFMAs instead of one per MFMA — on
       // gfx950 a ds_read_b32 per MFMA, not the matrix pipe, sets the pace (tools/microbench/mfma_f32.hip).
       auto compute = [&](const int (&xs_slot)[NZ], int zmask, int g_slot, int th) {
+        if constexpr (C4) {
+          // vector-ALU engine (four-channel groups: a 16x16x4 MFMA would carry 4 useful rows and columns of 16).
+          // Wave w owns input channel w; a lane takes quads of 4 consecutive x positions: 4 ds_read_b128 of g_y and,
+          // per window row, one ds_read_b128 + two neighbours of x feed 48 FMAs.
+          const int wq = a.W >> 2, nquads = th * wq, ci = wave;
+          for (int q = lane; q < nquads; q += 64) {
+            const int y = q / wq, x0 = (q - y * wq) * 4;
+            const bool bl = x0 == 0, br = x0 + 4 == a.W;
+            float g[4][4];
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+              const float4 t = *(const float4*)__builtin_assume_aligned(gr + (size_t)g_slot * gslot + (size_t)co * gs + y * a.W + x0, 16);
+              g[co][0] = t.x; g[co][1] = t.y; g[co][2] = t.z; g[co][3] = t.w;
+              if (ci == 0) bsum4[co] += (t.x + t.y) + (t.z + t.w);
+            }
+#pragma unroll
+            for (int r = 0; r < NZ * 3; ++r) {
+              const float* rp = xr + (size_t)xs_slot[r / 3] * xslot + (size_t)ci * cs + (y + r % 3) * a.W + x0;
+              const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+              const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+              const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+#pragma unroll
+              for (int co = 0; co < 4; ++co)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) acc4[co][r * 3 + dx] = fmaf(g[co][j], v[j + dx], acc4[co][r * 3 + dx]);
+            }
+          }
+          return;
+        }
         const int npos = th * a.W;                       // multiple of 4
         const int ng = (npos + 15) >> 4;
         const int per = (ng + nwaves - 1) / nwaves;
@@ -551,6 +654,31 @@ __global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, c
           __syncthreads();
         }
       }
+      if constexpr (C4) {
+        // lanes -> one value per (co, tap) of this wave's input channel; slot = (chunk, group)
+        constexpr int T = NZ * 9;
+        float* wsp4 = ws + ((size_t)blockIdx.x * a.groups + grp) * (16 * T);
+#pragma unroll
+        for (int co = 0; co < 4; ++co)
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            float v = acc4[co][t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) wsp4[(wave * 4 + co) * T + t] = v;
+          }
+        if (wave == 0) {
+          float* wb = ws + (size_t)gridDim.x * a.groups * (16 * T) + ((size_t)blockIdx.x * a.groups + grp) * 4;
+#pragma unroll
+          for (int co = 0; co < 4; ++co) {
+            float v = bsum4[co];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) wb[co] = v;
+          }
+        }
+        continue;
+      }
       // sum the wave partials through LDS, three taps per round; D: row (co) = kq*4 + r, column (ci) = col.
       // With a workspace the workgroup's partial sums are STORED (slot = chunk, group, block) and a second small
       // kernel adds the chunks in a fixed order; without one they go to g_w by float atomics (zeroed first).
@@ -621,6 +749,25 @@ __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, 
   }
 }
 
+// second stage of the four-channel ring kernel's reduction.  Workspace: [chunk][group][ci][co*taps + t], then [chunk][group][co] (bias).
+__global__ void __launch_bounds__(256) gconv_c4_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int taps) {
+  const int per = 16 * taps;                                  // per (chunk, group): [ci][co][t]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < groups * per) {
+    float sum = 0.0f;
+    for (int c = 0; c < chunks; ++c) sum += ws[(size_t)c * groups * per + idx];
+    const int grp = idx / per, r = idx % per;
+    const int ci = r / (4 * taps), co = (r / taps) % 4, t = r % taps;
+    gw[((size_t)(grp * 4 + co) * 4 + ci) * taps + t] = sum;
+  }
+  if (gbias && idx < groups * 4) {
+    const float* wb = ws + (size_t)chunks * groups * per;
+    float sum = 0.0f;
+    for (int c = 0; c < chunks; ++c) sum += wb[(size_t)c * groups * 4 + idx];
+    gbias[idx] = sum;
+  }
+}
+
 // bias gradient: g_bias[c] = sum over batch and positions of g_y (one wave per channel row chunk)
 __global__ void gconv_bias_grad_kernel(const float* gy, float* gbias, int B, int C, size_t vol) {
   const int c = blockIdx.x;
@@ -636,23 +783,54 @@ __global__ void gconv_bias_grad_kernel(const float* gy, float* gbias, int B, int
   if (threadIdx.x == 0) gbias[c] = red[0] + red[1] + red[2] + red[3];
 }
 
-bool plan_tiles_budget(GconvArgs& a, int dim, size_t extra_per_pos_bytes, size_t fixed_bytes, int cin_planes,
-                       int plane_mod, size_t budget) {
-  // LDS per workgroup = cin_planes*plane*4 + fixed + extra_per_pos*TD*TH*W  <= budget
+bool plan_tiles_min_halo(GconvArgs& a, int dim, size_t extra_per_pos_bytes, size_t fixed_bytes, int cin_planes,
+                         int plane_mod, size_t budget) {
+  // LDS per workgroup = cin_planes*plane*4 + fixed + extra_per_pos*TD*TH*W  <= budget.
+  // Among the (TD, TH) that fit, take the one that stages the fewest halo floats per output position
+  // ((TD+2)(TH+2) / (TD*TH), counted on the tiles that actually cover the tensor); ties -> the larger tile.
   a.Ws = a.W;                                     // rows keep the tensor width (no x halo)
   const int dzh = dim == 3 ? 2 : 0;
+  double best = 1e30;
+  bool found = false;
   for (int TD = dim == 3 ? a.D : 1; TD >= 1; --TD) {
     for (int TH = a.H; TH >= 1; --TH) {
       const int Hs = TH + 2;
       int plane = (TD + dzh) * Hs * a.Ws;
       plane += (plane_mod - (plane & 31) + 32) & 31;   // plane == plane_mod (mod 32): conflict-free operand reads
       const size_t bytes = (size_t)cin_planes * plane * 4 + fixed_bytes + extra_per_pos_bytes * TD * TH * a.W + 64;
+      if (bytes > budget) continue;
+      const int nD = (a.D + TD - 1) / TD, nH = (a.H + TH - 1) / TH;
+      const double staged = (double)nD * nH * (TD + dzh) * Hs;       // rows staged for the whole tensor
+      const double cost = staged / ((double)a.D * a.H) - 1e-9 * TD * TH;
+      if (cost < best) {
+        best = cost;
+        found = true;
+        a.TD = TD; a.TH = TH; a.Hs = Hs; a.plane = plane; a.nD = nD; a.nH = nH;
+      }
+      break;                                       // smaller TH at this TD only stages more
+    }
+  }
+  return found;
+}
+
+// depth-first policy: the full-height tile of the deepest depth that fits, else one slice with as many rows as fit
+// (stages more halo than plan_tiles_min_halo, but measured faster for the MFMA forward kernel's position-group split)
+bool plan_tiles_budget(GconvArgs& a, int dim, size_t extra_per_pos_bytes, size_t fixed_bytes, int cin_planes,
+                       int plane_mod, size_t budget) {
+  a.Ws = a.W;
+  const int dzh = dim == 3 ? 2 : 0;
+  for (int TD = dim == 3 ? a.D : 1; TD >= 1; --TD) {
+    for (int TH = a.H; TH >= 1; --TH) {
+      const int Hs = TH + 2;
+      int plane = (TD + dzh) * Hs * a.Ws;
+      plane += (plane_mod - (plane & 31) + 32) & 31;
+      const size_t bytes = (size_t)cin_planes * plane * 4 + fixed_bytes + extra_per_pos_bytes * TD * TH * a.W + 64;
       if (bytes <= budget) {
         a.TD = TD; a.TH = TH; a.Hs = Hs; a.plane = plane;
         a.nD = (a.D + TD - 1) / TD; a.nH = (a.H + TH - 1) / TH;
         return true;
       }
-      if (dim == 3 && TD > 1) break;               // shrink depth first, then rows
+      if (dim == 3 && TD > 1) break;
     }
   }
   return false;
@@ -683,9 +861,32 @@ int set_lds_attr(K kernel, size_t bytes) {
   return CT_OK;
 }
 
+// four-channel groups with 16-byte rows: the vector-ALU kernel
+int launch_c4(GconvArgs a, int dim, hipStream_t st) {
+  if (!plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudget) && !plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudgetMax)) return CT_EINVAL;
+  const size_t lds = (size_t)4 * a.plane * 4 + 2 * kSlack * 4;
+  dim3 grid(a.nD * a.nH, a.groups, a.B);
+  CT_CLEAR_ERROR();
+#define CT_C4_LAUNCH(DIMV, TR)                                                              \
+  do {                                                                                      \
+    if (set_lds_attr(gconv_c4_kernel<DIMV, TR>, lds) != CT_OK) return CT_ELAUNCH;           \
+    hipLaunchKernelGGL((gconv_c4_kernel<DIMV, TR>), grid, dim3(kThreads), lds, st, a);      \
+  } while (0)
+  if (dim == 2) { if (a.transposed) CT_C4_LAUNCH(2, true); else CT_C4_LAUNCH(2, false); }
+  else { if (a.transposed) CT_C4_LAUNCH(3, true); else CT_C4_LAUNCH(3, false); }
+#undef CT_C4_LAUNCH
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
+  if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0) return launch_c4(a, dim, st);
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;
-  if (!plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16)) return CT_EINVAL;
+  // short rows (W < 16: the 8^3 volumes) do better on the minimum-halo tiles, the others on the depth-first ones (measured)
+  const bool ok = a.W < 16 ? (plan_tiles_min_halo(a, dim, 0, wbytes, a.KB * 4, 16, kLdsBudget) ||
+                              plan_tiles_min_halo(a, dim, 0, wbytes, a.KB * 4, 16, kLdsBudgetMax))
+                           : plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16);
+  if (!ok) return CT_EINVAL;
   const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes + 2 * kSlack * 4;
   dim3 grid(a.nD * a.nH, a.groups, a.B);
   const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
@@ -704,7 +905,7 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
 // backward-weight, ring kernel (rows of W % 4 == 0 floats): the plan ...
 struct WrwRingPlan { size_t lds; int chunks, units_per_wg; };
 
-bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p) {
+bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p, int nch = 16) {
   const int B = a.B, groups = a.groups;
   // the tallest row tile whose rings fit the budget (64 KiB: two workgroups per CU, then whatever one CU
   // holds), then depth chunks until ~512 workgroups exist
@@ -712,7 +913,7 @@ bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p) {
   const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
   auto pad4 = [](int n) { return n + ((4 - (n & 63) + 64) & 63); };      // == 4 (mod 64): conflict-free ds_read_b128 operand reads
   auto ring_bytes = [&](int TH) {
-    const size_t b = ((size_t)R * 16 * pad4((TH + 2) * a.W) + (size_t)2 * 16 * pad4((TH * a.W + 15) & ~15) + 2 * kSlack) * 4;
+    const size_t b = ((size_t)R * nch * pad4((TH + 2) * a.W) + (size_t)2 * nch * pad4((TH * a.W + 15) & ~15) + 2 * kSlack) * 4;
     return b > red_bytes ? b : red_bytes;
   };
   int TH = 0;
@@ -757,11 +958,11 @@ int launch_wrw_ring(GconvArgs a, int dim, const float* g_y, float* g_w, float* g
   if (!ws && hipMemsetAsync(g_w, 0, (size_t)a.groups * a.Cout * a.Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
   dim3 grid(p.chunks, a.groups);
   if (dim == 2) {
-    if (set_lds_attr(gconv_wrw_ring_kernel<2>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_wrw_ring_kernel<2>, grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<2, false>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, false>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   } else {
-    if (set_lds_attr(gconv_wrw_ring_kernel<3>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL(gconv_wrw_ring_kernel<3>, grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<3, false>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, false>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   }
   if (ws) {
     const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
@@ -769,6 +970,30 @@ int launch_wrw_ring(GconvArgs a, int dim, const float* g_y, float* g_w, float* g
     hipLaunchKernelGGL(gconv_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, g_w, g_bias, p.chunks,
                        a.groups, a.Cin, a.Cout, a.taps);
   }
+  return CT_OK;
+}
+
+// backward-weight of four-channel groups: the ring kernel with its vector-ALU engine
+bool c4_wrw_eligible(const GconvArgs& a) { return a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0; }
+
+size_t c4_wrw_workspace(const GconvArgs& a, const WrwRingPlan& p) {
+  return ((size_t)p.chunks * a.groups * 16 * a.taps + (size_t)p.chunks * a.groups * 4) * sizeof(float);
+}
+
+int launch_c4_wrw(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_bias, float* ws, size_t ws_bytes, hipStream_t st) {
+  WrwRingPlan p;
+  if (!plan_wrw_ring(a, dim, p, 4)) return CT_EINVAL;
+  if (ws_bytes < c4_wrw_workspace(a, p)) return CT_EWORKSPACE;
+  dim3 grid(p.chunks, a.groups);
+  if (dim == 2) {
+    if (set_lds_attr(gconv_wrw_ring_kernel<2, true>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, true>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+  } else {
+    if (set_lds_attr(gconv_wrw_ring_kernel<3, true>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, true>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+  }
+  const int n = a.groups * 16 * a.taps;
+  hipLaunchKernelGGL(gconv_c4_wrw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, g_w, g_bias, p.chunks, a.groups, a.taps);
   return CT_OK;
 }
 
@@ -827,6 +1052,10 @@ int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
 size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout, int dim, const int* W) {
   GconvArgs a = {};
   if (gconv_common(a, B, groups, Cin, Cout, dim, W) != CT_OK || (a.W & 3) != 0) return 0;
+  if (c4_wrw_eligible(a)) {
+    WrwRingPlan p4;
+    if (plan_wrw_ring(a, dim, p4, 4)) return c4_wrw_workspace(a, p4);
+  }
   WrwRingPlan p;
   return plan_wrw_ring(a, dim, p) ? wrw_ring_workspace(a, p) : 0;
 }
@@ -840,8 +1069,13 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   a.x = x; a.transposed = 0;
   hipStream_t st = (hipStream_t)s;
   CT_CLEAR_ERROR();
-  r = (a.W & 3) == 0 ? launch_wrw_ring(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st)
-                     : launch_wrw_tiles(a, dim, g_y, g_w, st);
+  const bool aligned = ((((uintptr_t)x) | ((uintptr_t)g_y)) & 15) == 0;
+  if (workspace && aligned && c4_wrw_eligible(a)) {
+    r = launch_c4_wrw(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
+  } else {
+    r = (a.W & 3) == 0 ? launch_wrw_ring(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st)
+                       : launch_wrw_tiles(a, dim, g_y, g_w, st);
+  }
   if (r != CT_OK) return r;
   if (g_bias && !((a.W & 3) == 0 && workspace)) {       // the ring kernel's workspace path produces g_bias itself
     const size_t vol = (size_t)a.D * a.H * a.W;
