@@ -110,6 +110,61 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   }
 }
 
+// so3 exponential map of the per-head rotation parameters (Rodrigues; the map the reference imports from
+// pytorch3d, layers/utils.py:6,29,56):  theta = sqrt(max(|v|^2, eps)),  R = I + (sin theta / theta) K +
+// ((1 - cos theta) / theta^2) K^2,  K = hat(v), K^2 = v v^T - |v|^2 I.  One thread per head, evaluated in
+// double (H is 4..64: the cost is the launch) — in eager torch the map and its autograd are ~40 tiny launches per block.
+__global__ void so3_exp_fwd_kernel(const float* log_R, float* R, int H, float eps) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const double x = log_R[h * 3 + 0], y = log_R[h * 3 + 1], z = log_R[h * 3 + 2];
+  const double s = x * x + y * y + z * z;
+  const double th = sqrt(s > (double)eps ? s : (double)eps);
+  const double a = sin(th) / th, b = (1.0 - cos(th)) / (th * th);
+  const double v[3] = {x, y, z};
+  const double K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      R[h * 9 + i * 3 + j] = (float)((i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * (v[i] * v[j] - (i == j ? s : 0.0)));
+}
+
+// g_log_R from g_R:  d<G,R> = da <G,K> + a <G,dK> + db (v^T G v - s tr G) + b d(v^T G v - s tr G),
+// a and b depend on v through theta only where |v|^2 >= eps (torch.clamp passes the gradient at equality).
+__global__ void so3_exp_bwd_kernel(const float* log_R, const float* g_R, float* g_log_R, int H, float eps) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const double x = log_R[h * 3 + 0], y = log_R[h * 3 + 1], z = log_R[h * 3 + 2];
+  const double v[3] = {x, y, z};
+  double G[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = g_R[h * 9 + i];
+  const double s = x * x + y * y + z * z;
+  const bool live = s >= (double)eps;
+  const double th = sqrt(live ? s : (double)eps);
+  const double sn = sin(th), cs = cos(th);
+  const double a = sn / th, b = (1.0 - cs) / (th * th);
+  const double trG = G[0] + G[4] + G[8];
+  double Gv[3], GTv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Gv[i] = G[i * 3 + 0] * x + G[i * 3 + 1] * y + G[i * 3 + 2] * z;
+    GTv[i] = G[0 * 3 + i] * x + G[1 * 3 + i] * y + G[2 * 3 + i] * z;
+  }
+  const double gK[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};          // d<G,K>/dv
+  const double dLda = -z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7];
+  const double dLdb = x * Gv[0] + y * Gv[1] + z * Gv[2] - s * trG;
+  double radial = 0.0;
+  if (live) {
+    const double da = (th * cs - sn) / (th * th);
+    const double db = (th * sn - 2.0 * (1.0 - cs)) / (th * th * th);
+    radial = (dLda * da + dLdb * db) / th;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g_log_R[h * 3 + i] = (float)(a * gK[i] + b * (Gv[i] + GTv[i] - 2.0 * trG * v[i]) + radial * v[i]);
+}
+
 bool valid(const LatticeArgs& a) {
   return a.xyz && a.res && a.R && a.shift && a.B > 0 && a.H > 0 && a.N > 0 && (a.dim == 2 || a.dim == 3) &&
          a.B <= 65535 && a.H <= 65535;
@@ -145,6 +200,24 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   CT_CLEAR_ERROR();
   hipLaunchKernelGGL(lattice_bwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
                      g_residual, g_R, g_shift, g_scales, g_kscale);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_so3_exp_fwd(const float* log_R, float* R, int H, float eps, ct_stream_t s) {
+  if (!log_R || !R || H < 0 || !(eps > 0.0f)) return CT_EINVAL;
+  if (H == 0) return CT_OK;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(so3_exp_fwd_kernel, dim3((H + 63) / 64), dim3(64), 0, (hipStream_t)s, log_R, R, H, eps);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, float eps, ct_stream_t s) {
+  if (!log_R || !g_R || !g_log_R || H < 0 || !(eps > 0.0f)) return CT_EINVAL;
+  if (H == 0) return CT_OK;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(so3_exp_bwd_kernel, dim3((H + 63) / 64), dim3(64), 0, (hipStream_t)s, log_R, g_R, g_log_R, H, eps);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

@@ -20,6 +20,8 @@ def so3_exponential_map(log_rot, eps=1e-4):
     theta = sqrt(clamp(|v|^2, eps)),  R = I + (sin theta / theta) K + ((1 - cos theta) / theta^2) K^2,
     K = hat(v).  log_rot [H,3] -> [H,3,3]."""
     assert log_rot.dim() == 2 and log_rot.size(1) == 3
+    if log_rot.is_cuda and log_rot.dtype == torch.float32:
+        return ops.so3_exp(log_rot, eps)                  # one HIP launch each way instead of ~40 tiny ones
     sq = (log_rot * log_rot).sum(dim=1)
     theta = sq.clamp(min=eps).sqrt()
     a = theta.sin() / theta

@@ -307,6 +307,37 @@ def lattice(xyz, residual, R, shift, scales, kscale, dim):
     return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim)
 
 
+class So3ExpFn(torch.autograd.Function):
+    """so3 exponential map log_R [H,3] -> R [H,3,3] (pytorch3d's, layers/utils.py:6,29,56), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, log_R, eps):
+        _dev(log_R)
+        log_R = _f32c(log_R)
+        H = log_R.shape[0]
+        R = torch.empty(H, 3, 3, device=log_R.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(log_R.device):
+            _lib.check(lib.ct_so3_exp_fwd(_ptr(log_R), _ptr(R), H, float(eps), _stream()), "ct_so3_exp_fwd")
+        ctx.save_for_backward(log_R)
+        ctx.eps = float(eps)
+        return R
+
+    @staticmethod
+    def backward(ctx, g_R):
+        (log_R,) = ctx.saved_tensors
+        g_R = _f32c(g_R)
+        g = torch.empty_like(log_R)
+        lib = _lib.load()
+        with torch.cuda.device(log_R.device):
+            _lib.check(lib.ct_so3_exp_bwd(_ptr(log_R), _ptr(g_R), _ptr(g), log_R.shape[0], ctx.eps, _stream()), "ct_so3_exp_bwd")
+        return g, None
+
+
+def so3_exp(log_R, eps=1e-4):
+    return So3ExpFn.apply(log_R, eps)
+
+
 class AdaInFn(torch.autograd.Function):
     """relu?(instance_norm(x) * (gamma + 1) + beta), gamma_beta [B,2,C] (layers/utils.py:88-97)."""
 

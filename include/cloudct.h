@@ -150,6 +150,13 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
                    const float* g_keys, float* g_xyz, float* g_residual, float* g_R, float* g_shift, float* g_scales,
                    float* g_kscale, int B, int H, int N, int dim, ct_stream_t s);
 
+/* so3 exponential map of the per-head rotation parameters — the third-party call of the transformers
+ * (pytorch3d.transforms.so3.so3_exponential_map, layers/utils.py:6,29,56; eps = 1e-4 there):
+ *   theta = sqrt(max(|v|^2, eps));  R = I + (sin theta / theta) K + ((1 - cos theta) / theta^2) K^2,  K = hat(v)
+ * log_R f32[H,3] -> R f32[H,3,3];  backward: g_R f32[H,3,3] -> g_log_R f32[H,3] (overwritten). */
+int ct_so3_exp_fwd(const float* log_R, float* R, int H, float eps, ct_stream_t s);
+int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, float eps, ct_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Adaptive instance normalisation of the AdaIN blocks (AdaIn1dUpd: layers/utils.py:82-97 =
  * InstanceNorm1d(affine=False, eps) -> * (gamma + 1) -> + beta; followed by ReLU in `after`,
