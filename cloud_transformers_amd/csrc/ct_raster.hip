@@ -53,6 +53,7 @@ struct RasterArgs {
   int ncg;              // chunk groups (grid.x split of the chunk loop in gather-reduce kernels)
   int nsplit;           // splits of N for pure gather kernels
   int atomic_gpos;      // accumulate g_pos with global atomics (ncg > 1)
+  size_t gpos_stride;   // > 0: channel-chunk group cg writes its partial g_pos to g_pos + cg*gpos_stride floats (summed afterwards)
 };
 
 template <int DIM, bool FROM_KEYS>
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_gw_kernel(Raste
 #pragma unroll
         for (int v = 0; v < V; ++v) gw[v] += Tc[c.cell[v]] * s;
       }
-      store_gpos<DIM, FROM_KEYS>(a.g_pos, bh, a.N, n, pp, gw, first, atomic);
+      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first, atomic);
     }
     first = false;
   }
@@ -690,7 +691,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
         if (has_pad) gf = gf * p;
         dst[(size_t)ch * a.N + n] = gf;
       }
-      store_gpos<DIM, FROM_KEYS>(a.g_pos, bh, a.N, n, pp, gw, first, atomic);
+      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first, atomic);
     }
     first = false;
   }
@@ -913,7 +914,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
         }
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
-          float* pk = a.g_pos + (bh * DIM + j) * a.N + n0;
+          float* pk = a.g_pos + (size_t)cgi * a.gpos_stride + (bh * DIM + j) * a.N + n0;
           if (atomic) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) atomicAdd(pk + i, gs[i][j]);
@@ -1252,6 +1253,22 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
   return CT_OK;
 }
 
+// out[i] = sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
+__global__ void __launch_bounds__(256) sum_parts_kernel(const float* parts, float* out, size_t n, size_t stride, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = parts[i];
+  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
+  out[i] = s;
+}
+
+// channel-chunk groups a Splat(max) backward launch is split into (more workgroups for few (b,h) planes)
+inline int splat_bwd_ncg(int B, int H, int nchunks) {
+  int ncg = 1;
+  while ((long long)B * H * ncg < 512 && ncg * 2 <= nchunks) ncg *= 2;
+  return ncg;
+}
+
 template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
@@ -1261,10 +1278,22 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   a.CC = p.CC;
   a.nchunks = p.nchunks;
   a.nsplit = 1;
-  a.ncg = 1;
-  while ((long long)a.B * a.H * a.ncg < 512 && a.ncg * 2 <= p.nchunks) a.ncg *= 2;
-  a.atomic_gpos = a.ncg > 1;
+  a.ncg = splat_bwd_ncg(a.B, a.H, p.nchunks);
+  // g_keys sums over the channel chunks.  Across chunk GROUPS (different workgroups) that sum went through
+  // device-scope float atomics — a third of this kernel's time on the 64^2 C16 zoo head.  With the caller's
+  // workspace each group stores its partial and sum_parts_kernel adds them in a fixed order.
+  float* const g_pos_out = a.g_pos;
+  const size_t gpos_n = gpos_bytes<DIM, FROM_KEYS>(a) / 4;
+  const bool parts = a.ncg > 1 && p.lds_tile && ws && ws_bytes >= (size_t)a.ncg * gpos_n * 4;
+  if (parts) { a.g_pos = (float*)ws; a.gpos_stride = gpos_n; }
+  a.atomic_gpos = a.ncg > 1 && !parts;
   if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
+  struct SumParts {                                   // runs when the function returns, after the launch
+    bool on; const float* src; float* dst; size_t n; int k; hipStream_t st;
+    ~SumParts() {
+      if (on) hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, n, k);
+    }
+  } sum_parts{parts, (const float*)ws, g_pos_out, gpos_n, a.ncg, st};
   dim3 grid(a.ncg, a.H, a.B);
   if (p.lds_tile) {
     bool done = false;
@@ -1276,6 +1305,7 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
       if (two && wh_bytes <= (size_t)kBigLdsBytes && wh_bytes > (size_t)kMaxLdsBytes && (long long)a.B * a.H >= 256 &&
           quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
         a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
+        a.g_pos = g_pos_out; a.gpos_stride = 0; sum_parts.on = false;
         int t = round_threads(a.N >> 2);
         dim3 wgrid(1, a.H, a.B);
         if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
@@ -1477,8 +1507,12 @@ size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const i
   if (!valid_common(B, H, C, N, dim, W) || reduce != CT_REDUCE_MAX0) return 0;
   size_t G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
-  if (G * 4 <= (size_t)kBigLdsBytes) return 0;   // tile lives in LDS
-  return (size_t)B * H * C * G * 4;
+  if (G * 4 > (size_t)kBigLdsBytes) return (size_t)B * H * C * G * 4;   // claim copy of z (tile does not fit LDS)
+  // tile lives in LDS: partial g_keys / g_lc of the channel-chunk groups, if the launch is split into any
+  const bool two = G * 8 <= (size_t)kMaxLdsBytes;
+  const Plan p = make_plan(B, H, C, N, (int)G, two ? 2 : 1);
+  const int ncg = splat_bwd_ncg(B, H, p.nchunks);
+  return ncg > 1 ? (size_t)ncg * B * H * ((size_t)1 << dim) * N * 4 : 0;
 }
 
 int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,

@@ -54,7 +54,9 @@ def test_argument_validation_without_gpu(lib):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.ct_positions_fwd(p, p, p, 1, 1, 1, 2, one, None) == -1
     # workspace query is pure host arithmetic
-    assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 2, W, 0) == 0
+    assert lib.ct_splat_bwd_workspace_bytes(8, 64, 8, 100, 2, W, 0) == 0            # enough (b,h) planes: one workgroup per plane
+    # few planes: the launch is split into 2 channel-chunk groups, each stores a partial g_keys / g_lc (2^dim x N per plane)
+    assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 2, W, 0) == 2 * (2 * 4 * 4 * 100 * 4)
     big = _lib.int_array([64, 64, 64])
     assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 3, big, 0) == 2 * 4 * 8 * 64 ** 3 * 4
 
