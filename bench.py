@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--dim", type=int, default=2)
     p.add_argument("--reduce", default="max", choices=["max", "sum"])
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    p.add_argument("--graph-steps", type=int, default=10,
+                   help="steps captured per HIP graph (the K timed steps are replays of it plus single-step replays for the rest)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     return p.parse_args()
@@ -139,25 +141,38 @@ def main():
     # eager warm-up (also sets the LDS attributes before capture)
     step.run()
     torch.cuda.synchronize()
-    graph = None
+    graph = multi = None
+    gs = max(1, min(args.graph_steps, args.steps))
     if not args.no_graph:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step.run()
+            if gs > 1:                   # `gs` whole steps per graph: one graph launch (and its start-up gap) per gs steps
+                multi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(multi):
+                    for _ in range(gs):
+                        step.run()
         except Exception as ex:          # noqa: BLE001 — capture unavailable: time eager launches instead
             print("bench: HIP graph capture failed (%r), timing eager launches" % (ex,), file=sys.stderr)
-            graph = None
+            graph = multi = None
             torch.cuda.synchronize()
     run = graph.replay if graph is not None else step.run
 
-    for _ in range(args.warmup):
-        run()
+    def run_steps(k):
+        """exactly k steps"""
+        if multi is not None:
+            for _ in range(k // gs):
+                multi.replay()
+            k = k % gs
+        for _ in range(k):
+            run()
+
+    run_steps(args.warmup)
     barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     barrier(dist)
     dt = time.perf_counter() - t0
@@ -188,7 +203,7 @@ def main():
                                    "%dD grid W=%d, reduce=%s, keys=tanh(randn), seed 1234+rank"
                                    % (B, N, H, C, dim, W, args.reduce),
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
-                       "hip_graph": graph is not None},
+                       "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1},
             "roofline": {"bound": "hbm", "kernel": step.KERNELS.get(dom, dom) if args.reduce == "max" else dom,
                          "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
