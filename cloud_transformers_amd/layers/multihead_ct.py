@@ -117,7 +117,8 @@ class MultiHead(_MHCTCore):
         occ = self._occupancy(z, keys.size(0))
         result = self.after(self.slice.forward_keys(lattice, self.conv(z), pts_padd))
         with torch.no_grad():
-            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), None)
+            k_var, k_mean = torch.var_mean(keys)          # one reduction pass for both statistics
+            stats = (occ, k_mean, k_var, None)
         if return_lattice:
             result = result, lattice
         return result, stats
@@ -148,7 +149,8 @@ class MultiHeadPool(_MHCTCore):
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
         with torch.no_grad():
-            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), None)
+            k_var, k_mean = torch.var_mean(keys)          # one reduction pass for both statistics
+            stats = (occ, k_mean, k_var, None)
         result = z
         if return_lattice:
             result = result, lattice
@@ -186,7 +188,8 @@ class MultiHeadAdaIn(_MHCTCore):
         with torch.no_grad():
             # the reference moves these to the host and copies ALL keys to numpy on every
             # forward (multihead_ct_adain.py:127-131); here they stay on the device (no sync)
-            stats = (occ, torch.mean(keys).detach(), torch.var(keys).detach(), keys.detach())
+            k_var, k_mean = torch.var_mean(keys)
+            stats = (occ, k_mean, k_var, keys.detach())
         if return_lattice:
             result = result, lattice
         return result, stats
