@@ -1,20 +1,26 @@
-// Grouped 3x3 / 3x3x3 convolution over the rasterised planes and volumes, on the
-// gfx950 matrix cores (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32).
+// Grouped 3x3 / 3x3x3 convolution over the rasterised planes and volumes.
 //
 // The MHCT blocks convolve every head's grid with its own small filter bank
 // (`groups = heads`, C_in = C_out in {4,16,32,64} per group; reference call sites
 // layers/multihead_ct.py:50-65, unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29).
 // Per group this is an implicit GEMM  D[co, pos] = sum_{tap, ci} W[co, ci, tap] * X[ci, pos+tap]
-// with a tiny N (=C_out) and K (=C_in*3^d): too small for a library GEMM to tile well,
-// a perfect fit for one 16x16x4 MFMA per (tap, 4 input channels, 16 output positions):
-//     A (16x4)  = W[co 0..15][ci kb*4..+3][tap]        one f32 / lane, read from LDS
-//     B (4x16)  = X[ci kb*4..+3][16 positions + tap]   one f32 / lane, read from LDS (halo tile)
-//     D (16x16) = 4 accumulator registers / lane       (row = co, col = position)
-// A workgroup owns an output tile (TD x TH x W positions) of one (batch, group): the input
-// tile with its halo is staged once in LDS (zero-padded borders), each wave keeps P position
-// groups in flight so that one weight read feeds P MFMAs.
-// Backward-data is the same kernel with the filter bank read transposed and flipped.
-// Backward-weight is a second implicit GEMM (K = positions) accumulated across workgroups.
+// with a tiny N (=C_out) and K (=C_in*3^d): too small for a library GEMM to tile well.
+//
+// Kernels in this file:
+//   gconv_fwd_kernel        forward and backward-data (bank read transposed + flipped) on the matrix cores:
+//                           one exact-fp32 v_mfma_f32_16x16x4_f32 per (tap, 4 input channels, 16 positions);
+//                             A (16x4)  = W[co 0..15][ci kb*4..+3][tap]        read from LDS
+//                             B (4x16)  = X[ci kb*4..+3][16 positions + tap]   read from the LDS halo tile
+//                             D (16x16) = 4 accumulator registers / lane       (row = co, col = position)
+//                           a workgroup owns an output tile (TD x TH x W) of one (batch, group); each wave keeps
+//                           kP position groups in flight so that one weight read feeds kP MFMAs
+//   gconv_c4_kernel         the same two passes for four-channel groups on the vector ALU (a 16x16x4 MFMA would
+//                           carry 4 useful rows / K slots of 16)
+//   gconv_wrw_ring_kernel   backward-weight: implicit GEMM over K = (batch, positions), operands streamed through
+//                           LDS rings by LDS-DMA one phase ahead; MFMA engine (16-channel blocks) or vector-ALU
+//                           engine (four-channel groups); partial sums to a workspace, added by
+//                           gconv_wrw_reduce_kernel / gconv_c4_wrw_reduce_kernel in a fixed order
+//   gconv_bwd_weight_kernel backward-weight for rows that are not a multiple of 4 floats (tile form, float atomics)
 #include "ct_common.h"
 
 namespace {
@@ -201,6 +207,97 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
             const int co = mt * 16 + kq * 4 + r;
             if (co < a.Cout) yg[(size_t)co * vol + o] = acc[p][r];
           }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward / backward-data on the matrix cores, rows of W % 4 == 0 floats ("quad" form of gconv_fwd_kernel).
+// A wave walks spans of 16 quads = 64 positions; lane (col, kq) owns the quad `col` of the span (4 consecutive x
+// positions, one row) and input channel kb*4 + kq.  MFMA j of a span takes element j of every lane's quad as its
+// column (any assignment of positions to MFMA columns is valid), so per (window row, 4 input channels) ONE aligned
+// ds_read_b128 of the tile row plus its two neighbours feed the B operands of 12 MFMAs (3 horizontal taps x 4
+// elements) and ONE ds_read_b128 of the filter bank ([row][kb][kq][co][dx 0..2 + pad]) feeds their A operands:
+// 4 LDS reads per 12 MFMAs instead of 15.  The 4 accumulators of a lane's output channel are 4 consecutive
+// positions: results leave as 16-byte stores (the one-position form stores 4 bytes per lane).
+// grid = (nD*nH, groups, B)
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(kThreadsBig) gconv_fwd4_kernel(GconvArgs a) {
+  constexpr int NR = DIM == 3 ? 9 : 3;               // window rows (dz, dy)
+  extern __shared__ __align__(16) float lds[];
+  const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
+  const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
+  const int KB = a.KB;
+  float* xs = lds + kSlack;                                          // [KB*4][plane]
+  float* ws = lds + kSlack + (size_t)KB * 4 * a.plane + kSlack;       // [NR][KB][4 kq][16 co][4]
+  const size_t vol = (size_t)a.D * a.H * a.W;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  stage_halo_tile<DIM>(xs, a.x + ((size_t)b * a.groups + grp) * a.Cin * vol, a, KB * 4, td0, th0, lane, wave, nwaves);
+  const int col = lane & 15, kq = lane >> 4;
+  const int wq = a.W >> 2;
+  const int nquads = td * th * wq;
+  const int nspans = (nquads + 15) >> 4;
+  const int MT = (a.Cout + 15) >> 4;
+  float* yg = a.y + ((size_t)b * a.groups + grp) * a.Cout * vol;
+
+  for (int mt = 0; mt < MT; ++mt) {
+    __syncthreads();                                 // xs ready / previous bank consumed
+    // filter bank of this 16-row block: ws[((r*KB + kb)*4 + k)*64 + m*4 + dx] = W[co = mt*16+m][ci = kb*4+k][tap = r*3+dx]
+    for (int i = threadIdx.x; i < NR * KB * 256; i += blockDim.x) {
+      const int dx = i & 3, m = (i >> 2) & 15, k = (i >> 6) & 3, rk = i >> 8;
+      const int kb = rk % KB, r = rk / KB;
+      const int co = mt * 16 + m, ci = kb * 4 + k, tap = r * 3 + dx;
+      float v = 0.0f;
+      if (dx < 3 && co < a.Cout && ci < a.Cin)
+        v = a.transposed ? a.w[((size_t)(grp * a.Cin + ci) * a.Cout + co) * a.taps + (a.taps - 1 - tap)]
+                         : a.w[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + tap];
+      ws[i] = v;
+    }
+    __syncthreads();
+    float bias_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = mt * 16 + kq * 4 + r;
+      bias_r[r] = (a.bias != nullptr && co < a.Cout) ? a.bias[grp * a.Cout + co] : 0.0f;
+    }
+    for (int sp = wave; sp < nspans; sp += nwaves) {
+      const int q = min(sp * 16 + col, nquads - 1);   // clamped: inactive lanes read valid LDS
+      const int xq = q % wq, y = (q / wq) % th, z = q / (wq * th);
+      const int x0 = xq * 4;
+      const bool bl = x0 == 0, br = x0 + 4 == a.W;
+      const int off = (z * a.Hs + y) * a.W + x0;
+      floatx4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = bias_r[r];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int roff = ((r / 3) * a.Hs + (r % 3)) * a.W;
+        for (int kb = 0; kb < KB; ++kb) {
+          const float4 a4 = *(const float4*)__builtin_assume_aligned(ws + ((size_t)(r * KB + kb) * 4 + kq) * 64 + col * 4, 16);
+          const float* rp = xs + (size_t)(kb * 4 + kq) * a.plane + off + roff;
+          const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+          const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+          const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+          const float av[3] = {a4.x, a4.y, a4.z};
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dx], v[j + dx], acc[j], 0, 0, 0);
+        }
+      }
+      // D_j: row (output channel) = kq*4 + r, column = quad col, element j
+      if (sp * 16 + col < nquads) {
+        const size_t o = ((size_t)(td0 + z) * a.H + (th0 + y)) * a.W + x0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = mt * 16 + kq * 4 + r;
+          if (co < a.Cout) *(float4*)(yg + (size_t)co * vol + o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
         }
       }
     }
@@ -879,8 +976,49 @@ int launch_c4(GconvArgs a, int dim, hipStream_t st) {
   return CT_OK;
 }
 
+// quad form of the MFMA kernel (rows of W % 4 == 0 floats, 16-byte aligned tensors)
+int launch_fwd4(GconvArgs a, int dim, hipStream_t st) {
+  const int NR = dim == 3 ? 9 : 3;
+  const size_t wbytes = (size_t)NR * a.KB * 256 * 4;
+  // Tile budget: this kernel likes BIG tiles (one 1024-thread workgroup per CU: long MFMA runs per barrier, little
+  // halo) as long as one workgroup per CU exists — take the largest budget that still yields 256 of them, else the most
+  // workgroups (measured on the zoo shapes: 2D 32^2 H64 47 -> 37 us, 64^2 63 -> 43 us vs the 32 KiB tiles).
+  const size_t budgets[] = {(size_t)kLdsBudgetMax, (size_t)96 * 1024, (size_t)64 * 1024, (size_t)kLdsBudget};
+  bool ok = false;
+  GconvArgs best = a;
+  long long best_wgs = -1;
+  for (size_t budget : budgets) {
+    GconvArgs t = a;
+    const bool fits = a.W < 16 ? plan_tiles_min_halo(t, dim, 0, wbytes, a.KB * 4, 16, budget)
+                               : plan_tiles_budget(t, dim, 0, wbytes, a.KB * 4, 16, budget);
+    if (!fits) continue;
+    const long long wgs = (long long)t.nD * t.nH * a.groups * a.B;
+    if (wgs >= 256) { best = t; ok = true; break; }
+    if (wgs > best_wgs) { best = t; best_wgs = wgs; ok = true; }
+  }
+  if (!ok) return CT_EINVAL;
+  a = best;
+  const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes + 2 * kSlack * 4;
+  dim3 grid(a.nD * a.nH, a.groups, a.B);
+  const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
+  CT_CLEAR_ERROR();
+  if (dim == 2) {
+    if (set_lds_attr(gconv_fwd4_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_fwd4_kernel<2>, grid, dim3(threads), lds, st, a);
+  } else {
+    if (set_lds_attr(gconv_fwd4_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_fwd4_kernel<3>, grid, dim3(threads), lds, st, a);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
-  if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0) return launch_c4(a, dim, st);
+  const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
+  if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
+#ifndef CT_GCONV_NO_FWD4
+  if (rows16) return launch_fwd4(a, dim, st);
+#endif
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;
   // short rows (W < 16: the 8^3 volumes) do better on the minimum-halo tiles, the others on the depth-first ones (measured)
   const bool ok = a.W < 16 ? (plan_tiles_min_halo(a, dim, 0, wbytes, a.KB * 4, 16, kLdsBudget) ||
