@@ -110,6 +110,22 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   }
 }
 
+// zero every accumulation target of lattice_bwd_kernel in ONE launch (five stream memsets cost five launch gaps)
+__global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_xyz, size_t n_xyz, float* g_R, float* g_shift, float* g_scales,
+                                                           float* g_kscale, int H, int dim) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((n_xyz & 3) == 0 && (((uintptr_t)g_xyz) & 15) == 0) {
+    for (size_t k = i; k < (n_xyz >> 2); k += (size_t)gridDim.x * blockDim.x) ((float4*)g_xyz)[k] = z4;
+  } else {
+    for (size_t k = i; k < n_xyz; k += (size_t)gridDim.x * blockDim.x) g_xyz[k] = 0.0f;
+  }
+  if (i < (size_t)H * 9) g_R[i] = 0.0f;
+  if (i < (size_t)H * 3) g_shift[i] = 0.0f;
+  if (g_scales && i < (size_t)H * dim) g_scales[i] = 0.0f;
+  if (g_kscale && i == 0) g_kscale[0] = 0.0f;
+}
+
 // so3 exponential map of the per-head rotation parameters (Rodrigues; the map the reference imports from
 // pytorch3d, layers/utils.py:6,29,56):  theta = sqrt(max(|v|^2, eps)),  R = I + (sin theta / theta) K +
 // ((1 - cos theta) / theta^2) K^2,  K = hat(v), K^2 = v v^T - |v|^2 I.  One thread per head, evaluated in
@@ -192,12 +208,15 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   if (!valid(a) || !lattice || (!g_lattice && !g_keys) || !g_xyz || !g_residual || !g_R || !g_shift) return CT_EINVAL;
   if ((scales != nullptr) != (g_scales != nullptr) || (kscale != nullptr) != (g_kscale != nullptr)) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(g_xyz, 0, (size_t)B * 3 * N * 4, st) != hipSuccess) return CT_ELAUNCH;
-  if (hipMemsetAsync(g_R, 0, (size_t)H * 9 * 4, st) != hipSuccess) return CT_ELAUNCH;
-  if (hipMemsetAsync(g_shift, 0, (size_t)H * 3 * 4, st) != hipSuccess) return CT_ELAUNCH;
-  if (g_scales && hipMemsetAsync(g_scales, 0, (size_t)H * dim * 4, st) != hipSuccess) return CT_ELAUNCH;
-  if (g_kscale && hipMemsetAsync(g_kscale, 0, 4, st) != hipSuccess) return CT_ELAUNCH;
   CT_CLEAR_ERROR();
+  {
+    const size_t n_xyz = (size_t)B * 3 * N;
+    size_t blocks = (n_xyz / 4 + 255) / 256;
+    const size_t need = ((size_t)H * 9 + 255) / 256;       // the parameter slots are covered by the first threads
+    if (blocks < need) blocks = need;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(lattice_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_xyz, n_xyz, g_R, g_shift, g_scales, g_kscale, H, dim);
+  }
   hipLaunchKernelGGL(lattice_bwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
                      g_residual, g_R, g_shift, g_scales, g_kscale);
   CT_CHECK_LAUNCH();
