@@ -153,6 +153,9 @@ def main():
                 with torch.cuda.graph(multi):
                     for _ in range(gs):
                         step.run()
+                multi.replay()           # set-up, not a counted step: the first launch of a graph uploads it
+            graph.replay()
+            torch.cuda.synchronize()
         except Exception as ex:          # noqa: BLE001 — capture unavailable: time eager launches instead
             print("bench: HIP graph capture failed (%r), timing eager launches" % (ex,), file=sys.stderr)
             graph = multi = None
