@@ -70,3 +70,52 @@ def test_state_dict_is_plain_conv():
     ref = torch.nn.Conv3d(8, 8, 3, padding=1, groups=2)
     assert list(m.state_dict()) == list(ref.state_dict())
     ref.load_state_dict(m.state_dict(), strict=True)
+
+
+def _rand_cfg(rng):
+    dim = int(rng.integers(2, 4))
+    rows4 = rng.random() < 0.75                       # most cases on the 16-byte-row kernels (quad / ring / C4 forms)
+    Wx = int(rng.choice([4, 8, 12, 16, 20, 32, 64])) if rows4 else int(rng.integers(1, 23))
+    H = int(rng.integers(1, 21))
+    D = int(rng.integers(1, 13)) if dim == 3 else None
+    if rng.random() < 0.3:
+        cin = cout = 4                                # vector-ALU kernels
+    else:
+        cin, cout = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+    W = (D, H, Wx) if dim == 3 else (H, Wx)
+    return (int(rng.integers(1, 4)), int(rng.integers(1, 4)), cin, cout, dim, W, bool(rng.random() < 0.5))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gconv_fuzz(seed):
+    """Random shapes through every kernel family (MFMA one-position and quad forms, four-channel vector-ALU form, ring and
+    tile weight gradients, workspace reduction): ragged depth / height, single rows, channel counts off the 4 / 16 grid."""
+    from cloud_transformers_amd.layers.gconv import GroupedConv2d, GroupedConv3d
+    rng = np.random.default_rng(1000 + seed)
+    B, G, Cin, Cout, dim, W, bias = _rand_cfg(rng)
+    torch.manual_seed(seed)
+    cls = GroupedConv3d if dim == 3 else GroupedConv2d
+    m = cls(G * Cin, G * Cout, kernel_size=3, stride=1, padding=1, groups=G, bias=bias)
+    x = torch.randn(B, G * Cin, *W)
+    cot = torch.randn(B, G * Cout, *W)
+    xr = x.double().requires_grad_(True)
+    wr = m.weight.detach().double().requires_grad_(True)
+    br = m.bias.detach().double().requires_grad_(True) if bias else None
+    fn = torch.nn.functional.conv3d if dim == 3 else torch.nn.functional.conv2d
+    (fn(xr, wr, br, stride=1, padding=1, groups=G) * cot.double()).sum().backward()
+    yr = fn(xr, wr, br, stride=1, padding=1, groups=G)
+    m = m.cuda()
+    xc = x.cuda().requires_grad_(True)
+    y = m(xc)
+    (y * cot.cuda()).sum().backward()
+
+    def close(a, b, name, tol):
+        a, b = a.detach().cpu().double(), b.detach()
+        err = float((a - b).abs().max())
+        assert err <= tol * max(1.0, float(b.abs().max())), (name, (B, G, Cin, Cout, dim, W, bias), err)
+
+    close(y, yr, "y", 2e-5)
+    close(xc.grad, xr.grad, "g_x", 2e-5)
+    close(m.weight.grad, wr.grad, "g_w", 5e-5)
+    if bias:
+        close(m.bias.grad, br.grad, "g_bias", 5e-5)
