@@ -34,10 +34,20 @@ constexpr int kP = 4;                      // position groups per wave sharing o
 #define CT_GCONV_LDS (32 * 1024)
 #endif
 #ifndef CT_GCONV_LDS_WRW
-#define CT_GCONV_LDS_WRW (80 * 1024 - 512)
+#define CT_GCONV_LDS_WRW (152 * 1024)
 #endif
 constexpr int kLdsBudget = CT_GCONV_LDS;         // forward / backward-data tile budget: ~4 workgroups per CU (measured best)
 constexpr int kLdsBudgetWrw = CT_GCONV_LDS_WRW;  // backward-weight tile budget
+#ifndef CT_WRW_THREADS
+#define CT_WRW_THREADS 512
+#endif
+#ifndef CT_WRW_WANT
+#define CT_WRW_WANT 256
+#endif
+// MFMA engine of the ring kernel: one 512-thread workgroup per CU with the tallest row tile that fits, ~256 workgroups
+// (measured against 256 threads / 80 KiB / 512 workgroups: 16^3 C16 128 -> 93 us, 64^2 C16 58 -> 47 us).  The vector-ALU
+// engine is 4 waves (wave = input channel).
+constexpr int kWrwThreads = CT_WRW_THREADS;
 constexpr int kLdsBudgetMax = 152 * 1024;    // wide filter banks / large channel counts: one workgroup per CU
 
 struct GconvArgs {
@@ -564,8 +574,8 @@ __device__ __forceinline__ void wrw_group(floatx4 (&acc)[NZ * 9], float& gsum, c
   }
 }
 
-template <int DIM, bool C4>
-__global__ void __launch_bounds__(kThreads) gconv_wrw_ring_kernel(GconvArgs a, const float* gy, float* gw, float* ws, int units_per_wg) {
+template <int DIM, bool C4, int THREADS>
+__global__ void __launch_bounds__(THREADS) gconv_wrw_ring_kernel(GconvArgs a, const float* gy, float* gw, float* ws, int units_per_wg) {
   constexpr int NZ = DIM == 3 ? 3 : 1;
   constexpr int R = DIM == 3 ? 4 : 2;                   // x ring slots
   constexpr int NCH = C4 ? 4 : 16;                      // channels per block: 16 (MFMA engine) or the 4 of a C=4 group (vector ALU)
@@ -1045,17 +1055,21 @@ struct WrwRingPlan { size_t lds; int chunks, units_per_wg; };
 
 bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p, int nch = 16) {
   const int B = a.B, groups = a.groups;
+  const int threads = nch == 16 ? kWrwThreads : kThreads;
+  // the two engines were tuned separately: MFMA one big workgroup per CU, vector-ALU two of them and twice the workgroups
+  const size_t budget0 = nch == 16 ? (size_t)kLdsBudgetWrw : (size_t)(80 * 1024 - 512);
+  const int want_wgs = nch == 16 ? CT_WRW_WANT : 512;
   // the tallest row tile whose rings fit the budget (64 KiB: two workgroups per CU, then whatever one CU
   // holds), then depth chunks until ~512 workgroups exist
   const int R = dim == 3 ? 4 : 2;
-  const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
+  const size_t red_bytes = (size_t)(threads / 64) * 3 * 256 * 4;
   auto pad4 = [](int n) { return n + ((4 - (n & 63) + 64) & 63); };      // == 4 (mod 64): conflict-free ds_read_b128 operand reads
   auto ring_bytes = [&](int TH) {
     const size_t b = ((size_t)R * nch * pad4((TH + 2) * a.W) + (size_t)2 * nch * pad4((TH * a.W + 15) & ~15) + 2 * kSlack) * 4;
     return b > red_bytes ? b : red_bytes;
   };
   int TH = 0;
-  for (size_t budget : {(size_t)kLdsBudgetWrw, (size_t)kLdsBudgetMax}) {
+  for (size_t budget : {budget0, (size_t)kLdsBudgetMax}) {
     for (int t = a.H; t >= 1 && !TH; --t)
       if (ring_bytes(t) <= budget) TH = t;
     if (TH) break;
@@ -1066,7 +1080,7 @@ bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p, int nch = 16) {
   a.Hs = TH + 2; a.Ws = a.W; a.TD = 1;
   a.nD = 1; a.TZ = a.D;
   if (dim == 3) {
-    const int want = (512 + groups - 1) / groups;       // units wanted per group
+    const int want = (want_wgs + groups - 1) / groups;       // units wanted per group
     int nD = (want + B * a.nH - 1) / (B * a.nH);
     if (nD > a.D / 2) nD = a.D / 2 > 0 ? a.D / 2 : 1;    // at least two slices per chunk: each loads two extra x slices
     if (nD < 1) nD = 1;
@@ -1075,7 +1089,7 @@ bool plan_wrw_ring(GconvArgs& a, int dim, WrwRingPlan& p, int nch = 16) {
   }
   p.lds = ring_bytes(TH);
   const int U = B * a.nH * a.nD;
-  int chunks = (512 + groups - 1) / groups;           // ~512 workgroups in flight
+  int chunks = (want_wgs + groups - 1) / groups;
   if (chunks > U) chunks = U;
   if (chunks < 1) chunks = 1;
   p.units_per_wg = (U + chunks - 1) / chunks;
@@ -1096,11 +1110,11 @@ int launch_wrw_ring(GconvArgs a, int dim, const float* g_y, float* g_w, float* g
   if (!ws && hipMemsetAsync(g_w, 0, (size_t)a.groups * a.Cout * a.Cin * a.taps * 4, st) != hipSuccess) return CT_ELAUNCH;
   dim3 grid(p.chunks, a.groups);
   if (dim == 2) {
-    if (set_lds_attr(gconv_wrw_ring_kernel<2, false>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, false>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<2, false, kWrwThreads>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, false, kWrwThreads>), grid, dim3(kWrwThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   } else {
-    if (set_lds_attr(gconv_wrw_ring_kernel<3, false>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, false>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<3, false, kWrwThreads>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, false, kWrwThreads>), grid, dim3(kWrwThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   }
   if (ws) {
     const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
@@ -1124,11 +1138,11 @@ int launch_c4_wrw(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_b
   if (ws_bytes < c4_wrw_workspace(a, p)) return CT_EWORKSPACE;
   dim3 grid(p.chunks, a.groups);
   if (dim == 2) {
-    if (set_lds_attr(gconv_wrw_ring_kernel<2, true>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, true>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<2, true, kThreads>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<2, true, kThreads>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   } else {
-    if (set_lds_attr(gconv_wrw_ring_kernel<3, true>, p.lds) != CT_OK) return CT_ELAUNCH;
-    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, true>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
+    if (set_lds_attr(gconv_wrw_ring_kernel<3, true, kThreads>, p.lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, true, kThreads>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   }
   const int n = a.groups * 16 * a.taps;
   hipLaunchKernelGGL(gconv_c4_wrw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, g_w, g_bias, p.chunks, a.groups, a.taps);
