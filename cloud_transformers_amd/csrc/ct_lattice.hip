@@ -42,8 +42,9 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
   }
 }
 
-// grid = (ceil(N/256), H, B).  Point-wise outputs: g_res; g_xyz accumulated over heads with atomics
-// (zeroed first).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
+// grid = (ceil(N/256), H, B).  Point-wise output: the cotangent gp of the moved point, stored per head in g_res;
+// lattice_bwd_finish_kernel then sums it over the heads into g_xyz and scales g_res by kscale in place (g_xyz used
+// to be accumulated with B*3*N*H device-scope float atomics, most of this pass's time).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
 // reduced per workgroup and added with one atomic each.
 __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const float* lattice, const float* g_lattice,
                                                           const float* g_keys, float* g_xyz, float* g_res, float* g_R, float* g_shift,
@@ -77,10 +78,7 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   for (int c = 0; c < 3; ++c) gp[c] = R[c * 3 + 0] * gq[0] + R[c * 3 + 1] * gq[1] + R[c * 3 + 2] * gq[2];
   if (ok) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = ks * gp[c];
-      atomicAdd(&g_xyz[((size_t)b * 3 + c) * a.N + n], gp[c]);
-    }
+    for (int c = 0; c < 3; ++c) g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = gp[c];   // unscaled: lattice_bwd_finish_kernel
   }
   // 16 per-head parameter partials: g_R[c][j] = p_c * gq_j (9), g_shift[c] = gp_c (3), g_scales[j] (3), g_kscale (1)
   float part[16];
@@ -110,20 +108,29 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   }
 }
 
-// zero every accumulation target of lattice_bwd_kernel in ONE launch (five stream memsets cost five launch gaps)
-__global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_xyz, size_t n_xyz, float* g_R, float* g_shift, float* g_scales,
-                                                           float* g_kscale, int H, int dim) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((n_xyz & 3) == 0 && (((uintptr_t)g_xyz) & 15) == 0) {
-    for (size_t k = i; k < (n_xyz >> 2); k += (size_t)gridDim.x * blockDim.x) ((float4*)g_xyz)[k] = z4;
-  } else {
-    for (size_t k = i; k < n_xyz; k += (size_t)gridDim.x * blockDim.x) g_xyz[k] = 0.0f;
-  }
-  if (i < (size_t)H * 9) g_R[i] = 0.0f;
-  if (i < (size_t)H * 3) g_shift[i] = 0.0f;
-  if (g_scales && i < (size_t)H * dim) g_scales[i] = 0.0f;
+// zero the per-head parameter cotangents (atomic targets of lattice_bwd_kernel) in ONE launch
+__global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_R, float* g_shift, float* g_scales, float* g_kscale, int H, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < H * 9) g_R[i] = 0.0f;
+  if (i < H * 3) g_shift[i] = 0.0f;
+  if (g_scales && i < H * dim) g_scales[i] = 0.0f;
   if (g_kscale && i == 0) g_kscale[0] = 0.0f;
+}
+
+// g_xyz[b,c,n] = sum_h gp[b,h,c,n];  g_res[b,h,c,n] = kscale * gp[b,h,c,n]  (in place).  One thread per (b, c, n).
+__global__ void __launch_bounds__(256) lattice_bwd_finish_kernel(float* g_res, float* g_xyz, const float* kscale, int B, int H, int N) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // over (c, n)
+  const int b = blockIdx.y;
+  if (i >= (size_t)3 * N) return;
+  const float ks = kscale ? kscale[0] : 1.0f;
+  float* p = g_res + (size_t)b * H * 3 * N + i;
+  float s = 0.0f;
+  for (int h = 0; h < H; ++h) {
+    const float v = p[(size_t)h * 3 * N];
+    s += v;
+    if (kscale) p[(size_t)h * 3 * N] = ks * v;
+  }
+  g_xyz[(size_t)b * 3 * N + i] = s;
 }
 
 // so3 exponential map of the per-head rotation parameters (Rodrigues; the map the reference imports from
@@ -209,16 +216,11 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   if ((scales != nullptr) != (g_scales != nullptr) || (kscale != nullptr) != (g_kscale != nullptr)) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
   CT_CLEAR_ERROR();
-  {
-    const size_t n_xyz = (size_t)B * 3 * N;
-    size_t blocks = (n_xyz / 4 + 255) / 256;
-    const size_t need = ((size_t)H * 9 + 255) / 256;       // the parameter slots are covered by the first threads
-    if (blocks < need) blocks = need;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(lattice_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_xyz, n_xyz, g_R, g_shift, g_scales, g_kscale, H, dim);
-  }
+  hipLaunchKernelGGL(lattice_zero_kernel, dim3((H * 9 + 255) / 256), dim3(256), 0, st, g_R, g_shift, g_scales, g_kscale, H, dim);
   hipLaunchKernelGGL(lattice_bwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
                      g_residual, g_R, g_shift, g_scales, g_kscale);
+  hipLaunchKernelGGL(lattice_bwd_finish_kernel, dim3((unsigned)(((size_t)3 * N + 255) / 256), B), dim3(256), 0, st, g_residual, g_xyz,
+                     kscale, B, H, N);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

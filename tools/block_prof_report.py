@@ -4,7 +4,7 @@ import csv
 import glob
 import sys
 
-ITERS = 100
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = list(csv.DictReader(open(glob.glob("gpurun_out/prof_block/*kernel_stats.csv")[0])))
 tot = 0.0
 out = []
