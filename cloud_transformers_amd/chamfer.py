@@ -14,7 +14,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import _lib
-from .ops import _dev, _ptr, _stream
+from .ops import _dev, _ptr, _stream, _on
 
 
 class ChamferFunction(Function):
@@ -34,7 +34,7 @@ class ChamferFunction(Function):
         idx1 = torch.empty(B, n, device=dev, dtype=torch.int32)
         idx2 = torch.empty(B, m, device=dev, dtype=torch.int32)
         lib = _lib.load()
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.ct_chamfer_fwd(_ptr(xyz1), _ptr(xyz2), _ptr(dist1), _ptr(dist2), _ptr(idx1), _ptr(idx2),
                                           B, n, m, _stream()), "ct_chamfer_fwd")
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
@@ -51,7 +51,7 @@ class ChamferFunction(Function):
         gradxyz1 = torch.empty_like(xyz1)
         gradxyz2 = torch.empty_like(xyz2)
         lib = _lib.load()
-        with torch.cuda.device(xyz1.device):
+        with _on(xyz1.device):
             _lib.check(lib.ct_chamfer_bwd(_ptr(xyz1), _ptr(xyz2), _ptr(graddist1), _ptr(graddist2),
                                           _ptr(idx1), _ptr(idx2), _ptr(gradxyz1), _ptr(gradxyz2),
                                           B, n, m, _stream()), "ct_chamfer_bwd")

@@ -15,7 +15,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import _lib
-from .ops import _dev, _ptr, _stream
+from .ops import _dev, _ptr, _stream, _on
 
 
 class emdFunction(Function):
@@ -36,7 +36,7 @@ class emdFunction(Function):
         lib = _lib.load()
         nws = lib.ct_emd_workspace_bytes(batchsize, n)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.ct_emd_fwd(_ptr(xyz1), _ptr(xyz2), _ptr(dist), _ptr(assignment), _ptr(ws), nws,
                                       batchsize, n, float(eps), int(iters), _stream()), "ct_emd_fwd")
         ctx.save_for_backward(xyz1, xyz2, assignment)
@@ -51,7 +51,7 @@ class emdFunction(Function):
         gradxyz2 = torch.zeros_like(xyz2)
         lib = _lib.load()
         B, n, _ = xyz1.shape
-        with torch.cuda.device(xyz1.device):
+        with _on(xyz1.device):
             _lib.check(lib.ct_emd_bwd(_ptr(xyz1), _ptr(xyz2), _ptr(graddist), _ptr(assignment), _ptr(gradxyz1),
                                       B, n, _stream()), "ct_emd_bwd")
         return gradxyz1, gradxyz2, None, None

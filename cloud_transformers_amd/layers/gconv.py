@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import _lib
-from ..ops import _ptr, _stream
+from ..ops import _ptr, _stream, _on
 
 
 class GroupedConvFn(torch.autograd.Function):
@@ -27,7 +27,7 @@ class GroupedConvFn(torch.autograd.Function):
         W = list(x.shape[2:])
         y = torch.empty(B, groups * Cout, *W, device=x.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(lib.ct_gconv_fwd(_ptr(x), _ptr(weight), _ptr(bias.contiguous()) if bias is not None else None,
                                         _ptr(y), B, groups, Cin, Cout, dim, _lib.int_array(W), _stream()),
                        "ct_gconv_fwd")
@@ -44,7 +44,7 @@ class GroupedConvFn(torch.autograd.Function):
         lib = _lib.load()
         Wa = _lib.int_array(W)
         g_x = g_w = g_b = None
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             if ctx.needs_input_grad[0]:
                 g_x = torch.empty_like(x)
                 _lib.check(lib.ct_gconv_bwd_data(_ptr(g_y), _ptr(weight), _ptr(g_x), B, groups, Cin, Cout, dim, Wa,

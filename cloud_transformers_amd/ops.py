@@ -32,6 +32,25 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes `device` current for the launch: a no-op object when it already is (the usual case;
+    half the host cost of torch.cuda.device(), 0.6 vs 1.4 us per op)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -69,7 +88,7 @@ class PositionsFn(torch.autograd.Function):
         lc = torch.empty(B, H, V, N, device=keys.device, dtype=torch.float32)
         idx = torch.empty(B, H, V, N, device=keys.device, dtype=torch.int64)
         lib = _lib.load()
-        with torch.cuda.device(keys.device):
+        with _on(keys.device):
             _lib.check(lib.ct_positions_fwd(_ptr(keys), _ptr(lc), _ptr(idx), B, H, N, dim,
                                             _lib.int_array(W), _stream()), "ct_positions_fwd")
         ctx.save_for_backward(keys)
@@ -85,7 +104,7 @@ class PositionsFn(torch.autograd.Function):
         g_lc = _f32c(g_lc)
         g_keys = torch.empty_like(keys)
         lib = _lib.load()
-        with torch.cuda.device(keys.device):
+        with _on(keys.device):
             _lib.check(lib.ct_positions_bwd(_ptr(keys), _ptr(g_lc), _ptr(g_keys), B, H, N, len(W),
                                             _lib.int_array(W), _stream()), "ct_positions_bwd")
         return g_keys, None, None
@@ -106,7 +125,7 @@ class SplatKeysFn(torch.autograd.Function):
         padt, pad_code = _pad_args(pad, B, N)
         grid = torch.empty(B, HC, *W, device=feat.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(feat.device):
+        with _on(feat.device):
             _lib.check(lib.ct_splat_fwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
                                         B, H, C, N, dim, _lib.int_array(W), _lib.REDUCE[reduce], _stream()),
                        "ct_splat_fwd")
@@ -127,7 +146,7 @@ class SplatKeysFn(torch.autograd.Function):
         Wa = _lib.int_array(W)
         ws_bytes = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, _lib.REDUCE[reduce])
         ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
-        with torch.cuda.device(feat.device):
+        with _on(feat.device):
             _lib.check(lib.ct_splat_bwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid), _ptr(g_grid),
                                         _ptr(g_feat), _ptr(g_keys), _ptr(ws), ws_bytes,
                                         B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_bwd")
@@ -147,7 +166,7 @@ class SliceKeysFn(torch.autograd.Function):
         padt, pad_code = _pad_args(pad, B, N)
         out = torch.empty(B, HC, N, device=grid.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(grid.device):
+        with _on(grid.device):
             _lib.check(lib.ct_slice_fwd(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(out),
                                         B, H, C, N, dim, _lib.int_array(W), _stream()), "ct_slice_fwd")
         ctx.save_for_backward(keys, grid, padt)
@@ -164,7 +183,7 @@ class SliceKeysFn(torch.autograd.Function):
         g_grid = torch.empty_like(grid)
         g_keys = torch.empty_like(keys)
         lib = _lib.load()
-        with torch.cuda.device(grid.device):
+        with _on(grid.device):
             _lib.check(lib.ct_slice_bwd(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
                                         _ptr(g_grid), _ptr(g_keys), B, H, C, N, dim, _lib.int_array(W), _stream()),
                        "ct_slice_bwd")
@@ -193,7 +212,7 @@ class SplatLcFn(torch.autograd.Function):
         padt, pad_code = _pad_args(pad, B, N)
         grid = torch.empty(B, HC, *W, device=feat.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(feat.device):
+        with _on(feat.device):
             _lib.check(lib.ct_splat_lc_fwd(_ptr(lc), _ptr(idx), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
                                            B, H, C, N, dim, _lib.int_array(W), _lib.REDUCE[reduce], _stream()),
                        "ct_splat_lc_fwd")
@@ -214,7 +233,7 @@ class SplatLcFn(torch.autograd.Function):
         Wa = _lib.int_array(W)
         ws_bytes = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, _lib.REDUCE[reduce])
         ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
-        with torch.cuda.device(feat.device):
+        with _on(feat.device):
             _lib.check(lib.ct_splat_lc_bwd(_ptr(lc), _ptr(idx), _ptr(feat), _ptr(padt), pad_code, _ptr(grid),
                                            _ptr(g_grid), _ptr(g_feat), _ptr(g_lc), _ptr(ws), ws_bytes,
                                            B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_lc_bwd")
@@ -236,7 +255,7 @@ class SliceLcFn(torch.autograd.Function):
         padt, pad_code = _pad_args(pad, B, N)
         out = torch.empty(B, HC, N, device=grid.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(grid.device):
+        with _on(grid.device):
             _lib.check(lib.ct_slice_lc_fwd(_ptr(lc), _ptr(idx), _ptr(grid), _ptr(padt), pad_code, _ptr(out),
                                            B, H, C, N, dim, _lib.int_array(W), _stream()), "ct_slice_lc_fwd")
         ctx.save_for_backward(lc, idx, grid, padt)
@@ -253,7 +272,7 @@ class SliceLcFn(torch.autograd.Function):
         g_grid = torch.empty_like(grid)
         g_lc = torch.empty_like(lc)
         lib = _lib.load()
-        with torch.cuda.device(grid.device):
+        with _on(grid.device):
             _lib.check(lib.ct_slice_lc_bwd(_ptr(lc), _ptr(idx), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
                                            _ptr(g_grid), _ptr(g_lc), B, H, C, N, dim, _lib.int_array(W), _stream()),
                        "ct_slice_lc_bwd")
@@ -276,7 +295,7 @@ class LatticeFn(torch.autograd.Function):
         keys = torch.empty(B, H * dim, N, device=xyz.device, dtype=torch.float32)
         lattice = torch.empty_like(keys)
         lib = _lib.load()
-        with torch.cuda.device(xyz.device):
+        with _on(xyz.device):
             _lib.check(lib.ct_lattice_fwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
                                           _ptr(keys), _ptr(lattice), B, H, N, dim, _stream()), "ct_lattice_fwd")
         ctx.save_for_backward(xyz, residual, R, shift, scales, ks, lattice)
@@ -294,7 +313,7 @@ class LatticeFn(torch.autograd.Function):
         g_scales = torch.empty_like(scales) if scales is not None else None
         g_ks = torch.empty_like(ks) if ks is not None else None
         lib = _lib.load()
-        with torch.cuda.device(xyz.device):
+        with _on(xyz.device):
             _lib.check(lib.ct_lattice_bwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
                                           _ptr(lattice), _ptr(g_lattice), _ptr(g_keys), _ptr(g_xyz), _ptr(g_res),
                                           _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), B, H, N, dim, _stream()),
@@ -317,7 +336,7 @@ class So3ExpFn(torch.autograd.Function):
         H = log_R.shape[0]
         R = torch.empty(H, 3, 3, device=log_R.device, dtype=torch.float32)
         lib = _lib.load()
-        with torch.cuda.device(log_R.device):
+        with _on(log_R.device):
             _lib.check(lib.ct_so3_exp_fwd(_ptr(log_R), _ptr(R), H, float(eps), _stream()), "ct_so3_exp_fwd")
         ctx.save_for_backward(log_R)
         ctx.eps = float(eps)
@@ -329,7 +348,7 @@ class So3ExpFn(torch.autograd.Function):
         g_R = _f32c(g_R)
         g = torch.empty_like(log_R)
         lib = _lib.load()
-        with torch.cuda.device(log_R.device):
+        with _on(log_R.device):
             _lib.check(lib.ct_so3_exp_bwd(_ptr(log_R), _ptr(g_R), _ptr(g), log_R.shape[0], ctx.eps, _stream()), "ct_so3_exp_bwd")
         return g, None
 
@@ -351,7 +370,7 @@ class AdaInFn(torch.autograd.Function):
         mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(lib.ct_adain_fwd(_ptr(x), _ptr(gamma_beta), _ptr(y), _ptr(mean), _ptr(rstd), B, C, N,
                                         float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
         ctx.save_for_backward(x, gamma_beta, mean, rstd)
@@ -366,7 +385,7 @@ class AdaInFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         g_gb = torch.empty_like(gamma_beta)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(lib.ct_adain_bwd(_ptr(x), _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), _ptr(gx), _ptr(g_gb),
                                         B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
         return gx, g_gb, None, None
@@ -449,6 +468,6 @@ def grid_occupancy_count(grid):
     grid = _f32c(grid)
     count = torch.empty((), device=grid.device, dtype=torch.int64)
     lib = _lib.load()
-    with torch.cuda.device(grid.device):
+    with _on(grid.device):
         _lib.check(lib.ct_grid_occupancy(_ptr(grid), grid.numel(), _ptr(count), _stream()), "ct_grid_occupancy")
     return count
