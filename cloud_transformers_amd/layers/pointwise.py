@@ -1,11 +1,13 @@
 """Point-wise (kernel_size 1) Conv1d of the MHCT blocks — `keys_values_pred`, the union's `after` and
 `shortcut` projections (reference layers/multihead_ct.py:31-33,149-160).
 
-A plain library GEMM, and it stays one: forward and the data gradient go through torch's conv1d (MIOpen
-picks rocBLAS/Tensile GEMMs for them).  For the WEIGHT gradient MIOpen picks an NHWC implicit-GEMM
-kernel bracketed by layout transposes of x and g_y; `g_w = sum_b g_y[b] @ x[b]^T` as one rocBLAS batched
-GEMM on the tensors as they lie needs no transposes and is 18-24 % faster on the whole fwd+bwd of these
-layers at B8 N4096 (tools/conv1d_bench.py).  `PointwiseConv1d` subclasses nn.Conv1d: same parameters,
+A plain library GEMM, and it stays one — three rocBLAS batched GEMMs on the tensors as they lie:
+`y[b] = W @ x[b]`, `g_x[b] = W^T @ g_y[b]` (W and W^T as broadcast views), `g_w = sum_b g_y[b] @ x[b]^T`.
+torch's conv1d reaches the same GEMMs through MIOpen for forward / data gradient (5-10 % slower at these
+shapes), but for the WEIGHT gradient MIOpen picks an NHWC implicit-GEMM kernel bracketed by layout
+transposes of x and g_y: 18-24 % slower on the whole fwd+bwd of these layers at B8 N4096
+(tools/conv1d_bench.py).
+`PointwiseConv1d` subclasses nn.Conv1d: same parameters,
 same state-dict keys, same results.
 """
 import torch
@@ -18,7 +20,11 @@ class _PointwiseConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.conv1d(x, weight, bias)
+        w2 = weight[:, :, 0]
+        # bmm with W broadcast over the batch keeps the [B, O, N] layout (torch.matmul(W, x) folds the batch into
+        # the GEMM's M and returns a transposed view, which costs transposing copies downstream)
+        y = torch.bmm(w2.unsqueeze(0).expand(x.size(0), -1, -1), x)
+        return y if bias is None else y + bias[None, :, None]
 
     @staticmethod
     def backward(ctx, g_y):
@@ -26,7 +32,7 @@ class _PointwiseConvFn(torch.autograd.Function):
         g_y = g_y.contiguous()
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
-            g_x = F.conv1d(g_y, weight.transpose(0, 1).contiguous())
+            g_x = torch.bmm(weight[:, :, 0].t().unsqueeze(0).expand(g_y.size(0), -1, -1), g_y)    # W^T as a view
         if ctx.needs_input_grad[1]:
             g_w = torch.bmm(g_y, x.transpose(1, 2)).sum(0).unsqueeze(-1)      # [O, I, 1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
