@@ -1011,10 +1011,10 @@ __global__ void positions_bwd_kernel(const float* keys, const float* g_lc, float
   for (int j = 0; j < DIM; ++j) g_keys[(bh * DIM + j) * N + n] = gs[j] * mask[j];
 }
 
-__global__ void __launch_bounds__(256) occupancy_kernel(const float* grid, long long n, unsigned long long* count) {
+__global__ void __launch_bounds__(1024) occupancy_kernel(const float* grid, long long n, unsigned long long* count) {
   // dwordx4 stream, wave + block reduction, ONE atomic per workgroup (thousands of atomics on a
   // single address serialise at ~12 ns each and used to dominate this kernel)
-  __shared__ unsigned s_part[4];
+  __shared__ unsigned s_part[16];
   unsigned local = 0;
   const long long n4 = n >> 2;
   const float4* g4 = (const float4*)grid;
@@ -1034,7 +1034,8 @@ __global__ void __launch_bounds__(256) occupancy_kernel(const float* grid, long 
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = local;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long t = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    unsigned long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_part[w];
     if (t) atomicAdd(count, t);
   }
 }
@@ -1593,10 +1594,11 @@ int ct_grid_occupancy(const float* grid, int64_t n, int64_t* count, ct_stream_t 
   if (hipMemsetAsync(count, 0, sizeof(int64_t), st) != hipSuccess) return CT_ELAUNCH;
   if (n == 0) return CT_OK;
   CT_CLEAR_ERROR();
-  int blocks = (int)((n + 4095) / 4096);
-  if (blocks > 1024) blocks = 1024;
+  // one 1024-thread workgroup per CU at most: the per-workgroup atomics on the single counter serialise (~12 ns each)
+  int blocks = (int)((n + 16383) / 16384);
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(256), 0, st, grid, (long long)n, (unsigned long long*)count);
+  hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(1024), 0, st, grid, (long long)n, (unsigned long long*)count);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
