@@ -11,10 +11,11 @@ from cloud_transformers_amd.layers import multihead_ct as M
 
 
 def main():
-    B, N = 8, 4096
+    small = len(sys.argv) > 1 and sys.argv[1] == "small"          # tests/test_graph_gpu.py: a quick functional run
+    B, N, dim = (2, 512, 64) if small else (8, 4096, 512)
     torch.manual_seed(1)
-    m = M.MultiHeadUnion(512, [16, 16], [64, 16], [2, 3], [16, 16]).cuda()
-    x = torch.randn(B, 512, N, device="cuda", requires_grad=True)
+    m = (M.MultiHeadUnion(dim, [4, 8], [16, 8], [2, 3], [4, 4]) if small else M.MultiHeadUnion(dim, [16, 16], [64, 16], [2, 3], [16, 16])).cuda()
+    x = torch.randn(B, dim, N, device="cuda", requires_grad=True)
     pcd = torch.rand(B, 3, N, device="cuda") * 2 - 1
 
     def step():
