@@ -1273,6 +1273,46 @@ inline int splat_bwd_ncg(int B, int H, int nchunks) {
   return ncg;
 }
 
+// the launches of Splat(max) backward; `parts` (set by the caller) tells whether the kernels wrote per-group partial
+// g_keys that still have to be summed — the whole-head form clears it
+template <int DIM, bool FROM_KEYS>
+int launch_splat_max_bwd(RasterArgs a, const GridW<DIM>& g, const Plan& p, bool two, float* g_pos_out, bool& parts, void* ws,
+                         size_t ws_bytes, hipStream_t st) {
+  dim3 grid(a.ncg, a.H, a.B);
+  if (!p.lds_tile) {
+    size_t need = (size_t)a.B * a.H * a.C * g.G * 4;
+    if (!ws || ws_bytes < need) return CT_EWORKSPACE;
+    if (hipMemcpyAsync(ws, a.tile_in, need, hipMemcpyDeviceToDevice, st) != hipSuccess) return CT_ELAUNCH;
+    a.claim = (unsigned*)ws;
+    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
+    return CT_OK;
+  }
+  if constexpr (DIM == 2) {
+#ifndef CT_NO_WHOLE_HEAD
+    // whole-head form: z and g_z tiles of ALL channels of a (b,h) plane resident (<= 160 KiB,
+    // one 1024-thread workgroup per CU): one staging pass, keys read once, g_keys written once
+    const size_t wh_bytes = (size_t)2 * a.C * g.G * 4;
+    if (two && wh_bytes <= (size_t)kBigLdsBytes && wh_bytes > (size_t)kMaxLdsBytes && (long long)a.B * a.H >= 256 &&
+        quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
+      a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
+      a.g_pos = g_pos_out; a.gpos_stride = 0; parts = false;
+      int t = round_threads(a.N >> 2);
+      dim3 wgrid(1, a.H, a.B);
+      if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
+      else CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512, false), wgrid, t, wh_bytes, st, a, g);
+      return CT_OK;
+    }
+#endif
+    if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
+      CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
+      return CT_OK;
+    }
+  }
+  if (two) CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
+  else CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, p.lds_bytes, st, a, g);
+  return CT_OK;
+}
+
 template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
@@ -1288,49 +1328,18 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   // workspace each group stores its partial and sum_parts_kernel adds them in a fixed order.
   float* const g_pos_out = a.g_pos;
   const size_t gpos_n = gpos_bytes<DIM, FROM_KEYS>(a) / 4;
-  const bool parts = a.ncg > 1 && p.lds_tile && ws && ws_bytes >= (size_t)a.ncg * gpos_n * 4;
+  bool parts = a.ncg > 1 && p.lds_tile && ws && ws_bytes >= (size_t)a.ncg * gpos_n * 4;
   if (parts) { a.g_pos = (float*)ws; a.gpos_stride = gpos_n; }
   a.atomic_gpos = a.ncg > 1 && !parts;
   if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
-  struct SumParts {                                   // runs when the function returns, after the launch
-    bool on; const float* src; float* dst; size_t n; int k; hipStream_t st;
-    ~SumParts() {
-      if (on) hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, n, k);
-    }
-  } sum_parts{parts, (const float*)ws, g_pos_out, gpos_n, a.ncg, st};
-  dim3 grid(a.ncg, a.H, a.B);
-  if (p.lds_tile) {
-    bool done = false;
-    if constexpr (DIM == 2) {
-#ifndef CT_NO_WHOLE_HEAD
-      // whole-head form: z and g_z tiles of ALL channels of a (b,h) plane resident (<= 160 KiB,
-      // one 1024-thread workgroup per CU): one staging pass, keys read once, g_keys written once
-      const size_t wh_bytes = (size_t)2 * a.C * g.G * 4;
-      if (two && wh_bytes <= (size_t)kBigLdsBytes && wh_bytes > (size_t)kMaxLdsBytes && (long long)a.B * a.H >= 256 &&
-          quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
-        a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
-        a.g_pos = g_pos_out; a.gpos_stride = 0; sum_parts.on = false;
-        int t = round_threads(a.N >> 2);
-        dim3 wgrid(1, a.H, a.B);
-        if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
-        else CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512, false), wgrid, t, wh_bytes, st, a, g);
-        return CT_OK;
-      }
-#endif
-      if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
-        CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
-        done = true;
-      }
-    }
-    if (done) return CT_OK;
-    if (two) CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
-    else CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, p.lds_bytes, st, a, g);
-  } else {
-    size_t need = (size_t)a.B * a.H * a.C * g.G * 4;
-    if (!ws || ws_bytes < need) return CT_EWORKSPACE;
-    if (hipMemcpyAsync(ws, a.tile_in, need, hipMemcpyDeviceToDevice, st) != hipSuccess) return CT_ELAUNCH;
-    a.claim = (unsigned*)ws;
-    CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
+  const int ncg = a.ncg;
+  const int r = launch_splat_max_bwd<DIM, FROM_KEYS>(a, g, p, two, g_pos_out, parts, ws, ws_bytes, st);
+  if (r != CT_OK) return r;
+  if (parts) {
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos_out, gpos_n,
+                       gpos_n, ncg);
+    CT_CHECK_LAUNCH();
   }
   return CT_OK;
 }
