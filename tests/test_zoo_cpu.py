@@ -1,0 +1,49 @@
+"""Level-1 integration: the reference's own model_zoo files, exec'd the way utils/train_util.py:23-34
+does, resolve `layers.*` / `unet2d.*` to THIS package and build models whose state-dict layout (every parameter /
+buffer name and shape) is the one the reference's layers produce — released checkpoints load with strict=True.
+
+The expected layouts are data recorded from the reference by tests/golden/gen_zoo_state_dicts.py.  The model files
+themselves are read from /root/reference at test time, so this test only runs in the build container (it is skipped
+where the reference is not mounted; it needs no GPU: construction and state dicts only)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, %(root)r)            # this package's layers/ unet2d/ utils/ chamfer_extension/ emd_linear/ first
+sys.path.append(%(ref)r)                # the reference last: only model_zoo/ (and its harness) come from it
+import layers.multihead_ct as L
+assert L.__file__.startswith(%(root)r), L.__file__
+ns = {"__name__": "zoo_model"}
+exec(compile(open(%(ref)r + "/" + sys.argv[1]).read(), sys.argv[1], "exec"), ns)
+model = ns["Model"]()
+sd = model.state_dict()
+# a reference-layout state dict (same keys / shapes, fresh values) must load strictly
+fake = {k: torch.zeros_like(v) for k, v in sd.items()}
+model.load_state_dict(fake, strict=True)
+print(json.dumps({k: list(v.shape) for k, v in sd.items()}))
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference not mounted (build container only)")
+@pytest.mark.parametrize("rel", ["model_zoo/s3dis/segmenter.py", "model_zoo/s3dis/segmenter_pad.py",
+                                 "model_zoo/scanobject/classifier.py", "model_zoo/scanobject/classifier_scales.py",
+                                 "model_zoo/completion/inpainter.py"])
+def test_reference_zoo_file_builds_on_this_package(rel):
+    with open(os.path.join(ROOT, "tests", "golden", "zoo_state_dicts.json")) as f:
+        expected = json.load(f)[rel]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "ref": REF}, rel], capture_output=True, text=True,
+                       timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert set(got) == set(expected), (sorted(set(expected) - set(got))[:5], sorted(set(got) - set(expected))[:5])
+    wrong = {k: (got[k], expected[k]) for k in got if got[k] != expected[k]}
+    assert not wrong, list(wrong.items())[:5]
