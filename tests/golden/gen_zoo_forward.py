@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Whole-model golden: the reference's S3DIS segmenter (model_zoo/s3dis/segmenter.py on the reference's own layers, CPU,
+the two third-party stand-ins of gen_golden.py) evaluated on a small seeded cloud.  Weights are NOT stored: they are
+the ones `torch.manual_seed(SEED); Model()` produces, and this package's modules draw their initial parameters in the
+same order (checked by tests/test_zoo_cpu.py::test_same_seed_same_weights), so the GPU test rebuilds them from the seed.
+
+Saved to tests/golden/zoo_segmenter_forward.npz: the input cloud, the logits in eval mode and in training mode (batch
+statistics), and d(sum of logits * cot)/d(cloud) in eval mode.
+
+usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_zoo_forward.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G          # noqa: E402
+
+SEED, B, N = 0, 2, 512
+
+
+def main():
+    G._install_shims()
+    if G.REF not in sys.path:
+        sys.path.insert(0, G.REF)
+    ns = {"__name__": "zoo_model"}
+    with open(os.path.join(G.REF, "model_zoo/s3dis/segmenter.py")) as f:
+        exec(compile(f.read(), "segmenter.py", "exec"), ns)
+    torch.manual_seed(SEED)
+    model = ns["Model"]()
+    g = torch.Generator().manual_seed(SEED + 1)
+    xyz = torch.rand(B, 3, N, generator=g) * 2 - 1
+    rgb = torch.rand(B, 3, N, generator=g)
+    cloud = torch.cat([xyz, rgb], dim=1)[:, :, None].contiguous()          # [B, 6, 1, N] as the loaders deliver it
+    cot = torch.randn(B, 13, 1, N, generator=g)
+    model.eval()
+    x = cloud.clone().requires_grad_(True)
+    out_eval, _ = model(x)
+    (out_eval * cot).sum().backward()
+    g_cloud = x.grad.clone()
+    model.train()
+    with torch.no_grad():
+        out_train, _ = model(cloud)
+    np.savez_compressed(os.path.join(HERE, "zoo_segmenter_forward.npz"), seed=SEED, cloud=cloud.numpy(), cot=cot.numpy(),
+                        out_eval=out_eval.detach().numpy(), g_cloud=g_cloud.numpy(), out_train=out_train.numpy())
+    print("saved", out_eval.shape, float(out_eval.abs().max()), float(g_cloud.abs().max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -47,3 +47,46 @@ def test_reference_zoo_file_builds_on_this_package(rel):
     assert set(got) == set(expected), (sorted(set(expected) - set(got))[:5], sorted(set(got) - set(expected))[:5])
     wrong = {k: (got[k], expected[k]) for k in got if got[k] != expected[k]}
     assert not wrong, list(wrong.items())[:5]
+
+
+REF_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r + "/tests/golden")
+import gen_golden as G
+G._install_shims()
+sys.path.insert(0, G.REF)
+ns = {"__name__": "zoo_model"}
+exec(compile(open(G.REF + "/" + sys.argv[1]).read(), sys.argv[1], "exec"), ns)
+torch.manual_seed(0)
+torch.save(ns["Model"]().state_dict(), sys.argv[2])
+"""
+
+OURS_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+sys.path.append(%(ref)r)
+ns = {"__name__": "zoo_model"}
+exec(compile(open(%(ref)r + "/" + sys.argv[1]).read(), sys.argv[1], "exec"), ns)
+torch.manual_seed(0)
+sd = ns["Model"]().state_dict()
+ref = torch.load(sys.argv[2])
+bad = [k for k in sd if not torch.equal(sd[k], ref[k])]
+print("DIFFERING", len(bad), bad[:5])
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference not mounted (build container only)")
+@pytest.mark.parametrize("rel", ["model_zoo/s3dis/segmenter.py", "model_zoo/completion/inpainter.py"])
+def test_same_seed_same_weights(rel, tmp_path):
+    """This package's modules draw their initial parameters in the reference's order: after torch.manual_seed(s) a zoo
+    model built here has bit-identical weights to the one built on the reference's layers.  (That is what lets the
+    whole-model GPU parity test, tests/test_zoo_gpu.py, rebuild the golden's weights from a seed instead of a 37 MB file.)"""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    sd_path = str(tmp_path / "ref_sd.pt")
+    a = subprocess.run([sys.executable, "-c", REF_CHILD % {"root": ROOT}, rel, sd_path], capture_output=True, text=True,
+                       timeout=300, env=env, cwd="/tmp")
+    assert a.returncode == 0, a.stderr[-3000:]
+    b = subprocess.run([sys.executable, "-c", OURS_CHILD % {"root": ROOT, "ref": REF}, rel, sd_path], capture_output=True,
+                       text=True, timeout=300, env=env, cwd="/tmp")
+    assert b.returncode == 0, b.stderr[-3000:]
+    assert "DIFFERING 0 " in b.stdout, b.stdout[-500:]

@@ -1,0 +1,70 @@
+"""Whole-model parity on the GPU: an S3DIS-segmenter network assembled from this package's blocks against the
+reference's own model (model_zoo/s3dis/segmenter.py on the reference's layers, CPU) — golden
+tests/golden/zoo_segmenter_forward.npz, made by tests/golden/gen_zoo_forward.py.
+
+The golden stores no weights: both sides are `torch.manual_seed(seed)` + default initialisation, and this package's
+modules draw their parameters in the reference's order (tests/test_zoo_cpu.py::test_same_seed_same_weights).  The
+network below is this test's own statement of the architecture (stem, twelve MultiHeadUnion blocks cycling the three
+zoo head configurations, classifier head: model_zoo/s3dis/segmenter.py:14-75), built in the same order."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import os
+
+pytestmark = pytest.mark.gpu
+
+ZOO = [([4, 4], [128, 32]), ([16, 16], [64, 16]), ([16, 32], [16, 8])]
+
+
+class Segmenter(nn.Module):
+    def __init__(self, n_classes=13, dim=512):
+        super().__init__()
+        from cloud_transformers_amd.layers.multihead_ct import MultiHeadUnion
+        self.first_process = nn.Sequential(nn.Conv1d(6, dim, kernel_size=1, bias=True), nn.BatchNorm1d(dim), nn.ReLU(inplace=True))
+        self.attentions_encoder = nn.ModuleList([MultiHeadUnion(model_dim=dim, features_dims=f, heads=[16, 16], tensor_sizes=s,
+                                                                model_dim_out=dim, tensor_dims=[2, 3])
+                                                 for _ in range(4) for f, s in ZOO])
+        self.final = nn.Sequential(nn.Conv1d(dim, dim, kernel_size=1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(inplace=True),
+                                   nn.Conv1d(dim, n_classes, kernel_size=1))
+
+    def forward(self, cloud):                       # [B, 6, 1, N]
+        cloud = cloud.squeeze(2)
+        x = self.first_process(cloud)
+        for blk in self.attentions_encoder:
+            x, _ = blk(x, cloud[:, :3])
+        return self.final(x).unsqueeze(2)
+
+
+def _model(seed):
+    torch.manual_seed(seed)          # CPU generator: parameters are drawn on the CPU exactly as the golden's were
+    return Segmenter().cuda()
+
+
+def _close(a, b, name, tol):
+    a, b = a.detach().cpu().double().numpy(), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), (name, err, np.abs(b).max())
+
+
+def test_segmenter_eval_forward_and_input_gradient_match_the_reference():
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_segmenter_forward.npz"))
+    net = _model(int(gold["seed"])).eval()
+    cloud = torch.from_numpy(gold["cloud"]).cuda().requires_grad_(True)
+    out = net(cloud)
+    assert tuple(out.shape) == gold["out_eval"].shape
+    _close(out, gold["out_eval"], "logits (eval)", 1e-5)      # measured 2e-7
+    (out * torch.from_numpy(gold["cot"]).cuda()).sum().backward()
+    # gradient through 12 stacked blocks of arg-max routing and clamped keys: 99.5 % of the entries within 1e-4 of the
+    # reference (measured 99.8 %; median error 1e-7), the worst within 2e-3 (measured 6.5e-4)
+    err = np.abs(cloud.grad.cpu().double().numpy() - gold["g_cloud"].astype(np.float64))
+    assert np.median(err) <= 1e-6 and np.mean(err <= 1e-4) >= 0.995 and err.max() <= 2e-3, (np.median(err), np.mean(err <= 1e-4), err.max())
+
+
+def test_segmenter_training_mode_forward_matches_the_reference():
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_segmenter_forward.npz"))
+    net = _model(int(gold["seed"])).train()
+    with torch.no_grad():
+        out = net(torch.from_numpy(gold["cloud"]).cuda())
+    _close(out, gold["out_train"], "logits (train, batch statistics)", 2e-4)     # measured 5e-5 on a range of 1.8
