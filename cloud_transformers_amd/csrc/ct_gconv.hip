@@ -1027,7 +1027,12 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
 #ifndef CT_GCONV_NO_FWD4
-  if (rows16) return launch_fwd4(a, dim, st);
+  if (rows16) {
+    // the quad form keeps the whole filter bank of a 16-row block in LDS ([rows][KB][4][16][4] floats): with 64 input
+    // channels per group in 3D that alone is 147 KiB — such shapes take the one-position form below (27 % smaller bank)
+    const int r = launch_fwd4(a, dim, st);
+    if (r != CT_EINVAL) return r;
+  }
 #endif
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;
   // short rows (W < 16: the 8^3 volumes) do better on the minimum-halo tiles, the others on the depth-first ones (measured)

@@ -5,7 +5,8 @@ the ones `torch.manual_seed(SEED); Model()` produces, and this package's modules
 same order (checked by tests/test_zoo_cpu.py::test_same_seed_same_weights), so the GPU test rebuilds them from the seed.
 
 Saved to tests/golden/zoo_segmenter_forward.npz: the input cloud, the logits in eval mode and in training mode (batch
-statistics), and d(sum of logits * cot)/d(cloud) in eval mode.
+statistics), and d(sum of logits * cot)/d(cloud) in eval mode.  tests/golden/zoo_classifier_forward.npz: the same for the
+ScanObjectNN classifier (model_zoo/scanobject/classifier.py: MultiHeadPool, Res2D/3D blocks, class + mask heads), eval mode.
 
 usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_zoo_forward.py
 """
@@ -47,6 +48,22 @@ def main():
     np.savez_compressed(os.path.join(HERE, "zoo_segmenter_forward.npz"), seed=SEED, cloud=cloud.numpy(), cot=cot.numpy(),
                         out_eval=out_eval.detach().numpy(), g_cloud=g_cloud.numpy(), out_train=out_train.numpy())
     print("saved", out_eval.shape, float(out_eval.abs().max()), float(g_cloud.abs().max()))
+
+    # ScanObjectNN classifier, eval mode (dropout off)
+    ns = {"__name__": "zoo_model"}
+    with open(os.path.join(G.REF, "model_zoo/scanobject/classifier.py")) as f:
+        exec(compile(f.read(), "classifier.py", "exec"), ns)
+    torch.manual_seed(SEED)
+    model = ns["Model"]().eval()
+    cloud = (torch.rand(B, 3, N, generator=g) * 2 - 1)[:, :, None].contiguous()
+    cot_c = torch.randn(B, 15, generator=g)
+    cot_m = torch.randn(B, 1, 1, N, generator=g)
+    x = cloud.clone().requires_grad_(True)
+    cls, mask, _ = model(x)
+    ((cls * cot_c).sum() + (mask * cot_m).sum()).backward()
+    np.savez_compressed(os.path.join(HERE, "zoo_classifier_forward.npz"), seed=SEED, cloud=cloud.numpy(), cot_cls=cot_c.numpy(),
+                        cot_mask=cot_m.numpy(), cls=cls.detach().numpy(), mask=mask.detach().numpy(), g_cloud=x.grad.numpy())
+    print("saved", cls.shape, mask.shape, float(cls.abs().max()), float(mask.abs().max()), float(x.grad.abs().max()))
 
 
 if __name__ == "__main__":

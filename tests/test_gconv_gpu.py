@@ -19,6 +19,10 @@ CASES = [
     (1, 2, 16, 16, 3, (16, 16, 16), True),    # 3D C=16 (tiled in depth)
     (1, 1, 4, 4, 3, (32, 32, 32), True),      # zoo 3D W=32
     (1, 2, 32, 32, 3, (8, 8, 8), False),
+    (1, 2, 32, 64, 3, (8, 8, 8), False),      # classifier Res3DBlock(512, 1024, groups=16) on the 8^3 pool
+    (1, 2, 64, 64, 3, (4, 4, 4), False),      # ... after Pool3DBlock(2): 64 channels per group, filter bank > LDS in the quad form
+    (1, 2, 64, 64, 3, (2, 2, 2), False),
+    (1, 2, 64, 64, 2, (4, 4), False),         # classifier Res2DBlock(1024, 1024, groups=16) on 4^2
 ]
 
 

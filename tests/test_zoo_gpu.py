@@ -68,3 +68,54 @@ def test_segmenter_training_mode_forward_matches_the_reference():
     with torch.no_grad():
         out = net(torch.from_numpy(gold["cloud"]).cuda())
     _close(out, gold["out_train"], "logits (train, batch statistics)", 2e-4)     # measured 5e-5 on a range of 1.8
+
+
+class Classifier(nn.Module):
+    """ScanObjectNN classifier (model_zoo/scanobject/classifier.py:36-148), eval-mode statement: the twelve-block encoder,
+    a 3D and a 2D MultiHeadPool each followed by grouped Res blocks with pooling, the class head and the per-point mask head."""
+
+    def __init__(self, n_classes=15, dim=512):
+        super().__init__()
+        from cloud_transformers_amd.layers.multihead_ct import MultiHeadPool, MultiHeadUnion
+        from cloud_transformers_amd.layers.grouped_conv import Pool3DBlock, Res2DBlock, Res3DBlock
+        self.first_process = nn.Sequential(nn.Conv1d(3, dim, kernel_size=1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(inplace=True))
+        self.attentions_encoder = nn.ModuleList([MultiHeadUnion(model_dim=dim, features_dims=f, heads=[16, 16], tensor_sizes=s,
+                                                                model_dim_out=dim, tensor_dims=[2, 3])
+                                                 for _ in range(4) for f, s in ZOO])
+        self.pool3d = MultiHeadPool(model_dim=dim, in_feature_dim=32, heads=16, tensor_size=8, tensor_dim=3)
+        self.after_pool3d = nn.Sequential(Res3DBlock(512, 1024, groups=16), Pool3DBlock(2), Res3DBlock(1024, 1024, groups=16),
+                                          Pool3DBlock(2), Res3DBlock(1024, 1024, groups=16), nn.AdaptiveAvgPool3d((1, 1, 1)))
+        self.pool2d = MultiHeadPool(model_dim=dim, in_feature_dim=16, heads=16, tensor_size=16, tensor_dim=2)
+        self.after_pool2d = nn.Sequential(Res2DBlock(256, 512, groups=16), nn.MaxPool2d(2), Res2DBlock(512, 1024, groups=16),
+                                          nn.MaxPool2d(2), Res2DBlock(1024, 1024, groups=16), nn.AdaptiveAvgPool2d((1, 1)))
+        self.class_vector = nn.Sequential(nn.Linear(2048, 1024), nn.BatchNorm1d(1024), nn.ReLU(inplace=True))
+        self.class_head = nn.Sequential(nn.Dropout(0.5), nn.Linear(1024, n_classes))
+        self.mask_head = nn.Sequential(nn.Dropout(0.5), nn.Conv1d(dim + 1024, 256, kernel_size=1, bias=False), nn.BatchNorm1d(256),
+                                       nn.ReLU(), nn.Conv1d(256, 1, kernel_size=1))
+
+    def forward(self, cloud):                       # [B, 3, 1, N]
+        xyz = cloud.squeeze(2)
+        x = self.first_process(xyz)
+        for blk in self.attentions_encoder:
+            x, _ = blk(x, xyz)
+        to_3d, _ = self.pool3d(x, xyz)
+        to_2d, _ = self.pool2d(x, xyz)
+        pooled = torch.cat([self.after_pool2d(to_2d).reshape(-1, 1024), self.after_pool3d(to_3d).reshape(-1, 1024)], dim=-1)
+        vect = self.class_vector(pooled)
+        mask = self.mask_head(torch.cat([x, vect[:, :, None].expand(-1, -1, x.size(-1))], dim=1))
+        return self.class_head(vect), mask.unsqueeze(2)
+
+
+def test_classifier_eval_forward_and_input_gradient_match_the_reference():
+    """Covers what the segmenter does not: MultiHeadPool (Splat-only heads), the grouped Res2D / Res3D blocks with their
+    pooling (MFMA grouped conv at 16..64 channels per group), the dense heads."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_classifier_forward.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    net = Classifier().cuda().eval()
+    cloud = torch.from_numpy(gold["cloud"]).cuda().requires_grad_(True)
+    cls, mask = net(cloud)
+    _close(cls, gold["cls"], "class logits", 1e-4)
+    _close(mask, gold["mask"], "mask logits", 1e-4)
+    ((cls * torch.from_numpy(gold["cot_cls"]).cuda()).sum() + (mask * torch.from_numpy(gold["cot_mask"]).cuda()).sum()).backward()
+    err = np.abs(cloud.grad.cpu().double().numpy() - gold["g_cloud"].astype(np.float64))
+    assert np.median(err) <= 1e-6 and np.mean(err <= 1e-4) >= 0.99 and err.max() <= 5e-3, (np.median(err), np.mean(err <= 1e-4), err.max())
