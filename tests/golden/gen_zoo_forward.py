@@ -23,6 +23,16 @@ import gen_golden as G          # noqa: E402
 SEED, B, N = 0, 2, 512
 
 
+def perturb(model, seed):
+    """Move every parameter off its initial value, deterministically (tests/test_zoo_gpu.py applies the same function):
+    at initialisation the blocks' key BatchNorm weights and the AdaIN residual scales are exactly zero, which would leave
+    the learned-key paths out of the comparison."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * (0.01 if p.dim() >= 2 else 0.05))
+
+
 def main():
     G._install_shims()
     if G.REF not in sys.path:
@@ -32,6 +42,7 @@ def main():
         exec(compile(f.read(), "segmenter.py", "exec"), ns)
     torch.manual_seed(SEED)
     model = ns["Model"]()
+    perturb(model, SEED + 2)
     g = torch.Generator().manual_seed(SEED + 1)
     xyz = torch.rand(B, 3, N, generator=g) * 2 - 1
     rgb = torch.rand(B, 3, N, generator=g)
@@ -42,11 +53,20 @@ def main():
     out_eval, _ = model(x)
     (out_eval * cot).sum().backward()
     g_cloud = x.grad.clone()
+    # training mode (batch statistics): the twelve re-normalising blocks amplify rounding differences between any two
+    # implementations (block by block they agree to 1e-5), so the golden also keeps the first 64 channels after each of
+    # the first three blocks, where a tight comparison is meaningful
     model.train()
+    taps = []
+    hooks = [model.attentions_encoder[i].register_forward_hook(lambda m, a, o: taps.append(o[0][:, :64].detach().clone()))
+             for i in range(3)]
     with torch.no_grad():
         out_train, _ = model(cloud)
+    for h in hooks:
+        h.remove()
     np.savez_compressed(os.path.join(HERE, "zoo_segmenter_forward.npz"), seed=SEED, cloud=cloud.numpy(), cot=cot.numpy(),
-                        out_eval=out_eval.detach().numpy(), g_cloud=g_cloud.numpy(), out_train=out_train.numpy())
+                        out_eval=out_eval.detach().numpy(), g_cloud=g_cloud.numpy(), out_train=out_train.numpy(),
+                        train_block1=taps[0].numpy(), train_block2=taps[1].numpy(), train_block3=taps[2].numpy())
     print("saved", out_eval.shape, float(out_eval.abs().max()), float(g_cloud.abs().max()))
 
     # ScanObjectNN classifier, eval mode (dropout off)
@@ -54,7 +74,9 @@ def main():
     with open(os.path.join(G.REF, "model_zoo/scanobject/classifier.py")) as f:
         exec(compile(f.read(), "classifier.py", "exec"), ns)
     torch.manual_seed(SEED)
-    model = ns["Model"]().eval()
+    model = ns["Model"]()
+    perturb(model, SEED + 2)
+    model.eval()
     cloud = (torch.rand(B, 3, N, generator=g) * 2 - 1)[:, :, None].contiguous()
     cot_c = torch.randn(B, 15, generator=g)
     cot_m = torch.randn(B, 1, 1, N, generator=g)
