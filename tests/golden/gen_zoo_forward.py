@@ -6,7 +6,8 @@ same order (checked by tests/test_zoo_cpu.py::test_same_seed_same_weights), so t
 
 Saved to tests/golden/zoo_segmenter_forward.npz: the input cloud, the logits in eval mode and in training mode (batch
 statistics), and d(sum of logits * cot)/d(cloud) in eval mode.  tests/golden/zoo_classifier_forward.npz: the same for the
-ScanObjectNN classifier (model_zoo/scanobject/classifier.py: MultiHeadPool, Res2D/3D blocks, class + mask heads), eval mode.
+ScanObjectNN classifier (model_zoo/scanobject/classifier.py: MultiHeadPool, Res2D/3D blocks, class + mask heads), eval mode;
+tests/golden/zoo_inpainter_forward.npz: the completion inpainter (encoder, style mapping, twelve AdaIN decoder blocks), eval mode.
 
 usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_zoo_forward.py
 """
@@ -86,6 +87,40 @@ def main():
     np.savez_compressed(os.path.join(HERE, "zoo_classifier_forward.npz"), seed=SEED, cloud=cloud.numpy(), cot_cls=cot_c.numpy(),
                         cot_mask=cot_m.numpy(), cls=cls.detach().numpy(), mask=mask.detach().numpy(), g_cloud=x.grad.numpy())
     print("saved", cls.shape, mask.shape, float(cls.abs().max()), float(mask.abs().max()), float(x.grad.abs().max()))
+
+    # completion inpainter (model_zoo/completion/inpainter.py): encoder -> style vector -> AdaIN decoder over a noise cloud
+    ns = {"__name__": "zoo_model"}
+    with open(os.path.join(G.REF, "model_zoo/completion/inpainter.py")) as f:
+        exec(compile(f.read(), "inpainter.py", "exec"), ns)
+    torch.manual_seed(SEED)
+    model = ns["Model"]()
+    perturb(model, SEED + 2)
+    model.eval()
+    part = (torch.rand(B, 3, 256, generator=g) * 2 - 1)[:, :, None].contiguous()            # partial cloud to the encoder
+    sphere = torch.nn.functional.normalize(torch.randn(B, 3, N, generator=g), dim=1)          # noise on the unit sphere
+    noise = torch.cat([sphere, (torch.rand(B, 1, N, generator=g) > 0.5).float()], dim=1)      # + the "is a real point" label
+    cot_r = torch.randn(B, 3, 1, N, generator=g)
+    nz = noise.clone().requires_grad_(True)
+    pt = part.clone().requires_grad_(True)
+    # every decoder layer re-normalises per cloud (instance norm), which amplifies rounding differences layer by layer like
+    # training-mode BatchNorm does: keep the style vector and the first 64 channels after the stem and the first two
+    # decoder blocks for tight comparisons
+    taps = {}
+    hooks = [model.mapping.register_forward_hook(lambda m, a, o: taps.__setitem__("z", o.detach().clone())),
+             model.attentions_decoder[0].register_forward_hook(lambda m, a, o: taps.__setitem__("dec1", o[0][:, :64].detach().clone())),
+             model.attentions_decoder[1].register_forward_hook(lambda m, a, o: taps.__setitem__("dec2", o[0][:, :64].detach().clone()))]
+    # ... and, for the backward, the cotangent arriving at the inputs of the last two decoder blocks
+    hooks += [model.attentions_decoder[11].register_full_backward_hook(lambda m, gi, go: taps.__setitem__("g_dec12", gi[0][:, :64].detach().clone())),
+              model.attentions_decoder[10].register_full_backward_hook(lambda m, gi, go: taps.__setitem__("g_dec11", gi[0][:, :64].detach().clone()))]
+    rec, _ = model(nz, pt)
+    (rec * cot_r).sum().backward()
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "zoo_inpainter_forward.npz"), seed=SEED, part=part.numpy(), noise=noise.numpy(),
+                        cot=cot_r.numpy(), rec=rec.detach().numpy(), g_noise=nz.grad.numpy(), g_part=pt.grad.numpy(),
+                        z=taps["z"].numpy(), dec1=taps["dec1"].numpy(), dec2=taps["dec2"].numpy(),
+                        g_dec12=taps["g_dec12"].numpy(), g_dec11=taps["g_dec11"].numpy())
+    print("saved", rec.shape, float(rec.abs().max()), float(nz.grad.abs().max()), float(pt.grad.abs().max()))
 
 
 if __name__ == "__main__":

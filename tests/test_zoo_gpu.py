@@ -147,3 +147,101 @@ def test_classifier_eval_forward_and_input_gradient_match_the_reference():
     ((cls * torch.from_numpy(gold["cot_cls"]).cuda()).sum() + (mask * torch.from_numpy(gold["cot_mask"]).cuda()).sum()).backward()
     err = np.abs(cloud.grad.cpu().double().numpy() - gold["g_cloud"].astype(np.float64))
     assert np.median(err) <= 3e-6 and np.mean(err <= 1e-4) >= 0.97 and err.max() <= 2e-2, (np.median(err), np.mean(err <= 1e-4), err.max())
+
+
+class Inpainter(nn.Module):
+    """Completion inpainter (model_zoo/completion/inpainter.py:22-185): the classifier's encoder trunk reduced to a 1024-d
+    code, a Linear+ReLU mapping to the style vector, and a decoder over a noise cloud — Conv1d + AdaIN + ReLU stem, twelve
+    MultiHeadUnionAdaIn blocks, Conv1d + AdaIN + ReLU + Conv1d head; every AdaIN layer takes the style vector."""
+
+    class Encoder(nn.Module):
+        def __init__(self, dim=512):
+            super().__init__()
+            from cloud_transformers_amd.layers.multihead_ct import MultiHeadPool, MultiHeadUnion
+            from cloud_transformers_amd.layers.grouped_conv import Pool3DBlock, Res2DBlock, Res3DBlock
+            self.first_process = nn.Sequential(nn.Conv1d(3, dim, kernel_size=1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(inplace=True))
+            self.attentions_encoder = nn.ModuleList([MultiHeadUnion(model_dim=dim, features_dims=f, heads=[16, 16], tensor_sizes=s,
+                                                                    model_dim_out=dim, tensor_dims=[2, 3])
+                                                     for _ in range(4) for f, s in ZOO])
+            self.pool3d = MultiHeadPool(model_dim=dim, in_feature_dim=32, heads=16, tensor_size=8, tensor_dim=3)
+            self.after_pool3d = nn.Sequential(Res3DBlock(512, 1024, groups=16), Pool3DBlock(2), Res3DBlock(1024, 1024, groups=16),
+                                              Pool3DBlock(2), Res3DBlock(1024, 1024, groups=16), nn.AdaptiveAvgPool3d((1, 1, 1)))
+            self.pool2d = MultiHeadPool(model_dim=dim, in_feature_dim=16, heads=16, tensor_size=16, tensor_dim=2)
+            self.after_pool2d = nn.Sequential(Res2DBlock(256, 512, groups=16), nn.MaxPool2d(2), Res2DBlock(512, 1024, groups=16),
+                                              nn.MaxPool2d(2), Res2DBlock(1024, 1024, groups=16), nn.AdaptiveAvgPool2d((1, 1)))
+            self.class_head = nn.Sequential(nn.Linear(2048, 1024), nn.BatchNorm1d(1024), nn.ReLU(inplace=True))
+
+        def forward(self, cloud):
+            xyz = cloud.squeeze(2)
+            x = self.first_process(xyz)
+            for blk in self.attentions_encoder:
+                x, _ = blk(x, xyz)
+            to_3d, _ = self.pool3d(x, xyz)
+            to_2d, _ = self.pool2d(x, xyz)
+            return self.class_head(torch.cat([self.after_pool2d(to_2d).reshape(-1, 1024), self.after_pool3d(to_3d).reshape(-1, 1024)], dim=-1))
+
+    def __init__(self, num_latent=512, dim=512):
+        super().__init__()
+        from cloud_transformers_amd.layers.multihead_ct import MultiHeadUnionAdaIn
+        from cloud_transformers_amd.layers.utils import AdaIn1dUpd
+        self.encoder = Inpainter.Encoder(dim)
+        self.mapping = nn.Sequential(nn.Linear(1024, num_latent), nn.ReLU(inplace=True))
+        self.start = nn.Sequential(nn.Conv1d(4, dim, kernel_size=1, bias=False), AdaIn1dUpd(dim, num_latent=num_latent), nn.ReLU(True))
+        self.attentions_decoder = nn.ModuleList([MultiHeadUnionAdaIn(model_dim=dim, features_dims=f, heads=[16, 16], tensor_sizes=s,
+                                                                     model_dim_out=dim, n_latent=num_latent, tensor_dims=[2, 3])
+                                                 for _ in range(4) for f, s in ZOO])
+        self.final = nn.Sequential(nn.Conv1d(dim + 4, dim, kernel_size=1, bias=False), AdaIn1dUpd(dim, num_latent=num_latent),
+                                   nn.ReLU(inplace=True), nn.Conv1d(dim, 3, kernel_size=1))
+
+    def forward(self, noise, partial):
+        from cloud_transformers_amd.layers.multihead_ct import forward_style
+        z = self.mapping(self.encoder(partial).reshape(-1, 1024))
+        x = forward_style(self.start, noise, z)
+        for blk in self.attentions_decoder:
+            x, _ = blk(x, z, noise[:, :3])
+        return forward_style(self.final, torch.cat([x, noise], dim=1), z).unsqueeze(2)
+
+
+def test_inpainter_eval_forward_and_gradients_match_the_reference():
+    """The AdaIN path at model level: style vector from the encoder, fused AdaIN(+ReLU) kernels in the stem / head /
+    blocks, MultiHeadUnionAdaIn with its learnable residual scale (perturbed away from its zero initial value)."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_inpainter_forward.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    net = Inpainter()
+    _perturb(net, int(gold["seed"]) + 2)
+    net = net.cuda().eval()
+    noise = torch.from_numpy(gold["noise"]).cuda().requires_grad_(True)
+    part = torch.from_numpy(gold["part"]).cuda().requires_grad_(True)
+    taps = {}
+    hooks = [net.mapping.register_forward_hook(lambda m, a, o: taps.__setitem__("z", o.detach().clone())),
+             net.attentions_decoder[0].register_forward_hook(lambda m, a, o: taps.__setitem__("dec1", o[0][:, :64].detach().clone())),
+             net.attentions_decoder[1].register_forward_hook(lambda m, a, o: taps.__setitem__("dec2", o[0][:, :64].detach().clone()))]
+    hooks += [net.attentions_decoder[11].register_full_backward_hook(lambda m, gi, go: taps.__setitem__("g_dec12", gi[0][:, :64].detach().clone())),
+              net.attentions_decoder[10].register_full_backward_hook(lambda m, gi, go: taps.__setitem__("g_dec11", gi[0][:, :64].detach().clone()))]
+    rec = net(noise, part)
+    # tight where it is meaningful: the style vector (12 encoder blocks, pools, Res blocks, eval BatchNorm) and the
+    # activations after the first decoder blocks; every decoder layer re-normalises per cloud, which amplifies rounding
+    # differences layer by layer, so the reconstruction and the gradients get statistical bounds
+    _close(taps["z"], gold["z"], "style vector", 1e-5)                      # measured 7e-8
+    _close(taps["dec1"], gold["dec1"], "after decoder block 1", 1e-4)      # measured 8e-5 max, 2e-7 median (scale 7)
+    _close(taps["dec2"], gold["dec2"], "after decoder block 2", 5e-4)      # measured 2e-4 max, 7e-6 median (scale 8)
+    err = np.abs(rec.detach().cpu().double().numpy() - gold["rec"].astype(np.float64))
+    scale = np.abs(gold["rec"]).max()
+    assert np.median(err) <= 2e-3 * scale and err.max() <= 3e-2 * scale, ("reconstruction", np.median(err), err.max(), scale)
+    (rec * torch.from_numpy(gold["cot"]).cuda()).sum().backward()
+    for h in hooks:
+        h.remove()
+    # backward: by the last decoder blocks the forward activations of the two implementations have drifted ~1e-3 apart
+    # (instance norm divides by sqrt(var + 1e-5): channels whose variance over the cloud is below eps amplify a 1e-7
+    # input difference up to 316x per layer — measured: style vector 7e-8, after decoder block 1 median 2e-7 / max 8e-5,
+    # after block 2 median 7e-6), so cotangents are compared statistically.  Block by block, on identical inputs, every
+    # gradient of an AdaIN block agrees with the oracle to ~1e-6 (tests/test_blocks_gpu.py, tests/test_adain_gpu.py).
+    for key in ("g_dec12", "g_dec11"):
+        ref = gold[key].astype(np.float64)
+        err = np.abs(taps[key].cpu().double().numpy() - ref)
+        assert np.median(err) <= 1e-2 * np.abs(ref).max() and err.max() <= 0.3 * np.abs(ref).max(), (key, np.median(err), err.max(), np.abs(ref).max())
+    for got, ref, name in ((noise.grad, gold["g_noise"], "d/d noise"), (part.grad, gold["g_part"], "d/d partial cloud")):
+        ref = ref.astype(np.float64)
+        err = np.abs(got.cpu().double().numpy() - ref)
+        scale = np.abs(ref).max()
+        assert np.median(err) <= 3e-2 * scale and err.max() <= 0.3 * scale, (name, np.median(err), err.max(), scale)
