@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
 // reduced per workgroup and added with one atomic each.
 __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const float* lattice, const float* g_lattice,
                                                           const float* g_keys, float* g_xyz, float* g_res, float* g_R, float* g_shift,
-                                                          float* g_scales, float* g_kscale) {
+                                                          float* g_scales, float* g_kscale, float* parts) {
   __shared__ float red[4][16];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   if (threadIdx.x < 16) {
     const int i = threadIdx.x;
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < 9) atomicAdd(&g_R[h * 9 + i], v);
+    if (parts) {        // workspace: this workgroup's 16 partials, summed in a fixed order by lattice_param_sum_kernel
+      parts[(((size_t)b * gridDim.x + blockIdx.x) * a.H + h) * 16 + i] = v;
+    } else if (i < 9) atomicAdd(&g_R[h * 9 + i], v);
     else if (i < 12) atomicAdd(&g_shift[h * 3 + (i - 9)], v);
     else if (i < 15) { if (g_scales && (i - 12) < a.dim) atomicAdd(&g_scales[h * a.dim + (i - 12)], v); }
     else if (g_kscale) atomicAdd(g_kscale, v);
@@ -115,6 +117,25 @@ __global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_R, float* g_
   if (i < H * 3) g_shift[i] = 0.0f;
   if (g_scales && i < H * dim) g_scales[i] = 0.0f;
   if (g_kscale && i == 0) g_kscale[0] = 0.0f;
+}
+
+// parameter cotangents from the per-workgroup partials [B * nbx][H][16]: one thread per (h, i), ascending workgroup order
+__global__ void __launch_bounds__(256) lattice_param_sum_kernel(const float* parts, int nwg, int H, int dim, float* g_R, float* g_shift,
+                                                                float* g_scales, float* g_kscale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < H * 16) {
+    const int h = t >> 4, i = t & 15;
+    float s = 0.0f;
+    for (int w = 0; w < nwg; ++w) s += parts[((size_t)w * H + h) * 16 + i];
+    if (i < 9) g_R[h * 9 + i] = s;
+    else if (i < 12) g_shift[h * 3 + (i - 9)] = s;
+    else if (i < 15) { if (g_scales && (i - 12) < dim) g_scales[h * dim + (i - 12)] = s; }
+  }
+  if (g_kscale && t == 0) {           // the residual scale is one scalar for all heads
+    float s = 0.0f;
+    for (int w = 0; w < nwg * H; ++w) s += parts[(size_t)w * 16 + 15];
+    g_kscale[0] = s;
+  }
 }
 
 // g_xyz[b,c,n] = sum_h gp[b,h,c,n];  g_res[b,h,c,n] = kscale * gp[b,h,c,n]  (in place).  One thread per (b, c, n).
@@ -207,20 +228,31 @@ int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, cons
   return CT_OK;
 }
 
+size_t ct_lattice_bwd_workspace_bytes(int B, int H, int N) {
+  if (B <= 0 || H <= 0 || N <= 0) return 0;
+  return (size_t)B * ((N + 255) / 256) * H * 16 * sizeof(float);
+}
+
 int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
                    const float* kscale, const float* lattice, const float* g_lattice, const float* g_keys, float* g_xyz,
-                   float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, int B, int H, int N, int dim,
-                   ct_stream_t s) {
+                   float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, void* workspace,
+                   size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s) {
   LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
   if (!valid(a) || !lattice || (!g_lattice && !g_keys) || !g_xyz || !g_residual || !g_R || !g_shift) return CT_EINVAL;
   if ((scales != nullptr) != (g_scales != nullptr) || (kscale != nullptr) != (g_kscale != nullptr)) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
+  if (workspace && workspace_bytes < ct_lattice_bwd_workspace_bytes(B, H, N)) return CT_EWORKSPACE;
+  float* parts = (float*)workspace;
+  const int nbx = (N + 255) / 256;
   CT_CLEAR_ERROR();
-  hipLaunchKernelGGL(lattice_zero_kernel, dim3((H * 9 + 255) / 256), dim3(256), 0, st, g_R, g_shift, g_scales, g_kscale, H, dim);
-  hipLaunchKernelGGL(lattice_bwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
-                     g_residual, g_R, g_shift, g_scales, g_kscale);
+  if (!parts) hipLaunchKernelGGL(lattice_zero_kernel, dim3((H * 9 + 255) / 256), dim3(256), 0, st, g_R, g_shift, g_scales, g_kscale, H, dim);
+  hipLaunchKernelGGL(lattice_bwd_kernel, dim3(nbx, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
+                     g_residual, g_R, g_shift, g_scales, g_kscale, parts);
   hipLaunchKernelGGL(lattice_bwd_finish_kernel, dim3((unsigned)(((size_t)3 * N + 255) / 256), B), dim3(256), 0, st, g_residual, g_xyz,
                      kscale, B, H, N);
+  if (parts)
+    hipLaunchKernelGGL(lattice_param_sum_kernel, dim3((H * 16 + 255) / 256), dim3(256), 0, st, parts, B * nbx, H, dim, g_R, g_shift,
+                       g_scales, g_kscale);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

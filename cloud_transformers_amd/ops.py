@@ -314,9 +314,12 @@ class LatticeFn(torch.autograd.Function):
         g_ks = torch.empty_like(ks) if ks is not None else None
         lib = _lib.load()
         with _on(xyz.device):
+            ws_bytes = lib.ct_lattice_bwd_workspace_bytes(B, H, N)
+            ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
             _lib.check(lib.ct_lattice_bwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
                                           _ptr(lattice), _ptr(g_lattice), _ptr(g_keys), _ptr(g_xyz), _ptr(g_res),
-                                          _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), B, H, N, dim, _stream()),
+                                          _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), _ptr(ws), ws_bytes,
+                                          B, H, N, dim, _stream()),
                        "ct_lattice_bwd")
         return g_xyz, g_res, g_R, g_shift, g_scales, (g_ks.reshape(ks_shape) if g_ks is not None else None), None
 

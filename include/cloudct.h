@@ -141,14 +141,17 @@ int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_
  * caller), shift f32[H,3], scales f32[H,dim] | NULL, kscale device f32[1] | NULL (= 1).
  * Forward writes keys and lattice f32[B,H*dim,N].  Backward takes the cotangents of the lattice and /
  * or of the pre-tanh keys (either may be NULL, not both) and overwrites g_xyz, g_residual, g_R, g_shift (and g_scales / g_kscale iff scales / kscale given).
+ * With a workspace of ct_lattice_bwd_workspace_bytes the per-head parameter cotangents are summed in a fixed order (reproducible);
+ * with workspace NULL they are accumulated with one float atomic per workgroup and parameter.
  * ---------------------------------------------------------------------- */
 int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift,
                    const float* scales, const float* kscale, float* keys, float* lattice,
                    int B, int H, int N, int dim, ct_stream_t s);
+size_t ct_lattice_bwd_workspace_bytes(int B, int H, int N);
 int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift,
                    const float* scales, const float* kscale, const float* lattice, const float* g_lattice,
                    const float* g_keys, float* g_xyz, float* g_residual, float* g_R, float* g_shift, float* g_scales,
-                   float* g_kscale, int B, int H, int N, int dim, ct_stream_t s);
+                   float* g_kscale, void* workspace, size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s);
 
 /* so3 exponential map of the per-head rotation parameters — the third-party call of the transformers
  * (pytorch3d.transforms.so3.so3_exponential_map, layers/utils.py:6,29,56; eps = 1e-4 there):
