@@ -526,9 +526,6 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 
 // `count` contiguous floats -> LDS at dst (wave-uniform); 16-byte pieces when src / dst / count allow
 __device__ __forceinline__ void dma_run(float* dst, const float* src, int count, int lane, bool vec) {
-#ifdef CT_WRW_NO_DMA
-  return;
-#endif
   const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(dst));
   if (vec) {
     const int n16 = count >> 2;
@@ -698,9 +695,7 @@ __global__ void __launch_bounds__(THREADS) gconv_wrw_ring_kernel(GconvArgs a, co
         for (int gi = g_beg; gi < g_end; ++gi) {
           const bool bl = x0 == 0, br = x0 + 4 == a.W;
           const int o = y * a.W + x0;
-#ifndef CT_WRW_NO_MFMA
           wrw_group<NZ, NZ == 3 ? 7 : 1>(acc, gsum, xb, ga + gi * 16, o, a.W, bl, br);
-#endif
           x0 += 16;
           while (x0 >= a.W) { x0 -= a.W; ++y; }
           if (y >= th) { y = th - 1; x0 = a.W - 4; }      // padded tail: stay in bounds (g_y is 0 there)
@@ -1026,14 +1021,12 @@ int launch_fwd4(GconvArgs a, int dim, hipStream_t st) {
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
-#ifndef CT_GCONV_NO_FWD4
   if (rows16) {
     // the quad form keeps the whole filter bank of a 16-row block in LDS ([rows][KB][4][16][4] floats): with 64 input
     // channels per group in 3D that alone is 147 KiB — such shapes take the one-position form below (27 % smaller bank)
     const int r = launch_fwd4(a, dim, st);
     if (r != CT_EINVAL) return r;
   }
-#endif
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;
   // short rows (W < 16: the 8^3 volumes) do better on the minimum-halo tiles, the others on the depth-first ones (measured)
   const bool ok = a.W < 16 ? (plan_tiles_min_halo(a, dim, 0, wbytes, a.KB * 4, 16, kLdsBudget) ||
