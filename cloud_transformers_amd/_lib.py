@@ -84,7 +84,8 @@ SIGNATURES = {
     "ct_slice_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_lc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_grid_occupancy": (_i, [_vp, ctypes.c_int64, _vp, _vp]),
-    "ct_lattice_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ct_lattice_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ct_lattice_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_lattice_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ct_lattice_bwd": (_i, [_vp] * 15 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_so3_exp_fwd": (_i, [_vp, _vp, _i, _f, _vp]),

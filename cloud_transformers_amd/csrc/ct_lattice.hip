@@ -23,22 +23,64 @@ struct LatticeArgs {
   int B, H, N, dim;
 };
 
-__global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* keys, float* lattice) {
+// stat_parts (nullable): per-workgroup (sum, sum of squares) of the keys it wrote, [workgroup][2], for the lattice
+// statistics the blocks report (mean / variance of the keys, layers/multihead_ct.py:109-112) — reduced by
+// lattice_stats_kernel instead of two more passes over the keys.
+__global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* keys, float* lattice, float* stat_parts) {
+  __shared__ float red[4][2];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
-  if (n >= a.N) return;
-  const float ks = a.kscale ? a.kscale[0] : 1.0f;
-  float p[3];
+  float s1 = 0.0f, s2 = 0.0f;
+  if (n < a.N) {
+    const float ks = a.kscale ? a.kscale[0] : 1.0f;
+    float p[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] + a.shift[h * 3 + c];
-  const float* R = a.R + h * 9;
-  for (int j = 0; j < a.dim; ++j) {
-    float k = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
-    if (a.scales) k *= a.scales[h * a.dim + j];
-    const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
-    keys[o] = k;
-    lattice[o] = tanhf(k);
+    for (int c = 0; c < 3; ++c)
+      p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] + a.shift[h * 3 + c];
+    const float* R = a.R + h * 9;
+    for (int j = 0; j < a.dim; ++j) {
+      float k = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
+      if (a.scales) k *= a.scales[h * a.dim + j];
+      const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
+      keys[o] = k;
+      lattice[o] = tanhf(k);
+      s1 += k;
+      s2 += k * k;
+    }
+  }
+  if (stat_parts) {
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const size_t wg = ((size_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
+      stat_parts[wg * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+  }
+}
+
+// key_stats[0] = mean, key_stats[1] = unbiased variance of all n keys, from the per-workgroup partials (double accumulation)
+__global__ void __launch_bounds__(256) lattice_stats_kernel(const float* stat_parts, size_t nwg, double n, float* key_stats) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (size_t i = threadIdx.x; i < nwg; i += blockDim.x) {
+    s1 += (double)stat_parts[i * 2 + 0];
+    s2 += (double)stat_parts[i * 2 + 1];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3], t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = t1 / n;
+    key_stats[0] = (float)mean;
+    key_stats[1] = (float)(n > 1.0 ? (t2 - n * mean * mean) / (n - 1.0) : 0.0);
   }
 }
 
@@ -218,12 +260,24 @@ bool valid(const LatticeArgs& a) {
 
 extern "C" {
 
+size_t ct_lattice_fwd_workspace_bytes(int B, int H, int N) {
+  if (B <= 0 || H <= 0 || N <= 0) return 0;
+  return (size_t)B * H * ((N + 255) / 256) * 2 * sizeof(float);
+}
+
 int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
-                   const float* kscale, float* keys, float* lattice, int B, int H, int N, int dim, ct_stream_t s) {
+                   const float* kscale, float* keys, float* lattice, float* key_stats, void* workspace, size_t workspace_bytes,
+                   int B, int H, int N, int dim, ct_stream_t s) {
   LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
   if (!valid(a) || !keys || !lattice) return CT_EINVAL;
+  if (key_stats && (!workspace || workspace_bytes < ct_lattice_fwd_workspace_bytes(B, H, N))) return CT_EWORKSPACE;
+  const int nbx = (N + 255) / 256;
   CT_CLEAR_ERROR();
-  hipLaunchKernelGGL(lattice_fwd_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice);
+  hipLaunchKernelGGL(lattice_fwd_kernel, dim3(nbx, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice,
+                     key_stats ? (float*)workspace : nullptr);
+  if (key_stats)
+    hipLaunchKernelGGL(lattice_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)workspace, (size_t)B * H * nbx,
+                       (double)B * H * dim * N, key_stats);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

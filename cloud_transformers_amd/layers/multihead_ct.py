@@ -79,7 +79,8 @@ class _MHCTCore(nn.Module):
         kernel each way (ct_lattice_fwd / _bwd); only the H 3x3 rotations are built by torch."""
         t = self.transform
         R = so3_exponential_map(t.log_R)
-        return ops.lattice(orig_pcd, keys_res, R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim)
+        return ops.lattice(orig_pcd, keys_res, R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim,
+                           with_stats=True)
 
     def _occupancy(self, z, batch):
         with torch.no_grad():
@@ -112,13 +113,12 @@ class MultiHead(_MHCTCore):
         k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
         keys_res = self.key_bn(k_part)
         values = self.values_bn(v_part)
-        keys, lattice = self._lattice(orig_pcd, keys_res)
+        keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, keys.size(0))
         result = self.after(self.slice.forward_keys(lattice, self.conv(z), pts_padd))
         with torch.no_grad():
-            k_var, k_mean = torch.var_mean(keys)          # one reduction pass for both statistics
-            stats = (occ, k_mean, k_var, None)
+            stats = (occ, kstats[0], kstats[1], None)       # mean / variance of the keys, reduced by the lattice kernel
         if return_lattice:
             result = result, lattice
         return result, stats
@@ -145,12 +145,11 @@ class MultiHeadPool(_MHCTCore):
         k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
         keys_res = self.key_bn(k_part)
         values = self.values_bn(v_part)
-        keys, lattice = self._lattice(orig_pcd, keys_res)
+        keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
         with torch.no_grad():
-            k_var, k_mean = torch.var_mean(keys)          # one reduction pass for both statistics
-            stats = (occ, k_mean, k_var, None)
+            stats = (occ, kstats[0], kstats[1], None)       # mean / variance of the keys, reduced by the lattice kernel
         result = z
         if return_lattice:
             result = result, lattice
@@ -181,15 +180,14 @@ class MultiHeadAdaIn(_MHCTCore):
         k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
         keys_res = forward_style(self.keys_bn, k_part, style)
         values = forward_style(self.values_bn, v_part, style)
-        keys, lattice = self._lattice(orig_pcd, keys_res, self.scale)
+        keys, lattice, kstats = self._lattice(orig_pcd, keys_res, self.scale)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
         result = forward_style(self.after, self.slice.forward_keys(lattice, self.conv(z)), style)
         with torch.no_grad():
             # the reference moves these to the host and copies ALL keys to numpy on every
             # forward (multihead_ct_adain.py:127-131); here they stay on the device (no sync)
-            k_var, k_mean = torch.var_mean(keys)
-            stats = (occ, k_mean, k_var, keys.detach())
+            stats = (occ, kstats[0], kstats[1], keys.detach())
         if return_lattice:
             result = result, lattice
         return result, stats

@@ -284,7 +284,7 @@ class SliceLcFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 class LatticeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, residual, R, shift, scales, kscale, dim):
+    def forward(ctx, xyz, residual, R, shift, scales, kscale, dim, with_stats=False):
         _dev(xyz, residual, R, shift, scales, kscale)
         xyz, residual, R, shift = _f32c(xyz), _f32c(residual), _f32c(R), _f32c(shift)
         scales = _f32c(scales) if scales is not None else None
@@ -295,15 +295,25 @@ class LatticeFn(torch.autograd.Function):
         keys = torch.empty(B, H * dim, N, device=xyz.device, dtype=torch.float32)
         lattice = torch.empty_like(keys)
         lib = _lib.load()
+        stats = ws = None
+        ws_bytes = 0
+        if with_stats:
+            stats = torch.empty(2, device=xyz.device, dtype=torch.float32)
+            ws_bytes = lib.ct_lattice_fwd_workspace_bytes(B, H, N)
+            ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
         with _on(xyz.device):
             _lib.check(lib.ct_lattice_fwd(_ptr(xyz), _ptr(residual), _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
-                                          _ptr(keys), _ptr(lattice), B, H, N, dim, _stream()), "ct_lattice_fwd")
+                                          _ptr(keys), _ptr(lattice), _ptr(stats), _ptr(ws), ws_bytes, B, H, N, dim, _stream()),
+                       "ct_lattice_fwd")
         ctx.save_for_backward(xyz, residual, R, shift, scales, ks, lattice)
         ctx.meta = (B, H, N, dim, kscale.shape if kscale is not None else None)
+        if with_stats:
+            ctx.mark_non_differentiable(stats)
+            return keys, lattice, stats
         return keys, lattice
 
     @staticmethod
-    def backward(ctx, g_keys, g_lattice):
+    def backward(ctx, g_keys, g_lattice, _g_stats=None):
         xyz, residual, R, shift, scales, ks, lattice = ctx.saved_tensors
         B, H, N, dim, ks_shape = ctx.meta
         g_keys = _f32c(g_keys) if g_keys is not None else None
@@ -321,12 +331,13 @@ class LatticeFn(torch.autograd.Function):
                                           _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), _ptr(ws), ws_bytes,
                                           B, H, N, dim, _stream()),
                        "ct_lattice_bwd")
-        return g_xyz, g_res, g_R, g_shift, g_scales, (g_ks.reshape(ks_shape) if g_ks is not None else None), None
+        return g_xyz, g_res, g_R, g_shift, g_scales, (g_ks.reshape(ks_shape) if g_ks is not None else None), None, None
 
 
-def lattice(xyz, residual, R, shift, scales, kscale, dim):
-    """(keys, tanh(keys)) of an MHCT block; R = so3_exponential_map(log_R) [H,3,3]."""
-    return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim)
+def lattice(xyz, residual, R, shift, scales, kscale, dim, with_stats=False):
+    """(keys, tanh(keys)) of an MHCT block; R = so3_exponential_map(log_R) [H,3,3].  with_stats: also a
+    non-differentiable f32[2] = (mean, unbiased variance) of the keys, reduced inside the same launch."""
+    return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim, with_stats)
 
 
 class So3ExpFn(torch.autograd.Function):

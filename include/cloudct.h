@@ -144,9 +144,12 @@ int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_
  * With a workspace of ct_lattice_bwd_workspace_bytes the per-head parameter cotangents are summed in a fixed order (reproducible);
  * with workspace NULL they are accumulated with one float atomic per workgroup and parameter.
  * ---------------------------------------------------------------------- */
+size_t ct_lattice_fwd_workspace_bytes(int B, int H, int N);
 int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift,
                    const float* scales, const float* kscale, float* keys, float* lattice,
-                   int B, int H, int N, int dim, ct_stream_t s);
+                   float* key_stats /* NULL | f32[2]: mean and unbiased variance of the keys (the blocks' lattice statistics,
+                                       layers/multihead_ct.py:109-112); needs the workspace */,
+                   void* workspace, size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s);
 size_t ct_lattice_bwd_workspace_bytes(int B, int H, int N);
 int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift,
                    const float* scales, const float* kscale, const float* lattice, const float* g_lattice,
