@@ -161,29 +161,37 @@ __global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_R, float* g_
   if (g_kscale && i == 0) g_kscale[0] = 0.0f;
 }
 
-// parameter cotangents from the per-workgroup partials [B * nbx][H][16]: one thread per (h, i), ascending workgroup
-// order; ONE workgroup (H * 16 outputs, thread-strided), so the per-head sums of the residual scale can be combined in LDS
+// parameter cotangents from the per-workgroup partials [B * nbx][H][16].  One workgroup per head: its 256 threads are
+// 16 partial indices x 16 lanes over the workgroups (coalesced 64-byte rows), combined by a fixed-order tree in LDS.
+// The residual scale is one scalar for all heads: workgroup 0 also sums partial 15 of every (workgroup, head).
 __global__ void __launch_bounds__(256) lattice_param_sum_kernel(const float* parts, int nwg, int H, int dim, float* g_R, float* g_shift,
                                                                 float* g_scales, float* g_kscale) {
-  __shared__ float ksum[256];
-  float kpart = 0.0f;                 // this thread's share of sum_h (partial 15 of head h)
-  for (int t = threadIdx.x; t < H * 16; t += blockDim.x) {
-    const int h = t >> 4, i = t & 15;
-    float s = 0.0f;
-    for (int w = 0; w < nwg; ++w) s += parts[((size_t)w * H + h) * 16 + i];
-    if (i < 9) g_R[h * 9 + i] = s;
-    else if (i < 12) g_shift[h * 3 + (i - 9)] = s;
-    else if (i < 15) { if (g_scales && (i - 12) < dim) g_scales[h * dim + (i - 12)] = s; }
-    else kpart += s;
+  __shared__ float red[16][17];
+  __shared__ float kred[256];
+  const int h = blockIdx.x;
+  const int i = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  float s = 0.0f;
+  for (int w = wl; w < nwg; w += 16) s += parts[((size_t)w * H + h) * 16 + i];
+  red[wl][i] = s;
+  __syncthreads();
+  if (wl == 0 && i < 15) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][i];
+    if (i < 9) g_R[h * 9 + i] = t;
+    else if (i < 12) g_shift[h * 3 + (i - 9)] = t;
+    else if (g_scales && (i - 12) < dim) g_scales[h * dim + (i - 12)] = t;
   }
-  if (g_kscale) {                     // one scalar for all heads: fixed-order tree over the 256 thread shares
-    ksum[threadIdx.x] = kpart;
+  if (g_kscale && h == 0) {
+    float k = 0.0f;
+    for (int j = threadIdx.x; j < nwg * H; j += blockDim.x) k += parts[(size_t)j * 16 + 15];
+    kred[threadIdx.x] = k;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) ksum[threadIdx.x] += ksum[threadIdx.x + o];
+      if ((int)threadIdx.x < o) kred[threadIdx.x] += kred[threadIdx.x + o];
       __syncthreads();
     }
-    if (threadIdx.x == 0) g_kscale[0] = ksum[0];
+    if (threadIdx.x == 0) g_kscale[0] = kred[0];
   }
 }
 
@@ -312,7 +320,7 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   hipLaunchKernelGGL(lattice_bwd_finish_kernel, dim3((unsigned)(((size_t)3 * N + 255) / 256), B), dim3(256), 0, st, g_residual, g_xyz,
                      kscale, B, H, N);
   if (parts)
-    hipLaunchKernelGGL(lattice_param_sum_kernel, dim3(1), dim3(256), 0, st, parts, B * nbx, H, dim, g_R, g_shift,
+    hipLaunchKernelGGL(lattice_param_sum_kernel, dim3(H), dim3(256), 0, st, parts, B * nbx, H, dim, g_R, g_shift,
                        g_scales, g_kscale);
   CT_CHECK_LAUNCH();
   return CT_OK;
