@@ -824,16 +824,29 @@ __global__ void __launch_bounds__(THREADS) gconv_wrw_ring_kernel(GconvArgs a, co
   }
 }
 
+// sum_c src[c * stride + idx] over `chunks` partial slots: blockDim = (64, 4), lane y takes chunks y, y+4, ...; the four
+// lane sums are added in lane order (fixed).  More loads in flight than one thread walking every chunk.
+__device__ __forceinline__ float sum_chunks(const float* src, size_t stride, size_t idx, bool valid, int chunks, float (*red)[64]) {
+  float s = 0.0f;
+  if (valid)
+    for (int c = threadIdx.y; c < chunks; c += 4) s += src[(size_t)c * stride + idx];
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  __syncthreads();
+  return t;
+}
+
 // second stage of the ring kernel's reduction: g_w[grp, co, ci, t] = sum over chunks (ascending) of the stored partials
 __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int Cin,
                                                                int Cout, int taps) {
+  __shared__ float red[4][64];
   const int CiB = (Cin + 15) >> 4, CoB = (Cout + 15) >> 4;
   const int per_blk = taps * 256;
   const size_t per_chunk = (size_t)groups * CoB * CiB * per_blk;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // (grp, cob, cib, t, co16, ci16)
-  if (idx < per_chunk) {
-    float sum = 0.0f;
-    for (int c = 0; c < chunks; ++c) sum += ws[(size_t)c * per_chunk + idx];
+  const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;             // (grp, cob, cib, t, co16, ci16)
+  const float sum = sum_chunks(ws, per_chunk, idx, idx < per_chunk, chunks, red);
+  if (idx < per_chunk && threadIdx.y == 0) {
     const int i = (int)(idx % 256), t = (int)((idx / 256) % taps);
     const int blk = (int)(idx / per_blk);
     const int cib = blk % CiB, cob = (blk / CiB) % CoB, grp = blk / (CiB * CoB);
@@ -842,31 +855,29 @@ __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, 
   }
   // bias partials follow the filter partials: [chunk][grp][cob][16]
   const size_t nb = (size_t)groups * CoB * 16;
-  if (gbias && idx < nb) {
-    const float* wb = ws + (size_t)chunks * per_chunk;
-    float sum = 0.0f;
-    for (int c = 0; c < chunks; ++c) sum += wb[(size_t)c * nb + idx];
-    const int co = (int)((idx / 16) % CoB) * 16 + (int)(idx % 16), grp = (int)(idx / (16 * CoB));
-    if (co < Cout) gbias[grp * Cout + co] = sum;
+  if (gbias && (size_t)blockIdx.x * 64 < nb) {                         // workgroup-uniform
+    const float bsum = sum_chunks(ws + (size_t)chunks * per_chunk, nb, idx, idx < nb, chunks, red);
+    if (idx < nb && threadIdx.y == 0) {
+      const int co = (int)((idx / 16) % CoB) * 16 + (int)(idx % 16), grp = (int)(idx / (16 * CoB));
+      if (co < Cout) gbias[grp * Cout + co] = bsum;
+    }
   }
 }
 
 // second stage of the four-channel ring kernel's reduction.  Workspace: [chunk][group][ci][co*taps + t], then [chunk][group][co] (bias).
 __global__ void __launch_bounds__(256) gconv_c4_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int taps) {
+  __shared__ float red[4][64];
   const int per = 16 * taps;                                  // per (chunk, group): [ci][co][t]
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < groups * per) {
-    float sum = 0.0f;
-    for (int c = 0; c < chunks; ++c) sum += ws[(size_t)c * groups * per + idx];
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  const float sum = sum_chunks(ws, (size_t)groups * per, idx, idx < groups * per, chunks, red);
+  if (idx < groups * per && threadIdx.y == 0) {
     const int grp = idx / per, r = idx % per;
     const int ci = r / (4 * taps), co = (r / taps) % 4, t = r % taps;
     gw[((size_t)(grp * 4 + co) * 4 + ci) * taps + t] = sum;
   }
-  if (gbias && idx < groups * 4) {
-    const float* wb = ws + (size_t)chunks * groups * per;
-    float sum = 0.0f;
-    for (int c = 0; c < chunks; ++c) sum += wb[(size_t)c * groups * 4 + idx];
-    gbias[idx] = sum;
+  if (gbias && blockIdx.x * 64 < groups * 4) {                // workgroup-uniform
+    const float bsum = sum_chunks(ws + (size_t)chunks * groups * per, (size_t)groups * 4, idx, idx < groups * 4, chunks, red);
+    if (idx < groups * 4 && threadIdx.y == 0) gbias[idx] = bsum;
   }
 }
 
@@ -1117,7 +1128,7 @@ int launch_wrw_ring(GconvArgs a, int dim, const float* g_y, float* g_w, float* g
   if (ws) {
     const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
     const size_t n = (size_t)a.groups * CoB * CiB * a.taps * 256;
-    hipLaunchKernelGGL(gconv_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, g_w, g_bias, p.chunks,
+    hipLaunchKernelGGL(gconv_wrw_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64, 4), 0, st, ws, g_w, g_bias, p.chunks,
                        a.groups, a.Cin, a.Cout, a.taps);
   }
   return CT_OK;
@@ -1143,7 +1154,7 @@ int launch_c4_wrw(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_b
     hipLaunchKernelGGL((gconv_wrw_ring_kernel<3, true, kThreads>), grid, dim3(kThreads), p.lds, st, a, g_y, g_w, ws, p.units_per_wg);
   }
   const int n = a.groups * 16 * a.taps;
-  hipLaunchKernelGGL(gconv_c4_wrw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, g_w, g_bias, p.chunks, a.groups, a.taps);
+  hipLaunchKernelGGL(gconv_c4_wrw_reduce_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, ws, g_w, g_bias, p.chunks, a.groups, a.taps);
   return CT_OK;
 }
 
