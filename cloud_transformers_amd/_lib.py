@@ -94,6 +94,7 @@ SIGNATURES = {
     "ct_adain_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_gconv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_gconv_supported": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_gconv_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_gconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_chamfer_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

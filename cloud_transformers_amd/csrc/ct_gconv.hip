@@ -1185,6 +1185,21 @@ int launch_wrw_tiles(GconvArgs a, int dim, const float* g_y, float* g_w, hipStre
   return CT_OK;
 }
 
+// plan-only checks behind ct_gconv_supported
+bool fwd_plan_ok(GconvArgs a, int dim) {
+  if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 &&
+      (plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudget) || plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudgetMax))) return true;
+  const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;          // the one-position form: what the quad form falls back to
+  return plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16);
+}
+
+bool wrw_plan_ok(GconvArgs a, int dim) {
+  WrwRingPlan p;
+  if ((a.W & 3) == 0 && plan_wrw_ring(a, dim, p, c4_wrw_eligible(a) ? 4 : 16)) return true;
+  const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
+  return plan_tiles(a, dim, (size_t)16 * 4, 1024 + red_bytes, 16, 4, kLdsBudgetWrw);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1210,6 +1225,14 @@ int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
   return launch_fwd(a, dim, (hipStream_t)s);
 }
 
+int ct_gconv_supported(int B, int groups, int Cin, int Cout, int dim, const int* W) {
+  GconvArgs a = {};
+  if (gconv_common(a, B, groups, Cin, Cout, dim, W) != CT_OK) return 0;
+  GconvArgs t = {};
+  gconv_common(t, B, groups, Cout, Cin, dim, W);                  // backward-data: the same pass with the channel roles swapped
+  return fwd_plan_ok(a, dim) && fwd_plan_ok(t, dim) && wrw_plan_ok(a, dim) ? 1 : 0;
+}
+
 size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout, int dim, const int* W) {
   GconvArgs a = {};
   if (gconv_common(a, B, groups, Cin, Cout, dim, W) != CT_OK || (a.W & 3) != 0) return 0;
@@ -1231,14 +1254,18 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   hipStream_t st = (hipStream_t)s;
   CT_CLEAR_ERROR();
   const bool aligned = ((((uintptr_t)x) | ((uintptr_t)g_y)) & 15) == 0;
+  bool ring_bias = (a.W & 3) == 0 && workspace != nullptr;        // the ring kernels' workspace path produces g_bias itself
   if (workspace && aligned && c4_wrw_eligible(a)) {
     r = launch_c4_wrw(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
   } else {
-    r = (a.W & 3) == 0 ? launch_wrw_ring(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st)
-                       : launch_wrw_tiles(a, dim, g_y, g_w, st);
+    r = (a.W & 3) == 0 ? launch_wrw_ring(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st) : CT_EINVAL;
+    if (r == CT_EINVAL) {                                          // rows off the 16-byte grid, or rings that do not fit LDS
+      ring_bias = false;
+      r = launch_wrw_tiles(a, dim, g_y, g_w, st);
+    }
   }
   if (r != CT_OK) return r;
-  if (g_bias && !((a.W & 3) == 0 && workspace)) {       // the ring kernel's workspace path produces g_bias itself
+  if (g_bias && !ring_bias) {
     const size_t vol = (size_t)a.D * a.H * a.W;
     hipLaunchKernelGGL(gconv_bias_grad_kernel, dim3(groups * Cout), dim3(256), 0, st, g_y, g_bias, B, groups * Cout, vol);
   }

@@ -61,10 +61,22 @@ class GroupedConvFn(torch.autograd.Function):
 
 def _eligible(mod, x):
     nd = x.dim() - 2
-    return (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32
+    if not (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32
             and tuple(mod.kernel_size) == (3,) * nd and tuple(mod.stride) == (1,) * nd
             and tuple(mod.padding) == (1,) * nd and tuple(mod.dilation) == (1,) * nd
-            and mod.padding_mode == "zeros")
+            and mod.padding_mode == "zeros"):
+        return False
+    # shapes whose tiles do not fit LDS (very wide rows with many channels per group) take the library convolution
+    W = tuple(x.shape[2:])
+    key = (x.shape[0], mod.groups, mod.in_channels // mod.groups, mod.out_channels // mod.groups, W)
+    ok = _SUPPORTED.get(key)
+    if ok is None:
+        ok = bool(_lib.load().ct_gconv_supported(key[0], key[1], key[2], key[3], nd, _lib.int_array(W)))
+        _SUPPORTED[key] = ok
+    return ok
+
+
+_SUPPORTED = {}
 
 
 class GroupedConv2d(nn.Conv2d):

@@ -194,6 +194,8 @@ int ct_gconv_fwd(const float* x, const float* w, const float* bias, float* y,
                  int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
 int ct_gconv_bwd_data(const float* g_y, const float* w, float* g_x,
                       int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
+int ct_gconv_supported(int B, int groups, int Cin, int Cout, int dim, const int* W);   /* 1: all three passes have a tile plan; 0: fall back to the library conv
+                                                                                              (very wide rows with many channels per group) */
 size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout, int dim, const int* W);
 int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias,
                         void* workspace, size_t workspace_bytes,

@@ -123,3 +123,22 @@ def test_gconv_fuzz(seed):
     close(m.weight.grad, wr.grad, "g_w", 5e-5)
     if bias:
         close(m.bias.grad, br.grad, "g_bias", 5e-5)
+
+
+def test_shapes_without_a_tile_plan_take_the_library_convolution():
+    """Very wide rows with many channels per group do not fit any LDS tile plan (ct_gconv_supported == 0): the module
+    answers through its parent class (MIOpen) instead of failing — found by a 300-seed soak of the fuzz above."""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.layers.gconv import GroupedConv3d
+    lib = _lib.load()
+    W = (6, 10, 64)
+    assert lib.ct_gconv_supported(2, 2, 38, 22, 3, _lib.int_array(W)) == 0
+    assert lib.ct_gconv_supported(8, 16, 16, 16, 3, _lib.int_array((16, 16, 16))) == 1
+    torch.manual_seed(0)
+    m = GroupedConv3d(2 * 38, 2 * 22, 3, padding=1, groups=2, bias=False).cuda()
+    x = torch.randn(2, 2 * 38, *W, device="cuda", requires_grad=True)
+    y = m(x)
+    y.sum().backward()
+    ref = torch.nn.functional.conv3d(x.detach().double(), m.weight.detach().double(), padding=1, groups=2)
+    assert float((y.detach().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    assert x.grad is not None and m.weight.grad is not None
