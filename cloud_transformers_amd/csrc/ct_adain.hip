@@ -149,8 +149,10 @@ struct AdainBwdArgs {
   int relu;
 };
 
-__device__ __forceinline__ float masked(float gy, float xh, float g1, float be, int relu) {
-  return (relu && !(xh * g1 + be > 0.0f)) ? 0.0f : gy;
+// the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * ((gamma + 1) * rstd) + beta, same
+// operation order, contraction off), so an element is masked in backward iff the forward wrote a zero for it
+__device__ __forceinline__ float masked(float gy, float xc, float gfw, float be, int relu) {
+  return (relu && !(xc * gfw + be > 0.0f)) ? 0.0f : gy;
 }
 
 template <int NV>
@@ -160,6 +162,7 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
   const int nq = a.N >> 2;
   const float mu = a.mean[row], rs = a.rstd[row];
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float gfw = g1 * rs;                            // the forward's scale
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
   const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)row * a.N);
   const float4* gr = reinterpret_cast<const float4*>(a.gy + (size_t)row * a.N);
@@ -171,8 +174,8 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
     const float4 xv = ok ? xr[q] : make_float4(mu, mu, mu, mu);
     const float4 gv = ok ? gr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-    g[k] = make_float4(masked(gv.x, xh[k].x, g1, be, a.relu), masked(gv.y, xh[k].y, g1, be, a.relu),
-                       masked(gv.z, xh[k].z, g1, be, a.relu), masked(gv.w, xh[k].w, g1, be, a.relu));
+    g[k] = make_float4(masked(gv.x, xv.x - mu, gfw, be, a.relu), masked(gv.y, xv.y - mu, gfw, be, a.relu),
+                       masked(gv.z, xv.z - mu, gfw, be, a.relu), masked(gv.w, xv.w - mu, gfw, be, a.relu));
   }
   float s[2] = {0.f, 0.f};
 #pragma unroll
@@ -202,13 +205,14 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
   const float mu = a.mean[row], rs = a.rstd[row];
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float gfw = g1 * rs;                            // the forward's scale
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
   const float* xr = a.x + (size_t)row * a.N;
   const float* gr = a.gy + (size_t)row * a.N;
   float s[2] = {0.f, 0.f};
   for (int n = threadIdx.x; n < a.N; n += kThreads) {
     const float xh = (xr[n] - mu) * rs;
-    const float g = masked(gr[n], xh, g1, be, a.relu);
+    const float g = masked(gr[n], xr[n] - mu, gfw, be, a.relu);
     s[0] += g;
     s[1] += g * xh;
   }
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   float* or_ = a.gx + (size_t)row * a.N;
   for (int n = threadIdx.x; n < a.N; n += kThreads) {
     const float xh = (xr[n] - mu) * rs;
-    const float g = masked(gr[n], xh, g1, be, a.relu);
+    const float g = masked(gr[n], xr[n] - mu, gfw, be, a.relu);
     or_[n] = sc * (g - m0 - xh * m1);
   }
 }

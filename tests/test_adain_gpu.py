@@ -88,3 +88,20 @@ def test_adain_abi_rejects_bad_arguments():
     assert lib.ct_adain_fwd(None, None, None, None, None, 1, 1, 4, 1e-5, 0, None) == -1
     assert lib.ct_adain_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), -1, 1, 4, 1e-5, 0, None) == -1
     assert lib.ct_adain_fwd(None, None, None, None, None, 0, 8, 4, 1e-5, 0, None) == 0      # empty batch: nothing to do
+
+
+@pytest.mark.parametrize("N", [4096, 20000])          # register-resident rows and the strided kernel
+def test_relu_mask_in_backward_is_the_forward_mask(N):
+    """The backward recomputes the ReLU mask instead of reading the output: it must be the forward's mask bit for bit
+    (an element within rounding of zero decided differently would move a whole cotangent) — g_beta[b,c] = sum_n gy * [y > 0]."""
+    from cloud_transformers_amd import ops
+    torch.manual_seed(N)
+    B, C = 3, 68
+    x = (torch.randn(B, C, N, device="cuda") * 4 + 2.5).requires_grad_(True)
+    gb = torch.randn(B, 2, C, device="cuda", requires_grad=True)
+    gy = torch.randn(B, C, N, device="cuda")
+    y = ops.adain(x, gb, 1e-5, True)
+    y.backward(gy)
+    expect = (gy.double() * (y.detach() > 0)).sum(dim=2)
+    got = gb.grad[:, 1].double()
+    assert float((got - expect).abs().max()) <= 2e-3, float((got - expect).abs().max())     # one wrong element would show as ~1
