@@ -331,18 +331,34 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
   float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
   const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
   const bool has_pad = a.pad_dtype != CT_PAD_NONE;
-  if (threadIdx.x < cc) {
-    const unsigned* slot = (const unsigned*)(gout + (size_t)threadIdx.x * g.G);
-    const float M = __uint_as_float(slot[0]);
-    const float K = (float)slot[1];
-    const float MK = M * K;
-    const bool fixed = MK < 1e37f;
-    int ex = 0;
-    if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
-    ex = max(ex, -90);
-    s_q[threadIdx.x] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
-    s_iq[threadIdx.x] = ldexpf(1.0f, 30 - ex);
+  // One quantum for the whole chunk: M = max over its channels' slots (an upper bound for each of them; the
+  // gather kernel publishes per-chunk maxima anyway).  A workgroup-uniform quantum lives in scalar registers,
+  // so the inner loop carries no LDS reads besides the atomics, and — a power of two — it is folded into the
+  // corner weights once per point: (f*w)*2^k == f*(w*2^k) exactly.
+  if (threadIdx.x < 64) {
+    float M = 0.0f, K = 0.0f;
+    for (int ch = threadIdx.x; ch < cc; ch += 64) {
+      const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
+      M = fmaxf(M, __uint_as_float(slot[0]));
+      K = fmaxf(K, (float)slot[1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      M = fmaxf(M, __shfl_xor(M, o, 64));
+      K = fmaxf(K, __shfl_xor(K, o, 64));
+    }
+    if (threadIdx.x == 0) {
+      const float MK = M * K;
+      const bool fixed = MK < 1e37f;
+      int ex = 0;
+      if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
+      ex = max(ex, -90);
+      s_q[0] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
+      s_iq[0] = ldexpf(1.0f, 30 - ex);
+    }
   }
+  __syncthreads();      // slots are read before the tile is touched
+  const float q = s_q[0], iq = s_iq[0];
+  const bool fixed = q >= 0.0f;
   for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
@@ -350,6 +366,9 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
     PointPos<DIM, FROM_KEYS> pp;
     load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
     const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    float wq[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) wq[v] = c.w[v] * iq;
     // channels in groups of 4: the group's loads are issued together, then its 16/32 atomics
     for (int c4 = 0; c4 < cc; c4 += 4) {
       float f[4];
@@ -360,11 +379,10 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
         const int ch = c4 + u;
         if (ch < cc) {
           const float fu = has_pad ? f[u] * p : f[u];
-          const float iq = s_iq[ch];
           int* Tc = acc + (size_t)ch * g.G;
-          if (s_q[ch] >= 0.0f) {            // block-uniform
+          if (fixed) {            // block-uniform
 #pragma unroll
-            for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn((fu * c.w[v]) * iq));
+            for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn(fu * wq[v]));
           } else {
 #pragma unroll
             for (int v = 0; v < V; ++v) atomicAdd((float*)&Tc[c.cell[v]], fu * c.w[v]);
@@ -374,9 +392,139 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) {
-    const float q = s_q[i / g.G];
-    gout[i] = q < 0.0f ? lds[i] : (float)acc[i] * q;
+  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = fixed ? (float)acc[i] * q : lds[i];
+}
+
+// ---------------------------------------------------------------------------
+// K1q: quad form of the two streaming scatters of the hot path (corners from keys, N % 4 == 0,
+//   16-byte aligned rows, G % 4 == 0): Splat(max0) forward and the fixed-point scatter-add of
+//   Slice backward (quantum from the slots, as K1t).  Each thread owns 4 consecutive points; keys
+//   and src move as dwordx4 along N and the loads of a group of CG channels are issued before the
+//   group's LDS atomics, so a wave keeps CG KiB of HBM reads in flight instead of CG*256 B.
+//   grid = (nchunks, H, B)
+// ---------------------------------------------------------------------------
+template <int DIM, bool ADD, bool HAS_PAD>
+__global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatter_quad_kernel(RasterArgs a, GridW<DIM> g) {
+  constexpr int V = 1 << DIM;
+  constexpr int CG = DIM == 2 ? 4 : 2;
+  extern __shared__ __align__(16) float lds[];
+  __shared__ float s_qq[2];
+  int* acc = (int*)lds;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
+  const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
+  float q = 1.0f, iq = 1.0f;
+  bool fixed = true;
+  if (ADD) {
+    if (threadIdx.x < 64) {
+      float M = 0.0f, K = 0.0f;
+      for (int ch = threadIdx.x; ch < cc; ch += 64) {
+        const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
+        M = fmaxf(M, __uint_as_float(slot[0]));
+        K = fmaxf(K, (float)slot[1]);
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        M = fmaxf(M, __shfl_xor(M, o, 64));
+        K = fmaxf(K, __shfl_xor(K, o, 64));
+      }
+      if (threadIdx.x == 0) {
+        const float MK = M * K;
+        const bool fx = MK < 1e37f;
+        int ex = 0;
+        if (fx && MK > 0.0f) (void)frexpf(MK, &ex);
+        ex = max(ex, -90);
+        s_qq[0] = fx ? ldexpf(1.0f, ex - 30) : -1.0f;
+        s_qq[1] = fx ? ldexpf(1.0f, 30 - ex) : 1.0f;      // float fallback: weights stay unscaled
+      }
+    }
+    __syncthreads();
+    q = s_qq[0];
+    iq = s_qq[1];
+    fixed = q >= 0.0f;
+  }
+  for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  // cell offsets of the V corners relative to the base cell
+  Corners<DIM> off;
+  {
+    const float one[DIM] = {};
+    int f0[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) f0[j] = 0;
+    ct_corners<DIM>(one, one, f0, g, off);
+  }
+  const int nq = a.N >> 2;
+  for (int qd = threadIdx.x; qd < nq; qd += blockDim.x) {
+    const int n0 = qd << 2;
+    float cw[4][V];
+    int base[4];
+    {
+      float kk[DIM][4];
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) {
+        const float4 t = *(const float4*)(a.pos.keys + (bh * DIM + j) * a.N + n0);
+        kk[j][0] = t.x; kk[j][1] = t.y; kk[j][2] = t.z; kk[j][3] = t.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float w0[DIM], w1[DIM];
+        int f[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) ct_axis(kk[j][i], g.hw[j], g.W[j], w0[j], w1[j], f[j]);
+        Corners<DIM> c;
+        ct_corners<DIM>(w0, w1, f, g, c);
+        base[i] = c.cell[0];
+#pragma unroll
+        for (int v = 0; v < V; ++v) cw[i][v] = ADD ? c.w[v] * iq : c.w[v];   // power-of-two scale: exact
+      }
+    }
+    float pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n0 + i) : 1.0f;
+    for (int cg0 = 0; cg0 < cc; cg0 += CG) {
+      float fv[CG][4];
+#pragma unroll
+      for (int cj = 0; cj < CG; ++cj) {
+        const float4 t = (cg0 + cj < cc) ? *(const float4*)(src + (size_t)(cg0 + cj) * a.N + n0) : make_float4(0, 0, 0, 0);
+        fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+      }
+#pragma unroll
+      for (int cj = 0; cj < CG; ++cj) {
+        const int ch = cg0 + cj;
+        if (ch < cc) {
+          int* Tc = acc + (size_t)ch * g.G;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float f = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const float prod = f * cw[i][v];
+              int* cell = Tc + base[i] + off.cell[v];
+              if (!ADD) {
+                // zero floor: only positive products can win, and positive IEEE-754 floats order like their bit patterns
+                if (prod > 0.0f) atomicMax((unsigned*)cell, __float_as_uint(prod));
+              } else if (fixed) {     // block-uniform
+                atomicAdd(cell, __float2int_rn(prod));
+              } else {
+                atomicAdd((float*)cell, prod);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) {
+    if (ADD && fixed) {
+      const int4 t = ((const int4*)acc)[i];
+      ((float4*)gout)[i] = make_float4((float)t.x * q, (float)t.y * q, (float)t.z * q, (float)t.w * q);
+    } else {
+      ((float4*)gout)[i] = ((const float4*)lds)[i];
+    }
   }
 }
 
@@ -1153,6 +1301,18 @@ int set_lds(K kernel, size_t bytes) {
   } while (0)
 #define CT_QUAD_T_APPLY_(...) CT_QUAD_T(__VA_ARGS__)
 
+// the quad scatters (4 points per thread, dwordx4) need corners from keys and 16-byte aligned rows
+bool scatter_quad_ok(const RasterArgs& a, bool from_keys, int G) {
+  if (!from_keys || (a.N & 3) != 0 || (G & 3) != 0) return false;
+  return ((((uintptr_t)a.src) | ((uintptr_t)a.pos.keys) | ((uintptr_t)a.tile_out)) & 15) == 0;
+}
+
+int scatter_quad_threads(int dim, int N) {
+  const int cap = dim == 2 ? 1024 : 512;
+  const int t = round_threads(N >> 2);
+  return t > cap ? cap : t;
+}
+
 // scatter: Splat fwd (max/sum) and Slice bwd g_grid
 template <int DIM, bool FROM_KEYS>
 int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
@@ -1177,7 +1337,13 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
         CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
       }
     } else {
-      CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+      if (scatter_quad_ok(a, FROM_KEYS, g.G)) {
+        const int qt = scatter_quad_threads(DIM, a.N);
+        if (a.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, false, true>), grid, qt, p.lds_bytes, st, a, g);
+        else CT_LAUNCH((scatter_quad_kernel<DIM, false, false>), grid, qt, p.lds_bytes, st, a, g);
+      } else {
+        CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+      }
     }
   } else {
     if (hipMemsetAsync(a.tile_out, 0, (size_t)a.B * a.H * a.C * g.G * 4, st) != hipSuccess) return CT_ELAUNCH;
@@ -1383,6 +1549,12 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   sa.CC = ps.CC; sa.nchunks = ps.nchunks;
   const int sthreads = ps.threads;   // (finer chunks / smaller workgroups were measured: no gain)
   dim3 sgrid(sa.nchunks, a.H, a.B);
+  if (scatter_quad_ok(sa, true, g.G)) {
+    const int qt = scatter_quad_threads(DIM, a.N);
+    if (sa.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, true, true>), sgrid, qt, (size_t)sa.CC * g.G * 4, st, sa, g);
+    else CT_LAUNCH((scatter_quad_kernel<DIM, true, false>), sgrid, qt, (size_t)sa.CC * g.G * 4, st, sa, g);
+    return CT_OK;
+  }
   CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, sthreads, (size_t)sa.CC * g.G * 4 + (size_t)2 * sa.CC * 4, st, sa, g);
   return CT_OK;
 }
