@@ -53,6 +53,7 @@ struct RasterArgs {
   int ncg;              // chunk groups (grid.x split of the chunk loop in gather-reduce kernels)
   int nsplit;           // splits of N for pure gather kernels
   int atomic_gpos;      // accumulate g_pos with global atomics (ncg > 1)
+  int cnt_mask;         // STATS: contributions are counted in cnt_mask+1 (a power of two) counters indexed by cell & cnt_mask
   size_t gpos_stride;   // > 0: channel-chunk group cg writes its partial g_pos to g_pos + cg*gpos_stride floats (summed afterwards)
 };
 
@@ -884,10 +885,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
     // STATS (Slice backward): by-products for the fixed-point scatter that follows —
     // per-channel max |src*pad| and the max number of contributions per cell
     unsigned* s_max = (unsigned*)(lds + (size_t)a.CC * g.G);         // [CC]
-    int* s_cnt = (int*)(lds + (size_t)a.CC * g.G + a.CC);            // [G]
+    int* s_cnt = (int*)(lds + (size_t)a.CC * g.G + a.CC);            // [cnt_mask + 1]
     __syncthreads();
     if (STATS) {
-      for (int i = threadIdx.x; i < a.CC + g.G; i += blockDim.x) s_max[i] = 0u;
+      for (int i = threadIdx.x; i < a.CC + a.cnt_mask + 1; i += blockDim.x) s_max[i] = 0u;
     }
     stage_tile(T, a.tile_in + toff, cc * g.G);
     if (MODE == QM_SPLAT_MAX_BWD) stage_tile(T2, a.tile_in2 + toff, cc * g.G);
@@ -933,7 +934,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int v = 0; v < V; ++v) atomicAdd(&s_cnt[base[i] + off.cell[v]], 1);
+          for (int v = 0; v < V; ++v) atomicAdd(&s_cnt[(base[i] + off.cell[v]) & a.cnt_mask], 1);
       }
       float gw[4][V];
       if (kGw) {
@@ -1086,7 +1087,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
       __syncthreads();
       unsigned kmax = 0;
       if (first) {
-        for (int i = threadIdx.x; i < g.G; i += blockDim.x) kmax = max(kmax, (unsigned)s_cnt[i]);
+        for (int i = threadIdx.x; i <= a.cnt_mask; i += blockDim.x) kmax = max(kmax, (unsigned)s_cnt[i]);
         for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
       }
       unsigned* slots = (unsigned*)(a.tile_out + toff);
@@ -1525,8 +1526,16 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   Plan pg = make_plan(a.B, a.H, a.C, a.N, g.G, 1, /*want=*/1);
   Plan ps = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
   if (!pg.lds_tile || !ps.lds_tile) return CT_EINVAL;
-  const size_t extra = (size_t)(pg.CC + g.G) * 4;
+  // contributions per cell are counted in a power-of-two table indexed by cell & mask: one counter per cell when
+  // that fits beside the tile, otherwise several cells share a counter — the maximum over the table is then still
+  // an upper bound of the per-cell maximum, which is all K has to be (a looser bound costs log2 of the slack in
+  // the 30-bit fixed-point resolution)
+  int cnt = 1024;
+  while (cnt < g.G) cnt *= 2;
+  while (cnt > 1024 && pg.lds_bytes + (size_t)(pg.CC + cnt) * 4 > (size_t)kBigLdsBytes) cnt /= 2;
+  const size_t extra = (size_t)(pg.CC + cnt) * 4;
   if (pg.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
+  ga.cnt_mask = cnt - 1;
   ga.CC = pg.CC; ga.nchunks = pg.nchunks; ga.ncg = 1; ga.atomic_gpos = 0;
   ga.nsplit = 1;
   while ((long long)a.B * a.H * ga.nsplit < 256 && (a.N >> 2) / (ga.nsplit * 2) >= 128) ga.nsplit *= 2;
