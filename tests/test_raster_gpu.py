@@ -301,3 +301,39 @@ def test_fuzz_shapes_against_oracle(cfg):
     close(o, o_ref, 2e-5 if reduce == "max" else 1e-4)
     close(fc.grad, f.grad)
     close(kc.grad, k.grad)
+
+
+@pytest.mark.parametrize("N", [256, 250])        # quad kernels (N % 4 == 0) and the one-point-per-thread forms
+def test_non_finite_cotangents_take_the_float_path(N):
+    """The fixed-point scatter-add cannot represent inf/NaN: a slab that holds one is accumulated with float
+    atomics instead (IEEE semantics, as the reference's index_add), and the other slabs keep their fixed-point
+    accuracy.  Checked on Slice backward (g_grid) and Splat(sum) forward against the oracle."""
+    from cloud_transformers_amd import ops
+    g = torch.Generator().manual_seed(N)
+    B, H, C, dim, W = 2, 3, 5, 2, 8
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    src = torch.randn(B, H * C, N, generator=g)
+    src[0, 2, 17] = float("inf")
+    src[1, 7, 3] = float("-inf")
+    src[1, 11, 100] = float("nan")
+    lc, idx = R.positions(keys, [W, W], H, dim)
+    z_ref = R.splat(lc, idx, src, None, [W, W], H, dim, "sum")
+
+    def same(got, ref):
+        got, ref = got.cpu(), ref.detach()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        fin = torch.isfinite(ref)
+        assert torch.equal(got[~fin & ~torch.isnan(ref)], ref[~fin & ~torch.isnan(ref)])        # +-inf in the same cells
+        assert float((got[fin] - ref[fin]).abs().max()) <= 1e-4 * max(1.0, float(ref[fin].abs().max()))
+
+    z = ops.splat_keys(keys.cuda(), src.cuda(), None, [W, W], H, dim, "sum")
+    same(z, z_ref)
+    # Slice backward wrt the grid is the same scatter-add applied to the output cotangent
+    grid = torch.zeros(B, H * C, W, W, device="cuda", requires_grad=True)
+    o = ops.slice_keys(keys.cuda(), grid, None, [W, W], H, dim)
+    o.backward(src.cuda())
+    same(grid.grad, z_ref)
+    # Splat(max): +inf wins its cells, -inf and NaN never beat the zero floor
+    zm_ref = R.splat(lc, idx, torch.nan_to_num(src, nan=-1.0, posinf=float("inf"), neginf=-1.0), None, [W, W], H, dim, "max")
+    zm = ops.splat_keys(keys.cuda(), src.cuda(), None, [W, W], H, dim, "max")
+    assert torch.equal(zm.cpu(), zm_ref)
