@@ -2,7 +2,7 @@
 tests/test_raster_gpu.py::test_fuzz_shapes_against_oracle).  `python tools/soak_fuzz.py [n_gconv_seeds] [n_raster_batches]`.
 
 Round-1 runs: 600 grouped-conv seeds clean (after ct_gconv_supported: two shapes without an LDS tile plan used to fail);
-288 raster cases with one expected difference: a feature that randn drew as exactly 0.0 ties with the zero floor of an empty
+672 raster cases (288, then 384 after the quad scatter kernels) with two expected differences, both the same thing: a feature that randn drew as exactly 0.0 ties with the zero floor of an empty
 cell, where the oracle's scatter_reduce stand-in gives the candidate half the cotangent and torch_scatter's CPU rule (strict >)
 and this implementation give it none (backward differs on exact ties only)."""
 import os
