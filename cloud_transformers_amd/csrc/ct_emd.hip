@@ -6,11 +6,13 @@
 //     (GetMax -> Assign -> recount -> compaction of the unassigned list) is ONE
 //     kernel with one 1024-thread workgroup per batch: an iteration is 2 launches
 //     (update, bid) instead of the reference's 7;
+//   * the per-batch kernel is latency-bound (dependent L2 accesses from one workgroup), so it walks the
+//     unassigned LIST rather than all n points and batches the loads of each dependency level;
 //   * Bid is the O(U*n) part.  A 256-thread workgroup takes ceil(U / blocks)
-//     bidders; T = 256 / bidders lanes (a power of two <= 64, inside one wave)
-//     share a bidder and scan interleaved targets of an LDS tile
-//     {x,y,z,price} (conflict-free ds_read_b128), then merge their (best,
-//     second best) pairs with wave shuffles — no LDS reduction, no barrier;
+//     bidders; T = 256 / bidders lanes (a power of two, 4..256) share a bidder and scan interleaved
+//     targets of an LDS tile {x,y,z,price} (conflict-free ds_read_b128, four in flight), then merge
+//     their (best, second best) pairs with wave shuffles (and through LDS when a bidder spans whole
+//     waves); the next tiles' global loads are in flight while a tile is scanned;
 //   * the per-target maximum increment is an integer atomicMax on the float's bit
 //     pattern (increments are > 0), not a compare-and-swap loop;
 //   * GetMax ties (several bidders within 1e-6 of the maximum) resolve to the
@@ -59,8 +61,7 @@ __global__ void emd_init_kernel(EmdWs w, int* assignment, size_t total) {
 __global__ void __launch_bounds__(1024)
 emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2, float* dist,
                   int n, int do_assign, int last, int do_compact, int do_dist) {
-  __shared__ int s_scan[1024];
-  __shared__ int s_base;
+  __shared__ int s_scan[16];
   const int b = blockIdx.x;
   const size_t off = (size_t)b * n;
   int* ass = assignment + off;
@@ -71,40 +72,76 @@ emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2
   float* max_inc = w.max_inc + off;
   float* price = w.price + off;
 
+  // Every loop below is latency-bound (dependent L2 accesses, one workgroup per batch): each thread takes kUpR
+  // entries per pass and issues the loads of one dependency level for all of them before using any, so a pass
+  // costs a few memory latencies instead of a few per entry.  GetMax / Assign walk the unassigned list of the
+  // previous compaction — exactly the points with assignment == -1, since only the bid kernel ran in between —
+  // instead of testing all n points.
+  constexpr int kUpR = 8;
   if (do_assign) {
+    const int U = w.unass_cnt[b];
+    const int* list = w.unass_idx + off;
     // GetMax
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      if (ass[j] == -1) {
-        const int t = bid[j];
-        const float bi = bid_inc[j];
-        const float mi = ld_coherent(&max_inc[t]);
-        if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6) atomicMax(&max_idx[t], j);
+    for (int i0 = 0; i0 < U; i0 += 1024 * kUpR) {
+      int j[kUpR], t[kUpR];
+      float bi[kUpR], mi[kUpR];
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        const int i = i0 + u * 1024 + (int)threadIdx.x;
+        j[u] = i < U ? list[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        t[u] = j[u] >= 0 ? bid[j[u]] : 0;
+        bi[u] = j[u] >= 0 ? bid_inc[j[u]] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) mi[u] = j[u] >= 0 ? max_inc[t[u]] : 0.0f;     // written by the bid kernel
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        if (j[u] >= 0 && (double)bi[u] - 1e-6 <= (double)mi[u] && (double)mi[u] <= (double)bi[u] + 1e-6)
+          atomicMax(&max_idx[t[u]], j[u]);
       }
     }
     __threadfence_block();
     __syncthreads();
     // Assign
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      if (ld_coherent(&ass[j]) == -1) {
-        const int t = bid[j];
-        if (last || ld_coherent(&max_idx[t]) == j) {
-          const float bi = bid_inc[j];
+    for (int i0 = 0; i0 < U; i0 += 1024 * kUpR) {
+      int j[kUpR], t[kUpR], prev[kUpR];
+      float bi[kUpR];
+      bool win[kUpR];
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        const int i = i0 + u * 1024 + (int)threadIdx.x;
+        j[u] = i < U ? list[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        t[u] = j[u] >= 0 ? bid[j[u]] : 0;
+        bi[u] = j[u] >= 0 ? bid_inc[j[u]] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) win[u] = j[u] >= 0 && (last || ld_coherent(&max_idx[t[u]]) == j[u]);
+      // a target has one winner, so the winners of a pass touch disjoint targets and disjoint previous owners
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) prev[u] = (win[u] && !last) ? ass_inv[t[u]] : -1;
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+        if (win[u]) {
           if (!last) {
-            const int prev = ass_inv[t];
-            if (prev != -1) __hip_atomic_store(&ass[prev], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ass_inv[t] = j;
-            price[t] += bi;
-            max_inc[t] = -1e9f;
-            max_idx[t] = -1;
-            __hip_atomic_store(&ass[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev[u] != -1) __hip_atomic_store(&ass[prev[u]], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ass_inv[t[u]] = j[u];
+            price[t[u]] += bi[u];
+            max_inc[t[u]] = -1e9f;
+            max_idx[t[u]] = -1;
           } else {
             // forced assignment of every remaining bidder: several bidders may share a
             // target, so the price update must be atomic to stay well defined
-            ass_inv[t] = j;
-            atomicAdd(&price[t], bi);
-            max_inc[t] = -1e9f;
-            __hip_atomic_store(&ass[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ass_inv[t[u]] = j[u];
+            atomicAdd(&price[t[u]], bi[u]);
+            max_inc[t[u]] = -1e9f;
           }
+          __hip_atomic_store(&ass[j[u]], t[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -113,30 +150,46 @@ emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2
   }
 
   if (do_compact) {
-    // ascending list of unassigned points (block-wide exclusive scan per 1024-point chunk)
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += blockDim.x) {
-      const int j = c0 + threadIdx.x;
-      const int flag = (j < n && ld_coherent(&ass[j]) == -1) ? 1 : 0;
-      // inclusive scan: wave shuffle + per-wave totals
-      int v = flag;
+    // ascending list of unassigned points: a thread owns n/1024 (<= 64 per segment) consecutive points, keeps their
+    // flags as a bit mask, and one block-wide exclusive scan of the per-thread counts places its entries
+    int base = 0;
+    for (int seg = 0; seg < n; seg += 65536) {
+      const int per = min(n - seg, 65536) >> 10;        // n % 1024 == 0
+      const int j0 = seg + (int)threadIdx.x * per;
+      unsigned long long mask = 0ull;
+      for (int u0 = 0; u0 < per; u0 += kUpR) {
+        int a[kUpR];
+#pragma unroll
+        for (int u = 0; u < kUpR; ++u) a[u] = (u0 + u < per) ? ld_coherent(&ass[j0 + u0 + u]) : 0;
+#pragma unroll
+        for (int u = 0; u < kUpR; ++u)
+          if (a[u] == -1) mask |= 1ull << (u0 + u);
+      }
+      const int cnt = __popcll(mask);
+      int v = cnt;                                      // inclusive scan: wave shuffle + per-wave totals
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
+        const int tt = __shfl_up(v, d, 64);
+        if (lane >= d) v += tt;
       }
+      __syncthreads();                                  // s_scan of the previous segment has been consumed
       if (lane == 63) s_scan[wave] = v;
       __syncthreads();
-      int wave_off = 0;
-      for (int q = 0; q < wave; ++q) wave_off += s_scan[q];
-      const int base = s_base;
-      if (flag) w.unass_idx[off + base + wave_off + v - 1] = j;
-      __syncthreads();
-      if (threadIdx.x == blockDim.x - 1) s_base = base + wave_off + v;
-      __syncthreads();
+      int wave_off = 0, total = 0;
+      for (int q = 0; q < (int)(blockDim.x >> 6); ++q) {
+        const int c = s_scan[q];
+        if (q < wave) wave_off += c;
+        total += c;
+      }
+      int pos = base + wave_off + v - cnt;
+      while (mask) {
+        const int u = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        w.unass_idx[off + pos++] = j0 + u;
+      }
+      base += total;
     }
-    if (threadIdx.x == 0) w.unass_cnt[b] = s_base;
+    if (threadIdx.x == 0) w.unass_cnt[b] = base;
   }
 
   if (do_dist) {
@@ -170,10 +223,26 @@ __device__ __forceinline__ Top2 merge_top2(const Top2& a, const Top2& o) {
   return r;
 }
 
-// grid = (blocks per batch, B)
+// one candidate target against a lane's running (best, second best); strict '>' so that an ascending scan keeps
+// the lowest index on ties (emd_cuda.cu:150-157) — branch-free
+__device__ __forceinline__ void top2_push(Top2& t, float d, int idx) {
+  const bool gt = d > t.best;
+  const bool gt2 = d > t.better;
+  t.better = gt ? t.best : (gt2 ? d : t.better);
+  t.idx = gt ? idx : t.idx;
+  t.best = gt ? d : t.best;
+}
+
+// grid = (blocks per batch, B).  n % 1024 == 0 (checked by ct_emd_fwd), so every tile is full.
+// Late iterations have a handful of bidders and are pure latency: the next tile's global loads are in flight
+// while the current one is scanned (registers -> the other LDS buffer, one barrier per tile), a bidder gets up
+// to all 256 lanes, and the scan is unrolled by 4 so that four ds_read_b128 and four sqrt chains overlap.
 __global__ void __launch_bounds__(kBidThreads)
 emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict__ xyz2, int n, float eps) {
-  __shared__ float4 tile[kTile];
+  __shared__ float4 tile[2][kTile];
+  __shared__ float s_best[kBidThreads / 64], s_better[kBidThreads / 64];
+  __shared__ int s_idx[kBidThreads / 64];
+  constexpr int kPer = kTile / kBidThreads;                     // tile elements staged per thread
   const int b = blockIdx.y;
   const size_t off = (size_t)b * n;
   const int U = w.unass_cnt[b];
@@ -184,9 +253,9 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   const int mine = max(0, min(per_blk, U - first));
   if (mine == 0) return;                                        // block-uniform
   int T = kBidThreads / per_blk;                                // lanes per bidder
-  T = T < 1 ? 1 : (T > 64 ? 64 : T);
-  T = 1 << (31 - __clz(T));                                     // power of two: bidders never straddle a wave
-  // per_blk > 256 cannot happen: nblk = n/64 >= U/64  =>  per_blk <= 64
+  T = T < 1 ? 1 : T;
+  T = 1 << (31 - __clz(T));                                     // power of two: a bidder is a lane group of a wave, or whole waves
+  // per_blk > 256 cannot happen: nblk = n/64 >= U/64  =>  per_blk <= 64  =>  T >= 4
   const int slot = threadIdx.x / T, sub = threadIdx.x % T;
   const bool active = slot < mine;
   int j = -1;
@@ -197,37 +266,81 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
     y1 = xyz1[(off + j) * 3 + 1];
     z1 = xyz1[(off + j) * 3 + 2];
   }
-  Top2 t2 = {-1e9f, -1e9f, 0x7fffffff};
-  for (int k0 = 0; k0 < n; k0 += kTile) {
-    const int cnt = min(kTile, n - k0);
-    __syncthreads();
-    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
-      const float* p = xyz2 + (off + k0 + k) * 3;
-      tile[k] = make_float4(p[0], p[1], p[2], w.price[off + k0 + k]);
+  // software pipeline: tile t is scanned from LDS while tiles t+2 .. t+1+kDepth are in flight to registers
+  constexpr int kDepth = 4;
+  float4 stage[kDepth][kPer];
+  auto fetch = [&](int t, float4 (&st)[kPer]) {
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+      const size_t k = off + (size_t)t * kTile + e * kBidThreads + threadIdx.x;
+      const float* p = xyz2 + k * 3;
+      st[e] = make_float4(p[0], p[1], p[2], w.price[k]);
     }
-    __syncthreads();
-    if (active) {
-      for (int k = sub; k < cnt; k += T) {
-        const float4 q = tile[k];
-        const float x2 = q.x - x1, y2 = q.y - y1, z2 = q.z - z1;
-        const float d2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
-        // evaluated in double like the reference (its literal 3.0 is a double), rounded once
-        const float d = (float)(3.0 - (double)sqrtf(d2) - (double)q.w);
-        if (d > t2.best) {
-          t2.better = t2.best; t2.best = d; t2.idx = k0 + k;
-        } else if (d > t2.better) {
-          t2.better = d;
+  };
+  auto commit = [&](int buf, const float4 (&st)[kPer]) {
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) tile[buf][e * kBidThreads + threadIdx.x] = st[e];
+  };
+  const int ntiles = n / kTile;
+#pragma unroll
+  for (int r = 0; r < kDepth; ++r)
+    if (r < ntiles) fetch(r, stage[r]);
+  commit(0, stage[0]);
+  if (kDepth < ntiles) fetch(kDepth, stage[0]);
+  __syncthreads();
+  Top2 t2 = {-1e9f, -1e9f, 0x7fffffff};
+  for (int t0 = 0; t0 < ntiles; t0 += kDepth) {
+#pragma unroll
+    for (int r = 0; r < kDepth; ++r) {
+      const int t = t0 + r;
+      if (t < ntiles) {                                        // block-uniform
+        if (active) {
+          const float4* tl = tile[t & 1];
+          const int k0 = t * kTile;
+          for (int k = sub; k < kTile; k += 4 * T) {           // kTile / T is a multiple of 4 (T <= 256)
+            float4 q[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = tl[k + u * T];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float x2 = q[u].x - x1, y2 = q[u].y - y1, z2 = q[u].z - z1;
+              const float d2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+              // evaluated in double like the reference (its literal 3.0 is a double), rounded once
+              d[u] = (float)(3.0 - (double)sqrtf(d2) - (double)q[u].w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) top2_push(t2, d[u], k0 + k + u * T);
+          }
         }
+        if (t + 1 < ntiles) {
+          // the other buffer was last read before the previous barrier; its register slot is then free again
+          commit((t + 1) & 1, stage[(r + 1) % kDepth]);
+          if (t + 1 + kDepth < ntiles) fetch(t + 1 + kDepth, stage[(r + 1) % kDepth]);
+        }
+        __syncthreads();
       }
     }
   }
-  // butterfly over the T lanes of a bidder (all inside one wave; inactive lanes hold the identity)
-  for (int m = 1; m < T; m <<= 1) {
+  // butterfly over the lanes of a bidder inside its wave (inactive lanes hold the identity)
+  const int Tw = T < 64 ? T : 64;
+  for (int m = 1; m < Tw; m <<= 1) {
     Top2 o;
     o.best = __shfl_xor(t2.best, m, 64);
     o.better = __shfl_xor(t2.better, m, 64);
     o.idx = __shfl_xor(t2.idx, m, 64);
     t2 = merge_top2(t2, o);
+  }
+  if (T > 64) {                      // block-uniform: a bidder spans T/64 whole waves
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_best[wave] = t2.best; s_better[wave] = t2.better; s_idx[wave] = t2.idx; }
+    __syncthreads();
+    if (sub == 0) {
+      for (int q = 1; q < T / 64; ++q) {
+        Top2 o = {s_best[wave + q], s_better[wave + q], s_idx[wave + q]};
+        t2 = merge_top2(t2, o);
+      }
+    }
   }
   if (active && sub == 0) {
     const float inc = t2.best - t2.better + eps;
