@@ -77,9 +77,9 @@ class SplatSliceStep:
     PASSES = ("splat_fwd", "slice_fwd", "slice_bwd", "splat_bwd")
     # HIP kernel behind each pass on the headline shape (name as rocprofv3 prints it)
     KERNELS = {
-        "splat_fwd": "scatter_kernel<2, true, false, true>",
+        "splat_fwd": "scatter_quad_kernel<2, false, false>",
         "slice_fwd": "quad_kernel<2, 0, 4, 512, false, false>",
-        "slice_bwd": "quad_kernel<2, 1, 4, 512, true, false> + scatter_add_fx_stream_kernel<2, true>",
+        "slice_bwd": "quad_kernel<2, 1, 4, 512, true, false> + scatter_quad_kernel<2, true, false>",
         "splat_bwd": "quad_kernel<2, 2, 4, 1024, false, false>",
     }
     # passes that are exactly one kernel launch (slice_bwd is two: ~43 us + ~50 us on the headline shape)
