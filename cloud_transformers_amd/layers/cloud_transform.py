@@ -11,6 +11,15 @@ each of `Splat` / `Slice` offers `forward_keys(keys, …)`: the fused hot path
 used by the MultiHead* blocks, which recomputes the corner weights/indices
 inside the kernels and never materialises `local_coordinate` /
 `flattened_index` (or the reference's (B,H,C,V,N) intermediates) in HBM.
+
+Code written the reference's way — `lc, idx = positions(keys); z = splat(lc, idx, f);
+o = slice(lc, idx, conv(z))` (layers/multihead_ct.py:99-107) — takes the same fused
+path: `DifferentiablePositions.forward` tags the pair it returns with the keys it
+came from, and `Splat` / `Slice` given exactly that untouched pair (same tensor
+objects, no in-place edit since, same grid) run `forward_keys` on those keys.  The
+value and the gradient wrt the keys are those of the explicit path (the kernels
+recompute the very same weights and indices); a pair that was detached, cloned,
+sliced or edited is a different tensor and takes the explicit `(lc, idx)` kernels.
 """
 import torch
 from torch import nn
@@ -47,7 +56,32 @@ class DifferentiablePositions(DifferentiableGridModule):
 
     def forward(self, keys):
         assert keys.size(1) == self.heads * self.dim
-        return ops.positions(keys, self.tensor_size, self.heads, self.dim)
+        lc, idx = ops.positions(keys, self.tensor_size, self.heads, self.dim)
+        if keys.is_cuda and keys.dtype == torch.float32:
+            tag = _Provenance(keys, self.tensor_size, self.heads, self.dim, lc, idx)
+            lc._ct_src = tag
+            idx._ct_src = tag
+        return lc, idx
+
+
+class _Provenance:
+    """Where a (local_coordinate, flattened_index) pair came from: lets Splat / Slice run the fused keys path."""
+    __slots__ = ("keys", "config", "versions")
+
+    def __init__(self, keys, tensor_size, heads, dim, lc, idx):
+        self.keys = keys
+        self.config = (tuple(tensor_size), heads, dim)
+        self.versions = (keys._version, lc._version, idx._version)
+
+    def keys_for(self, module, lc, idx):
+        """The keys if (lc, idx) is the untouched pair this tag was made for and `module` has the same grid, else None."""
+        if getattr(idx, "_ct_src", None) is not self:
+            return None
+        if (tuple(module.tensor_size), module.heads, module.dim) != self.config:
+            return None
+        if (self.keys._version, lc._version, idx._version) != self.versions:
+            return None
+        return self.keys
 
 
 class Splat(DifferentiableGridModule):
@@ -65,6 +99,10 @@ class Splat(DifferentiableGridModule):
     def forward(self, local_coordinate, flattened_index, features, pts_padding=None):
         assert features.dtype == torch.float32
         assert features.size(1) % self.heads == 0
+        tag = getattr(local_coordinate, "_ct_src", None)
+        keys = tag.keys_for(self, local_coordinate, flattened_index) if tag is not None else None
+        if keys is not None:
+            return self.forward_keys(keys, features, pts_padding)
         return ops.splat_lc(local_coordinate, flattened_index, features, pts_padding,
                             self.tensor_size, self.heads, self.dim, self.reduce)
 
@@ -79,6 +117,10 @@ class Slice(DifferentiableGridModule):
 
     def forward(self, local_coordinate, flattened_index, convolved, pts_padding=None):
         assert convolved.size(1) % self.heads == 0
+        tag = getattr(local_coordinate, "_ct_src", None)
+        keys = tag.keys_for(self, local_coordinate, flattened_index) if tag is not None else None
+        if keys is not None:
+            return self.forward_keys(keys, convolved, pts_padding)
         return ops.slice_lc(local_coordinate, flattened_index, convolved, pts_padding,
                             self.tensor_size, self.heads, self.dim)
 

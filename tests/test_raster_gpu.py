@@ -337,3 +337,61 @@ def test_non_finite_cotangents_take_the_float_path(N):
     zm_ref = R.splat(lc, idx, torch.nan_to_num(src, nan=-1.0, posinf=float("inf"), neginf=-1.0), None, [W, W], H, dim, "max")
     zm = ops.splat_keys(keys.cuda(), src.cuda(), None, [W, W], H, dim, "max")
     assert torch.equal(zm.cpu(), zm_ref)
+
+
+def test_reference_style_chain_takes_the_fused_path():
+    """`lc, idx = positions(keys); splat(lc, idx, f); slice(lc, idx, z)` — the way the reference's MultiHead is written
+    (layers/multihead_ct.py:99-107) — runs the fused keys kernels when the pair is the untouched output of
+    DifferentiablePositions, with the values and gradients of the explicit (lc, idx) kernels; an edited, cloned or
+    foreign pair takes the explicit kernels."""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.cloud_transform import DifferentiablePositions, Slice, Splat
+    g = torch.Generator().manual_seed(21)
+    B, H, C, N, dim, W = 2, 4, 8, 512, 2, 16
+    keys0 = torch.tanh(torch.randn(B, H * dim, N, generator=g)).cuda()
+    feat0 = torch.randn(B, H * C, N, generator=g).cuda()
+    cot = torch.randn(B, H * C, N, generator=g).cuda()
+    pos, splat, slc = DifferentiablePositions(W, H, dim).cuda(), Splat(W, H, dim).cuda(), Slice(W, H, dim).cuda()
+
+    calls = []
+    real = {n: getattr(ops, n) for n in ("splat_keys", "slice_keys", "splat_lc", "slice_lc")}
+
+    def spy(name):
+        def f(*a, **k):
+            calls.append(name)
+            return real[name](*a, **k)
+        return f
+
+    def run(mutate):
+        k = keys0.clone().requires_grad_(True)
+        f = feat0.clone().requires_grad_(True)
+        lc, idx = pos(k)
+        lc, idx = mutate(lc, idx)
+        z = splat(lc, idx, f)
+        o = slc(lc, idx, z)
+        (o * cot).sum().backward()
+        return z.detach(), o.detach(), k.grad, f.grad
+
+    for n in real:
+        setattr(ops, n, spy(n))
+    try:
+        fused = run(lambda lc, idx: (lc, idx))
+        assert calls == ["splat_keys", "slice_keys"], calls
+        del calls[:]
+        explicit = run(lambda lc, idx: (lc.clone(), idx))           # a clone is a different tensor: explicit kernels
+        assert calls == ["splat_lc", "slice_lc"], calls
+        del calls[:]
+        run(lambda lc, idx: (lc.mul_(1.0), idx))                     # edited in place since: explicit kernels
+        assert calls == ["splat_lc", "slice_lc"], calls
+        del calls[:]
+        other = Splat(W * 2, H, dim).cuda()                         # another grid than the pair was made for
+        lc, idx = pos(keys0)
+        other(lc, idx, feat0)                                       # (indices of the W grid are valid cells of the 2W grid)
+        assert calls == ["splat_lc"], calls
+    finally:
+        for n, fn in real.items():
+            setattr(ops, n, fn)
+    assert torch.equal(fused[0], explicit[0])                       # max: bit-exact
+    close(fused[1], explicit[1], 1e-6)
+    close(fused[2], explicit[2])
+    close(fused[3], explicit[3])
