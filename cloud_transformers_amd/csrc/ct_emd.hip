@@ -226,11 +226,10 @@ __device__ __forceinline__ Top2 merge_top2(const Top2& a, const Top2& o) {
 // one candidate target against a lane's running (best, second best); strict '>' so that an ascending scan keeps
 // the lowest index on ties (emd_cuda.cu:150-157) — branch-free
 __device__ __forceinline__ void top2_push(Top2& t, float d, int idx) {
-  const bool gt = d > t.best;
-  const bool gt2 = d > t.better;
-  t.better = gt ? t.best : (gt2 ? d : t.better);
-  t.idx = gt ? idx : t.idx;
-  t.best = gt ? d : t.best;
+  // better <= best always, so the new second best is the median of (best, better, d): one v_med3_f32
+  t.idx = d > t.best ? idx : t.idx;
+  t.better = __builtin_amdgcn_fmed3f(t.best, t.better, d);
+  t.best = fmaxf(t.best, d);
 }
 
 // grid = (blocks per batch, B).  n % 1024 == 0 (checked by ct_emd_fwd), so every tile is full.
