@@ -68,3 +68,28 @@ def test_large_cloud_validity():
     assert torch.allclose(((a - sel) ** 2).sum(-1), dist, atol=1e-6)
     assert all(ass[i].unique().numel() > 0.9 * 16384 for i in range(2))
     assert float(dist.sqrt().mean()) < 0.05
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_matches_oracle_exactly(seed):
+    """Random (B, n, eps, iters) and clouds with structure (clusters, duplicated points, a shared point set): the
+    assignment and the distances are the oracle's, bit for bit."""
+    from cloud_transformers_amd.emd import emdModule
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 4))
+    n = int(rng.choice([1024, 2048, 3072, 5120]))
+    eps = float(rng.choice([0.002, 0.005, 0.02]))
+    iters = int(rng.choice([1, 2, 7, 25, 60]))
+    a = rng.random((B, n, 3), dtype=np.float32)
+    b = rng.random((B, n, 3), dtype=np.float32)
+    kind = seed % 3
+    if kind == 1:        # clustered targets: many near-ties, long auctions
+        b = (b * 0.05 + rng.random((B, 8, 3), dtype=np.float32)[:, rng.integers(0, 8, n)]).astype(np.float32)
+    elif kind == 2:      # exact duplicates and points shared by both clouds (zero distances)
+        b[:, n // 2:] = b[:, : n - n // 2]
+        a[:, : n // 4] = b[:, : n // 4]
+    st, d_ref, ass_ref = emd_ref.forward(a, b, eps, iters)
+    assert st == 1
+    dist, ass = emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), eps, iters)
+    assert np.array_equal(ass.cpu().numpy(), ass_ref), float((ass.cpu().numpy() == ass_ref).mean())
+    assert np.array_equal(dist.cpu().numpy(), d_ref)
