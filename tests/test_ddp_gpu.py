@@ -35,8 +35,8 @@ def test_ddp_syncbn_single_rank_matches_plain():
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        ddp = torch.nn.parallel.DistributedDataParallel(
-            torch.nn.SyncBatchNorm.convert_sync_batchnorm(model), device_ids=[0])
+        ddp = P.data_parallel(model, 0)
+        assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in ddp.modules())
         out, stats = ddp(x, pcd)
         loss = out.square().mean()
         loss.backward()

@@ -34,6 +34,17 @@ def _worker(rank, world, port, q):
     per_rank_units = 8 * 4096
     t = P.max_over_ranks(dist, 0.5 if rank == 0 else 1.0)
     res["value"] = world * per_rank_units / t
+    # data_parallel: same weights everywhere, each rank its own samples -> every rank ends with the mean gradient
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.ReLU(), torch.nn.Linear(3, 1))
+    ddp = P.data_parallel(net, None, sync_bn=False)
+    x = torch.full((2, 4), float(rank + 1))
+    ddp(x).sum().backward()
+    res["ddp_grad"] = net[0].weight.grad.flatten().tolist()
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.ReLU(), torch.nn.Linear(3, 1))
+    (sum(ref(torch.full((2, 4), float(r + 1))).sum() for r in range(world)) / world).backward()
+    res["ref_grad"] = ref[0].weight.grad.flatten().tolist()
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -57,6 +68,8 @@ def test_world_size_2_helpers():
     assert out[0]["gather"] == out[1]["gather"] == [[0.0] * 3, [1.0] * 3]
     assert out[0]["objects"] == out[1]["objects"] == [{"rank": 0, "ids": [0]}, {"rank": 1, "ids": [0, 1]}]
     assert out[0]["value"] == out[1]["value"] == 2 * 8 * 4096 / 1.0
+    for r in range(world):
+        assert out[r]["ddp_grad"] == pytest.approx(out[r]["ref_grad"], rel=1e-6, abs=1e-7)
 
 
 def test_single_process_fallbacks():

@@ -2,7 +2,12 @@
 per-GPU work: 4096-point clouds, batch 8): stem Conv1d(6->512)+BN+ReLU, twelve MultiHeadUnion blocks cycling the
 zoo's three head configurations (model_zoo/s3dis/segmenter.py:28-45), Conv-BN-ReLU-Conv head to 13 classes;
 cross-entropy loss, backward, SGD step; synthetic data, random-initialised weights.  Prints ms per step and points/s
-on one MI355X: eager launches, and forward+backward replayed as one HIP graph with the optimizer step outside it."""
+on one MI355X: eager launches, and forward+backward replayed as one HIP graph with the optimizer step outside it.
+
+Data parallel (the reference's recipe, train_segmentation.py:58-61,128-130): launched by
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/segmenter_step_bench.py`
+every rank builds the same network, converts it to SyncBatchNorm, wraps it in DistributedDataParallel (RCCL) and steps its
+own batch of 8 clouds; rank 0 prints the max-over-ranks step time and the whole-job points/s (weak scaling)."""
 import os
 import sys
 
@@ -43,8 +48,54 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def main_ddp(world, rank, local_rank, N):
+    import torch.distributed as dist
+    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks
+    B = 8
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.manual_seed(0)                               # same initial weights on every rank
+    net = Segmenter().cuda()
+    ddp = data_parallel(net, local_rank, broadcast_buffers=os.environ.get("CT_DDP_BCAST", "0") == "1")
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
+    torch.manual_seed(1234 + rank)                     # its own shard of the batch
+    cloud = torch.cat([torch.rand(B, 3, N, device="cuda") * 2 - 1, torch.rand(B, 3, N, device="cuda")], dim=1)
+    labels = torch.randint(13, (B, N), device="cuda")
+    lossf = nn.CrossEntropyLoss()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = lossf(ddp(cloud), labels)
+        loss.backward()                                # bucketed gradient all-reduce overlaps with this
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    steps = 10
+    barrier(dist)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0) / steps
+    nbytes = sum(p.numel() for p in net.parameters()) * 4
+    if rank == 0:
+        print(f"S3DIS-shaped segmenter, DDP + SyncBatchNorm over RCCL, {world} x MI355X, B{B} N{N} per GPU, fp32: "
+              f"{dt * 1e3:.1f} ms per step, {world * B * N / dt / 1e3:.0f} k points/s whole job "
+              f"(gradient all-reduce {nbytes / 1e6:.1f} MB per step) | loss {float(loss):.3f}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     B, N = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return main_ddp(int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), N)
     torch.manual_seed(0)
     net = Segmenter().cuda()
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
