@@ -1,16 +1,18 @@
 """Soak: many more random cases through the fuzz tests' own generators (tests/test_gconv_gpu.py::test_gconv_fuzz,
-tests/test_raster_gpu.py::test_fuzz_shapes_against_oracle).  `python tools/soak_fuzz.py [n_gconv_seeds] [n_raster_batches]`.
+tests/test_raster_gpu.py::test_fuzz_shapes_against_oracle).  `python tools/soak_fuzz.py [n_gconv_seeds] [n_raster_batches] [n_emd_seeds]`.
 
 Round-1 runs: 600 grouped-conv seeds clean (after ct_gconv_supported: two shapes without an LDS tile plan used to fail);
 672 raster cases (288, then 384 after the quad scatter kernels) with two expected differences, both the same thing: a feature that randn drew as exactly 0.0 ties with the zero floor of an empty
 cell, where the oracle's scatter_reduce stand-in gives the candidate half the cotangent and torch_scatter's CPU rule (strict >)
-and this implementation give it none (backward differs on exact ties only)."""
+and this implementation give it none (backward differs on exact ties only).
+60 EMD fuzz seeds (sizes 1024-5120, clustered / duplicated / shared clouds): assignments and distances equal the oracle's exactly."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gconv_gpu as G          # noqa: E402
 import tests.test_raster_gpu as T         # noqa: E402
+import tests.test_emd_gpu as E            # noqa: E402
 
 
 def main():
@@ -34,6 +36,15 @@ def main():
                 bad += 1
                 print("raster cfg", cfg, "FAILED", str(e)[:300].replace("\n", " "))
     print("raster:", n, "cases, failures:", bad)
+    n_e = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    bad = 0
+    for seed in range(100, 100 + n_e):
+        try:
+            E.test_fuzz_matches_oracle_exactly(seed)
+        except Exception as e:             # noqa: BLE001
+            bad += 1
+            print("emd seed", seed, "FAILED", str(e)[:300].replace("\n", " "))
+    print("emd:", n_e, "seeds, failures:", bad)
 
 
 if __name__ == "__main__":
