@@ -82,7 +82,7 @@ class SplatSliceStep:
         "slice_bwd": "quad_kernel<2, 1, 4, 512, true, false> + scatter_quad_kernel<2, true, false>",
         "splat_bwd": "quad_kernel<2, 2, 4, 1024, false, false>",
     }
-    # passes that are exactly one kernel launch (slice_bwd is two: ~43 us + ~50 us on the headline shape)
+    # passes that are exactly one kernel launch (slice_bwd is two: ~47 us + ~42 us on the headline shape)
     SINGLE_KERNEL = ("splat_fwd", "slice_fwd", "splat_bwd")
 
     def run(self):
