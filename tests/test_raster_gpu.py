@@ -109,6 +109,8 @@ ORACLE_CASES = [
     (2, 16, 4, 512, 3, 8, False),
     (1, 1, 1, 1, 2, 2, False),
     (1, 2, 7, 65, 2, (5, 9), True),
+    (1, 2, 4, 200000, 2, 32, False),       # long clouds: every workgroup loops over many quads
+    (1, 1, 2, 100003, 3, 16, True),        # ... and the one-point-per-thread kernels (odd N)
 ]
 
 
