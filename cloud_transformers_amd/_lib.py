@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("CLOUDCT_LIB") or os.path.join(LIB_DIR, "libcloudct.so
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["ct_raster.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip",
-               "ct_adain.hip"]
+               "ct_adain.hip", "ct_bnorm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # index/weight math must round exactly like the reference's fp32 op sequence
                "-ffp-contract=off"]
@@ -64,6 +64,7 @@ def build(force=False, verbose=False):
 
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_ll = ctypes.c_longlong
 _ip = ctypes.POINTER(ctypes.c_int)
 
 # name -> (restype, argtypes); mirrors include/cloudct.h one to one
@@ -92,6 +93,9 @@ SIGNATURES = {
     "ct_so3_exp_bwd": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "ct_adain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "ct_adain_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ct_bn_relu_supported": (_i, [_i, _i, _i]),
+    "ct_bn_relu_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "ct_bn_relu_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_gconv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_supported": (_i, [_i, _i, _i, _i, _i, _ip]),

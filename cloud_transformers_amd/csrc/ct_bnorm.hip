@@ -1,0 +1,255 @@
+// Training-mode BatchNorm1d fused with the ReLU that follows it in the MHCT blocks' `after` stacks
+// (layers/multihead_ct.py:67-68,149-153: nn.Sequential(BatchNorm1d, ReLU(inplace=True))), forward and backward, one
+// launch each:
+//   mean_c = mean over (b, n) of x[b,c,n],  var_c = biased variance,  xhat = (x - mean_c) * rsqrt(var_c + eps)
+//   y = relu?(xhat * weight_c + bias_c);   running_mean / running_var updated like torch (momentum, unbiased variance)
+// The library pair moves the activation 2x (norm) + 2x (ReLU) forward and again in backward; here a channel's B*N values
+// are read once, held in registers between the statistics and the normalisation, and written once.
+//
+// Layout: x, y, gy, gx (B, C, N) contiguous.  One workgroup of 1024 threads owns one channel: its B rows of N floats
+// (N % 4 == 0) as float4, NV <= 8 per thread (the backward holds x and gy), so B*N <= 32768 — the training shapes of
+// the segmenter / classifier (B8 N4096, B8 N2048); ct_bn_relu_supported tells the caller which shapes qualify (the
+// others stay on the library BatchNorm + ReLU).
+#include "ct_common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / CT_WAVE;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = CT_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CT_WAVE);
+  return v;
+}
+
+// sums of K values over the workgroup; every thread gets the results (fixed order: deterministic)
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float (*red)[kWaves]) {
+  const int lane = threadIdx.x & (CT_WAVE - 1), wave = threadIdx.x / CT_WAVE;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) red[k][wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += red[k][w];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+struct BnArgs {
+  const float* x;
+  const float* weight;
+  const float* bias;
+  float* running_mean;   // nullable
+  float* running_var;
+  float* save_mean;
+  float* save_rstd;
+  int B, C, N;
+  float eps, momentum;
+  int relu;
+  long long xbs, ybs;    // batch strides of x and y in floats (C*N when contiguous; larger for a channel slice)
+};
+
+// float offset of quad q (over the B rows of channel c, N/4 quads each) in a tensor whose batch stride is bs floats
+__device__ __forceinline__ size_t quad_offset(int q, int nq, int c, long long bs, int N) {
+  const int b = q / nq, n4 = q - b * nq;
+  return (size_t)b * (size_t)bs + (size_t)c * N + ((size_t)n4 << 2);
+}
+
+template <int NV>
+__global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* __restrict__ y) {
+  __shared__ float red[1][kWaves];
+  const int c = blockIdx.x;
+  const int nq = a.N >> 2, total = a.B * nq;
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    v[k] = q < total ? *reinterpret_cast<const float4*>(a.x + quad_offset(q, nq, c, a.xbs, a.N)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s[0] += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  block_sum<1>(s, red);
+  const float M = (float)a.B * (float)a.N;
+  const float mu = s[0] / M;
+  float ss[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < total) {
+      const float dx = v[k].x - mu, dy = v[k].y - mu, dz = v[k].z - mu, dw = v[k].w - mu;
+      ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  block_sum<1>(ss, red);
+  const float var = ss[0] / M;
+  const float rs = rsqrtf(var + a.eps);
+  if (threadIdx.x == 0) {
+    a.save_mean[c] = mu;
+    a.save_rstd[c] = rs;
+    if (a.running_mean) {
+      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mu;
+      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (var * (M / (M - 1.0f)));
+    }
+  }
+  const float g = a.weight[c] * rs;
+  const float be = a.bias[c];
+  const float lo = a.relu ? 0.0f : -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < total) {
+      float4 o;
+      o.x = fmaxf((v[k].x - mu) * g + be, lo);
+      o.y = fmaxf((v[k].y - mu) * g + be, lo);
+      o.z = fmaxf((v[k].z - mu) * g + be, lo);
+      o.w = fmaxf((v[k].w - mu) * g + be, lo);
+      *reinterpret_cast<float4*>(y + quad_offset(q, nq, c, a.ybs, a.N)) = o;
+    }
+  }
+}
+
+struct BnBwdArgs {
+  const float* x;
+  const float* weight;
+  const float* bias;
+  const float* save_mean;
+  const float* save_rstd;
+  const float* gy;
+  float* gx;
+  float* g_weight;
+  float* g_bias;
+  int B, C, N;
+  int relu;
+  long long xbs, gybs, gxbs;   // batch strides in floats
+};
+
+// the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * (weight * rstd) + bias, same operation
+// order, contraction off), so an element is masked in backward iff the forward wrote a zero for it
+__device__ __forceinline__ float masked(float gy, float xc, float gfw, float be, int relu) {
+  return (relu && !(xc * gfw + be > 0.0f)) ? 0.0f : gy;
+}
+
+// With g' = gy masked by the ReLU:  g_bias = sum g',  g_weight = sum g' * xhat,
+//   gx = weight * rstd * (g' - mean(g') - xhat * mean(g' * xhat))
+template <int NV>
+__global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdArgs a) {
+  __shared__ float red[2][kWaves];
+  const int c = blockIdx.x;
+  const int nq = a.N >> 2, total = a.B * nq;
+  const float mu = a.save_mean[c], rs = a.save_rstd[c];
+  const float w = a.weight[c];
+  const float gfw = w * rs;                            // the forward's scale
+  const float be = a.bias[c];
+  float4 xh[NV], g[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    const bool ok = q < total;
+    const float4 xv = ok ? *reinterpret_cast<const float4*>(a.x + quad_offset(q, nq, c, a.xbs, a.N)) : make_float4(mu, mu, mu, mu);
+    const float4 gv = ok ? *reinterpret_cast<const float4*>(a.gy + quad_offset(q, nq, c, a.gybs, a.N)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    g[k] = make_float4(masked(gv.x, xv.x - mu, gfw, be, a.relu), masked(gv.y, xv.y - mu, gfw, be, a.relu),
+                       masked(gv.z, xv.z - mu, gfw, be, a.relu), masked(gv.w, xv.w - mu, gfw, be, a.relu));
+  }
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    s[0] += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+    s[1] += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    a.g_bias[c] = s[0];
+    a.g_weight[c] = s[1];
+  }
+  const float M = (float)a.B * (float)a.N;
+  const float m0 = s[0] / M, m1 = s[1] / M;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + k * kThreads;
+    if (q < total)
+      *reinterpret_cast<float4*>(a.gx + quad_offset(q, nq, c, a.gxbs, a.N)) =
+          make_float4(gfw * (g[k].x - m0 - xh[k].x * m1), gfw * (g[k].y - m0 - xh[k].y * m1),
+                      gfw * (g[k].z - m0 - xh[k].z * m1), gfw * (g[k].w - m0 - xh[k].w * m1));
+  }
+}
+
+int nv_for(long long quads) {
+  const long long per = (quads + kThreads - 1) / kThreads;
+  int nv = 1;
+  while (nv < per) nv <<= 1;
+  return nv;
+}
+
+bool shape_ok(int B, int C, int N, int max_nv) {
+  if (B <= 0 || C <= 0 || N <= 0 || (N & 3) != 0) return false;
+  const long long quads = (long long)B * (N >> 2);
+  if (quads > (long long)kThreads * max_nv) return false;
+  return (long long)B * N >= 2;      // one value per channel has no variance (torch raises)
+}
+
+}  // namespace
+
+#define CT_BN_DISPATCH(NVV, KERNEL, ...)                                                                 \
+  switch (NVV) {                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(C), dim3(kThreads), 0, stream, __VA_ARGS__); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(C), dim3(kThreads), 0, stream, __VA_ARGS__); break;     \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(C), dim3(kThreads), 0, stream, __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL((KERNEL<8>), dim3(C), dim3(kThreads), 0, stream, __VA_ARGS__); break;    \
+  }
+
+// 1 when both ct_bn_relu_fwd and ct_bn_relu_bwd take (B, C, N): N % 4 == 0 and 2 <= B*N <= 32768
+extern "C" int ct_bn_relu_supported(int B, int C, int N) { return shape_ok(B, C, N, 8) ? 1 : 0; }
+
+// a batch stride is valid when it is 0 (= contiguous, C*N) or a multiple of 4 floats that is at least C*N
+static bool stride_ok(long long bs, int C, int N, long long& out) {
+  const long long dense = (long long)C * N;
+  if (bs == 0) { out = dense; return true; }
+  if (bs < dense || (bs & 3) != 0) return false;
+  out = bs;
+  return true;
+}
+
+extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                              float* running_mean, float* running_var, float* y, long long y_batch_stride,
+                              float* save_mean, float* save_rstd, int B, int C, int N, float eps, float momentum,
+                              int relu, ct_stream_t s) {
+  hipStream_t stream = (hipStream_t)s;
+  if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
+  if (!shape_ok(B, C, N, 8)) return CT_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return CT_EINVAL;
+  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0};
+  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs)) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                              const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
+                              float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N,
+                              int relu, ct_stream_t s) {
+  hipStream_t stream = (hipStream_t)s;
+  if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
+  if (!shape_ok(B, C, N, 8)) return CT_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) return CT_EINVAL;
+  BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0};
+  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(gy_batch_stride, C, N, a.gybs) ||
+      !stride_ok(gx_batch_stride, C, N, a.gxbs))
+    return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, a)
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}

@@ -44,6 +44,23 @@ def forward_style(module_list, input, z):
     return input
 
 
+def run_after(module_list, input):
+    """Apply an `after` Sequential; a training-mode nn.BatchNorm1d directly followed by nn.ReLU runs as the fused
+    ct_bn_relu kernels when the shape qualifies (ops.bn_relu_eligible) — SyncBatchNorm, eval mode and every other layer
+    go through their own forward."""
+    layers = list(module_list)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if i + 1 < len(layers) and type(layers[i + 1]) is nn.ReLU and ops.bn_relu_eligible(layer, input):
+            input = ops.bn_relu(input, layer, relu=True)
+            i += 2
+        else:
+            input = layer(input)
+            i += 1
+    return input
+
+
 def _grouped_conv(tensor_dim, channels, heads):
     conv = GroupedConv3d if tensor_dim == 3 else GroupedConv2d      # nn.Conv{2,3}d subclasses on the MFMA kernels
     return nn.Sequential(conv(channels, channels, kernel_size=3, stride=1, padding=1, groups=heads, bias=True))
@@ -82,6 +99,16 @@ class _MHCTCore(nn.Module):
         return ops.lattice(orig_pcd, keys_res, R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim,
                            with_stats=True)
 
+    def _norm_keys_values(self, key_values):
+        """key_bn on the first 3H channels, values_bn on the rest (multihead_ct.py:89-91): fused kernels on the slices
+        where they lie when both norms qualify, the modules on split views otherwise (SyncBatchNorm, eval mode, ...)."""
+        Ck = self.heads * 3
+        Cv = key_values.size(1) - Ck
+        if ops.bn_relu_eligible(self.key_bn, key_values, Ck) and ops.bn_relu_eligible(self.values_bn, key_values, Cv):
+            return ops.split_bn(key_values, self.key_bn, self.values_bn)
+        k_part, v_part = torch.split(key_values, [Ck, Cv], dim=1)   # backward: one cat
+        return self.key_bn(k_part), self.values_bn(v_part)
+
     def _occupancy(self, z, batch):
         with torch.no_grad():
             return ops.grid_occupancy_count(z).float() / (batch * self.in_feature_dim * self.heads)
@@ -110,13 +137,11 @@ class MultiHead(_MHCTCore):
             orig_pcd, pts_padd = orig_pcd
         H = self.heads
         key_values = self.keys_values_pred(input)
-        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
-        keys_res = self.key_bn(k_part)
-        values = self.values_bn(v_part)
+        keys_res, values = self._norm_keys_values(key_values)
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, keys.size(0))
-        result = self.after(self.slice.forward_keys(lattice, self.conv(z), pts_padd))
+        result = run_after(self.after, self.slice.forward_keys(lattice, self.conv(z), pts_padd))
         with torch.no_grad():
             stats = (occ, kstats[0], kstats[1], None)       # mean / variance of the keys, reduced by the lattice kernel
         if return_lattice:
@@ -142,9 +167,7 @@ class MultiHeadPool(_MHCTCore):
     def forward(self, input, orig_pcd, return_lattice=False):
         H = self.heads
         key_values = self.keys_values_pred(input)
-        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
-        keys_res = self.key_bn(k_part)
-        values = self.values_bn(v_part)
+        keys_res, values = self._norm_keys_values(key_values)
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
@@ -240,7 +263,7 @@ class MultiHeadUnion(_UnionBase):
             r, s = attention(x, orig_pcd)
             results.append(r)
             stats.append(s)
-        return residual + self.after(torch.cat(results, dim=1)), stats
+        return residual + run_after(self.after, torch.cat(results, dim=1)), stats
 
 
 class MultiHeadUnionAdaIn(_UnionBase):

@@ -410,6 +410,132 @@ def adain(x, gamma_beta, eps=1e-5, relu=False):
     return AdaInFn.apply(x, gamma_beta, eps, relu)
 
 
+class BnReluFn(torch.autograd.Function):
+    """relu?(batch_norm(x)) in training mode (batch statistics, running statistics updated in place): the
+    nn.Sequential(BatchNorm1d, ReLU) tail of the blocks' `after` stacks (layers/multihead_ct.py:67-68,149-153)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        _dev(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        B, C, N = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib = _lib.load()
+        with _on(x.device):
+            _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(weight), _ptr(bias),
+                                          _ptr(running_mean) if running_mean is not None else None,
+                                          _ptr(running_var) if running_var is not None else None,
+                                          _ptr(y), 0, _ptr(mean), _ptr(rstd), B, C, N, float(eps), float(momentum),
+                                          int(bool(relu)), _stream()), "ct_bn_relu_fwd")
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.relu = int(bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        B, C, N = x.shape
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        g_w = torch.empty_like(weight)
+        g_b = torch.empty_like(bias)
+        lib = _lib.load()
+        with _on(x.device):
+            _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), _ptr(gy), 0,
+                                          _ptr(gx), 0, _ptr(g_w), _ptr(g_b), B, C, N, ctx.relu, _stream()), "ct_bn_relu_bwd")
+        return gx, g_w, g_b, None, None, None, None, None
+
+
+class SplitBnFn(torch.autograd.Function):
+    """(key_bn(x[:, :Ck]), values_bn(x[:, Ck:])) in training mode — the two BatchNorms on the halves of the
+    keys_values_pred output (layers/multihead_ct.py:89-91).  The kernels read the channel slices of x where they lie
+    (batch stride C*N) and the backward writes both input cotangents straight into the halves of ONE [B,C,N] tensor:
+    neither the contiguous copies of the slices nor the concatenation of their cotangents exist."""
+
+    @staticmethod
+    def forward(ctx, x, wk, bk, rmk, rvk, epsk, momk, wv, bv, rmv, rvv, epsv, momv):
+        _dev(x, wk, wv)
+        x = _f32c(x)
+        B, C, N = x.shape
+        Ck = wk.numel()
+        Cv = C - Ck
+        assert wv.numel() == Cv
+        lib = _lib.load()
+        outs, saved = [], []
+        with _on(x.device):
+            for c0, Cs, w, b, rm, rv, eps, mom in ((0, Ck, wk, bk, rmk, rvk, epsk, momk), (Ck, Cv, wv, bv, rmv, rvv, epsv, momv)):
+                w, b = _f32c(w), _f32c(b)
+                y = torch.empty(B, Cs, N, device=x.device, dtype=torch.float32)
+                mean = torch.empty(Cs, device=x.device, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                _lib.check(lib.ct_bn_relu_fwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(y), 0,
+                                              _ptr(mean), _ptr(rstd), B, Cs, N, float(eps), float(mom), 0, _stream()),
+                           "ct_bn_relu_fwd")
+                outs.append(y)
+                saved += [w, b, mean, rstd]
+        ctx.save_for_backward(x, *saved)
+        ctx.Ck = Ck
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, gk, gv):
+        x, wk, bk, mk, rk, wv, bv, mv, rv = ctx.saved_tensors
+        B, C, N = x.shape
+        Ck = ctx.Ck
+        gx = torch.empty_like(x)
+        grads = []
+        lib = _lib.load()
+        with _on(x.device):
+            for c0, Cs, w, b, mean, rstd, gy in ((0, Ck, wk, bk, mk, rk, gk), (Ck, C - Ck, wv, bv, mv, rv, gv)):
+                gy = _f32c(gy) if gy is not None else torch.zeros(B, Cs, N, device=x.device, dtype=torch.float32)
+                g_w, g_b = torch.empty_like(w), torch.empty_like(b)
+                _lib.check(lib.ct_bn_relu_bwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), 0,
+                                              _ptr(gx) + c0 * N * 4, C * N, _ptr(g_w), _ptr(g_b), B, Cs, N, 0, _stream()),
+                           "ct_bn_relu_bwd")
+                grads.append((g_w, g_b))
+        (gwk, gbk), (gwv, gbv) = grads
+        return gx, gwk, gbk, None, None, None, None, gwv, gbv, None, None, None, None
+
+
+_bn_supported = {}
+
+
+def bn_relu_eligible(bn, x, channels=None):
+    """True when `bn` (an nn.BatchNorm1d, exactly) applied to x (or, with `channels`, to a slice of that many of its
+    channels) can run as ct_bn_relu_*: training mode with running statistics and a fixed momentum, affine, CUDA fp32
+    [B,C,N] contiguous, and a shape the register-resident kernels take (ct_bn_relu_supported)."""
+    C = x.size(1) if channels is None and x.dim() == 3 else channels
+    if not (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+            and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+            and x.is_contiguous() and x.data_ptr() % 16 == 0 and C == bn.num_features):
+        return False
+    key = (x.size(0), C, x.size(2))
+    ok = _bn_supported.get(key)
+    if ok is None:
+        ok = _bn_supported[key] = bool(_lib.load().ct_bn_relu_supported(*key))
+    return ok
+
+
+def split_bn(x, bn_a, bn_b):
+    """(bn_a(x[:, :Ca]), bn_b(x[:, Ca:])) through SplitBnFn; the caller checked bn_relu_eligible for both modules (each
+    against its own slice's shape) and that x is contiguous."""
+    for bn in (bn_a, bn_b):
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    return SplitBnFn.apply(x, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, bn_a.eps, bn_a.momentum,
+                           bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var, bn_b.eps, bn_b.momentum)
+
+
+def bn_relu(x, bn, relu=True):
+    """relu?(bn(x)) through the fused kernels; the caller checked bn_relu_eligible(bn, x).  Updates the module's running
+    statistics and num_batches_tracked exactly as nn.BatchNorm1d.forward does in training mode."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+
+
 # ---------------------------------------------------------------------------
 # functional entry points
 # ---------------------------------------------------------------------------

@@ -164,6 +164,29 @@ int ct_so3_exp_fwd(const float* log_R, float* R, int H, float eps, ct_stream_t s
 int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, float eps, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Training-mode BatchNorm1d fused with the ReLU that follows it in the blocks' `after` stacks
+ * (nn.Sequential(nn.BatchNorm1d(C), nn.ReLU(inplace=True)): layers/multihead_ct.py:67-68,149-153), one launch
+ * forward and one backward:
+ *   y[b,c,n] = relu?( (x - mean_c) * rsqrt(var_c + eps) * weight[c] + bias[c] ),  mean / biased var over (b, n)
+ * x, y, gy, gx f32[B,C,N], rows of N contiguous floats, 16-byte aligned; each has a batch stride in floats (0 = C*N,
+ * contiguous; a multiple of 4 >= C*N for a channel slice of a wider tensor: key_bn / values_bn act on the two halves
+ * of the keys_values_pred output, layers/multihead_ct.py:89-91, and their input cotangents are written straight into
+ * the two halves of that tensor's cotangent).  weight, bias f32[C]; save_mean, save_rstd f32[C] are written by the
+ * forward and read by the backward.  running_mean / running_var f32[C] (both or neither) are updated in place as
+ * torch does: r = (1 - momentum) * r + momentum * (mean | unbiased var).  Backward overwrites gx, g_weight, g_bias;
+ * with relu != 0 the mask is recomputed from x.  Shapes: ct_bn_relu_supported(B, C, N) != 0 (N % 4 == 0,
+ * 2 <= B*N <= 32768: a channel is held in registers); anything else is CT_EINVAL and stays on the library pair.
+ * ---------------------------------------------------------------------- */
+int ct_bn_relu_supported(int B, int C, int N);
+int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                   float* running_mean, float* running_var, float* y, long long y_batch_stride, float* save_mean,
+                   float* save_rstd, int B, int C, int N, float eps, float momentum, int relu, ct_stream_t s);
+int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                   const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
+                   float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N, int relu,
+                   ct_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Adaptive instance normalisation of the AdaIN blocks (AdaIn1dUpd: layers/utils.py:82-97 =
  * InstanceNorm1d(affine=False, eps) -> * (gamma + 1) -> + beta; followed by ReLU in `after`,
  * layers/multihead_ct_adain.py:64-66,183-187), one launch forward and one backward:

@@ -1,0 +1,139 @@
+"""GPU parity of the fused training-mode BatchNorm1d + ReLU (ct_bn_relu_fwd / _bwd) against torch's own
+F.batch_norm + relu evaluated in float64 on the CPU: output, running statistics, and all three gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, rm, rv, eps, momentum, relu, gy):
+    x = x.double().requires_grad_(True)
+    w = w.double().requires_grad_(True)
+    b = b.double().requires_grad_(True)
+    rm, rv = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.double())
+    return y.detach(), rm, rv, x.grad, w.grad, b.grad
+
+
+@pytest.mark.parametrize("B,C,N,relu", [(8, 64, 4096, True), (8, 48, 2048, True), (2, 5, 256, False), (3, 7, 1000, True),
+                                        (1, 3, 4, True), (8, 16, 4096, False)])
+def test_bn_relu_matches_torch(B, C, N, relu):
+    from cloud_transformers_amd import ops
+    torch.manual_seed(B * 100 + C)
+    bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(B, C, N) * 3 + 0.7
+    gy = torch.randn(B, C, N)
+    y_ref, rm_ref, rv_ref, gx_ref, gw_ref, gb_ref = _ref(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                        bn.eps, bn.momentum, relu, gy)
+    bn = bn.cuda().train()
+    xc = x.cuda().requires_grad_(True)
+    assert ops.bn_relu_eligible(bn, xc)
+    y = ops.bn_relu(xc, bn, relu=relu)
+    y.backward(gy.cuda())
+    tol = dict(rtol=1e-4, atol=1e-4)
+    assert torch.allclose(y.detach().cpu().double(), y_ref, **tol)
+    assert torch.allclose(bn.running_mean.cpu().double(), rm_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu().double(), rv_ref, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    scale = max(1.0, float(gx_ref.abs().max()))
+    assert float((xc.grad.cpu().double() - gx_ref).abs().max()) <= 1e-4 * scale
+    assert torch.allclose(bn.weight.grad.cpu().double(), gw_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(gw_ref.abs().max()) * 1e-1))
+    assert torch.allclose(bn.bias.grad.cpu().double(), gb_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(gb_ref.abs().max()) * 1e-1))
+
+
+def test_run_after_dispatch():
+    """The blocks' `after` stacks: BatchNorm1d + ReLU in training mode on a supported shape runs fused; eval mode,
+    SyncBatchNorm, odd N and too large channels go through the modules' own forward — with the same result."""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.multihead_ct import run_after
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU(inplace=True)).cuda()
+    ref = torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU()).cuda()
+    ref.load_state_dict(seq.state_dict())
+    calls = []
+    real = ops.bn_relu
+    ops.bn_relu = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        x = torch.randn(4, 32, 512, device="cuda")
+        out = run_after(seq, x.clone())
+        assert calls == [1]
+        assert torch.allclose(out, ref(x), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(seq[0].running_var, ref[0].running_var, rtol=1e-5, atol=1e-6)
+        del calls[:]
+        seq.eval(), ref.eval()
+        assert torch.allclose(run_after(seq, x.clone()), ref(x), rtol=1e-5, atol=1e-6) and not calls
+        seq.train(), ref.train()
+        assert torch.allclose(run_after(seq, x[:, :, :511].contiguous()), ref(x[:, :, :511].contiguous()), rtol=1e-4, atol=1e-5) and not calls
+        big = torch.randn(16, 32, 4096, device="cuda")              # B*N > 32768: a channel no longer fits the registers
+        assert torch.allclose(run_after(seq, big.clone()), ref(big), rtol=1e-4, atol=1e-5) and not calls
+        sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU())).cuda()
+        assert not ops.bn_relu_eligible(sync[0], x)
+    finally:
+        ops.bn_relu = real
+
+
+def test_abi_rejects_unsupported_shapes():
+    from cloud_transformers_amd import _lib
+    lib = _lib.load()
+    assert lib.ct_bn_relu_supported(8, 512, 4096) == 1
+    assert lib.ct_bn_relu_supported(16, 512, 4096) == 0
+    assert lib.ct_bn_relu_supported(8, 512, 4095) == 0
+    assert lib.ct_bn_relu_supported(1, 4, 1) == 0
+    buf = torch.zeros(1 << 16, device="cuda")
+    p = buf.data_ptr()
+    assert lib.ct_bn_relu_fwd(p, 0, p, p, None, None, p, 0, p, p, 16, 8, 4096, 1e-5, 0.1, 1, None) == -1     # CT_EINVAL
+    assert lib.ct_bn_relu_fwd(p, 0, p, p, p, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1           # one running buffer only
+    assert lib.ct_bn_relu_fwd(p, 8 * 64 - 4, p, p, None, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # batch stride < C*N
+    assert lib.ct_bn_relu_fwd(p, 8 * 64 + 2, p, p, None, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # not a multiple of 4
+
+
+def test_split_bn_equals_the_two_modules_on_split_views():
+    """key_bn / values_bn on the halves of one tensor (layers/multihead_ct.py:89-91): values, running statistics and
+    every gradient equal torch's BatchNorm1d modules applied to torch.split views."""
+    from cloud_transformers_amd import ops
+    torch.manual_seed(3)
+    B, Ck, Cv, N = 4, 12, 40, 1024
+    mods = [torch.nn.BatchNorm1d(Ck), torch.nn.BatchNorm1d(Cv)]
+    with torch.no_grad():
+        for m in mods:
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.uniform_(-0.5, 0.5)
+    ref = [torch.nn.BatchNorm1d(Ck), torch.nn.BatchNorm1d(Cv)]
+    for r, m in zip(ref, mods):
+        r.load_state_dict(m.state_dict())
+        r.double()
+    x = torch.randn(B, Ck + Cv, N) * 2 + 0.3
+    gk, gv = torch.randn(B, Ck, N), torch.randn(B, Cv, N)
+    xr = x.double().requires_grad_(True)
+    a, b = torch.split(xr, [Ck, Cv], dim=1)
+    ya, yb = ref[0](a), ref[1](b)
+    (ya * gk.double()).sum().backward(retain_graph=True)
+    (yb * gv.double()).sum().backward()
+    mods = [m.cuda().train() for m in mods]
+    xc = x.cuda().requires_grad_(True)
+    assert ops.bn_relu_eligible(mods[0], xc, Ck) and ops.bn_relu_eligible(mods[1], xc, Cv)
+    ka, kb = ops.split_bn(xc, mods[0], mods[1])
+    ((ka * gk.cuda()).sum() + (kb * gv.cuda()).sum()).backward()
+    tol = dict(rtol=1e-4, atol=1e-4)
+    assert torch.allclose(ka.detach().cpu().double(), ya.detach(), **tol) and torch.allclose(kb.detach().cpu().double(), yb.detach(), **tol)
+    assert torch.allclose(xc.grad.cpu().double(), xr.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(xr.grad.abs().max())))
+    for m, r in zip(mods, ref):
+        assert torch.allclose(m.running_mean.cpu().double(), r.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(m.running_var.cpu().double(), r.running_var, rtol=1e-5, atol=1e-6)
+        assert int(m.num_batches_tracked) == 1
+        assert torch.allclose(m.weight.grad.cpu().double(), r.weight.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(m.bias.grad.cpu().double(), r.bias.grad, rtol=1e-4, atol=1e-3)
+    # only one output used downstream: the other half's cotangent is None -> zeros
+    xc2 = x.cuda().requires_grad_(True)
+    ka2, _ = ops.split_bn(xc2, mods[0], mods[1])
+    ka2.sum().backward()
+    assert float(xc2.grad[:, Ck:].abs().max()) == 0.0
