@@ -55,6 +55,9 @@ struct BnArgs {
   float eps, momentum;
   int relu;
   long long xbs, ybs;    // batch strides of x and y in floats (C*N when contiguous; larger for a channel slice)
+  const float* residual; // nullable: added after the ReLU (the union block's skip connection)
+  long long rbs;
+  long long* num_batches_tracked;   // nullable: incremented once per launch, as nn.BatchNorm1d.forward does
 };
 
 // float offset of quad q (over the B rows of channel c, N/4 quads each) in a tensor whose batch stride is bs floats
@@ -99,6 +102,7 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* _
       a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mu;
       a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (var * (M / (M - 1.0f)));
     }
+    if (c == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
   }
   const float g = a.weight[c] * rs;
   const float be = a.bias[c];
@@ -112,6 +116,10 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* _
       o.y = fmaxf((v[k].y - mu) * g + be, lo);
       o.z = fmaxf((v[k].z - mu) * g + be, lo);
       o.w = fmaxf((v[k].w - mu) * g + be, lo);
+      if (a.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(a.residual + quad_offset(q, nq, c, a.rbs, a.N));
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
       *reinterpret_cast<float4*>(y + quad_offset(q, nq, c, a.ybs, a.N)) = o;
     }
   }
@@ -220,16 +228,20 @@ static bool stride_ok(long long bs, int C, int N, long long& out) {
 }
 
 extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
-                              float* running_mean, float* running_var, float* y, long long y_batch_stride,
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
                               float* save_mean, float* save_rstd, int B, int C, int N, float eps, float momentum,
                               int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
   if (!shape_ok(B, C, N, 8)) return CT_EINVAL;
-  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return CT_EINVAL;
-  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0};
-  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs)) return CT_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) return CT_EINVAL;
+  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
+           residual, 0, num_batches_tracked};
+  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs) ||
+      !stride_ok(residual_batch_stride, C, N, a.rbs))
+    return CT_EINVAL;
   CT_CLEAR_ERROR();
   CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
   CT_CHECK_LAUNCH();

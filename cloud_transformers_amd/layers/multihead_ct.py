@@ -44,21 +44,26 @@ def forward_style(module_list, input, z):
     return input
 
 
-def run_after(module_list, input):
-    """Apply an `after` Sequential; a training-mode nn.BatchNorm1d directly followed by nn.ReLU runs as the fused
-    ct_bn_relu kernels when the shape qualifies (ops.bn_relu_eligible) — SyncBatchNorm, eval mode and every other layer
-    go through their own forward."""
+def run_after(module_list, input, residual=None):
+    """Apply an `after` Sequential (and add `residual` to its result); a training-mode nn.BatchNorm1d directly followed by
+    nn.ReLU runs as the fused ct_bn_relu kernels when the shape qualifies (ops.bn_relu_eligible), the skip connection
+    added in the same pass when that pair ends the stack — SyncBatchNorm, eval mode and every other layer go through
+    their own forward."""
     layers = list(module_list)
     i = 0
     while i < len(layers):
         layer = layers[i]
         if i + 1 < len(layers) and type(layers[i + 1]) is nn.ReLU and ops.bn_relu_eligible(layer, input):
-            input = ops.bn_relu(input, layer, relu=True)
+            last = i + 2 == len(layers)
+            fuse_res = last and residual is not None and residual.shape == input.shape and residual.dtype == input.dtype
+            input = ops.bn_relu(input, layer, relu=True, residual=residual if fuse_res else None)
+            if fuse_res:
+                residual = None
             i += 2
         else:
             input = layer(input)
             i += 1
-    return input
+    return input if residual is None else residual + input
 
 
 def _grouped_conv(tensor_dim, channels, heads):
@@ -263,7 +268,7 @@ class MultiHeadUnion(_UnionBase):
             r, s = attention(x, orig_pcd)
             results.append(r)
             stats.append(s)
-        return residual + run_after(self.after, torch.cat(results, dim=1)), stats
+        return run_after(self.after, torch.cat(results, dim=1), residual), stats
 
 
 class MultiHeadUnionAdaIn(_UnionBase):

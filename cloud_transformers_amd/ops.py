@@ -410,42 +410,61 @@ def adain(x, gamma_beta, eps=1e-5, relu=False):
     return AdaInFn.apply(x, gamma_beta, eps, relu)
 
 
+def _batch_stride(t, C, N):
+    """Batch stride (floats) of t if it is a [B,C,N] tensor whose rows are contiguous, whose channels are N apart and
+    whose batches are a multiple of 4 >= C*N apart, 16-byte aligned — a contiguous tensor or a channel slice of a wider
+    one (what torch.cat's backward hands out); None otherwise."""
+    if (t.dim() == 3 and t.dtype == torch.float32 and t.size(1) == C and t.size(2) == N and t.stride(2) == 1
+            and (t.stride(1) == N or C == 1) and t.stride(0) >= C * N and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t.stride(0)
+    return None
+
+
 class BnReluFn(torch.autograd.Function):
-    """relu?(batch_norm(x)) in training mode (batch statistics, running statistics updated in place): the
-    nn.Sequential(BatchNorm1d, ReLU) tail of the blocks' `after` stacks (layers/multihead_ct.py:67-68,149-153)."""
+    """relu?(batch_norm(x)) [+ residual] in training mode (batch statistics; running statistics and num_batches_tracked
+    updated in place by the kernel): the nn.Sequential(BatchNorm1d, ReLU) tail of the blocks' `after` stacks and the
+    union's skip connection (layers/multihead_ct.py:67-68,149-153,198)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, residual):
         _dev(x, weight, bias)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         B, C, N = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        rbs = 0
+        if residual is not None:
+            rbs = _batch_stride(residual, C, N)
+            if rbs is None:
+                residual = _f32c(residual)
+                rbs = 0
         lib = _lib.load()
         with _on(x.device):
-            _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(weight), _ptr(bias),
-                                          _ptr(running_mean) if running_mean is not None else None,
-                                          _ptr(running_var) if running_var is not None else None,
-                                          _ptr(y), 0, _ptr(mean), _ptr(rstd), B, C, N, float(eps), float(momentum),
-                                          int(bool(relu)), _stream()), "ct_bn_relu_fwd")
+            _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                          _ptr(nbt), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd), B, C, N,
+                                          float(eps), float(momentum), int(bool(relu)), _stream()), "ct_bn_relu_fwd")
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.relu = int(bool(relu))
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         B, C, N = x.shape
-        gy = _f32c(gy)
+        gybs = _batch_stride(gy, C, N)          # a slice of the concatenation's cotangent is read where it lies
+        if gybs is None:
+            gy = _f32c(gy)
+            gybs = 0
         gx = torch.empty_like(x)
         g_w = torch.empty_like(weight)
         g_b = torch.empty_like(bias)
         lib = _lib.load()
         with _on(x.device):
-            _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), _ptr(gy), 0,
+            _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
                                           _ptr(gx), 0, _ptr(g_w), _ptr(g_b), B, C, N, ctx.relu, _stream()), "ct_bn_relu_bwd")
-        return gx, g_w, g_b, None, None, None, None, None
+        return gx, g_w, g_b, None, None, None, None, None, None, (gy if ctx.has_residual else None)
 
 
 class SplitBnFn(torch.autograd.Function):
@@ -455,7 +474,7 @@ class SplitBnFn(torch.autograd.Function):
     neither the contiguous copies of the slices nor the concatenation of their cotangents exist."""
 
     @staticmethod
-    def forward(ctx, x, wk, bk, rmk, rvk, epsk, momk, wv, bv, rmv, rvv, epsv, momv):
+    def forward(ctx, x, wk, bk, rmk, rvk, nbk, epsk, momk, wv, bv, rmv, rvv, nbv, epsv, momv):
         _dev(x, wk, wv)
         x = _f32c(x)
         B, C, N = x.shape
@@ -465,14 +484,15 @@ class SplitBnFn(torch.autograd.Function):
         lib = _lib.load()
         outs, saved = [], []
         with _on(x.device):
-            for c0, Cs, w, b, rm, rv, eps, mom in ((0, Ck, wk, bk, rmk, rvk, epsk, momk), (Ck, Cv, wv, bv, rmv, rvv, epsv, momv)):
+            for c0, Cs, w, b, rm, rv, nb, eps, mom in ((0, Ck, wk, bk, rmk, rvk, nbk, epsk, momk),
+                                                       (Ck, Cv, wv, bv, rmv, rvv, nbv, epsv, momv)):
                 w, b = _f32c(w), _f32c(b)
                 y = torch.empty(B, Cs, N, device=x.device, dtype=torch.float32)
                 mean = torch.empty(Cs, device=x.device, dtype=torch.float32)
                 rstd = torch.empty_like(mean)
-                _lib.check(lib.ct_bn_relu_fwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(y), 0,
-                                              _ptr(mean), _ptr(rstd), B, Cs, N, float(eps), float(mom), 0, _stream()),
-                           "ct_bn_relu_fwd")
+                _lib.check(lib.ct_bn_relu_fwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nb),
+                                              None, 0, _ptr(y), 0, _ptr(mean), _ptr(rstd), B, Cs, N, float(eps), float(mom),
+                                              0, _stream()), "ct_bn_relu_fwd")
                 outs.append(y)
                 saved += [w, b, mean, rstd]
         ctx.save_for_backward(x, *saved)
@@ -489,14 +509,18 @@ class SplitBnFn(torch.autograd.Function):
         lib = _lib.load()
         with _on(x.device):
             for c0, Cs, w, b, mean, rstd, gy in ((0, Ck, wk, bk, mk, rk, gk), (Ck, C - Ck, wv, bv, mv, rv, gv)):
-                gy = _f32c(gy) if gy is not None else torch.zeros(B, Cs, N, device=x.device, dtype=torch.float32)
+                if gy is None:
+                    gy = torch.zeros(B, Cs, N, device=x.device, dtype=torch.float32)
+                gybs = _batch_stride(gy, Cs, N)
+                if gybs is None:
+                    gy, gybs = _f32c(gy), 0
                 g_w, g_b = torch.empty_like(w), torch.empty_like(b)
-                _lib.check(lib.ct_bn_relu_bwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), 0,
+                _lib.check(lib.ct_bn_relu_bwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
                                               _ptr(gx) + c0 * N * 4, C * N, _ptr(g_w), _ptr(g_b), B, Cs, N, 0, _stream()),
                            "ct_bn_relu_bwd")
                 grads.append((g_w, g_b))
         (gwk, gbk), (gwv, gbv) = grads
-        return gx, gwk, gbk, None, None, None, None, gwv, gbv, None, None, None, None
+        return gx, gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None
 
 
 _bn_supported = {}
@@ -521,19 +545,17 @@ def bn_relu_eligible(bn, x, channels=None):
 def split_bn(x, bn_a, bn_b):
     """(bn_a(x[:, :Ca]), bn_b(x[:, Ca:])) through SplitBnFn; the caller checked bn_relu_eligible for both modules (each
     against its own slice's shape) and that x is contiguous."""
-    for bn in (bn_a, bn_b):
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-    return SplitBnFn.apply(x, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, bn_a.eps, bn_a.momentum,
-                           bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var, bn_b.eps, bn_b.momentum)
+    return SplitBnFn.apply(x, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, bn_a.num_batches_tracked,
+                           bn_a.eps, bn_a.momentum,
+                           bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var, bn_b.num_batches_tracked,
+                           bn_b.eps, bn_b.momentum)
 
 
-def bn_relu(x, bn, relu=True):
-    """relu?(bn(x)) through the fused kernels; the caller checked bn_relu_eligible(bn, x).  Updates the module's running
-    statistics and num_batches_tracked exactly as nn.BatchNorm1d.forward does in training mode."""
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+def bn_relu(x, bn, relu=True, residual=None):
+    """relu?(bn(x)) [+ residual] through the fused kernels; the caller checked bn_relu_eligible(bn, x).  Updates the
+    module's running statistics and num_batches_tracked exactly as nn.BatchNorm1d.forward does in training mode."""
+    return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                          bn.momentum, relu, residual)
 
 
 # ---------------------------------------------------------------------------

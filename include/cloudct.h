@@ -167,7 +167,10 @@ int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, 
  * Training-mode BatchNorm1d fused with the ReLU that follows it in the blocks' `after` stacks
  * (nn.Sequential(nn.BatchNorm1d(C), nn.ReLU(inplace=True)): layers/multihead_ct.py:67-68,149-153), one launch
  * forward and one backward:
- *   y[b,c,n] = relu?( (x - mean_c) * rsqrt(var_c + eps) * weight[c] + bias[c] ),  mean / biased var over (b, n)
+ *   y[b,c,n] = relu?( (x - mean_c) * rsqrt(var_c + eps) * weight[c] + bias[c] ) [+ residual[b,c,n]],
+ *   mean / biased var over (b, n); `residual` (nullable) is the union block's skip connection
+ *   (layers/multihead_ct.py:198: `residual + self.after(...)`), its cotangent is gy itself;
+ *   num_batches_tracked (nullable, int64[1]) is incremented, as nn.BatchNorm1d.forward does
  * x, y, gy, gx f32[B,C,N], rows of N contiguous floats, 16-byte aligned; each has a batch stride in floats (0 = C*N,
  * contiguous; a multiple of 4 >= C*N for a channel slice of a wider tensor: key_bn / values_bn act on the two halves
  * of the keys_values_pred output, layers/multihead_ct.py:89-91, and their input cotangents are written straight into
@@ -179,7 +182,8 @@ int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, 
  * ---------------------------------------------------------------------- */
 int ct_bn_relu_supported(int B, int C, int N);
 int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
-                   float* running_mean, float* running_var, float* y, long long y_batch_stride, float* save_mean,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, const float* residual,
+                   long long residual_batch_stride, float* y, long long y_batch_stride, float* save_mean,
                    float* save_rstd, int B, int C, int N, float eps, float momentum, int relu, ct_stream_t s);
 int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
                    const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,

@@ -90,10 +90,10 @@ def test_abi_rejects_unsupported_shapes():
     assert lib.ct_bn_relu_supported(1, 4, 1) == 0
     buf = torch.zeros(1 << 16, device="cuda")
     p = buf.data_ptr()
-    assert lib.ct_bn_relu_fwd(p, 0, p, p, None, None, p, 0, p, p, 16, 8, 4096, 1e-5, 0.1, 1, None) == -1     # CT_EINVAL
-    assert lib.ct_bn_relu_fwd(p, 0, p, p, p, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1           # one running buffer only
-    assert lib.ct_bn_relu_fwd(p, 8 * 64 - 4, p, p, None, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # batch stride < C*N
-    assert lib.ct_bn_relu_fwd(p, 8 * 64 + 2, p, p, None, None, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # not a multiple of 4
+    assert lib.ct_bn_relu_fwd(p, 0, p, p, None, None, None, None, 0, p, 0, p, p, 16, 8, 4096, 1e-5, 0.1, 1, None) == -1     # CT_EINVAL
+    assert lib.ct_bn_relu_fwd(p, 0, p, p, p, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1           # one running buffer only
+    assert lib.ct_bn_relu_fwd(p, 8 * 64 - 4, p, p, None, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # batch stride < C*N
+    assert lib.ct_bn_relu_fwd(p, 8 * 64 + 2, p, p, None, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # not a multiple of 4
 
 
 def test_split_bn_equals_the_two_modules_on_split_views():
@@ -137,3 +137,32 @@ def test_split_bn_equals_the_two_modules_on_split_views():
     ka2, _ = ops.split_bn(xc2, mods[0], mods[1])
     ka2.sum().backward()
     assert float(xc2.grad[:, Ck:].abs().max()) == 0.0
+
+
+def test_residual_and_strided_cotangent():
+    """run_after(after, x, residual): the skip connection is added inside the kernel and receives the output cotangent;
+    a cotangent that is a channel slice of a wider tensor (torch.cat's backward) is read where it lies."""
+    from cloud_transformers_amd.layers.multihead_ct import run_after
+    torch.manual_seed(9)
+    B, C, N = 4, 24, 512
+    seq = torch.nn.Sequential(torch.nn.BatchNorm1d(C), torch.nn.ReLU(inplace=True)).cuda()
+    ref = torch.nn.Sequential(torch.nn.BatchNorm1d(C), torch.nn.ReLU()).cuda()
+    with torch.no_grad():
+        seq[0].weight.uniform_(0.5, 1.5)
+        seq[0].bias.uniform_(-0.5, 0.5)
+    ref.load_state_dict(seq.state_dict())
+    x = torch.randn(B, C, N, device="cuda")
+    res = torch.randn(B, C, N, device="cuda")
+    wide = torch.randn(B, C + 8, N, device="cuda")
+    outs = []
+    for mod, fused in ((seq, True), (ref, False)):
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        w = wide.clone().requires_grad_(True)
+        y = run_after(mod, xi, ri) if fused else ri + mod(xi)
+        z = torch.cat([y, w[:, :8]], dim=1)               # y's cotangent arrives as a slice of z's
+        (z * wide).sum().backward()
+        outs.append((y.detach(), xi.grad, ri.grad, mod[0].weight.grad.clone(), mod[0].bias.grad.clone(),
+                     mod[0].running_mean.clone(), int(mod[0].num_batches_tracked)))
+    for a, b in zip(outs[0][:6], outs[1][:6]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-4), float((a - b).abs().max())
+    assert outs[0][6] == outs[1][6] == 1
