@@ -136,19 +136,24 @@ class MultiHead(_MHCTCore):
         # keys start as the pure rigid transform of xyz (multihead_ct.py:79-80)
         nn.init.zeros_(self.key_bn.weight)
 
-    def forward(self, input, orig_pcd, return_lattice=False):
+    def _forward_pre(self, input, orig_pcd):
+        """Everything up to (not including) `after`: (sliced features, stats, lattice)."""
         pts_padd = None
         if isinstance(orig_pcd, tuple):
             orig_pcd, pts_padd = orig_pcd
-        H = self.heads
         key_values = self.keys_values_pred(input)
         keys_res, values = self._norm_keys_values(key_values)
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, keys.size(0))
-        result = run_after(self.after, self.slice.forward_keys(lattice, self.conv(z), pts_padd))
+        pre = self.slice.forward_keys(lattice, self.conv(z), pts_padd)
         with torch.no_grad():
             stats = (occ, kstats[0], kstats[1], None)       # mean / variance of the keys, reduced by the lattice kernel
+        return pre, stats, lattice
+
+    def forward(self, input, orig_pcd, return_lattice=False):
+        pre, stats, lattice = self._forward_pre(input, orig_pcd)
+        result = run_after(self.after, pre)
         if return_lattice:
             result = result, lattice
         return result, stats
@@ -263,12 +268,19 @@ class MultiHeadUnion(_UnionBase):
     def forward(self, x, orig_pcd):
         x = self.prenorm(x)
         residual = self.shortcut(x)
-        results, stats = [], []
+        pres, stats = [], []
         for attention in self.attentions:
-            r, s = attention(x, orig_pcd)
-            results.append(r)
+            r, s, _ = attention._forward_pre(x, orig_pcd)
+            pres.append(r)
             stats.append(s)
-        return run_after(self.after, torch.cat(results, dim=1), residual), stats
+        # the heads' BatchNorm + ReLU write straight into their channel ranges of the concatenation when they qualify
+        norms = [a.after for a in self.attentions]
+        if len(pres) > 1 and all(len(n) == 2 and type(n[1]) is nn.ReLU and ops.bn_relu_eligible(n[0], p)
+                                 for n, p in zip(norms, pres)):
+            joined = ops.join_bn_relu(pres, [n[0] for n in norms])
+        else:
+            joined = torch.cat([run_after(n, p) for n, p in zip(norms, pres)], dim=1)
+        return run_after(self.after, joined, residual), stats
 
 
 class MultiHeadUnionAdaIn(_UnionBase):

@@ -523,6 +523,68 @@ class SplitBnFn(torch.autograd.Function):
         return gx, gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None
 
 
+class JoinBnReluFn(torch.autograd.Function):
+    """cat([relu(bn_i(x_i)) for i], dim=1) — the heads' `after` stacks of a union block followed by its concatenation
+    (layers/multihead_ct.py:67-68,187-196): every head's kernel writes its channel range of the result where it belongs
+    and, in backward, reads its range of the cotangent where it lies; the separate outputs and their copy never exist.
+    Arguments: n, then per head (x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        heads = [args[i * 8:(i + 1) * 8] for i in range(n)]
+        xs = [_f32c(h[0]) for h in heads]
+        _dev(*xs)
+        B, _, N = xs[0].shape
+        Ct = sum(x.size(1) for x in xs)
+        y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
+        lib = _lib.load()
+        saved, c0 = [], 0
+        with _on(y.device):
+            for x, (_, w, b, rm, rv, nbt, eps, mom) in zip(xs, heads):
+                w, b = _f32c(w), _f32c(b)
+                C = x.size(1)
+                mean = torch.empty(C, device=y.device, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nbt), None, 0,
+                                              _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd), B, C, N, float(eps),
+                                              float(mom), 1, _stream()), "ct_bn_relu_fwd")
+                saved += [x, w, b, mean, rstd]
+                c0 += C
+        ctx.save_for_backward(*saved)
+        ctx.n = n
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        B, Ct, N = gy.shape
+        gybs = _batch_stride(gy, Ct, N)
+        if gybs is None:
+            gy, gybs = _f32c(gy), Ct * N
+        lib = _lib.load()
+        grads, c0 = [None], 0
+        with _on(gy.device):
+            for i in range(n):
+                x, w, b, mean, rstd = saved[i * 5:(i + 1) * 5]
+                C = x.size(1)
+                gx, g_w, g_b = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
+                _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs,
+                                              _ptr(gx), 0, _ptr(g_w), _ptr(g_b), B, C, N, 1, _stream()), "ct_bn_relu_bwd")
+                grads += [gx, g_w, g_b, None, None, None, None, None]
+                c0 += C
+        return tuple(grads)
+
+
+def join_bn_relu(xs, bns):
+    """cat([relu(bn(x)) for x, bn in zip(xs, bns)], dim=1) through JoinBnReluFn; the caller checked bn_relu_eligible for
+    every pair."""
+    args = []
+    for x, bn in zip(xs, bns):
+        args += [x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum]
+    return JoinBnReluFn.apply(len(xs), *args)
+
+
 _bn_supported = {}
 
 

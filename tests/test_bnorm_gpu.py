@@ -166,3 +166,31 @@ def test_residual_and_strided_cotangent():
     for a, b in zip(outs[0][:6], outs[1][:6]):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-4), float((a - b).abs().max())
     assert outs[0][6] == outs[1][6] == 1
+
+
+def test_join_bn_relu_equals_cat_of_the_modules():
+    from cloud_transformers_amd import ops
+    torch.manual_seed(4)
+    B, N, Cs = 4, 512, (16, 40, 8)
+    mods = [torch.nn.BatchNorm1d(c).cuda() for c in Cs]
+    refs = [torch.nn.BatchNorm1d(c).cuda() for c in Cs]
+    for m, r in zip(mods, refs):
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.uniform_(-0.5, 0.5)
+        r.load_state_dict(m.state_dict())
+    xs = [torch.randn(B, c, N, device="cuda") for c in Cs]
+    cot = torch.randn(B, sum(Cs), N, device="cuda")
+    xa = [x.clone().requires_grad_(True) for x in xs]
+    xb = [x.clone().requires_grad_(True) for x in xs]
+    ya = ops.join_bn_relu(xa, mods)
+    yb = torch.cat([torch.relu(r(x)) for r, x in zip(refs, xb)], dim=1)
+    (ya * cot).sum().backward()
+    (yb * cot).sum().backward()
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
+    for a, b, m, r in zip(xa, xb, mods, refs):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=2e-4)
+        assert torch.allclose(m.weight.grad, r.weight.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(m.bias.grad, r.bias.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(m.running_var, r.running_var, rtol=1e-5, atol=1e-6)
+        assert int(m.num_batches_tracked) == int(r.num_batches_tracked) == 1
