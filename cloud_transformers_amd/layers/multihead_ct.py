@@ -136,13 +136,16 @@ class MultiHead(_MHCTCore):
         # keys start as the pure rigid transform of xyz (multihead_ct.py:79-80)
         nn.init.zeros_(self.key_bn.weight)
 
-    def _forward_pre(self, input, orig_pcd):
-        """Everything up to (not including) `after`: (sliced features, stats, lattice)."""
+    def _forward_pre(self, input, orig_pcd, kv=None):
+        """Everything up to (not including) `after`: (sliced features, stats, lattice).  `kv` = (keys_res, values) when the
+        union block computed the projection and its norms for all heads at once."""
         pts_padd = None
         if isinstance(orig_pcd, tuple):
             orig_pcd, pts_padd = orig_pcd
-        key_values = self.keys_values_pred(input)
-        keys_res, values = self._norm_keys_values(key_values)
+        if kv is None:
+            keys_res, values = self._norm_keys_values(self.keys_values_pred(input))
+        else:
+            keys_res, values = kv
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, keys.size(0))
@@ -269,8 +272,12 @@ class MultiHeadUnion(_UnionBase):
         x = self.prenorm(x)
         residual = self.shortcut(x)
         pres, stats = [], []
-        for attention in self.attentions:
-            r, s, _ = attention._forward_pre(x, orig_pcd)
+        # the heads share x: one stacked GEMM for their keys_values_pred projections (and for its gradients)
+        convs = [a.keys_values_pred[0] for a in self.attentions]
+        kbs, vbs = [a.key_bn for a in self.attentions], [a.values_bn for a in self.attentions]
+        kvs = ops.union_keys_values(x, convs, kbs, vbs) if ops.union_keys_values_eligible(x, convs, kbs, vbs) else None
+        for i, attention in enumerate(self.attentions):
+            r, s, _ = attention._forward_pre(x, orig_pcd, None if kvs is None else kvs[i])
             pres.append(r)
             stats.append(s)
         # the heads' BatchNorm + ReLU write straight into their channel ranges of the concatenation when they qualify

@@ -585,6 +585,120 @@ def join_bn_relu(xs, bns):
     return JoinBnReluFn.apply(len(xs), *args)
 
 
+class UnionKeysValuesFn(torch.autograd.Function):
+    """The `keys_values_pred` projections of all heads of a union block and the key_bn / values_bn norms on their
+    outputs (layers/multihead_ct.py:31-33,89-91), as ONE GEMM with the heads' weights stacked: the heads share the input,
+    so forward is one [sum Co, Cin] x [Cin, N] product per cloud instead of one per head, the data gradient one product
+    with K = sum Co instead of one per head plus autograd's accumulation of their results, the weight gradient one
+    product.  The norms read their channel ranges of the GEMM output where they lie and write their input cotangents
+    into the ranges of ONE tensor, which is the data / weight gradient GEMMs' operand.
+    Arguments: n, x, then per head: weight [Co,Cin,1], key_bn (w, b, rm, rv, nbt, eps, mom), values_bn (same 7).
+    Returns (keys_res_0, values_0, keys_res_1, values_1, ...)."""
+
+    PER_HEAD = 15
+
+    @staticmethod
+    def forward(ctx, n, x, *args):
+        P = UnionKeysValuesFn.PER_HEAD
+        heads = [args[i * P:(i + 1) * P] for i in range(n)]
+        x = _f32c(x)
+        _dev(x)
+        B, Cin, N = x.shape
+        Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)               # [sum Co, Cin]
+        Ct = Wc.size(0)
+        y = torch.bmm(Wc.unsqueeze(0).expand(B, -1, -1), x)                 # [B, sum Co, N]
+        lib = _lib.load()
+        outs, saved, meta, c0 = [], [], [], 0
+        with _on(x.device):
+            for h in heads:
+                Co = h[0].size(0)
+                for (w, b, rm, rv, nbt, eps, mom) in (h[1:8], h[8:15]):
+                    w, b = _f32c(w), _f32c(b)
+                    C = w.numel()
+                    o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+                    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+                    rstd = torch.empty_like(mean)
+                    _lib.check(lib.ct_bn_relu_fwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nbt),
+                                                  None, 0, _ptr(o), 0, _ptr(mean), _ptr(rstd), B, C, N, float(eps), float(mom),
+                                                  0, _stream()), "ct_bn_relu_fwd")
+                    outs.append(o)
+                    saved += [w, b, mean, rstd]
+                    meta.append((c0, C))
+                    c0 += C
+                assert c0 == sum(hh[0].size(0) for hh in heads[:len(meta) // 2]), "key_bn + values_bn must cover the projection"
+        ctx.save_for_backward(x, y, Wc, *saved)
+        ctx.meta = meta
+        ctx.couts = [h[0].size(0) for h in heads]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        x, y, Wc = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        B, Cin, N = x.shape
+        Ct = Wc.size(0)
+        g_y = torch.empty_like(y)
+        lib = _lib.load()
+        bn_grads = []
+        with _on(x.device):
+            for i, (c0, C) in enumerate(ctx.meta):
+                w, b, mean, rstd = saved[i * 4:(i + 1) * 4]
+                gy = gouts[i]
+                if gy is None:
+                    gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
+                gybs = _batch_stride(gy, C, N)
+                if gybs is None:
+                    gy, gybs = _f32c(gy), 0
+                g_w, g_b = torch.empty_like(w), torch.empty_like(b)
+                _lib.check(lib.ct_bn_relu_bwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
+                                              _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_w), _ptr(g_b), B, C, N, 0, _stream()),
+                           "ct_bn_relu_bwd")
+                bn_grads.append((g_w, g_b))
+        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[1] else None
+        g_Wc = torch.bmm(g_y, x.transpose(1, 2)).sum(0)                     # [sum Co, Cin]
+        grads, r0 = [None, g_x], 0
+        for hi, Co in enumerate(ctx.couts):
+            (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]
+            grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None]
+            r0 += Co
+        return tuple(grads)
+
+
+def union_keys_values(x, convs, key_bns, values_bns):
+    """[(key_bn_i(y_i[:, :Ck]), values_bn_i(y_i[:, Ck:])) with y_i = conv_i(x)] for the heads of a union block through
+    UnionKeysValuesFn; the caller checked union_keys_values_eligible."""
+    args = []
+    for conv, kb, vb in zip(convs, key_bns, values_bns):
+        args.append(conv.weight)
+        for bn in (kb, vb):
+            args += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum]
+    outs = UnionKeysValuesFn.apply(len(convs), x, *args)
+    return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(convs))]
+
+
+def union_keys_values_eligible(x, convs, key_bns, values_bns):
+    """Plain bias-free 1x1 Conv1d projections of the same input and norms the fused kernels take."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous() and len(convs) > 1):
+        return False
+    for conv, kb, vb in zip(convs, key_bns, values_bns):
+        if not (isinstance(conv, torch.nn.Conv1d) and conv.kernel_size == (1,) and conv.stride == (1,) and conv.padding == (0,)
+                and conv.dilation == (1,) and conv.groups == 1 and conv.bias is None and conv.in_channels == x.size(1)
+                and conv.out_channels == kb.num_features + vb.num_features):
+            return False
+        probe = (x.size(0), x.size(2))
+        for bn in (kb, vb):
+            if not (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+                    and bn.momentum is not None):
+                return False
+            key = (probe[0], bn.num_features, probe[1])
+            ok = _bn_supported.get(key)
+            if ok is None:
+                ok = _bn_supported[key] = bool(_lib.load().ct_bn_relu_supported(*key))
+            if not ok:
+                return False
+    return True
+
+
 _bn_supported = {}
 
 

@@ -194,3 +194,50 @@ def test_join_bn_relu_equals_cat_of_the_modules():
         assert torch.allclose(m.bias.grad, r.bias.grad, rtol=1e-4, atol=1e-3)
         assert torch.allclose(m.running_var, r.running_var, rtol=1e-5, atol=1e-6)
         assert int(m.num_batches_tracked) == int(r.num_batches_tracked) == 1
+
+
+def test_union_keys_values_equals_per_head_modules():
+    """One stacked GEMM + norms for all heads (ops.union_keys_values) against conv_i -> split -> key_bn_i / values_bn_i."""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
+    torch.manual_seed(8)
+    B, Cin, N = 4, 32, 512
+    spec = [(12, 16), (6, 40)]                      # (3H, H*C) per head
+    def build():
+        torch.manual_seed(8)
+        convs = [PointwiseConv1d(Cin, ck + cv, kernel_size=1, bias=False).cuda() for ck, cv in spec]
+        kbs = [torch.nn.BatchNorm1d(ck).cuda() for ck, _ in spec]
+        vbs = [torch.nn.BatchNorm1d(cv).cuda() for _, cv in spec]
+        with torch.no_grad():
+            for bn in kbs + vbs:
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+        return convs, kbs, vbs
+    x0 = torch.randn(B, Cin, N, device="cuda")
+    cots = [(torch.randn(B, ck, N, device="cuda"), torch.randn(B, cv, N, device="cuda")) for ck, cv in spec]
+    res = []
+    for fused in (True, False):
+        convs, kbs, vbs = build()
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            assert ops.union_keys_values_eligible(x, convs, kbs, vbs)
+            outs = ops.union_keys_values(x, convs, kbs, vbs)
+        else:
+            outs = []
+            for conv, kb, vb, (ck, cv) in zip(convs, kbs, vbs, spec):
+                a, b = torch.split(conv(x), [ck, cv], dim=1)
+                outs.append((kb(a.contiguous()), vb(b.contiguous())))
+        sum((k * gk).sum() + (v * gv).sum() for (k, v), (gk, gv) in zip(outs, cots)).backward()
+        res.append(([t.detach() for kv in outs for t in kv], x.grad, [c.weight.grad for c in convs],
+                    [bn.weight.grad for bn in kbs + vbs], [bn.bias.grad for bn in kbs + vbs],
+                    [bn.running_var.clone() for bn in kbs + vbs], [int(bn.num_batches_tracked) for bn in kbs + vbs]))
+    f, r = res
+    for a, b in zip(f[0], r[0]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(f[1], r[1], rtol=1e-4, atol=1e-3)
+    for group in (2, 3, 4):
+        for a, b in zip(f[group], r[group]):
+            assert torch.allclose(a, b, rtol=1e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), float((a - b).abs().max())
+    for a, b in zip(f[5], r[5]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert f[6] == r[6] == [1, 1, 1, 1]
