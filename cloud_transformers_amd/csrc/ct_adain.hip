@@ -54,6 +54,9 @@ struct AdainArgs {
   int B, C, N;
   float eps;
   int relu;
+  long long xbs, ybs;        // batch strides in floats (C*N when contiguous; larger for a channel slice of a wider tensor)
+  const float* residual;     // nullable: added after the ReLU (the union block's skip connection)
+  long long rbs;
 };
 
 template <int NV>
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
   __shared__ float red[2][kWaves];
   const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
   const int nq = a.N >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)row * a.N);
+  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.xbs + (size_t)c * a.N);
   float4 v[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -92,7 +95,8 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
   const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
   const float lo = a.relu ? 0.0f : -INFINITY;
-  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * a.N);
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)b * a.ybs + (size_t)c * a.N);
+  const float4* rr = a.residual ? reinterpret_cast<const float4*>(a.residual + (size_t)b * a.rbs + (size_t)c * a.N) : nullptr;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
@@ -102,6 +106,10 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
       o.y = fmaxf((v[k].y - mu) * g + be, lo);
       o.z = fmaxf((v[k].z - mu) * g + be, lo);
       o.w = fmaxf((v[k].w - mu) * g + be, lo);
+      if (rr) {
+        const float4 r = rr[q];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
       yr[q] = o;
     }
   }
@@ -110,7 +118,7 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
 __global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainArgs a, float* __restrict__ y) {
   __shared__ float red[2][kWaves];
   const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
-  const float* xr = a.x + (size_t)row * a.N;
+  const float* xr = a.x + (size_t)b * a.xbs + (size_t)c * a.N;
   float s[1] = {0.f};
   for (int n = threadIdx.x; n < a.N; n += kThreads) s[0] += xr[n];
   block_sum<1>(s, red);
@@ -130,8 +138,9 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainArgs a
   const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
   const float lo = a.relu ? 0.0f : -INFINITY;
-  float* yr = y + (size_t)row * a.N;
-  for (int n = threadIdx.x; n < a.N; n += kThreads) yr[n] = fmaxf((xr[n] - mu) * g + be, lo);
+  float* yr = y + (size_t)b * a.ybs + (size_t)c * a.N;
+  const float* rr = a.residual ? a.residual + (size_t)b * a.rbs + (size_t)c * a.N : nullptr;
+  for (int n = threadIdx.x; n < a.N; n += kThreads) yr[n] = fmaxf((xr[n] - mu) * g + be, lo) + (rr ? rr[n] : 0.0f);
 }
 
 // Backward of y = relu?(xhat * (gamma + 1) + beta) wrt x, gamma, beta.  With g' = gy masked by the ReLU:
@@ -147,6 +156,7 @@ struct AdainBwdArgs {
   float* g_gamma_beta;
   int B, C, N;
   int relu;
+  long long xbs, gybs, gxbs; // batch strides in floats
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * ((gamma + 1) * rstd) + beta, same
@@ -164,8 +174,8 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
   const float gfw = g1 * rs;                            // the forward's scale
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
-  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)row * a.N);
-  const float4* gr = reinterpret_cast<const float4*>(a.gy + (size_t)row * a.N);
+  const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.xbs + (size_t)c * a.N);
+  const float4* gr = reinterpret_cast<const float4*>(a.gy + (size_t)b * a.gybs + (size_t)c * a.N);
   float4 xh[NV], g[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
   }
   const float inv_n = 1.0f / (float)a.N;
   const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
-  float4* or_ = reinterpret_cast<float4*>(a.gx + (size_t)row * a.N);
+  float4* or_ = reinterpret_cast<float4*>(a.gx + (size_t)b * a.gxbs + (size_t)c * a.N);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
@@ -207,8 +217,8 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
   const float gfw = g1 * rs;                            // the forward's scale
   const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
-  const float* xr = a.x + (size_t)row * a.N;
-  const float* gr = a.gy + (size_t)row * a.N;
+  const float* xr = a.x + (size_t)b * a.xbs + (size_t)c * a.N;
+  const float* gr = a.gy + (size_t)b * a.gybs + (size_t)c * a.N;
   float s[2] = {0.f, 0.f};
   for (int n = threadIdx.x; n < a.N; n += kThreads) {
     const float xh = (xr[n] - mu) * rs;
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   }
   const float inv_n = 1.0f / (float)a.N;
   const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
-  float* or_ = a.gx + (size_t)row * a.N;
+  float* or_ = a.gx + (size_t)b * a.gxbs + (size_t)c * a.N;
   for (int n = threadIdx.x; n < a.N; n += kThreads) {
     const float xh = (xr[n] - mu) * rs;
     const float g = masked(gr[n], xr[n] - mu, gfw, be, a.relu);
@@ -254,17 +264,30 @@ int nv_for(int N) {
     default: hipLaunchKernelGGL((KERNEL<16>), dim3(rows), dim3(kThreads), 0, stream, __VA_ARGS__); break; \
   }
 
-extern "C" int ct_adain_fwd(const float* x, const float* gamma_beta, float* y, float* mean, float* rstd, int B, int C,
-                            int N, float eps, int relu, ct_stream_t s) {
+// a batch stride: 0 = contiguous (C*N), else >= C*N floats (a multiple of 4 for the float4 kernels: checked by vec_ok's callers)
+static bool adain_stride(long long bs, int C, int N, long long& out) {
+  const long long dense = (long long)C * N;
+  if (bs == 0) { out = dense; return true; }
+  if (bs < dense) return false;
+  out = bs;
+  return true;
+}
+
+extern "C" int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                            long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                            int B, int C, int N, float eps, int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
   if ((size_t)B * C == 0 || N == 0) return CT_OK;
   if (!x || !gamma_beta || !y || !mean || !rstd) return CT_EINVAL;
   if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
   const int rows = B * C;
-  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu};
+  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0};
+  if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(y_batch_stride, C, N, a.ybs) ||
+      !adain_stride(residual_batch_stride, C, N, a.rbs))
+    return CT_EINVAL;
   CT_CLEAR_ERROR();
-  if (vec_ok(N, x, y, nullptr)) {
+  if (vec_ok(N, x, y, residual) && ((a.xbs | a.ybs | a.rbs) & 3) == 0) {
     CT_ADAIN_DISPATCH(nv_for(N), adain_fwd_reg_kernel, a, y)
   } else {
     hipLaunchKernelGGL(adain_fwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a, y);
@@ -273,9 +296,9 @@ extern "C" int ct_adain_fwd(const float* x, const float* gamma_beta, float* y, f
   return CT_OK;
 }
 
-extern "C" int ct_adain_bwd(const float* x, const float* gamma_beta, const float* mean, const float* rstd,
-                            const float* gy, float* gx, float* g_gamma_beta, int B, int C, int N, int relu,
-                            ct_stream_t s) {
+extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
+                            const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
+                            long long gx_batch_stride, float* g_gamma_beta, int B, int C, int N, int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (B < 0 || C < 0 || N < 0) return CT_EINVAL;
   if ((size_t)B * C == 0) return CT_OK;
@@ -284,9 +307,12 @@ extern "C" int ct_adain_bwd(const float* x, const float* gamma_beta, const float
   if (N == 0) return hipMemsetAsync(g_gamma_beta, 0, (size_t)B * 2 * C * sizeof(float), stream) == hipSuccess ? CT_OK : CT_ELAUNCH;
   if (!x || !gy || !gx) return CT_EINVAL;
   const int rows = B * C;
-  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu};
+  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0};
+  if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(gy_batch_stride, C, N, a.gybs) ||
+      !adain_stride(gx_batch_stride, C, N, a.gxbs))
+    return CT_EINVAL;
   CT_CLEAR_ERROR();
-  if (vec_ok(N, x, gy, gx)) {
+  if (vec_ok(N, x, gy, gx) && ((a.xbs | a.gybs | a.gxbs) & 3) == 0) {
     CT_ADAIN_DISPATCH(nv_for(N), adain_bwd_reg_kernel, a)
   } else {
     hipLaunchKernelGGL(adain_bwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a);

@@ -27,8 +27,8 @@ from .pointwise import PointwiseConv1d
 from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer, so3_exponential_map
 
 
-def forward_style(module_list, input, z):
-    """Apply a Sequential in which AdaIN layers also take the style vector `z`.
+def forward_style(module_list, input, z, residual=None):
+    """Apply a Sequential in which AdaIN layers also take the style vector `z` (and add `residual` to the result).
     Dispatch is by class name, like the reference (multihead_ct_adain.py:11)."""
     layers = list(module_list)
     i = 0
@@ -36,12 +36,20 @@ def forward_style(module_list, input, z):
         layer = layers[i]
         if "AdaIn1dUpd" in str(type(layer)):
             fuse = i + 1 < len(layers) and type(layers[i + 1]) is nn.ReLU and isinstance(layer, AdaIn1dUpd)
-            input = layer(input, z, relu=True) if fuse else layer(input, z)
-            i += 2 if fuse else 1
+            step = 2 if fuse else 1
+            last = i + step == len(layers)
+            fuse_res = (last and residual is not None and isinstance(layer, AdaIn1dUpd) and residual.shape == input.shape
+                        and residual.dtype == input.dtype)
+            if fuse_res:
+                input = layer(input, z, relu=fuse, residual=residual)
+                residual = None
+            else:
+                input = layer(input, z, relu=True) if fuse else layer(input, z)
+            i += step
         else:
             input = layer(input)
             i += 1
-    return input
+    return input if residual is None else residual + input
 
 
 def run_after(module_list, input, residual=None):
@@ -317,4 +325,4 @@ class MultiHeadUnionAdaIn(_UnionBase):
             r, s = attention(x, style, orig_pcd)
             results.append(r)
             stats.append(s)
-        return residual + forward_style(self.after, torch.cat(results, dim=1), style), stats
+        return forward_style(self.after, torch.cat(results, dim=1), style, residual), stats

@@ -81,15 +81,16 @@ class AdaIn1dUpd(nn.Module):
         self.instance_norm = nn.InstanceNorm1d(num_features, eps=1e-5, affine=False)
         self.linear = nn.Linear(num_latent, num_features * 2)
 
-    def forward(self, x, z, relu=False):
+    def forward(self, x, z, relu=False, residual=None):
         """`relu=True` folds the ReLU that follows this layer in the blocks' `after` stacks into the same
-        kernel (forward_style passes it and skips the nn.ReLU)."""
+        kernel (forward_style passes it and skips the nn.ReLU); `residual` is added to the result in the same pass."""
         gamma_beta = self.linear(z).reshape(-1, 2, self.num_features)
         if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:
-            return ops.adain(x, gamma_beta, self.instance_norm.eps, relu)    # one HIP launch (ct_adain_fwd)
+            return ops.adain(x, gamma_beta, self.instance_norm.eps, relu, residual)    # one HIP launch (ct_adain_fwd)
         # module built / probed off the accelerator (state-dict tooling): torch's own composition
         y = self.instance_norm(x) * (gamma_beta[:, 0, :, None] + 1) + gamma_beta[:, 1, :, None]
-        return torch.relu(y) if relu else y
+        y = torch.relu(y) if relu else y
+        return y if residual is None else y + residual
 
 
 def forward_stats(input, module, type):

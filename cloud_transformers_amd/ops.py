@@ -371,45 +371,6 @@ def so3_exp(log_R, eps=1e-4):
     return So3ExpFn.apply(log_R, eps)
 
 
-class AdaInFn(torch.autograd.Function):
-    """relu?(instance_norm(x) * (gamma + 1) + beta), gamma_beta [B,2,C] (layers/utils.py:88-97)."""
-
-    @staticmethod
-    def forward(ctx, x, gamma_beta, eps, relu):
-        _dev(x, gamma_beta)
-        x, gamma_beta = _f32c(x), _f32c(gamma_beta)
-        B, C, N = x.shape
-        assert gamma_beta.shape == (B, 2, C)
-        y = torch.empty_like(x)
-        mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        lib = _lib.load()
-        with _on(x.device):
-            _lib.check(lib.ct_adain_fwd(_ptr(x), _ptr(gamma_beta), _ptr(y), _ptr(mean), _ptr(rstd), B, C, N,
-                                        float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
-        ctx.save_for_backward(x, gamma_beta, mean, rstd)
-        ctx.relu = int(bool(relu))
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, gamma_beta, mean, rstd = ctx.saved_tensors
-        B, C, N = x.shape
-        gy = _f32c(gy)
-        gx = torch.empty_like(x)
-        g_gb = torch.empty_like(gamma_beta)
-        lib = _lib.load()
-        with _on(x.device):
-            _lib.check(lib.ct_adain_bwd(_ptr(x), _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), _ptr(gx), _ptr(g_gb),
-                                        B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
-        return gx, g_gb, None, None
-
-
-def adain(x, gamma_beta, eps=1e-5, relu=False):
-    """Adaptive instance norm of x [B,C,N] with per-(b,c) scale (+1) and bias gamma_beta [B,2,C]."""
-    return AdaInFn.apply(x, gamma_beta, eps, relu)
-
-
 def _batch_stride(t, C, N):
     """Batch stride (floats) of t if it is a [B,C,N] tensor whose rows are contiguous, whose channels are N apart and
     whose batches are a multiple of 4 >= C*N apart, 16-byte aligned — a contiguous tensor or a channel slice of a wider
@@ -418,6 +379,61 @@ def _batch_stride(t, C, N):
             and (t.stride(1) == N or C == 1) and t.stride(0) >= C * N and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
         return t.stride(0)
     return None
+
+
+class AdaInFn(torch.autograd.Function):
+    """relu?(instance_norm(x) * (gamma + 1) + beta) [+ residual], gamma_beta [B,2,C] (layers/utils.py:88-97).  x may be a
+    channel slice of a wider tensor (read where it lies), and so may the cotangent."""
+
+    @staticmethod
+    def forward(ctx, x, gamma_beta, eps, relu, residual):
+        _dev(x, gamma_beta)
+        if x.dtype != torch.float32:
+            raise TypeError("expected float32, got %s" % x.dtype)
+        B, C, N = x.shape
+        xbs = _batch_stride(x, C, N)
+        if xbs is None:
+            x, xbs = x.contiguous(), 0
+        gamma_beta = _f32c(gamma_beta)
+        assert gamma_beta.shape == (B, 2, C)
+        rbs = 0
+        if residual is not None:
+            rbs = _batch_stride(residual, C, N)
+            if rbs is None:
+                residual, rbs = _f32c(residual), 0
+        y = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+        mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib = _lib.load()
+        with _on(x.device):
+            _lib.check(lib.ct_adain_fwd(_ptr(x), xbs, _ptr(gamma_beta), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd),
+                                        B, C, N, float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
+        ctx.save_for_backward(x, gamma_beta, mean, rstd)
+        ctx.relu = int(bool(relu))
+        ctx.xbs = xbs
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma_beta, mean, rstd = ctx.saved_tensors
+        B, C, N = x.shape
+        gybs = _batch_stride(gy, C, N)
+        if gybs is None:
+            gy, gybs = _f32c(gy), 0
+        gx = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+        g_gb = torch.empty_like(gamma_beta)
+        lib = _lib.load()
+        with _on(x.device):
+            _lib.check(lib.ct_adain_bwd(_ptr(x), ctx.xbs, _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), gybs, _ptr(gx), 0,
+                                        _ptr(g_gb), B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
+        return gx, g_gb, None, None, (gy if ctx.has_residual else None)
+
+
+def adain(x, gamma_beta, eps=1e-5, relu=False, residual=None):
+    """Adaptive instance norm of x [B,C,N] with per-(b,c) scale (+1) and bias gamma_beta [B,2,C]; `residual` is added
+    to the result in the same pass."""
+    return AdaInFn.apply(x, gamma_beta, eps, relu, residual)
 
 
 class BnReluFn(torch.autograd.Function):

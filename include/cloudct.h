@@ -198,11 +198,16 @@ int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight
  * x, y, gy, gx f32[B,C,N]; gamma_beta f32[B,2,C] (the Linear(style) output: [:,0] scale, [:,1] bias);
  * mean, rstd f32[B*C] are written by the forward and read by the backward (biased variance).
  * Backward overwrites gx and g_gamma_beta f32[B,2,C]; with relu != 0 the mask is recomputed from x.
+ * Every [B,C,N] argument has a batch stride in floats (0 = C*N, contiguous; >= C*N for a channel slice of a wider
+ * tensor — keys_bn / values_bn on the halves of keys_values_pred, multihead_ct_adain.py:108-111); `residual` (nullable)
+ * is added after the ReLU (the union's skip connection, :216), its cotangent is gy itself.
  * ---------------------------------------------------------------------- */
-int ct_adain_fwd(const float* x, const float* gamma_beta, float* y, float* mean, float* rstd,
+int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                 long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
                  int B, int C, int N, float eps, int relu, ct_stream_t s);
-int ct_adain_bwd(const float* x, const float* gamma_beta, const float* mean, const float* rstd,
-                 const float* gy, float* gx, float* g_gamma_beta, int B, int C, int N, int relu, ct_stream_t s);
+int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean, const float* rstd,
+                 const float* gy, long long gy_batch_stride, float* gx, long long gx_batch_stride, float* g_gamma_beta,
+                 int B, int C, int N, int relu, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Grouped 3^dim convolution over the rasterised planes / volumes, stride 1, padding 1

@@ -85,9 +85,11 @@ def test_adain_abi_rejects_bad_arguments():
     from cloud_transformers_amd import _lib
     lib = _lib.load()
     x = torch.zeros(1, 1, 4, device="cuda")
-    assert lib.ct_adain_fwd(None, None, None, None, None, 1, 1, 4, 1e-5, 0, None) == -1
-    assert lib.ct_adain_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), -1, 1, 4, 1e-5, 0, None) == -1
-    assert lib.ct_adain_fwd(None, None, None, None, None, 0, 8, 4, 1e-5, 0, None) == 0      # empty batch: nothing to do
+    assert lib.ct_adain_fwd(None, 0, None, None, 0, None, 0, None, None, 1, 1, 4, 1e-5, 0, None) == -1
+    p = x.data_ptr()
+    assert lib.ct_adain_fwd(p, 0, p, None, 0, p, 0, p, p, -1, 1, 4, 1e-5, 0, None) == -1
+    assert lib.ct_adain_fwd(p, 2, p, None, 0, p, 0, p, p, 1, 1, 4, 1e-5, 0, None) == -1      # batch stride < C*N
+    assert lib.ct_adain_fwd(None, 0, None, None, 0, None, 0, None, None, 0, 8, 4, 1e-5, 0, None) == 0      # empty batch: nothing to do
 
 
 @pytest.mark.parametrize("N", [4096, 20000])          # register-resident rows and the strided kernel
@@ -105,3 +107,33 @@ def test_relu_mask_in_backward_is_the_forward_mask(N):
     expect = (gy.double() * (y.detach() > 0)).sum(dim=2)
     got = gb.grad[:, 1].double()
     assert float((got - expect).abs().max()) <= 2e-3, float((got - expect).abs().max())     # one wrong element would show as ~1
+
+
+@pytest.mark.parametrize("N", [512, 250])            # float4 rows and the strided kernel
+def test_channel_slices_residual_and_sliced_cotangent(N):
+    """x as a channel slice of a wider tensor, a skip connection added in the same pass, and a cotangent that is a
+    slice of a concatenation's: all read where they lie, same results as torch's composition."""
+    from cloud_transformers_amd import ops
+    torch.manual_seed(N)
+    B, C = 3, 20
+    wide = torch.randn(B, C + 12, N, device="cuda", requires_grad=True)
+    gb = torch.randn(B, 2, C, device="cuda", requires_grad=True)
+    res = torch.randn(B, C, N, device="cuda", requires_grad=True)
+    cot = torch.randn(B, C + 4, N, device="cuda")
+
+    def run(fused):
+        for t in (wide, gb, res):
+            t.grad = None
+        x = wide[:, 12:]                                   # rows contiguous, batch stride (C + 12) * N
+        if fused:
+            y = ops.adain(x, gb, 1e-5, True, res)
+        else:
+            xh = torch.nn.functional.instance_norm(x.contiguous(), eps=1e-5)
+            y = torch.relu(xh * (gb[:, 0, :, None] + 1) + gb[:, 1, :, None]) + res
+        z = torch.cat([y, wide[:, :4] * 0], dim=1)
+        (z * cot).sum().backward()
+        return y.detach(), wide.grad.clone(), gb.grad.clone(), res.grad.clone()
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=1e-4, atol=2e-4), float((u - v).abs().max())
