@@ -218,20 +218,29 @@ class MultiHeadAdaIn(_MHCTCore):
         self.scale = nn.Parameter(torch.tensor(0, dtype=torch.float32))
         self._build_transform(scales)
 
-    def forward(self, input, style, orig_pcd, return_lattice=False):
+    def _forward_pre(self, input, style, orig_pcd, kv=None):
+        """Everything up to (not including) `after`; `kv` = (keys_res, values) when the union block computed them."""
         H = self.heads
-        key_values = forward_style(self.keys_values_pred, input, style)
-        k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
-        keys_res = forward_style(self.keys_bn, k_part, style)
-        values = forward_style(self.values_bn, v_part, style)
+        if kv is None:
+            key_values = forward_style(self.keys_values_pred, input, style)
+            k_part, v_part = torch.split(key_values, [H * 3, key_values.size(1) - H * 3], dim=1)   # backward: one cat
+            keys_res = forward_style(self.keys_bn, k_part, style)
+            values = forward_style(self.values_bn, v_part, style)
+        else:
+            keys_res, values = kv
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res, self.scale)
         z = self.splat.forward_keys(lattice, values)
         occ = self._occupancy(z, keys.size(0))
-        result = forward_style(self.after, self.slice.forward_keys(lattice, self.conv(z)), style)
+        pre = self.slice.forward_keys(lattice, self.conv(z))
         with torch.no_grad():
             # the reference moves these to the host and copies ALL keys to numpy on every
             # forward (multihead_ct_adain.py:127-131); here they stay on the device (no sync)
             stats = (occ, kstats[0], kstats[1], keys.detach())
+        return pre, stats, lattice
+
+    def forward(self, input, style, orig_pcd, return_lattice=False):
+        pre, stats, lattice = self._forward_pre(input, style, orig_pcd)
+        result = forward_style(self.after, pre, style)
         if return_lattice:
             result = result, lattice
         return result, stats
@@ -320,9 +329,43 @@ class MultiHeadUnionAdaIn(_UnionBase):
     def forward(self, x, style, orig_pcd):
         x = self.prenorm(x)
         residual = forward_style(self.shortcut, x, style)
-        results, stats = [], []
-        for attention in self.attentions:
-            r, s = attention(x, style, orig_pcd)
-            results.append(r)
+        pres, stats = [], []
+        kvs = self._fused_keys_values(x, style)
+        for i, attention in enumerate(self.attentions):
+            r, s, _ = attention._forward_pre(x, style, orig_pcd, None if kvs is None else kvs[i])
+            pres.append(r)
             stats.append(s)
-        return forward_style(self.after, torch.cat(results, dim=1), style, residual), stats
+        afters = [a.after for a in self.attentions]
+        fusable = (len(pres) > 1 and all(len(n) == 2 and type(n[0]) is AdaIn1dUpd and type(n[1]) is nn.ReLU for n in afters)
+                   and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 for p in pres))
+        if fusable:        # the heads' AdaIN + ReLU write straight into their channel ranges of the concatenation
+            args = []
+            for n, p in zip(afters, pres):
+                args += [p, n[0].linear(style).reshape(-1, 2, n[0].num_features)]
+            joined = ops.JoinAdaInReluFn.apply(len(pres), afters[0][0].instance_norm.eps, *args)
+        else:
+            joined = torch.cat([forward_style(n, p, style) for n, p in zip(afters, pres)], dim=1)
+        return forward_style(self.after, joined, style, residual), stats
+
+    def _fused_keys_values(self, x, style):
+        """One stacked GEMM for all heads' keys_values_pred + their AdaIN norms (ops.UnionKeysValuesAdaInFn), or None."""
+        atts = list(self.attentions)
+        if not (len(atts) > 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()):
+            return None
+        args, eps = [], None
+        for a in atts:
+            kvp, kb, vb = a.keys_values_pred, a.keys_bn, a.values_bn
+            if not (len(kvp) == 1 and isinstance(kvp[0], nn.Conv1d) and kvp[0].kernel_size == (1,) and kvp[0].bias is None
+                    and kvp[0].stride == (1,) and kvp[0].padding == (0,) and kvp[0].groups == 1 and kvp[0].dilation == (1,)
+                    and kvp[0].in_channels == x.size(1)
+                    and len(kb) == 1 and type(kb[0]) is AdaIn1dUpd and len(vb) == 1 and type(vb[0]) is AdaIn1dUpd
+                    and kvp[0].out_channels == kb[0].num_features + vb[0].num_features):
+                return None
+            e = kb[0].instance_norm.eps
+            if vb[0].instance_norm.eps != e or (eps is not None and eps != e):
+                return None
+            eps = e
+            args += [kvp[0].weight, kb[0].linear(style).reshape(-1, 2, kb[0].num_features),
+                     vb[0].linear(style).reshape(-1, 2, vb[0].num_features)]
+        outs = ops.UnionKeysValuesAdaInFn.apply(len(atts), x, eps, *args)
+        return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(atts))]

@@ -436,6 +436,122 @@ def adain(x, gamma_beta, eps=1e-5, relu=False, residual=None):
     return AdaInFn.apply(x, gamma_beta, eps, relu, residual)
 
 
+class UnionKeysValuesAdaInFn(torch.autograd.Function):
+    """UnionKeysValuesFn for the AdaIN blocks (layers/multihead_ct_adain.py:104-111): one stacked GEMM for the heads'
+    keys_values_pred projections, keys_bn / values_bn = adaptive instance norms on channel ranges of its output.
+    Arguments: n, x, eps, then per head: weight [Co,Cin,1], gamma_beta of keys_bn [B,2,Ck], gamma_beta of values_bn
+    [B,2,Cv].  Returns (keys_res_0, values_0, keys_res_1, values_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, n, x, eps, *args):
+        heads = [args[i * 3:(i + 1) * 3] for i in range(n)]
+        x = _f32c(x)
+        _dev(x)
+        B, Cin, N = x.shape
+        Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)
+        Ct = Wc.size(0)
+        y = torch.bmm(Wc.unsqueeze(0).expand(B, -1, -1), x)
+        lib = _lib.load()
+        outs, saved, meta, c0 = [], [], [], 0
+        with _on(x.device):
+            for h in heads:
+                for gb in h[1:3]:
+                    gb = _f32c(gb)
+                    C = gb.size(2)
+                    o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+                    mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
+                    rstd = torch.empty_like(mean)
+                    _lib.check(lib.ct_adain_fwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), None, 0, _ptr(o), 0, _ptr(mean), _ptr(rstd),
+                                                B, C, N, float(eps), 0, _stream()), "ct_adain_fwd")
+                    outs.append(o)
+                    saved += [gb, mean, rstd]
+                    meta.append((c0, C))
+                    c0 += C
+        assert c0 == Ct, "keys_bn + values_bn must cover the projections"
+        ctx.save_for_backward(x, y, Wc, *saved)
+        ctx.meta = meta
+        ctx.couts = [h[0].size(0) for h in heads]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        x, y, Wc = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        B, Cin, N = x.shape
+        Ct = Wc.size(0)
+        g_y = torch.empty_like(y)
+        lib = _lib.load()
+        g_gbs = []
+        with _on(x.device):
+            for i, (c0, C) in enumerate(ctx.meta):
+                gb, mean, rstd = saved[i * 3:(i + 1) * 3]
+                gy = gouts[i]
+                if gy is None:
+                    gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
+                gybs = _batch_stride(gy, C, N)
+                if gybs is None:
+                    gy, gybs = _f32c(gy), 0
+                g_gb = torch.empty_like(gb)
+                _lib.check(lib.ct_adain_bwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
+                                            _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_gb), B, C, N, 0, _stream()), "ct_adain_bwd")
+                g_gbs.append(g_gb)
+        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[1] else None
+        g_Wc = torch.bmm(g_y, x.transpose(1, 2)).sum(0)
+        grads, r0 = [None, g_x, None], 0
+        for hi, Co in enumerate(ctx.couts):
+            grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
+            r0 += Co
+        return tuple(grads)
+
+
+class JoinAdaInReluFn(torch.autograd.Function):
+    """cat([relu(adain_i(x_i)) for i], dim=1): the AdaIN heads' `after` stacks followed by the union's concatenation
+    (layers/multihead_ct_adain.py:64-66,205-214) — JoinBnReluFn's counterpart.  Arguments: n, eps, then per head (x, gamma_beta)."""
+
+    @staticmethod
+    def forward(ctx, n, eps, *args):
+        xs = [_f32c(args[2 * i]) for i in range(n)]
+        gbs = [_f32c(args[2 * i + 1]) for i in range(n)]
+        _dev(*xs)
+        B, _, N = xs[0].shape
+        Ct = sum(x.size(1) for x in xs)
+        y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
+        lib = _lib.load()
+        saved, c0 = [], 0
+        with _on(y.device):
+            for x, gb in zip(xs, gbs):
+                C = x.size(1)
+                mean = torch.empty(B * C, device=y.device, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                _lib.check(lib.ct_adain_fwd(_ptr(x), 0, _ptr(gb), None, 0, _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd),
+                                            B, C, N, float(eps), 1, _stream()), "ct_adain_fwd")
+                saved += [x, gb, mean, rstd]
+                c0 += C
+        ctx.save_for_backward(*saved)
+        ctx.n = n
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, saved = ctx.n, ctx.saved_tensors
+        B, Ct, N = gy.shape
+        gybs = _batch_stride(gy, Ct, N)
+        if gybs is None:
+            gy, gybs = _f32c(gy), Ct * N
+        lib = _lib.load()
+        grads, c0 = [None, None], 0
+        with _on(gy.device):
+            for i in range(n):
+                x, gb, mean, rstd = saved[i * 4:(i + 1) * 4]
+                C = x.size(1)
+                gx, g_gb = torch.empty_like(x), torch.empty_like(gb)
+                _lib.check(lib.ct_adain_bwd(_ptr(x), 0, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs, _ptr(gx), 0,
+                                            _ptr(g_gb), B, C, N, 1, _stream()), "ct_adain_bwd")
+                grads += [gx, g_gb]
+                c0 += C
+        return tuple(grads)
+
+
 class BnReluFn(torch.autograd.Function):
     """relu?(batch_norm(x)) [+ residual] in training mode (batch statistics; running statistics and num_batches_tracked
     updated in place by the kernel): the nn.Sequential(BatchNorm1d, ReLU) tail of the blocks' `after` stacks and the

@@ -172,3 +172,52 @@ def test_pointwise_conv1d_matches_conv1d():
     # anything that is not a plain 1x1 projection falls through to nn.Conv1d
     k3 = PointwiseConv1d(8, 8, kernel_size=3, padding=1).cuda()
     assert k3(torch.randn(1, 8, 16, device="cuda")).shape == (1, 8, 16)
+
+
+@pytest.mark.parametrize("kind", ["bn", "adain"])
+def test_union_fusions_equal_the_per_head_path(kind):
+    """The union blocks' stacked keys_values_pred GEMM, norms on channel ranges and heads writing into the concatenation
+    against the same block evaluated head by head (fusions disabled): output and every gradient."""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers import multihead_ct as M
+    torch.manual_seed(12)
+    B, D, N = 2, 32, 512
+    if kind == "bn":
+        blk = M.MultiHeadUnion(D, [4, 4], [16, 8], [2, 3], [4, 2]).cuda().train()
+    else:
+        blk = M.MultiHeadUnionAdaIn(D, [4, 4], [16, 8], [2, 3], [4, 2], n_latent=24).cuda().train()
+        with torch.no_grad():
+            for a in blk.attentions:
+                a.scale.fill_(0.3)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if "key_bn.weight" in n:
+                p.fill_(0.2)
+    x0 = torch.randn(B, D, N, device="cuda")
+    pcd = torch.rand(B, 3, N, device="cuda") * 2 - 1
+    style = torch.randn(B, 24, device="cuda")
+    cot = torch.randn(B, D, N, device="cuda")
+
+    def run():
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out, _ = blk(x, pcd) if kind == "bn" else blk(x, style, pcd)
+        (out * cot).sum().backward()
+        return out.detach(), x.grad, {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+
+    fused = run()
+    saved = (ops.union_keys_values_eligible, ops.bn_relu_eligible, M.MultiHeadUnionAdaIn._fused_keys_values, M.AdaIn1dUpd)
+    ops.union_keys_values_eligible = lambda *a, **k: False
+    ops.bn_relu_eligible = lambda *a, **k: False
+    M.MultiHeadUnionAdaIn._fused_keys_values = lambda self, x, style: None
+    M.AdaIn1dUpd = type("NotAdaIn", (), {})           # `type(n[0]) is AdaIn1dUpd` fails: the heads' after stacks run one by one
+    try:
+        plain = run()
+    finally:
+        ops.union_keys_values_eligible, ops.bn_relu_eligible, M.MultiHeadUnionAdaIn._fused_keys_values, M.AdaIn1dUpd = saved
+    assert torch.allclose(fused[0], plain[0], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(fused[1], plain[1], rtol=1e-3, atol=1e-3 * max(1.0, float(plain[1].abs().max())))
+    assert fused[2].keys() == plain[2].keys()
+    for n in plain[2]:
+        a, b = fused[2][n], plain[2][n]
+        assert float((a - b).abs().max()) <= 2e-3 * max(1.0, float(b.abs().max())), (n, float((a - b).abs().max()))
