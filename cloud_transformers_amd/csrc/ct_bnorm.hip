@@ -8,8 +8,8 @@
 //
 // Layout: x, y, gy, gx (B, C, N) contiguous.  One workgroup of 1024 threads owns one channel: its B rows of N floats
 // (N % 4 == 0) as float4, NV <= 8 per thread (the backward holds x and gy), so B*N <= 32768 — the training shapes of
-// the segmenter / classifier (B8 N4096, B8 N2048); ct_bn_relu_supported tells the caller which shapes qualify (the
-// others stay on the library BatchNorm + ReLU).
+// the segmenter / classifier (B8 N4096, B8 N2048).  Longer channels and rows that are not float4-addressable take the
+// loop kernels below, which re-read the channel (from L2, mostly) for each pass.
 #include "ct_common.h"
 
 namespace {
@@ -191,6 +191,128 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdArgs a) {
   }
 }
 
+// Channels too long for the registers (B*N > 32768) or rows that are not float4-addressable: the same arithmetic with the
+// channel re-read from memory for each pass (a 256 KiB..1 MiB channel mostly stays in L2 between the passes).
+// VEC: N % 4 == 0, strides % 4 == 0, 16-byte aligned bases -> float4 accesses.
+template <bool VEC>
+__device__ __forceinline__ int chan_items(int B, int N) { return VEC ? B * (N >> 2) : B * N; }
+
+template <bool VEC>
+__device__ __forceinline__ size_t item_offset(int i, int N, int c, long long bs) {
+  if (VEC) return quad_offset(i, N >> 2, c, bs, N);
+  const int b = i / N, n = i - b * N;
+  return (size_t)b * (size_t)bs + (size_t)c * N + n;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* __restrict__ y) {
+  __shared__ float red[1][kWaves];
+  const int c = blockIdx.x;
+  const int total = chan_items<VEC>(a.B, a.N);
+  float s[1] = {0.f};
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+    if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p); s[0] += (v.x + v.y) + (v.z + v.w); }
+    else s[0] += p[0];
+  }
+  block_sum<1>(s, red);
+  const float M = (float)a.B * (float)a.N;
+  const float mu = s[0] / M;
+  float ss[1] = {0.f};
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+    if (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+      ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    } else {
+      const float d = p[0] - mu;
+      ss[0] += d * d;
+    }
+  }
+  block_sum<1>(ss, red);
+  const float var = ss[0] / M;
+  const float rs = rsqrtf(var + a.eps);
+  if (threadIdx.x == 0) {
+    a.save_mean[c] = mu;
+    a.save_rstd[c] = rs;
+    if (a.running_mean) {
+      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mu;
+      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (var * (M / (M - 1.0f)));
+    }
+    if (c == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+  }
+  const float g = a.weight[c] * rs;
+  const float be = a.bias[c];
+  const float lo = a.relu ? 0.0f : -INFINITY;
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+    float* o = y + item_offset<VEC>(i, a.N, c, a.ybs);
+    const float* r = a.residual ? a.residual + item_offset<VEC>(i, a.N, c, a.rbs) : nullptr;
+    if (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      float4 q;
+      q.x = fmaxf((v.x - mu) * g + be, lo);
+      q.y = fmaxf((v.y - mu) * g + be, lo);
+      q.z = fmaxf((v.z - mu) * g + be, lo);
+      q.w = fmaxf((v.w - mu) * g + be, lo);
+      if (r) { const float4 rv = *reinterpret_cast<const float4*>(r); q.x += rv.x; q.y += rv.y; q.z += rv.z; q.w += rv.w; }
+      *reinterpret_cast<float4*>(o) = q;
+    } else {
+      o[0] = fmaxf((p[0] - mu) * g + be, lo) + (r ? r[0] : 0.0f);
+    }
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
+  __shared__ float red[2][kWaves];
+  const int c = blockIdx.x;
+  const int total = chan_items<VEC>(a.B, a.N);
+  const float mu = a.save_mean[c], rs = a.save_rstd[c];
+  const float gfw = a.weight[c] * rs;
+  const float be = a.bias[c];
+  float s[2] = {0.f, 0.f};
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+    const float* pg = a.gy + item_offset<VEC>(i, a.N, c, a.gybs);
+    if (VEC) {
+      const float4 xv = *reinterpret_cast<const float4*>(px), gv = *reinterpret_cast<const float4*>(pg);
+      const float g0 = masked(gv.x, xv.x - mu, gfw, be, a.relu), g1 = masked(gv.y, xv.y - mu, gfw, be, a.relu);
+      const float g2 = masked(gv.z, xv.z - mu, gfw, be, a.relu), g3 = masked(gv.w, xv.w - mu, gfw, be, a.relu);
+      s[0] += (g0 + g1) + (g2 + g3);
+      s[1] += (g0 * ((xv.x - mu) * rs) + g1 * ((xv.y - mu) * rs)) + (g2 * ((xv.z - mu) * rs) + g3 * ((xv.w - mu) * rs));
+    } else {
+      const float g0 = masked(pg[0], px[0] - mu, gfw, be, a.relu);
+      s[0] += g0;
+      s[1] += g0 * ((px[0] - mu) * rs);
+    }
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    a.g_bias[c] = s[0];
+    a.g_weight[c] = s[1];
+  }
+  const float M = (float)a.B * (float)a.N;
+  const float m0 = s[0] / M, m1 = s[1] / M;
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+    const float* pg = a.gy + item_offset<VEC>(i, a.N, c, a.gybs);
+    float* po = a.gx + item_offset<VEC>(i, a.N, c, a.gxbs);
+    if (VEC) {
+      const float4 xv = *reinterpret_cast<const float4*>(px), gv = *reinterpret_cast<const float4*>(pg);
+      float4 o;
+      o.x = gfw * (masked(gv.x, xv.x - mu, gfw, be, a.relu) - m0 - ((xv.x - mu) * rs) * m1);
+      o.y = gfw * (masked(gv.y, xv.y - mu, gfw, be, a.relu) - m0 - ((xv.y - mu) * rs) * m1);
+      o.z = gfw * (masked(gv.z, xv.z - mu, gfw, be, a.relu) - m0 - ((xv.z - mu) * rs) * m1);
+      o.w = gfw * (masked(gv.w, xv.w - mu, gfw, be, a.relu) - m0 - ((xv.w - mu) * rs) * m1);
+      *reinterpret_cast<float4*>(po) = o;
+    } else {
+      po[0] = gfw * (masked(pg[0], px[0] - mu, gfw, be, a.relu) - m0 - ((px[0] - mu) * rs) * m1);
+    }
+  }
+}
+
 int nv_for(long long quads) {
   const long long per = (quads + kThreads - 1) / kThreads;
   int nv = 1;
@@ -198,12 +320,15 @@ int nv_for(long long quads) {
   return nv;
 }
 
-bool shape_ok(int B, int C, int N, int max_nv) {
-  if (B <= 0 || C <= 0 || N <= 0 || (N & 3) != 0) return false;
-  const long long quads = (long long)B * (N >> 2);
-  if (quads > (long long)kThreads * max_nv) return false;
-  return (long long)B * N >= 2;      // one value per channel has no variance (torch raises)
+// any channel with at least two values (one value has no variance: torch raises) that a workgroup can index with ints
+bool shape_ok(int B, int C, int N) {
+  if (B <= 0 || C <= 0 || N <= 0) return false;
+  const long long M = (long long)B * N;
+  return M >= 2 && M <= 0x7fffffffLL;
 }
+
+// the channel fits the registers (float4 rows, NV <= 8)
+bool reg_ok(int B, int N) { return (N & 3) == 0 && (long long)B * (N >> 2) <= (long long)kThreads * 8; }
 
 }  // namespace
 
@@ -215,14 +340,15 @@ bool shape_ok(int B, int C, int N, int max_nv) {
     default: hipLaunchKernelGGL((KERNEL<8>), dim3(C), dim3(kThreads), 0, stream, __VA_ARGS__); break;    \
   }
 
-// 1 when both ct_bn_relu_fwd and ct_bn_relu_bwd take (B, C, N): N % 4 == 0 and 2 <= B*N <= 32768
-extern "C" int ct_bn_relu_supported(int B, int C, int N) { return shape_ok(B, C, N, 8) ? 1 : 0; }
+// 1 when ct_bn_relu_fwd / _bwd take (B, C, N): every shape with 2 <= B*N < 2^31.  Channels with N % 4 == 0 and
+// B*N <= 32768 are held in registers (one read, one write); the others are re-read per pass.
+extern "C" int ct_bn_relu_supported(int B, int C, int N) { return shape_ok(B, C, N) ? 1 : 0; }
 
-// a batch stride is valid when it is 0 (= contiguous, C*N) or a multiple of 4 floats that is at least C*N
+// a batch stride is valid when it is 0 (= contiguous, C*N) or at least C*N
 static bool stride_ok(long long bs, int C, int N, long long& out) {
   const long long dense = (long long)C * N;
   if (bs == 0) { out = dense; return true; }
-  if (bs < dense || (bs & 3) != 0) return false;
+  if (bs < dense) return false;
   out = bs;
   return true;
 }
@@ -235,15 +361,22 @@ extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const fl
   hipStream_t stream = (hipStream_t)s;
   if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
-  if (!shape_ok(B, C, N, 8)) return CT_EINVAL;
-  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) return CT_EINVAL;
+  if (!shape_ok(B, C, N)) return CT_EINVAL;
   BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
            residual, 0, num_batches_tracked};
   if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs) ||
       !stride_ok(residual_batch_stride, C, N, a.rbs))
     return CT_EINVAL;
+  const bool vec = (N & 3) == 0 && ((a.xbs | a.ybs | a.rbs) & 3) == 0 &&
+                   ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0;
   CT_CLEAR_ERROR();
-  CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
+  if (vec && reg_ok(B, N)) {
+    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
+  } else if (vec) {
+    hipLaunchKernelGGL(bn_fwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, a, y);
+  } else {
+    hipLaunchKernelGGL(bn_fwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, a, y);
+  }
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
@@ -254,14 +387,21 @@ extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const fl
                               int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
-  if (!shape_ok(B, C, N, 8)) return CT_EINVAL;
-  if ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) return CT_EINVAL;
+  if (!shape_ok(B, C, N)) return CT_EINVAL;
   BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0};
   if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(gy_batch_stride, C, N, a.gybs) ||
       !stride_ok(gx_batch_stride, C, N, a.gxbs))
     return CT_EINVAL;
+  const bool vec = (N & 3) == 0 && ((a.xbs | a.gybs | a.gxbs) & 3) == 0 &&
+                   ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0;
   CT_CLEAR_ERROR();
-  CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, a)
+  if (vec && reg_ok(B, N)) {
+    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, a)
+  } else if (vec) {
+    hipLaunchKernelGGL(bn_bwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, a);
+  }
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

@@ -177,8 +177,9 @@ int ct_so3_exp_bwd(const float* log_R, const float* g_R, float* g_log_R, int H, 
  * the two halves of that tensor's cotangent).  weight, bias f32[C]; save_mean, save_rstd f32[C] are written by the
  * forward and read by the backward.  running_mean / running_var f32[C] (both or neither) are updated in place as
  * torch does: r = (1 - momentum) * r + momentum * (mean | unbiased var).  Backward overwrites gx, g_weight, g_bias;
- * with relu != 0 the mask is recomputed from x.  Shapes: ct_bn_relu_supported(B, C, N) != 0 (N % 4 == 0,
- * 2 <= B*N <= 32768: a channel is held in registers); anything else is CT_EINVAL and stays on the library pair.
+ * with relu != 0 the mask is recomputed from x.  Shapes: 2 <= B*N < 2^31 (ct_bn_relu_supported(B, C, N) != 0); a channel
+ * with N % 4 == 0 and B*N <= 32768 is held in registers between the statistics and the normalisation (one read, one
+ * write), longer channels and rows that are not float4-addressable are re-read per pass.
  * ---------------------------------------------------------------------- */
 int ct_bn_relu_supported(int B, int C, int N);
 int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,

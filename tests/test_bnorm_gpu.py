@@ -20,7 +20,8 @@ def _ref(x, w, b, rm, rv, eps, momentum, relu, gy):
 
 
 @pytest.mark.parametrize("B,C,N,relu", [(8, 64, 4096, True), (8, 48, 2048, True), (2, 5, 256, False), (3, 7, 1000, True),
-                                        (1, 3, 4, True), (8, 16, 4096, False)])
+                                        (1, 3, 4, True), (8, 16, 4096, False), (16, 24, 4096, True), (3, 9, 1001, True),
+                                        (2, 4, 40000, False)])
 def test_bn_relu_matches_torch(B, C, N, relu):
     from cloud_transformers_amd import ops
     torch.manual_seed(B * 100 + C)
@@ -51,8 +52,8 @@ def test_bn_relu_matches_torch(B, C, N, relu):
 
 
 def test_run_after_dispatch():
-    """The blocks' `after` stacks: BatchNorm1d + ReLU in training mode on a supported shape runs fused; eval mode,
-    SyncBatchNorm, odd N and too large channels go through the modules' own forward — with the same result."""
+    """The blocks' `after` stacks: BatchNorm1d + ReLU in training mode runs fused (register-resident, long-channel and
+    scalar-row kernels); eval mode and SyncBatchNorm go through the modules' own forward — with the same result."""
     from cloud_transformers_amd import ops
     from cloud_transformers_amd.layers.multihead_ct import run_after
     torch.manual_seed(0)
@@ -72,28 +73,32 @@ def test_run_after_dispatch():
         seq.eval(), ref.eval()
         assert torch.allclose(run_after(seq, x.clone()), ref(x), rtol=1e-5, atol=1e-6) and not calls
         seq.train(), ref.train()
-        assert torch.allclose(run_after(seq, x[:, :, :511].contiguous()), ref(x[:, :, :511].contiguous()), rtol=1e-4, atol=1e-5) and not calls
-        big = torch.randn(16, 32, 4096, device="cuda")              # B*N > 32768: a channel no longer fits the registers
-        assert torch.allclose(run_after(seq, big.clone()), ref(big), rtol=1e-4, atol=1e-5) and not calls
+        odd = x[:, :, :511].contiguous()                             # rows that are not float4-addressable: scalar loop kernels
+        assert torch.allclose(run_after(seq, odd.clone()), ref(odd), rtol=1e-4, atol=1e-5) and calls == [1]
+        del calls[:]
+        big = torch.randn(16, 32, 4096, device="cuda")              # B*N > 32768: the channel is re-read per pass
+        assert torch.allclose(run_after(seq, big.clone()), ref(big), rtol=1e-4, atol=1e-5) and calls == [1]
+        assert torch.allclose(seq[0].running_var, ref[0].running_var, rtol=1e-5, atol=1e-6)
+        del calls[:]
         sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU())).cuda()
         assert not ops.bn_relu_eligible(sync[0], x)
     finally:
         ops.bn_relu = real
 
 
-def test_abi_rejects_unsupported_shapes():
+def test_abi_argument_checks():
     from cloud_transformers_amd import _lib
     lib = _lib.load()
     assert lib.ct_bn_relu_supported(8, 512, 4096) == 1
-    assert lib.ct_bn_relu_supported(16, 512, 4096) == 0
-    assert lib.ct_bn_relu_supported(8, 512, 4095) == 0
-    assert lib.ct_bn_relu_supported(1, 4, 1) == 0
+    assert lib.ct_bn_relu_supported(16, 512, 4096) == 1          # long channels: loop kernels
+    assert lib.ct_bn_relu_supported(8, 512, 4095) == 1           # rows that are not float4-addressable: scalar loops
+    assert lib.ct_bn_relu_supported(1, 4, 1) == 0                # one value per channel has no variance
     buf = torch.zeros(1 << 16, device="cuda")
     p = buf.data_ptr()
-    assert lib.ct_bn_relu_fwd(p, 0, p, p, None, None, None, None, 0, p, 0, p, p, 16, 8, 4096, 1e-5, 0.1, 1, None) == -1     # CT_EINVAL
     assert lib.ct_bn_relu_fwd(p, 0, p, p, p, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1           # one running buffer only
     assert lib.ct_bn_relu_fwd(p, 8 * 64 - 4, p, p, None, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # batch stride < C*N
-    assert lib.ct_bn_relu_fwd(p, 8 * 64 + 2, p, p, None, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1  # not a multiple of 4
+    assert lib.ct_bn_relu_fwd(p, 0, p, p, None, None, None, None, 0, p, 0, p, p, 1, 8, 1, 1e-5, 0.1, 1, None) == -1         # B*N < 2
+    assert lib.ct_bn_relu_fwd(None, 0, p, p, None, None, None, None, 0, p, 0, p, p, 2, 8, 64, 1e-5, 0.1, 1, None) == -1
 
 
 def test_split_bn_equals_the_two_modules_on_split_views():
