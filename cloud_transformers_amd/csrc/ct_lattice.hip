@@ -88,51 +88,58 @@ __global__ void __launch_bounds__(256) lattice_stats_kernel(const float* stat_pa
 // lattice_bwd_finish_kernel then sums it over the heads into g_xyz and scales g_res by kscale in place (g_xyz used
 // to be accumulated with B*3*N*H device-scope float atomics, most of this pass's time).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
 // reduced per workgroup and added with one atomic each.
+// kBwdPts points per thread: the 16 parameter partials are accumulated in registers over them before the wave
+// reduction (96 shuffles per thread were most of this kernel with one point per thread)
+constexpr int kBwdPts = 4;
+
 __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const float* lattice, const float* g_lattice,
                                                           const float* g_keys, float* g_xyz, float* g_res, float* g_R, float* g_shift,
                                                           float* g_scales, float* g_kscale, float* parts) {
   __shared__ float red[4][16];
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
-  const bool ok = n < a.N;
   const float ks = a.kscale ? a.kscale[0] : 1.0f;
   const float* R = a.R + h * 9;
-  float p[3] = {0, 0, 0}, r[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, gsc[3] = {0, 0, 0};
-  if (ok) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      r[c] = a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n];
-      p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * r[c] + a.shift[h * 3 + c];
-    }
-    for (int j = 0; j < a.dim; ++j) {
-      const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
-      const float t = lattice[o];
-      float gk = g_lattice ? g_lattice[o] * (1.0f - t * t) : 0.0f;     // d tanh
-      if (g_keys) gk += g_keys[o];                                    // direct cotangent of the pre-tanh keys
-      const float rot = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
-      const float sc = a.scales ? a.scales[h * a.dim + j] : 1.0f;
-      gsc[j] = gk * rot;                                              // d / d scales_j
-      gq[j] = gk * sc;                                                // cotangent of the rotated coordinate
-    }
-  }
-  float gp[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) gp[c] = R[c * 3 + 0] * gq[0] + R[c * 3 + 1] * gq[1] + R[c * 3 + 2] * gq[2];
-  if (ok) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = gp[c];   // unscaled: lattice_bwd_finish_kernel
-  }
   // 16 per-head parameter partials: g_R[c][j] = p_c * gq_j (9), g_shift[c] = gp_c (3), g_scales[j] (3), g_kscale (1)
   float part[16];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int i = 0; i < 16; ++i) part[i] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) part[c * 3 + j] = p[c] * gq[j];
+  for (int k = 0; k < kBwdPts; ++k) {
+    const int n = (blockIdx.x * kBwdPts + k) * blockDim.x + threadIdx.x;
+    if (n < a.N) {
+      float p[3], r[3], gq[3] = {0, 0, 0}, gsc[3] = {0, 0, 0};
 #pragma unroll
-  for (int c = 0; c < 3; ++c) part[9 + c] = gp[c];
+      for (int c = 0; c < 3; ++c) {
+        r[c] = a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n];
+        p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * r[c] + a.shift[h * 3 + c];
+      }
+      for (int j = 0; j < a.dim; ++j) {
+        const size_t o = ((size_t)(b * a.H + h) * a.dim + j) * a.N + n;
+        const float t = lattice[o];
+        float gk = g_lattice ? g_lattice[o] * (1.0f - t * t) : 0.0f;     // d tanh
+        if (g_keys) gk += g_keys[o];                                    // direct cotangent of the pre-tanh keys
+        const float rot = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
+        const float sc = a.scales ? a.scales[h * a.dim + j] : 1.0f;
+        gsc[j] = gk * rot;                                              // d / d scales_j
+        gq[j] = gk * sc;                                                // cotangent of the rotated coordinate
+      }
+      float gp[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) part[12 + j] = gsc[j];
-  part[15] = gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2];
+      for (int c = 0; c < 3; ++c) {
+        gp[c] = R[c * 3 + 0] * gq[0] + R[c * 3 + 1] * gq[1] + R[c * 3 + 2] * gq[2];
+        g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = gp[c];      // unscaled: lattice_bwd_finish_kernel
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) part[c * 3 + j] += p[c] * gq[j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) part[9 + c] += gp[c];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part[12 + j] += gsc[j];
+      part[15] += gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     float v = part[i];
@@ -299,7 +306,7 @@ int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, cons
 
 size_t ct_lattice_bwd_workspace_bytes(int B, int H, int N) {
   if (B <= 0 || H <= 0 || N <= 0) return 0;
-  return (size_t)B * ((N + 255) / 256) * H * 16 * sizeof(float);
+  return (size_t)B * ((N + 256 * kBwdPts - 1) / (256 * kBwdPts)) * H * 16 * sizeof(float);
 }
 
 int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
@@ -312,7 +319,7 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   hipStream_t st = (hipStream_t)s;
   if (workspace && workspace_bytes < ct_lattice_bwd_workspace_bytes(B, H, N)) return CT_EWORKSPACE;
   float* parts = (float*)workspace;
-  const int nbx = (N + 255) / 256;
+  const int nbx = (N + 256 * kBwdPts - 1) / (256 * kBwdPts);
   CT_CLEAR_ERROR();
   if (!parts) hipLaunchKernelGGL(lattice_zero_kernel, dim3((H * 9 + 255) / 256), dim3(256), 0, st, g_R, g_shift, g_scales, g_kscale, H, dim);
   hipLaunchKernelGGL(lattice_bwd_kernel, dim3(nbx, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
