@@ -20,8 +20,11 @@ def so3_exponential_map(log_rot, eps=1e-4):
     theta = sqrt(clamp(|v|^2, eps)),  R = I + (sin theta / theta) K + ((1 - cos theta) / theta^2) K^2,
     K = hat(v).  log_rot [H,3] -> [H,3,3]."""
     assert log_rot.dim() == 2 and log_rot.size(1) == 3
-    if log_rot.is_cuda and log_rot.dtype == torch.float32:
-        return ops.so3_exp(log_rot, eps)                  # one HIP launch each way instead of ~40 tiny ones
+    if log_rot.dtype == torch.float32:
+        return ops.so3_exp(log_rot, eps)                  # one HIP launch each way instead of ~40 tiny ones; raises off the GPU
+    if not log_rot.is_cuda:
+        raise RuntimeError("cloud_transformers_amd has no CPU fallback: so3_exponential_map needs a HIP tensor")
+    # other floating types on the GPU (float64 checks): the same formula in torch ops
     sq = (log_rot * log_rot).sum(dim=1)
     theta = sq.clamp(min=eps).sqrt()
     a = theta.sin() / theta
@@ -85,9 +88,11 @@ class AdaIn1dUpd(nn.Module):
         """`relu=True` folds the ReLU that follows this layer in the blocks' `after` stacks into the same
         kernel (forward_style passes it and skips the nn.ReLU); `residual` is added to the result in the same pass."""
         gamma_beta = self.linear(z).reshape(-1, 2, self.num_features)
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:
-            return ops.adain(x, gamma_beta, self.instance_norm.eps, relu, residual)    # one HIP launch (ct_adain_fwd)
-        # module built / probed off the accelerator (state-dict tooling): torch's own composition
+        if x.dtype == torch.float32 and x.dim() == 3:
+            return ops.adain(x, gamma_beta, self.instance_norm.eps, relu, residual)    # one HIP launch (ct_adain_fwd); raises off the GPU
+        if not x.is_cuda:
+            raise RuntimeError("cloud_transformers_amd has no CPU fallback: AdaIn1dUpd needs a HIP tensor")
+        # other layouts / floating types on the GPU: torch's own composition
         y = self.instance_norm(x) * (gamma_beta[:, 0, :, None] + 1) + gamma_beta[:, 1, :, None]
         y = torch.relu(y) if relu else y
         return y if residual is None else y + residual

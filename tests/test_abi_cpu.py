@@ -63,6 +63,17 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ct_splat_bwd_workspace_bytes(2, 4, 8, 100, 3, big, 0) == 2 * 4 * 8 * 64 ** 3 * 4
 
 
+def test_norm_and_rotation_layers_refuse_cpu_tensors():
+    """No CPU composition behind the layers either: AdaIn1dUpd and the so3 exponential map raise off the GPU."""
+    from cloud_transformers_amd.layers.utils import AdaIn1dUpd, so3_exponential_map
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AdaIn1dUpd(4, 8)(torch.zeros(2, 4, 16), torch.zeros(2, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        so3_exponential_map(torch.zeros(3, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        so3_exponential_map(torch.zeros(3, 3, dtype=torch.float64))
+
+
 def test_ops_refuse_cpu_tensors():
     from cloud_transformers_amd import ops
     from cloud_transformers_amd.chamfer import chamfer_with_indices

@@ -40,7 +40,7 @@ elif v == "gconv_only":
     x = torch.randn(2, 16, 16, 16, device="cuda", requires_grad=True); y = torch.zeros(1, device="cuda")
 elif v == "lattice_only":
     from cloud_transformers_amd.layers.utils import so3_exponential_map
-    R = so3_exponential_map(torch.randn(4, 3)).cuda(); sh = torch.zeros(4, 3, device="cuda")
+    R = so3_exponential_map(torch.randn(4, 3, device="cuda")); sh = torch.zeros(4, 3, device="cuda")
     m = Fn(lambda res, xyz: ops.lattice(xyz, res, R, sh, None, None, 2)[1]).cuda()
     x = torch.randn(2, 12, 256, device="cuda", requires_grad=True); y = torch.rand(2, 3, 256, device="cuda")
 gm = torch.cuda.make_graphed_callables(m, (x, y))
