@@ -105,7 +105,7 @@ def main():
     nparam = sum(p.numel() for p in net.parameters())
 
     def fwd_bwd():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)       # fresh gradients each step (the graph re-creates them in place): no zero fills, no accumulation adds
         loss = lossf(net(cloud), labels)
         loss.backward()
         return loss
