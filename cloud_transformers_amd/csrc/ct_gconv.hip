@@ -66,6 +66,7 @@ struct GconvArgs {
   int KB;              // ceil(Cin / 4)
   int gstride;         // ring kernel: LDS stride between g_y channels
   int TZ;              // ring kernel: depth slices per unit (3D)
+  int msplit;          // forward kernels: workgroups that share a tile, each taking every msplit-th 16-row block of output channels
 };
 
 // A-operand tile of one group and one 16-row block of output channels, laid out so that the 64
@@ -144,7 +145,7 @@ __device__ __forceinline__ void stage_halo_tile(float* xs, const float* xg, cons
 template <int DIM>
 __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
   extern __shared__ __align__(16) float lds[];
-  const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  const int tile = blockIdx.x / a.msplit, ms = blockIdx.x % a.msplit, grp = blockIdx.y, b = blockIdx.z;
   const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
   const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
   const int Dz = DIM == 3 ? a.TD + 2 : 1;
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd_kernel(GconvArgs a) {
   const int ngroups16 = (npos + 15) >> 4;
   const int MT = (a.Cout + 15) >> 4;
 
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = ms; mt < MT; mt += a.msplit) {
     __syncthreads();                                 // xs ready / previous ws consumed
     stage_weights(ws, a, grp, mt);
     __syncthreads();
@@ -238,7 +239,7 @@ template <int DIM>
 __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4_kernel(GconvArgs a) {
   constexpr int NR = DIM == 3 ? 9 : 3;               // window rows (dz, dy)
   extern __shared__ __align__(16) float lds[];
-  const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  const int tile = blockIdx.x / a.msplit, ms = blockIdx.x % a.msplit, grp = blockIdx.y, b = blockIdx.z;
   const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
   const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
   const int KB = a.KB;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4_kernel(GconvArgs a) {
   const int MT = (a.Cout + 15) >> 4;
   float* yg = a.y + ((size_t)b * a.groups + grp) * a.Cout * vol;
 
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = ms; mt < MT; mt += a.msplit) {
     __syncthreads();                                 // xs ready / previous bank consumed
     // filter bank of this 16-row block: ws[((r*KB + kb)*4 + k)*64 + m*4 + dx] = W[co = mt*16+m][ci = kb*4+k][tap = r*3+dx]
     for (int i = threadIdx.x; i < NR * KB * 256; i += blockDim.x) {
@@ -963,6 +964,7 @@ int gconv_common(GconvArgs& a, int B, int groups, int Cin, int Cout, int dim, co
   a.D = dim == 3 ? W[0] : 1; a.H = dim == 3 ? W[1] : W[0]; a.W = dim == 3 ? W[2] : W[1];
   a.taps = dim == 3 ? 27 : 9;
   a.KB = (Cin + 3) / 4;
+  a.msplit = 1;
   return CT_OK;
 }
 
@@ -972,6 +974,17 @@ int set_lds_attr(K kernel, size_t bytes) {
       hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
     return CT_ELAUNCH;
   return CT_OK;
+}
+
+// Few tiles x groups x batches (the 8^3 / 4^3 / 2^3 volumes of the Res3D stacks at batch 2: 32 workgroups for 256 CUs):
+// several workgroups share a tile and split its 16-row blocks of output channels between them (each stages the small
+// halo tile itself) until one workgroup per CU exists.
+int pick_msplit(const GconvArgs& a) {
+  const long long wgs = (long long)a.nD * a.nH * a.groups * a.B;
+  const int MT = (a.Cout + 15) / 16;
+  int m = 1;
+  while (m < MT && wgs * m < 256) ++m;
+  return m;
 }
 
 // four-channel groups with 16-byte rows: the vector-ALU kernel
@@ -1015,7 +1028,8 @@ int launch_fwd4(GconvArgs a, int dim, hipStream_t st) {
   if (!ok) return CT_EINVAL;
   a = best;
   const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes + 2 * kSlack * 4;
-  dim3 grid(a.nD * a.nH, a.groups, a.B);
+  a.msplit = pick_msplit(a);
+  dim3 grid(a.nD * a.nH * a.msplit, a.groups, a.B);
   const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
   CT_CLEAR_ERROR();
   if (dim == 2) {
@@ -1045,7 +1059,8 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
                            : plan_tiles(a, dim, 0, wbytes, a.KB * 4, 16);
   if (!ok) return CT_EINVAL;
   const size_t lds = (size_t)a.KB * 4 * a.plane * 4 + wbytes + 2 * kSlack * 4;
-  dim3 grid(a.nD * a.nH, a.groups, a.B);
+  a.msplit = pick_msplit(a);
+  dim3 grid(a.nD * a.nH * a.msplit, a.groups, a.B);
   const int threads = lds > 48 * 1024 ? kThreadsBig : kThreads;
   CT_CLEAR_ERROR();
   if (dim == 2) {

@@ -23,6 +23,8 @@ CASES = [
     (1, 2, 64, 64, 3, (4, 4, 4), False),      # ... after Pool3DBlock(2): 64 channels per group, filter bank > LDS in the quad form
     (1, 2, 64, 64, 3, (2, 2, 2), False),
     (1, 2, 64, 64, 2, (4, 4), False),         # classifier Res2DBlock(1024, 1024, groups=16) on 4^2
+    (1, 3, 16, 48, 2, (8, 8), True),          # few workgroups: the 3 output-channel blocks of a tile go to different workgroups
+    (2, 16, 64, 64, 3, (8, 8, 8), False),     # inpainter Res3DBlock(1024, 1024, groups=16) at batch 2
 ]
 
 
