@@ -757,7 +757,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
                     saved += [w, b, mean, rstd]
                     meta.append((c0, C))
                     c0 += C
-                assert c0 == sum(hh[0].size(0) for hh in heads[:len(meta) // 2]), "key_bn + values_bn must cover the projection"
+        assert c0 == Ct, "key_bn + values_bn must cover the projections"
         ctx.save_for_backward(x, y, Wc, *saved)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
