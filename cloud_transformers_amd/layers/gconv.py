@@ -66,6 +66,13 @@ def _eligible(mod, x):
             and tuple(mod.padding) == (1,) * nd and tuple(mod.dilation) == (1,) * nd
             and mod.padding_mode == "zeros"):
         return False
+    # More than 32 channels per group (the grouped Res2D / Res3D stacks on the pooled 8^3 .. 2^3 volumes and 16^2 .. 4^2
+    # planes of the classifier / inpainter encoders): these kernels keep a group's filter bank and input tile in LDS and
+    # were built for the MultiHead convolutions (<= 32 channels per group on large grids); with 64 channels per group the
+    # bank alone is 110-147 KiB and is re-staged per tile, and the library convolution is 2-4x faster (B8 3D 1024->1024,
+    # groups 16, 8^3: 5.0 ms vs 1.5 ms fwd+bwd; 512->1024: 1.5 vs 0.9 ms; 2^3: 1.1 vs 0.28 ms) — it takes those layers.
+    if max(mod.in_channels, mod.out_channels) // mod.groups > 32:
+        return False
     # shapes whose tiles do not fit LDS (very wide rows with many channels per group) take the library convolution
     W = tuple(x.shape[2:])
     key = (x.shape[0], mod.groups, mod.in_channels // mod.groups, mod.out_channels // mod.groups, W)

@@ -47,7 +47,8 @@ def test_gconv_fwd_bwd(cfg):
 
     m = m.cuda()
     xc = x.cuda().requires_grad_(True)
-    y = m(xc)
+    from cloud_transformers_amd.layers.gconv import GroupedConvFn
+    y = GroupedConvFn.apply(xc, m.weight, m.bias, G)          # the kernels themselves (the module routes wide groups to the library)
     (y * cot.cuda()).sum().backward()
 
     def close(a, b, name, tol=2e-5):
@@ -60,6 +61,28 @@ def test_gconv_fwd_bwd(cfg):
     close(m.weight.grad, wr.grad, "g_w", 5e-5)
     if bias:
         close(m.bias.grad, br.grad, "g_bias", 5e-5)
+
+
+def test_wide_groups_take_the_library_convolution():
+    """More than 32 channels per group (the Res2D / Res3D stacks of the classifier and the inpainter on 8^3 .. 2^3
+    volumes): the library convolution is 2-4x faster there than these kernels (built for the MultiHead convs: <= 32
+    channels per group on large grids), so the modules route such layers to it — same results."""
+    from cloud_transformers_amd.layers import gconv as G
+    calls = []
+    real = G.GroupedConvFn.apply
+    G.GroupedConvFn.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+    try:
+        narrow = G.GroupedConv3d(64, 64, 3, padding=1, groups=2, bias=False).cuda()       # 32 per group
+        wide = G.GroupedConv3d(128, 128, 3, padding=1, groups=2, bias=False).cuda()       # 64 per group
+        mixed = G.GroupedConv2d(64, 128, 3, padding=1, groups=2, bias=False).cuda()       # 32 -> 64
+        narrow(torch.randn(1, 64, 4, 4, 4, device="cuda"))
+        assert calls == [1]
+        xw = torch.randn(1, 128, 4, 4, 4, device="cuda")
+        assert torch.allclose(wide(xw), torch.nn.functional.conv3d(xw, wide.weight, None, padding=1, groups=2), atol=1e-5)
+        mixed(torch.randn(1, 64, 8, 8, device="cuda"))
+        assert calls == [1]
+    finally:
+        G.GroupedConvFn.apply = real
 
 
 def test_ineligible_configs_use_parent_class():
@@ -112,7 +135,8 @@ def test_gconv_fuzz(seed):
     yr = fn(xr, wr, br, stride=1, padding=1, groups=G)
     m = m.cuda()
     xc = x.cuda().requires_grad_(True)
-    y = m(xc)
+    from cloud_transformers_amd.layers.gconv import GroupedConvFn
+    y = GroupedConvFn.apply(xc, m.weight, m.bias, G)          # the kernels themselves (the module routes wide groups to the library)
     (y * cot.cuda()).sum().backward()
 
     def close(a, b, name, tol):
