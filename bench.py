@@ -2,33 +2,41 @@
 """Headline benchmark: points/sec of the MHCT hot path (positions -> Splat ->
 Slice, forward + backward) on synthetic 4096-point clouds.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--mode op|ddp-step]
 
-A "step" is one fwd+bwd pass of the hot path over one batch of synthetic input
-(BASELINE.json north-star op-level shape: B=8, N=4096, H=64 heads, 32x32 grid,
-C=16 features/head), inputs resident in HBM.  The step is captured into a HIP
-graph so that the timed region is device time, not Python launch time.  One
-process per GPU; ranks shard independent clouds (no data-path collective), so
-scaling is weak: value = n_gpus * B * N / max-over-ranks step time.
+mode op (default).  A "step" is one fwd+bwd pass of the hot path over one batch of synthetic input
+(BASELINE.json north-star op-level shape: B=8, N=4096, H=64 heads, 32x32 grid, C=16 features/head), inputs
+resident in HBM, the two key cotangents (Slice's and Splat's) summed inside the step as autograd does.  The step
+is captured into a HIP graph so that the timed region is device time, not Python launch time.  One process per
+GPU; ranks shard independent clouds (no data-path collective), so scaling is weak:
+value = n_gpus * B * N / max-over-ranks step time.
+
+mode ddp-step.  The S3DIS-shaped training step (BASELINE configs[2]: stem + 12 MultiHeadUnion blocks + head,
+B=8 clouds x 4096 points per GPU, cross-entropy, SGD) under DistributedDataParallel + SyncBatchNorm on RCCL
+(train_segmentation.py:58-61,128-130): value = n_gpus * B * N / max-over-ranks step time.
+
+N > 1 without a launcher: this process starts N ranks of itself (cloud_transformers_amd/launch.py) before it
+touches the GPU and returns their exit code; under `torch.distributed.run` it is one rank.
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline     — the dominant kernel's algorithmic bytes / its HIP-event time vs 8 TB/s
-  cpu_baseline — the CPU oracle (a port of the reference's PyTorch CPU path)
-                 timed on this host on a bounded sample of the same workload
+  cpu_baseline — the CPU oracle (a port of the reference's PyTorch CPU path) timed on this host on a bounded
+                 sample of the same workload: all physical cores, and one thread (the reference's own setting,
+                 train_segmentation.py:25)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+METRIC = "points/sec fwd+bwd MHCT, 4096-pt batch, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 
 
 def parse():
@@ -36,6 +44,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--mode", default="op", choices=["op", "ddp-step"])
     p.add_argument("--batch", type=int, default=8)
     p.add_argument("--points", type=int, default=4096)
     p.add_argument("--heads", type=int, default=64)
@@ -47,13 +56,14 @@ def parse():
     p.add_argument("--graph-steps", type=int, default=10,
                    help="steps captured per HIP graph (the K timed steps are replays of it plus single-step replays for the rest)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    p.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg")
     return p.parse_args()
 
 
 def time_passes(step, iters=30):
     """Average device time (ms) of each of the four ABI passes, measured with HIP
     events on the stream the kernels are launched on (torch's current stream)."""
+    import torch
     res = {}
     for name in step.PASSES:
         fn = getattr(step, name)
@@ -71,11 +81,11 @@ def time_passes(step, iters=30):
     return res
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate
-    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, with the gfx950
-    correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide read)."""
+def measured_traffic(tag):
+    """HBM bytes per launch of the kernel behind `tag` from the COMMITTED rocprofv3 PMC passes
+    (profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this same command, with the gfx950 correction of MI355X_MICROARCH.md:
+    FETCH_SIZE counts half of a wide read).  Not measured in this run."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
@@ -83,38 +93,77 @@ def measured_traffic(kernel):
     except (OSError, ValueError):
         return None
     for name, rec in table.get("kernels", {}).items():
-        if kernel in name:
+        if tag in name:
             return rec.get("hbm_bytes_per_launch")
     return None
 
 
-def cpu_baseline(args):
-    """The oracle (a pure-PyTorch port of the reference op sequence, materialised
-    intermediates included) on a bounded sample: the same workload at batch 1."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:      # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
+
+
+def _time_oracle(args, batch, threads, budget, min_reps=3):
+    """median seconds per fwd+bwd of the oracle at `batch` clouds with `threads` torch threads"""
+    import torch
     from oracle import ref_cpu as R
-    threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1234)
-    Bs = 1
-    keys = torch.tanh(torch.randn(Bs, args.heads * args.dim, args.points, generator=g))
-    feat = torch.randn(Bs, args.heads * args.feat, args.points, generator=g)
-    cot = torch.randn(Bs, args.heads * args.feat, args.points, generator=g)
-    best = None
+    keys = torch.tanh(torch.randn(batch, args.heads * args.dim, args.points, generator=g))
+    feat = torch.randn(batch, args.heads * args.feat, args.points, generator=g)
+    cot = torch.randn(batch, args.heads * args.feat, args.points, generator=g)
+    times = []
     t_start = time.perf_counter()
-    reps = 0
-    while reps < 5 and (time.perf_counter() - t_start) < args.cpu_seconds:
+    R.splat_slice_step(keys, feat, cot, args.grid, args.heads, args.dim, args.reduce)      # warm-up (allocator, threads)
+    warm = time.perf_counter() - t_start
+    while len(times) < min_reps or (len(times) < 5 and time.perf_counter() - t_start + warm < budget):
         t0 = time.perf_counter()
         R.splat_slice_step(keys, feat, cot, args.grid, args.heads, args.dim, args.reduce)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
-    return {"value": Bs * args.points / best, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": "oracle/ref_cpu.splat_slice_step fwd+bwd, batch %d of the same workload "
-                      "(N=%d, H=%d, C=%d, %dD W=%d, reduce=%s), best of %d, torch threads=%d"
-                      % (Bs, args.points, args.heads, args.feat, args.dim, args.grid, args.reduce, reps, threads)}
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget and len(times) >= min_reps:
+            break
+    return statistics.median(times), len(times)
 
 
-def main():
-    args = parse()
+def cpu_baseline(args):
+    """The oracle (a pure-PyTorch port of the reference op sequence, materialised intermediates included) on a
+    bounded sample of the same workload: all physical cores at the full batch, and ONE thread — the setting every
+    reference script uses (torch.set_num_threads(1), train_segmentation.py:25) — at batch 1 of it."""
+    import torch
+    before = torch.get_num_threads()
+    cores = physical_cores()
+    shape = "N=%d, H=%d, C=%d, %dD W=%d, reduce=%s" % (args.points, args.heads, args.feat, args.dim, args.grid, args.reduce)
+    t1, r1 = _time_oracle(args, 1, 1, args.cpu_seconds * 0.5)
+    tn, rn = _time_oracle(args, args.batch, cores, args.cpu_seconds * 0.5)
+    torch.set_num_threads(before)
+    return {"value": args.batch * args.points / tn, "unit": "points/s", "cores": cores, "kind": "port",
+            "batch": args.batch, "cpu_model": cpu_model(),
+            "sample": "oracle/ref_cpu.splat_slice_step fwd+bwd, the whole workload (batch %d; %s), median of %d after a warm-up, "
+                      "torch threads = %d physical cores" % (args.batch, shape, rn, cores),
+            "single_thread": {"value": args.points / t1, "unit": "points/s", "cores": 1, "batch": 1,
+                              "sample": "same, batch 1 of the workload, torch.set_num_threads(1) as the reference's scripts, "
+                                        "median of %d after a warm-up" % r1}}
+
+
+def init_rank():
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +176,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    return rank, local_rank, world, dist
 
+
+def run_op(args):
+    import torch
+    rank, local_rank, world, dist = init_rank()
     from cloud_transformers_amd.step import SplatSliceStep
     from cloud_transformers_amd.parallel import barrier, max_over_ranks
 
@@ -185,16 +239,18 @@ def main():
     if rank == 0:
         alg = step.algorithmic_bytes()
         passes = time_passes(step)
-        # dominant KERNEL: the longest pass that is a single launch (slice_bwd is two shorter kernels;
-        # profiles/*_kernel_stats.csv lists every kernel's average for cross-checking)
-        dom = max(step.SINGLE_KERNEL, key=lambda k: passes[k])
-        dom_bytes = alg.get(dom + "_launch", alg[dom])
+        tags = step.launch_tags()
+        # dominant KERNEL: the longest pass that is a single launch (profiles/*_kernel_stats.csv lists every kernel's
+        # average for cross-checking)
+        single = [p for p in step.PASSES if "+" not in tags[p]] or list(step.PASSES)
+        dom = max(single, key=lambda k: passes[k])
+        dom_bytes = alg[dom]
         achieved = dom_bytes / (passes[dom] * 1e-3) / 1e9
         # the committed PMC passes were collected on the default workload only
         default_shape = (B, N, H, C, W, dim, args.reduce) == (8, 4096, 64, 16, 32, 2, "max")
-        traffic = measured_traffic(step.KERNELS.get(dom, dom)) if default_shape else None
+        traffic = measured_traffic(step.KERNEL_OF.get(tags[dom], tags[dom])) if default_shape else None
         out = {
-            "metric": "points/sec fwd+bwd MHCT, 4096-pt batch, 1/2/4/8 MI355X; % HBM roofline",   # BASELINE.json
+            "metric": METRIC,
             "value": world * B * N / (dt / args.steps),
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,15 +261,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "north-star op-level: B=%d clouds x N=%d pts, H=%d heads, C=%d feat/head, "
-                                   "%dD grid W=%d, reduce=%s, keys=tanh(randn), seed 1234+rank"
+                                   "%dD grid W=%d, reduce=%s, keys=tanh(randn), seed 1234+rank; step = Splat fwd, Slice fwd, "
+                                   "Slice bwd, Splat bwd (key cotangents summed)"
                                    % (B, N, H, C, dim, W, args.reduce),
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
+                       "world_size_seen": world,
                        "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1},
-            "roofline": {"bound": "hbm", "kernel": step.KERNELS.get(dom, dom) if args.reduce == "max" else dom,
+            "roofline": {"bound": "hbm", "kernel": step.KERNEL_OF.get(tags[dom], tags[dom]),
                          "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "committed PMC pass (profiles/traffic_latest.json), not measured in this run"
+                                           if traffic is not None else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": passes[dom]},
             "passes_ms": passes,
+            "kernels": {p: step.KERNEL_OF.get(t, t) for p, t in tags.items()},
             "step_roofline": {"algorithmic_bytes_per_step": alg["total"],
                               "achieved_GBs": alg["total"] / (ms * 1e-3) / 1e9,
                               "frac_of_8TBs": alg["total"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -224,6 +285,90 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_ddp_step(args):
+    """S3DIS-shaped segmenter training step under DDP + SyncBatchNorm (also at world size 1: the wrap is the same)."""
+    import torch
+    from torch import nn
+    rank, local_rank, world, dist = init_rank()
+    import torch.distributed as tdist
+    if dist is None:            # DDP needs a process group even for one rank
+        from cloud_transformers_amd.launch import free_port
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist = tdist
+    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from segmenter_step_bench import Segmenter
+
+    B, N = args.batch, args.points
+    torch.manual_seed(0)                               # same initial weights on every rank
+    net = Segmenter().cuda()
+    ddp = data_parallel(net, local_rank)
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
+    torch.manual_seed(1234 + rank)                     # its own shard of the batch
+    cloud = torch.cat([torch.rand(B, 3, N, device="cuda") * 2 - 1, torch.rand(B, 3, N, device="cuda")], dim=1)
+    labels = torch.randint(13, (B, N), device="cuda")
+    lossf = nn.CrossEntropyLoss()
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        loss = lossf(ddp(cloud), labels)
+        loss.backward()                                # bucketed gradient all-reduce overlaps with this
+        opt.step()
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        one()
+    barrier(dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one()
+    torch.cuda.synchronize()
+    barrier(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
+    if rank == 0:
+        nbytes = sum(p.numel() for p in net.parameters()) * 4
+        from cloud_transformers_amd import ops
+        out = {
+            "metric": METRIC, "value": world * B * N / (dt / args.steps), "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S3DIS-shaped segmenter training step (stem + 12 MultiHeadUnion + head, %.1f M parameters), "
+                                   "B=%d clouds x N=%d pts per GPU, cross-entropy + SGD, DistributedDataParallel + SyncBatchNorm on RCCL"
+                                   % (nbytes / 4e6, B, N),
+                       "per_gpu_batch": B, "parallelism": "dp%d" % world, "world_size_seen": world,
+                       "gradient_allreduce_MB_per_step": nbytes / 1e6,
+                       "sync_bn_collectives_per_step": getattr(ops, "sync_stats_collectives", lambda: None)(),
+                       "loss": float(loss)},
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    from cloud_transformers_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # parent: start one rank per GPU before anything here touches the GPU, return their exit code
+        import torch
+        have = torch.cuda.device_count()               # (does not initialise HIP)
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+        raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if launch.under_launcher() and world != args.gpus:
+        print("bench: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d" % (args.gpus, world, world),
+              file=sys.stderr)
+    if args.mode == "ddp-step":
+        if args.steps == 200 and args.warmup == 20:      # defaults are the op benchmark's: a training step is ~100x longer
+            args.steps, args.warmup = 20, 3
+        return run_ddp_step(args)
+    return run_op(args)
 
 
 if __name__ == "__main__":

@@ -29,6 +29,9 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
 CT_OK = 0
 REDUCE = {"max": 0, "sum": 1}
 PAD_NONE, PAD_F32, PAD_I32 = 0, 1, 2
+BWD_ACCUMULATE_KEYS = 1
+DEBUG_NO_HOT = 1
+DEBUG_FORCE_HOT = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -76,6 +79,10 @@ SIGNATURES = {
     "ct_splat_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_splat_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip, _i]),
     "ct_splat_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _vp]),
+    "ct_splat_bwd_ex_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i]),
+    "ct_splat_bwd_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _i, _vp]),
+    "ct_debug_set_flags": (None, [ctypes.c_uint]),
+    "ct_debug_last_launch": (ctypes.c_char_p, []),
     "ct_slice_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),

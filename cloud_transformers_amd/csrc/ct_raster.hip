@@ -14,6 +14,7 @@
 // Math spec: SURVEY.md Appendix A (derived from layers/cloud_transform.py:72-227
 // and layers/utils.py:100-186 of the reference).
 #include "ct_common.h"
+#include <string.h>
 
 #ifndef CT_QUAD_THREADS
 #define CT_QUAD_THREADS 512
@@ -55,6 +56,7 @@ struct RasterArgs {
   int atomic_gpos;      // accumulate g_pos with global atomics (ncg > 1)
   int cnt_mask;         // STATS: contributions are counted in cnt_mask+1 (a power of two) counters indexed by cell & cnt_mask
   size_t gpos_stride;   // > 0: channel-chunk group cg writes its partial g_pos to g_pos + cg*gpos_stride floats (summed afterwards)
+  int accumulate;       // hot Splat(max) backward: g_pos += result instead of g_pos = result
 };
 
 template <int DIM, bool FROM_KEYS>
@@ -231,6 +233,8 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[16];
   int* acc = (int*)lds;
+  float* s_q = lds + (size_t)a.CC * g.G;      // [CC] per-channel max, then quantum (< 0: float atomics)
+  float* s_iq = s_q + a.CC;                   // [CC] 1 / quantum
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
@@ -240,73 +244,68 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(
   const bool has_pad = a.pad_dtype != CT_PAD_NONE;
   lds_fill_zero(lds, cc * g.G);
   __syncthreads();
-  // phase 1: contributions per cell (counted in the first channel's tile) and max |src*pad|
-  float m = 0.0f;
-  bool finite = true;
+  // phase 1: contributions per cell (counted in the first channel's tile) ...
   for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
     Corners<DIM> c;
     PointPos<DIM, FROM_KEYS> pp;
     load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
 #pragma unroll
     for (int v = 0; v < V; ++v) atomicAdd(&acc[c.cell[v]], 1);
-    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
-    for (int ch = 0; ch < cc; ++ch) {
-      float f = src[(size_t)ch * a.N + n];
-      if (has_pad) f = f * p;
-      float af = fabsf(f);
-      finite = finite && (af < __builtin_inff());   // false for inf and NaN
-      m = fmaxf(m, af);
-    }
   }
   __syncthreads();
   float k = 0.0f;
   for (int i = threadIdx.x; i < g.G; i += blockDim.x) k = fmaxf(k, (float)acc[i]);
-  const float M = block_max(finite ? m : __builtin_inff(), red);
   const float K = block_max(k, red);
   for (int i = threadIdx.x; i < g.G; i += blockDim.x) acc[i] = 0;
-  __syncthreads();
-  const float MK = M * K;
-  if (MK < 1e37f) {
-    int ex = 0;
-    if (MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
-    ex = max(ex, -90);
-    const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
-    if (MK > 0.0f) {
-      for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
-        Corners<DIM> c;
-        PointPos<DIM, FROM_KEYS> pp;
-        load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
-        const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
-        for (int ch = 0; ch < cc; ++ch) {
-          float f = src[(size_t)ch * a.N + n];
-          if (has_pad) f = f * p;
-          int* Tc = acc + (size_t)ch * g.G;
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            float prod = f * c.w[v];
-            atomicAdd(&Tc[c.cell[v]], __float2int_rn(prod * inv_q));
-          }
-        }
-      }
-      __syncthreads();
-    }
-    for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = (float)acc[i] * q;
-  } else {
-    // non-finite or astronomically large slab: plain float atomics keep IEEE semantics
+  // ... and max |src*pad| PER CHANNEL: the quantum of a channel follows that channel's own magnitude (channels of one
+  // head may differ by orders of magnitude; a shared quantum would cost the quiet ones their precision)
+  for (int ch = 0; ch < cc; ++ch) {
+    float m = 0.0f;
     for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
-      Corners<DIM> c;
-      PointPos<DIM, FROM_KEYS> pp;
-      load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
-      const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
-      for (int ch = 0; ch < cc; ++ch) {
-        float f = src[(size_t)ch * a.N + n];
-        if (has_pad) f = f * p;
+      float f = src[(size_t)ch * a.N + n];
+      if (has_pad) f = f * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+      const float af = fabsf(f);
+      m = fmaxf(m, (af < __builtin_inff()) ? af : __builtin_inff());   // inf / NaN -> inf
+    }
+    const float M = block_max(m, red);
+    if (threadIdx.x == 0) s_q[ch] = M;
+  }
+  __syncthreads();
+  // s_q[ch] := quantum (negative: float atomics for that channel)
+  for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+    const float MK = s_q[ch] * K;
+    const bool fixed = MK < 1e37f;
+    int ex = 0;
+    if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
+    ex = max(ex, -90);
+    s_q[ch] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
+    s_iq[ch] = ldexpf(1.0f, 30 - ex);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+    Corners<DIM> c;
+    PointPos<DIM, FROM_KEYS> pp;
+    load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
+    const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
+    for (int ch = 0; ch < cc; ++ch) {
+      float f = src[(size_t)ch * a.N + n];
+      if (has_pad) f = f * p;
+      const float q = s_q[ch];
+      int* Tc = acc + (size_t)ch * g.G;
+      if (q >= 0.0f) {          // block-uniform
+        const float fq = f * s_iq[ch];        // a power of two: exact
 #pragma unroll
-        for (int v = 0; v < V; ++v) atomicAdd(&lds[(size_t)ch * g.G + c.cell[v]], f * c.w[v]);
+        for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn(fq * c.w[v]));
+      } else {                  // non-finite or astronomically large channel: plain float atomics keep IEEE semantics
+#pragma unroll
+        for (int v = 0; v < V; ++v) atomicAdd((float*)&Tc[c.cell[v]], f * c.w[v]);
       }
     }
-    __syncthreads();
-    copy_linear(gout, lds, cc * g.G);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) {
+    const float q = s_q[i / g.G];
+    gout[i] = q >= 0.0f ? (float)acc[i] * q : lds[i];
   }
 }
 
@@ -332,34 +331,19 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
   float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
   const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
   const bool has_pad = a.pad_dtype != CT_PAD_NONE;
-  // One quantum for the whole chunk: M = max over its channels' slots (an upper bound for each of them; the
-  // gather kernel publishes per-chunk maxima anyway).  A workgroup-uniform quantum lives in scalar registers,
-  // so the inner loop carries no LDS reads besides the atomics, and — a power of two — it is folded into the
-  // corner weights once per point: (f*w)*2^k == f*(w*2^k) exactly.
-  if (threadIdx.x < 64) {
-    float M = 0.0f, K = 0.0f;
-    for (int ch = threadIdx.x; ch < cc; ch += 64) {
-      const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
-      M = fmaxf(M, __uint_as_float(slot[0]));
-      K = fmaxf(K, (float)slot[1]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      M = fmaxf(M, __shfl_xor(M, o, 64));
-      K = fmaxf(K, __shfl_xor(K, o, 64));
-    }
-    if (threadIdx.x == 0) {
-      const float MK = M * K;
-      const bool fixed = MK < 1e37f;
-      int ex = 0;
-      if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
-      ex = max(ex, -90);
-      s_q[0] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
-      s_iq[0] = ldexpf(1.0f, 30 - ex);
-    }
+  // One quantum PER CHANNEL (its own max |src*pad| from its slot, K of the plane): channels of a head may differ by
+  // orders of magnitude, and a shared quantum would cost the quiet ones their precision.
+  for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+    const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
+    const float MK = __uint_as_float(slot[0]) * (float)slot[1];
+    const bool fixed = MK < 1e37f;
+    int ex = 0;
+    if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
+    ex = max(ex, -90);
+    s_q[ch] = fixed ? ldexpf(1.0f, ex - 30) : -1.0f;
+    s_iq[ch] = ldexpf(1.0f, 30 - ex);
   }
   __syncthreads();      // slots are read before the tile is touched
-  const float q = s_q[0], iq = s_iq[0];
-  const bool fixed = q >= 0.0f;
   for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
@@ -367,9 +351,6 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
     PointPos<DIM, FROM_KEYS> pp;
     load_point<DIM, FROM_KEYS>(a.pos, g, bh, a.N, n, c, pp);
     const float p = ct_load_pad(a.pad, a.pad_dtype, (size_t)b * a.N + n);
-    float wq[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) wq[v] = c.w[v] * iq;
     // channels in groups of 4: the group's loads are issued together, then its 16/32 atomics
     for (int c4 = 0; c4 < cc; c4 += 4) {
       float f[4];
@@ -381,9 +362,10 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
         if (ch < cc) {
           const float fu = has_pad ? f[u] * p : f[u];
           int* Tc = acc + (size_t)ch * g.G;
-          if (fixed) {            // block-uniform
+          if (s_q[ch] >= 0.0f) {            // block-uniform
+            const float fq = fu * s_iq[ch];  // a power of two: exact
 #pragma unroll
-            for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn(fu * wq[v]));
+            for (int v = 0; v < V; ++v) atomicAdd(&Tc[c.cell[v]], __float2int_rn(fq * c.w[v]));
           } else {
 #pragma unroll
             for (int v = 0; v < V; ++v) atomicAdd((float*)&Tc[c.cell[v]], fu * c.w[v]);
@@ -393,7 +375,10 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) gout[i] = fixed ? (float)acc[i] * q : lds[i];
+  for (int i = threadIdx.x; i < cc * g.G; i += blockDim.x) {
+    const float q = s_q[i / g.G];
+    gout[i] = q >= 0.0f ? (float)acc[i] * q : lds[i];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -409,7 +394,6 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
   constexpr int V = 1 << DIM;
   constexpr int CG = DIM == 2 ? 4 : 2;
   extern __shared__ __align__(16) float lds[];
-  __shared__ float s_qq[2];
   int* acc = (int*)lds;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const size_t bh = (size_t)b * a.H + h;
@@ -417,34 +401,21 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
   const int cc = min(a.CC, a.C - c0);
   float* gout = a.tile_out + (bh * a.C + c0) * (size_t)g.G;
   const float* src = a.src + (bh * a.C + c0) * (size_t)a.N;
-  float q = 1.0f, iq = 1.0f;
-  bool fixed = true;
+  float* s_q = lds + (size_t)a.CC * g.G;      // ADD: [CC] quantum per channel (< 0: float atomics), [CC] its inverse
+  float* s_iq = s_q + a.CC;
   if (ADD) {
-    if (threadIdx.x < 64) {
-      float M = 0.0f, K = 0.0f;
-      for (int ch = threadIdx.x; ch < cc; ch += 64) {
-        const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
-        M = fmaxf(M, __uint_as_float(slot[0]));
-        K = fmaxf(K, (float)slot[1]);
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        M = fmaxf(M, __shfl_xor(M, o, 64));
-        K = fmaxf(K, __shfl_xor(K, o, 64));
-      }
-      if (threadIdx.x == 0) {
-        const float MK = M * K;
-        const bool fx = MK < 1e37f;
-        int ex = 0;
-        if (fx && MK > 0.0f) (void)frexpf(MK, &ex);
-        ex = max(ex, -90);
-        s_qq[0] = fx ? ldexpf(1.0f, ex - 30) : -1.0f;
-        s_qq[1] = fx ? ldexpf(1.0f, 30 - ex) : 1.0f;      // float fallback: weights stay unscaled
-      }
+    // per channel: its own max |src*pad| (slot 0) and the plane's max contributions per cell (slot 1)
+    for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+      const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
+      const float MK = __uint_as_float(slot[0]) * (float)slot[1];
+      const bool fx = MK < 1e37f;
+      int ex = 0;
+      if (fx && MK > 0.0f) (void)frexpf(MK, &ex);
+      ex = max(ex, -90);
+      s_q[ch] = fx ? ldexpf(1.0f, ex - 30) : -1.0f;
+      s_iq[ch] = fx ? ldexpf(1.0f, 30 - ex) : 1.0f;      // float fallback: values stay unscaled
     }
     __syncthreads();
-    q = s_qq[0];
-    iq = s_qq[1];
-    fixed = q >= 0.0f;
   }
   for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
   __syncthreads();
@@ -479,7 +450,7 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
         ct_corners<DIM>(w0, w1, f, g, c);
         base[i] = c.cell[0];
 #pragma unroll
-        for (int v = 0; v < V; ++v) cw[i][v] = ADD ? c.w[v] * iq : c.w[v];   // power-of-two scale: exact
+        for (int v = 0; v < V; ++v) cw[i][v] = c.w[v];
       }
     }
     float pv[4];
@@ -497,9 +468,12 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
         const int ch = cg0 + cj;
         if (ch < cc) {
           int* Tc = acc + (size_t)ch * g.G;
+          const float iqc = ADD ? s_iq[ch] : 1.0f;
+          const bool fixed = !ADD || s_q[ch] >= 0.0f;     // block-uniform
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float f = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+            float f = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+            if (ADD) f = f * iqc;                          // power-of-two scale: exact
 #pragma unroll
             for (int v = 0; v < V; ++v) {
               const float prod = f * cw[i][v];
@@ -520,7 +494,8 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (cc * g.G) >> 2; i += blockDim.x) {
-    if (ADD && fixed) {
+    const float q = ADD ? s_q[(i << 2) / g.G] : -1.0f;     // G % 4 == 0: a float4 never straddles channels
+    if (ADD && q >= 0.0f) {
       const int4 t = ((const int4*)acc)[i];
       ((float4*)gout)[i] = make_float4((float)t.x * q, (float)t.y * q, (float)t.z * q, (float)t.w * q);
     } else {
@@ -552,7 +527,8 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
   constexpr int NG = CCR / CG;
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[16];
-  __shared__ float qs[CCR];     // quantum per channel; < 0 marks a float (non-finite) group
+  __shared__ float redg[16 * CG];   // per-wave maxima of the CG channels of a group
+  __shared__ float qs[CCR];     // quantum per channel; < 0 marks a float (non-finite) channel
   int* acc = (int*)lds;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const size_t bh = (size_t)b * a.H + h;
@@ -608,29 +584,42 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     if (gi * CG < cc) {     // block-uniform
-      float m = 0.0f;
-      bool finite = true;
+      // max |src*pad| PER CHANNEL of the group (inf / NaN -> inf): wave reduction, then across the waves through LDS
+      float m[CG];
 #pragma unroll
       for (int cj = 0; cj < CG; ++cj) {
+        m[cj] = 0.0f;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
           float x = sv[gi * CG + cj][i];
           if (has_pad) x = x * pv[i];
           sv[gi * CG + cj][i] = x;
-          float af = fabsf(x);
-          finite = finite && (af < __builtin_inff());
-          m = fmaxf(m, af);
+          const float af = fabsf(x);
+          m[cj] = fmaxf(m[cj], (af < __builtin_inff()) ? af : __builtin_inff());
         }
+        for (int off = 32; off > 0; off >>= 1) m[cj] = fmaxf(m[cj], __shfl_xor(m[cj], off, 64));
       }
-      const float M = block_max(finite ? m : __builtin_inff(), red);
-      const float MK = M * K;
-      const bool fixed = MK < 1e37f;
-      int ex = 0;
-      if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
-      ex = max(ex, -90);
-      const float q = ldexpf(1.0f, ex - 30), inv_q = ldexpf(1.0f, 30 - ex);
-      if (threadIdx.x < CG) qs[gi * CG + threadIdx.x] = fixed ? q : -1.0f;
-      if (active && MK > 0.0f) {
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int cj = 0; cj < CG; ++cj) redg[(threadIdx.x >> 6) * CG + cj] = m[cj];
+      }
+      __syncthreads();
+      float inv_q[CG];
+      bool fixed[CG];
+#pragma unroll
+      for (int cj = 0; cj < CG; ++cj) {
+        float M = redg[cj];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) M = fmaxf(M, redg[w * CG + cj]);
+        const float MK = M * K;
+        fixed[cj] = MK < 1e37f;
+        int ex = 0;
+        if (fixed[cj] && MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
+        ex = max(ex, -90);
+        inv_q[cj] = ldexpf(1.0f, 30 - ex);
+        if (threadIdx.x == 0) qs[gi * CG + cj] = fixed[cj] ? ldexpf(1.0f, ex - 30) : -1.0f;
+      }
+      if (active) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
           float w0[DIM], w1[DIM];
@@ -643,11 +632,13 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
           for (int cj = 0; cj < CG; ++cj) {
             const int ch = gi * CG + cj;
             if (ch < cc) {
+              if (fixed[cj]) {      // block-uniform
+                const float fq = sv[ch][i] * inv_q[cj];      // a power of two: exact
 #pragma unroll
-              for (int v = 0; v < V; ++v) {
-                float prod = sv[ch][i] * c.w[v];
-                if (fixed) atomicAdd(&acc[ch * g.G + c.cell[v]], __float2int_rn(prod * inv_q));
-                else atomicAdd(&lds[ch * g.G + c.cell[v]], prod);   // non-finite group: IEEE semantics
+                for (int v = 0; v < V; ++v) atomicAdd(&acc[ch * g.G + c.cell[v]], __float2int_rn(fq * c.w[v]));
+              } else {              // non-finite channel: IEEE semantics
+#pragma unroll
+                for (int v = 0; v < V; ++v) atomicAdd(&lds[ch * g.G + c.cell[v]], sv[ch][i] * c.w[v]);
               }
             }
           }
@@ -884,18 +875,19 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
     float* T2 = lds + (size_t)a.CC * g.G;             // g_z chunk (SPLAT_MAX_BWD only)
     // STATS (Slice backward): by-products for the fixed-point scatter that follows —
     // per-channel max |src*pad| and the max number of contributions per cell
-    unsigned* s_max = (unsigned*)(lds + (size_t)a.CC * g.G);         // [CC]
-    int* s_cnt = (int*)(lds + (size_t)a.CC * g.G + a.CC);            // [cnt_mask + 1]
+    // the maxima are kept per channel in 32 lane-indexed slots each (one conflict-free ds_max per thread,
+    // quad and channel) and folded at the end
+    unsigned* s_max = (unsigned*)(lds + (size_t)a.CC * g.G);         // [CC][32]
+    int* s_cnt = (int*)(lds + (size_t)a.CC * g.G + a.CC * 32);       // [cnt_mask + 1]
     __syncthreads();
     if (STATS) {
-      for (int i = threadIdx.x; i < a.CC + a.cnt_mask + 1; i += blockDim.x) s_max[i] = 0u;
+      for (int i = threadIdx.x; i < a.CC * 32 + a.cnt_mask + 1; i += blockDim.x) s_max[i] = 0u;
     }
     stage_tile(T, a.tile_in + toff, cc * g.G);
     if (MODE == QM_SPLAT_MAX_BWD) stage_tile(T2, a.tile_in2 + toff, cc * g.G);
     __syncthreads();
     const float* src = kSrc ? a.src + (bh * a.C + c0) * (size_t)a.N : nullptr;
     float* dst = kDst ? a.dst + (bh * a.C + c0) * (size_t)a.N : nullptr;
-    float stat_max = 0.0f;
     for (int q = q_beg + (int)threadIdx.x; q < q_end; q += blockDim.x) {
       const int n0 = q << 2;
       // corner weights and base cell of the 4 points (per-axis terms are recomputed
@@ -953,14 +945,17 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
           }
         }
         if (STATS) {
-          // one running max |src*pad| per thread for the whole chunk (inf/NaN -> inf)
+          // max |src*pad| per channel (inf/NaN -> inf)
 #pragma unroll
-          for (int cj = 0; cj < CG; ++cj)
+          for (int cj = 0; cj < CG; ++cj) {
+            float m = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float x = fabsf(has_pad ? fv[cj][i] * pv[i] : fv[cj][i]);
-              stat_max = fmaxf(stat_max, (x < __builtin_inff()) ? x : __builtin_inff());
+              m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());
             }
+            if (cg0 + cj < cc) atomicMax(&s_max[(cg0 + cj) * 32 + (threadIdx.x & 31)], __float_as_uint(m));
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1080,10 +1075,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
     }
     if (STATS) {
       // publish into the first two words of each channel's g_grid tile (tile_out), which the
-      // scatter kernel reads before it overwrites the tile.  The max is per chunk (an upper
-      // bound for each of its channels: costs at most the spread between channels in precision)
-      for (int o = 32; o > 0; o >>= 1) stat_max = fmaxf(stat_max, __shfl_xor(stat_max, o, 64));
-      if ((threadIdx.x & 63) == 0) atomicMax(&s_max[0], __float_as_uint(stat_max));
+      // scatter kernel reads before it overwrites the tile
+      __syncthreads();
+      for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+        unsigned m = 0u;
+        for (int j = 0; j < 32; ++j) m = max(m, s_max[ch * 32 + j]);
+        s_max[ch * 32] = m;
+      }
       __syncthreads();
       unsigned kmax = 0;
       if (first) {
@@ -1107,13 +1105,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
         }
       }
       for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
-        if (split) atomicMax(slots + (size_t)ch * g.G, s_max[0]);
-        else slots[(size_t)ch * g.G] = s_max[0];
+        if (split) atomicMax(slots + (size_t)ch * g.G, s_max[ch * 32]);
+        else slots[(size_t)ch * g.G] = s_max[ch * 32];
       }
     }
     first = false;
   }
 }
+
+#include "ct_raster_hot.h"
 
 // ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
@@ -1197,6 +1197,23 @@ __global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
     tiles[r * stride + 1] = 0.0f;
   }
 }
+
+// ---------------------------------------------------------------------------
+// test hooks: which kernel family an entry point picked, and a switch that keeps the hot-shape kernels off
+// (process-wide host state — autograd runs backward on its own thread; never read by the kernels; the tag buffer
+//  is not synchronised: it is for single-stream tests)
+// ---------------------------------------------------------------------------
+unsigned t_dbg_flags = 0;
+char t_last[256] = "";
+
+void note_reset() { t_last[0] = 0; }
+void note(const char* tag) {
+  size_t n = strlen(t_last), m = strlen(tag);
+  if (n + m + 2 >= sizeof(t_last)) return;
+  if (n) t_last[n++] = '+';
+  memcpy(t_last + n, tag, m + 1);
+}
+inline bool hot_enabled() { return (t_dbg_flags & CT_DEBUG_NO_HOT) == 0; }
 
 // ---------------------------------------------------------------------------
 // host-side planning
@@ -1334,22 +1351,27 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
         dim3 rgrid(a.nchunks, a.H, a.B);
         CT_LAUNCH((scatter_add_fx_reg_kernel<DIM, 4, kRegCh, CT_FXREG_CG>), rgrid, round_threads(a.N / 4),
                   (size_t)a.CC * g.G * 4, st, a, g);
+        note("scatter_add_fx_reg");
       } else {
-        CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes, st, a, g);
+        CT_LAUNCH((scatter_add_fx_kernel<DIM, FROM_KEYS>), grid, p.threads, p.lds_bytes + (size_t)a.CC * 8, st, a, g);
+        note("scatter_add_fx");
       }
     } else {
       if (scatter_quad_ok(a, FROM_KEYS, g.G)) {
         const int qt = scatter_quad_threads(DIM, a.N);
         if (a.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, false, true>), grid, qt, p.lds_bytes, st, a, g);
         else CT_LAUNCH((scatter_quad_kernel<DIM, false, false>), grid, qt, p.lds_bytes, st, a, g);
+        note("scatter_quad_max");
       } else {
         CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, true>), grid, p.threads, p.lds_bytes, st, a, g);
+        note("scatter_generic_max");
       }
     }
   } else {
     if (hipMemsetAsync(a.tile_out, 0, (size_t)a.B * a.H * a.C * g.G * 4, st) != hipSuccess) return CT_ELAUNCH;
     if (sum) CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, 0, st, a, g);
     else CT_LAUNCH((scatter_kernel<DIM, FROM_KEYS, false, false>), grid, p.threads, 0, st, a, g);
+    note("scatter_global_atomics");
   }
   return CT_OK;
 }
@@ -1376,6 +1398,120 @@ int pick_nsplit(int B, int H, int nchunks, int N) {
   return ns;
 }
 
+
+// ---------------------------------------------------------------------------
+// hot-shape dispatch (ct_raster_hot.h): 2D, corners from keys, N % 4 == 0, C % 4 == 0, G % 4 == 0, 16-byte
+// aligned rows, enough (b,h) planes to fill the chip with one workgroup per plane
+// ---------------------------------------------------------------------------
+constexpr int kHalfCuLdsBytes = 80 * 1024;     // two workgroups per CU
+
+struct HotPlan {
+  int CC, nchunks;
+  size_t lds;
+};
+
+// channels per chunk: a multiple of 4 such that `fixed + CC * per_ch` bytes fit half a CU's LDS (else a whole CU's)
+bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp) {
+  if ((C & 3) != 0) return false;
+  long long cc = ((long long)kHalfCuLdsBytes - (long long)fixed) / (long long)per_ch;
+  cc &= ~3ll;
+  if (cc < 4) {
+    cc = ((long long)kBigLdsBytes - (long long)fixed) / (long long)per_ch;
+    cc &= ~3ll;
+    if (cc < 4) return false;
+  }
+  if (cc > C) cc = C;
+  hp.nchunks = (int)((C + cc - 1) / cc);
+  hp.CC = (((C + hp.nchunks - 1) / hp.nchunks) + 3) & ~3;      // balanced chunks
+  hp.nchunks = (C + hp.CC - 1) / hp.CC;
+  hp.lds = fixed + (size_t)hp.CC * per_ch;
+  return true;
+}
+
+bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
+  return hot_enabled() && (a.N & 3) == 0 && (G & 3) == 0 && (a.C & 3) == 0 && (ptr_bits & 15) == 0 &&
+         ((long long)a.B * a.H >= 128 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
+}
+
+// kernels are instantiated for the 32 x 32 grid of the headline shape (immediate corner offsets) and for any grid
+#define CT_HOT_KERNEL0(KERNEL, PADV, WTV) KERNEL<PADV, WTV>
+#define CT_HOT_KERNEL1(KERNEL, PADV, WTV, QPTV) KERNEL<PADV, WTV, QPTV>
+#define CT_LAUNCH_HOT_(MK, GRID, NT, LDS, STREAM, ARGS, GW, ...)                          \
+  do {                                                                                   \
+    if ((ARGS).pad_dtype != CT_PAD_NONE)                                                  \
+      CT_LAUNCH((MK(true, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);           \
+    else if ((GW).W[0] == 32 && (GW).W[1] == 32)                                          \
+      CT_LAUNCH((MK(false, 32, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
+    else                                                                                  \
+      CT_LAUNCH((MK(false, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);          \
+  } while (0)
+
+int hot_threads(int nq) {
+  const int t = round_threads(nq);
+  return t > kHotThreads ? kHotThreads : t;
+}
+
+// Slice forward / gather with the channel-interleaved tile.  CT_EINVAL: not eligible.
+int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.dst | (uintptr_t)a.tile_in;
+  if (!hot_shape_ok(a, g.G, bits)) return CT_EINVAL;
+  HotPlan hp;
+  if (!hot_chunks(a.C, (size_t)g.G * 4, 0, hp)) return CT_EINVAL;
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = hp.nchunks;
+  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N);
+  const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
+  dim3 grid(hp.nchunks * a.nsplit, a.H, a.B);
+#define CT_MK_GATHER(PADV, WTV) CT_HOT_KERNEL0(gather_ci_kernel, PADV, WTV)
+  CT_LAUNCH_HOT_(CT_MK_GATHER, grid, hot_threads(nq), hp.lds, st, a, g);
+  note("gather_ci");
+  return CT_OK;
+}
+
+// Slice backward, fused.  CT_EINVAL: not eligible.
+int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos;
+  if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  HotPlan hp;
+  if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp)) return CT_EINVAL;
+  a.tile_in = grid; a.g_pos = g_pos;
+  a.CC = hp.CC; a.nchunks = hp.nchunks;
+  dim3 wgrid(1, a.H, a.B);
+  const int nq = a.N >> 2;
+#define CT_MK_SLICE_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(slice_bwd_fused_kernel, PADV, WTV, QPTV)
+  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
+  note("slice_bwd_fused");
+  return CT_OK;
+}
+
+// can the hot Splat(max) backward take this call, and does it keep g_keys in registers (may accumulate)?
+bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<2>& g, HotPlan& hp, bool& single) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
+                         (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
+  if (!hot_shape_ok(a, g.G, bits)) return false;
+  if (!hot_chunks(a.C, (size_t)g.G * 8, 16, hp)) return false;
+  single = (a.N >> 2) <= 2 * kHotThreads;
+  return true;
+}
+
+int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, hipStream_t st) {
+  a.CC = hp.CC; a.nchunks = hp.nchunks;
+  dim3 wgrid(1, a.H, a.B);
+  const int nq = a.N >> 2;
+#define CT_MK_SPLAT_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
+  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
+  else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
+  note("splat_max_bwd_hot");
+  return CT_OK;
+}
+
+// y += x
+__global__ void __launch_bounds__(256) add_inplace_kernel(float* y, const float* x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+
 template <int DIM, bool FROM_KEYS>
 int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
@@ -1385,8 +1521,13 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N);
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(p.nchunks * a.nsplit, a.H, a.B);
+  if constexpr (DIM == 2 && FROM_KEYS) {
+    const int r = run_gather_hot(a, g, st);
+    if (r != CT_EINVAL) return r;
+  }
   if constexpr (DIM == 2) {   // 3D exceeds the register budget of the quad form: generic kernel
     if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
+      note("gather_quad");
       a.ncg = p.nchunks;   // one chunk per workgroup
       CT_LAUNCH_QUAD((2, QM_GATHER, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
       return CT_OK;
@@ -1394,6 +1535,7 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   }
   if (p.lds_tile) CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
   else CT_LAUNCH((gather_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
+  note("gather_generic");
   return CT_OK;
 }
 
@@ -1417,10 +1559,12 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
   dim3 grid(a.ncg * a.nsplit, a.H, a.B);
   if (quad_ok(a, FROM_KEYS, p.lds_tile) && (g.G & 3) == 0) {
     CT_LAUNCH_QUAD((DIM, QM_GATHER_GW, (DIM == 2 ? CT_QUAD_CG : 2), CT_QUAD_THREADS, false), grid, quad_threads(a.N, a.nsplit), p.lds_bytes, st, a, g);
+    note("gather_gw_quad");
     return CT_OK;
   }
   if (p.lds_tile) CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, true>), grid, threads, p.lds_bytes, st, a, g);
   else CT_LAUNCH((gather_gw_kernel<DIM, FROM_KEYS, false>), grid, threads, 0, st, a, g);
+  note("gather_gw_generic");
   return CT_OK;
 }
 
@@ -1467,22 +1611,31 @@ int launch_splat_max_bwd(RasterArgs a, const GridW<DIM>& g, const Plan& p, bool 
       dim3 wgrid(1, a.H, a.B);
       if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
       else CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 512, false), wgrid, t, wh_bytes, st, a, g);
+      note("splat_max_bwd_whole_head");
       return CT_OK;
     }
 #endif
     if (two && quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
       CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, CT_QUAD_THREADS, false), grid, quad_threads(a.N, 1), p.lds_bytes, st, a, g);
+      note("splat_max_bwd_quad");
       return CT_OK;
     }
   }
   if (two) CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, true>), grid, p.threads, p.lds_bytes, st, a, g);
   else CT_LAUNCH((splat_max_bwd_kernel<DIM, FROM_KEYS, true, false>), grid, p.threads, p.lds_bytes, st, a, g);
+  note("splat_max_bwd_generic");
   return CT_OK;
 }
 
 template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
+  if constexpr (DIM == 2 && FROM_KEYS) {
+    HotPlan hp;
+    bool single = false;
+    if (splat_bwd_hot_plan(a, g, hp, single) && (single || !a.accumulate)) return run_splat_max_bwd_hot(a, g, hp, st);
+  }
+  if (a.accumulate) return CT_EINVAL;     // the caller redirects g_pos to scratch and adds (splat_bwd_impl)
   // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
   const bool two = (size_t)g.G * 8 <= (size_t)kMaxLdsBytes;
   Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, two ? 2 : 1);
@@ -1517,6 +1670,10 @@ template <int DIM>
 int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
   if ((g.G & 3) != 0) return CT_EINVAL;
+  if constexpr (DIM == 2) {
+    const int r = run_slice_bwd_hot(a, grid, g_pos, g, st);
+    if (r != CT_EINVAL) return r;
+  }
   // gather side: tile + [CC] maxima + [G] counters in LDS
   RasterArgs ga = a;
   ga.tile_in = grid; ga.g_pos = g_pos;     // ga.tile_out = g_grid receives the statistics
@@ -1532,8 +1689,8 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   // the 30-bit fixed-point resolution)
   int cnt = 1024;
   while (cnt < g.G) cnt *= 2;
-  while (cnt > 1024 && pg.lds_bytes + (size_t)(pg.CC + cnt) * 4 > (size_t)kBigLdsBytes) cnt /= 2;
-  const size_t extra = (size_t)(pg.CC + cnt) * 4;
+  while (cnt > 1024 && pg.lds_bytes + (size_t)(pg.CC * 32 + cnt) * 4 > (size_t)kBigLdsBytes) cnt /= 2;
+  const size_t extra = (size_t)(pg.CC * 32 + cnt) * 4;
   if (pg.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
   ga.cnt_mask = cnt - 1;
   ga.CC = pg.CC; ga.nchunks = pg.nchunks; ga.ncg = 1; ga.atomic_gpos = 0;
@@ -1558,13 +1715,16 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   sa.CC = ps.CC; sa.nchunks = ps.nchunks;
   const int sthreads = ps.threads;   // (finer chunks / smaller workgroups were measured: no gain)
   dim3 sgrid(sa.nchunks, a.H, a.B);
+  note(ga.nsplit > 1 ? "slice_bwd_gw_stats_nsplit" : "slice_bwd_gw_stats");
   if (scatter_quad_ok(sa, true, g.G)) {
     const int qt = scatter_quad_threads(DIM, a.N);
-    if (sa.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, true, true>), sgrid, qt, (size_t)sa.CC * g.G * 4, st, sa, g);
-    else CT_LAUNCH((scatter_quad_kernel<DIM, true, false>), sgrid, qt, (size_t)sa.CC * g.G * 4, st, sa, g);
+    if (sa.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, true, true>), sgrid, qt, (size_t)sa.CC * g.G * 4 + (size_t)sa.CC * 8, st, sa, g);
+    else CT_LAUNCH((scatter_quad_kernel<DIM, true, false>), sgrid, qt, (size_t)sa.CC * g.G * 4 + (size_t)sa.CC * 8, st, sa, g);
+    note("scatter_quad_add");
     return CT_OK;
   }
   CT_LAUNCH((scatter_add_fx_stream_kernel<DIM, true>), sgrid, sthreads, (size_t)sa.CC * g.G * 4 + (size_t)2 * sa.CC * 4, st, sa, g);
+  note("scatter_add_fx_stream");
   return CT_OK;
 }
 
@@ -1587,6 +1747,7 @@ int splat_fwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
                    int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st) {
   if (!valid_common(B, H, C, N, dim, W) || !feat || !grid || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   if (reduce != CT_REDUCE_MAX0 && reduce != CT_REDUCE_SUM) return CT_EINVAL;
+  note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = feat; a.tile_out = grid;
   return dim == 2 ? run_scatter<2, FROM_KEYS>(a, W, reduce == CT_REDUCE_SUM, st)
@@ -1596,8 +1757,32 @@ int splat_fwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
 template <bool FROM_KEYS>
 int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype, const float* grid,
                    const float* g_grid, float* g_feat, float* g_pos, void* ws, size_t ws_bytes,
-                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st) {
+                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st, int flags = 0) {
   if (!valid_common(B, H, C, N, dim, W) || !feat || !g_grid || !g_feat || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  note_reset();
+  if (flags & CT_BWD_ACCUMULATE_KEYS) {
+    // g_pos += result.  The hot Splat(max) backward does it in its own store; every other path computes into
+    // the tail of the workspace and adds.
+    const size_t gpos_n = (size_t)B * H * (FROM_KEYS ? dim : (1 << dim)) * N;
+    if (!ws || ws_bytes < gpos_n * 4) return CT_EWORKSPACE;
+    const size_t head = ws_bytes - gpos_n * 4;
+    if (reduce == CT_REDUCE_MAX0 && dim == 2 && FROM_KEYS && grid) {
+      RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+      a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = grid; a.tile_in2 = g_grid;
+      a.accumulate = 1;
+      const int r = run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st);
+      if (r != CT_EINVAL) return r;
+    }
+    float* tmp = (float*)((char*)ws + head);
+    const int r = splat_bwd_impl<FROM_KEYS>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, tmp, ws, head, B, H, C, N, dim, W,
+                                            reduce, st, 0);
+    if (r != CT_OK) return r;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, g_pos, (const float*)tmp, gpos_n);
+    CT_CHECK_LAUNCH();
+    note("add_inplace");
+    return CT_OK;
+  }
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos;
   if (reduce == CT_REDUCE_MAX0) {
@@ -1619,6 +1804,7 @@ template <bool FROM_KEYS>
 int slice_fwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, float* out,
                    int B, int H, int C, int N, int dim, const int* W, hipStream_t st) {
   if (!valid_common(B, H, C, N, dim, W) || !grid || !out || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.tile_in = grid; a.dst = out;
   return dim == 2 ? run_gather<2, FROM_KEYS>(a, W, st) : run_gather<3, FROM_KEYS>(a, W, st);
@@ -1628,6 +1814,7 @@ template <bool FROM_KEYS>
 int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, const float* g_out,
                    float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st) {
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
+  note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = g_out; a.tile_out = g_grid;
   // (A single fused kernel — grid tile + accumulator tile of a whole (b,h) plane in LDS, one
@@ -1717,6 +1904,25 @@ int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_
   return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
                               B, H, C, N, dim, W, reduce, (hipStream_t)s);
 }
+
+size_t ct_splat_bwd_ex_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce, int flags) {
+  size_t n = ct_splat_bwd_workspace_bytes(B, H, C, N, dim, W, reduce);
+  if ((flags & CT_BWD_ACCUMULATE_KEYS) && valid_common(B, H, C, N, dim, W)) n += (size_t)B * H * dim * N * 4;
+  return n;
+}
+
+int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,
+                    const float* g_grid, float* g_feat, float* g_keys, void* ws, size_t ws_bytes,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s) {
+  if (!keys || (flags & ~CT_BWD_ACCUMULATE_KEYS)) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
+                              B, H, C, N, dim, W, reduce, (hipStream_t)s, flags);
+}
+
+void ct_debug_set_flags(unsigned flags) { t_dbg_flags = flags; }
+
+const char* ct_debug_last_launch(void) { return t_last; }
 
 int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_dtype, float* out,
                  int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {

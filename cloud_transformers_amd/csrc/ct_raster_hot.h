@@ -1,0 +1,651 @@
+// Hot-shape kernels of the rasterize / de-rasterize backward passes (2D grids, corners from keys,
+// N % 4 == 0, 16-byte aligned rows, C % 4 == 0).  Included by ct_raster.hip inside its anonymous
+// namespace (uses RasterArgs, GridW, ct_axis, ct_corners ... from there).
+//
+// What bounds these passes is the LDS pipeline, not HBM (profiles/r1_bench_sq_counters.txt: 47-71 % of the
+// LDS cycles of the round-1 kernels were bank conflicts of one-dword random reads).  Two changes of data
+// layout cut the LDS cycles per point:
+//   * gather side: the grid tile is kept CHANNEL-INTERLEAVED in LDS — 4 channels of a cell are one 16-byte
+//     word — so one ds_read_b128 per corner fetches 4 channels (4 LDS cycles per conflict-free wave access for
+//     1 KiB, against 2 cycles per 256 B for ds_read_b32: MI355X_MICROARCH.md §LDS), 16 reads per point
+//     instead of 64;
+//   * Splat(max) backward: z and g_z of a channel pair share one 16-byte word {z0, z1, g0, g1}; the match
+//     test and the cotangent of BOTH channels come from one read, and the single-winner rule costs nothing
+//     on tie-free planes: a plane without exact ties has exactly one bit-equal contribution per non-zero
+//     cell, so the kernel counts matches against non-zero cells and only a plane where the counts differ
+//     (duplicated points) is redone with the compare-and-swap claims.
+// Slice backward is ONE kernel: g_out is read once into registers, feeds the g_keys gather and the
+// fixed-point scatter-add, whose quantum is PER CHANNEL (max |g_out| of that channel in the plane, found by
+// a block reduction of the register-resident group before its atomics are issued).
+#pragma once
+
+// exact power-of-two quantum of a slab whose sums are bounded by MK = max|src| * max contributions per cell
+__device__ __forceinline__ void fx_quantum(float MK, float& q, float& iq, bool& fixed) {
+  fixed = MK < 1e37f;                              // false for inf / NaN as well
+  int ex = 0;
+  if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);   // MK <= 2^ex
+  ex = max(ex, -90);
+  q = ldexpf(1.0f, ex - 30);
+  iq = ldexpf(1.0f, 30 - ex);
+}
+
+// wave64 reductions over DPP (no LDS traffic, no index registers): row_shr 1/2/4/8 leave each 16-lane row's result in
+// its last lane, row_bcast:15 / row_bcast:31 carry it across the rows, lane 63 holds the result (returned as a
+// wave-uniform value).  Lanes without a source read `old` = 0, the identity of both reductions.
+#define CT_DPP_STEP(V, OP, CTRL, ROWMASK) \
+  V = OP(V, (decltype(V))__builtin_amdgcn_update_dpp(0, (int)(V), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define CT_UMAX(a, b) max((a), (b))
+  CT_DPP_STEP(v, CT_UMAX, 0x111, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x112, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x114, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x118, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x142, 0xa);
+  CT_DPP_STEP(v, CT_UMAX, 0x143, 0xc);
+#undef CT_UMAX
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#define CT_IADD(a, b) ((a) + (b))
+  CT_DPP_STEP(v, CT_IADD, 0x111, 0xf);
+  CT_DPP_STEP(v, CT_IADD, 0x112, 0xf);
+  CT_DPP_STEP(v, CT_IADD, 0x114, 0xf);
+  CT_DPP_STEP(v, CT_IADD, 0x118, 0xf);
+  CT_DPP_STEP(v, CT_IADD, 0x142, 0xa);
+  CT_DPP_STEP(v, CT_IADD, 0x143, 0xc);
+#undef CT_IADD
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// per-axis terms and corner weights of one 2D point
+struct Pt2 {
+  float w0x, w1x, w0y, w1y;
+  float cw[4];
+  int base;
+};
+
+__device__ __forceinline__ void pt2_from_keys(float kx, float ky, const GridW<2>& g, int W1, Pt2& p) {
+  int fx, fy;
+  ct_axis(kx, g.hw[0], g.W[0], p.w0x, p.w1x, fx);
+  ct_axis(ky, g.hw[1], g.W[1], p.w0y, p.w1y, fy);
+  p.base = fx * W1 + fy;
+  p.cw[0] = p.w0x * p.w0y;      // corner order of ct_corners<2>: (0,0), (1,0), (0,1), (1,1)
+  p.cw[1] = p.w1x * p.w0y;
+  p.cw[2] = p.w0x * p.w1y;
+  p.cw[3] = p.w1x * p.w1y;
+}
+
+// ---------------------------------------------------------------------------
+// KF: Slice backward, fused.  One 512-thread workgroup per (b, h) plane (two per CU), thread = QPT quads of 4
+//   consecutive points (N <= 4 * QPT * blockDim).
+//   LDS: conv chunk [CC/4][G] x float4 (channel-interleaved) | int accumulators [CC][G] | base-cell counts [G]
+//        | per-channel max |g_out*pad| [C] | K
+//   per chunk of CC channels: stage + zero, then per group of 4 channels:
+//     g_out group -> registers, per-channel block max (one barrier), then per point: 4 ds_read_b128 (conv at the
+//     corners, 4 channels each) -> corner cotangents, and 16 ds_add_u32 of the rounded products.
+//   grid = (1, H, B)
+// ---------------------------------------------------------------------------
+constexpr int kHotThreads = 512;
+
+// IEEE float scatter-add of one channel of a plane into its LDS accumulator row (the channel holds inf / NaN or
+// would overflow the fixed-point bound): re-reads the channel's src row; rare.
+template <bool HAS_PAD>
+__device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int ch, float* row_acc) {
+  const int N = a.N, W1 = g.W[1];
+  const float* src = a.src + (bh * a.C + ch) * (size_t)N;
+  for (int q = threadIdx.x; q < (N >> 2); q += blockDim.x) {
+    const int n0 = q << 2;
+    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+    const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+    const float4 tf = *(const float4*)(src + n0);
+    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w}, f[4] = {tf.x, tf.y, tf.z, tf.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pt2 p;
+      pt2_from_keys(kx[i], ky[i], g, W1, p);
+      const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : f[i];
+      float* T = row_acc + p.base;
+      atomicAdd(T, x * p.cw[0]);
+      atomicAdd(T + W1, x * p.cw[1]);
+      atomicAdd(T + 1, x * p.cw[2]);
+      atomicAdd(T + W1 + 1, x * p.cw[3]);
+    }
+  }
+}
+
+template <bool HAS_PAD, int WT, int QPT>
+__global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g) {
+  extern __shared__ __align__(16) float lds[];
+  // WT > 0: square WT x WT grid known at compile time (corner offsets become instruction immediates)
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], CC = a.CC, N = a.N;
+  float4* T4 = (float4*)lds;
+  int* acc = (int*)(lds + (size_t)CC * G);
+  int* cnt = acc + (size_t)CC * G;
+  unsigned* s_max = (unsigned*)(cnt + G);
+  unsigned* s_k = s_max + a.C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int tid = threadIdx.x;
+  const int off[4] = {0, W1, 1, W1 + 1};
+  int n0[QPT], n0c[QPT];
+  bool active[QPT];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    n0[u] = (tid + u * (int)blockDim.x) << 2;
+    active[u] = n0[u] < N;
+    n0c[u] = active[u] ? n0[u] : 0;      // threads past the end load the first quad and ignore it
+  }
+
+  const float* keyx = a.pos.keys + (bh * 2 + 0) * N;      // wave-uniform row pointers
+  const float* keyy = a.pos.keys + (bh * 2 + 1) * N;
+  float pv[QPT][4];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0[u] + i) : 1.0f;
+  for (int i = tid; i < G + a.C + 1; i += blockDim.x) cnt[i] = 0;     // cnt, s_max, s_k are contiguous
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    if (active[u]) {
+      const float4 tx = *(const float4*)(keyx + n0[u]), ty = *(const float4*)(keyy + n0[u]);
+      const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Pt2 p;
+        pt2_from_keys(kx[i], ky[i], g, W1, p);
+        atomicAdd(&cnt[p.base], 1);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // contributions per cell = points based at the cell and at its three lower neighbours; cells of the last
+    // row / column are never a base, so the wrapped neighbours of column 0 read zeros
+    unsigned kloc = 0;
+    for (int X = tid; X < G; X += blockDim.x) {
+      unsigned c = (unsigned)cnt[X];
+      if (X >= 1) c += (unsigned)cnt[X - 1];
+      if (X >= W1) c += (unsigned)cnt[X - W1];
+      if (X >= W1 + 1) c += (unsigned)cnt[X - W1 - 1];
+      kloc = max(kloc, c);
+    }
+    kloc = wave_max_u32(kloc);
+    if ((tid & 63) == 0) atomicMax(s_k, kloc);
+  }
+
+  float gs[QPT][4][2];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
+
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const int c0 = chunk * CC;
+    const int cc = min(CC, a.C - c0);            // multiple of 4
+    const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+    float* gout = a.tile_out + (bh * a.C + c0) * (size_t)G;
+    // stage the conv chunk channel-interleaved (4 coalesced dword loads -> one conflict-free ds_write_b128)
+    for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
+      const int cq = t / G, cell = t - cq * G;
+      const float* p = gin + (size_t)(cq * 4) * G + cell;
+      T4[t] = make_float4(p[0], p[G], p[2 * (size_t)G], p[3 * (size_t)G]);
+    }
+    if (chunk == 0)
+      for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const float Kf = (float)(*s_k);
+    for (int cq = 0; cq < (cc >> 2); ++cq) {
+      const int ch0 = c0 + cq * 4;
+      // Quad 0's values stay in registers across the barrier; a second quad is read twice — now for the maxima,
+      // and again when it is processed (an L2 hit: the plane's group was fetched microseconds ago) — so that the
+      // live set stays inside 128 registers.
+      float fv[4][4];            // [channel][point] of the quad being processed
+      float mx[4];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;      // wave-uniform
+        const float4 t = *(const float4*)(row + n0c[0]);
+        fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = HAS_PAD ? fv[cj][i] * pv[0][i] : fv[cj][i];
+          x = active[0] ? x : 0.0f;               // threads past the end loaded the cloud's first quad
+          fv[cj][i] = x;
+          x = fabsf(x);
+          m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());     // inf / NaN -> inf
+        }
+        mx[cj] = m;
+      }
+#pragma unroll
+      for (int u = 1; u < QPT; ++u) {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+          const float4 t = *(const float4*)(row + n0c[u]);
+          const float tv[4] = {t.x, t.y, t.z, t.w};
+          float m = mx[cj];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float x = fabsf(HAS_PAD ? tv[i] * pv[u][i] : tv[i]);
+            x = active[u] ? x : 0.0f;
+            m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());
+          }
+          mx[cj] = m;
+        }
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const unsigned mb = wave_max_u32(__float_as_uint(mx[cj]));           // non-negative floats order like uints
+        if ((tid & 63) == 0) atomicMax(&s_max[ch0 + cj], mb);
+      }
+      __syncthreads();
+      // quantum per channel; a channel that holds inf / NaN (or overflows the bound) adds zeros here (iq = 0:
+      // x * 0 is 0 or NaN, both convert to 0) and is accumulated with IEEE float atomics in the rare block below
+      float iq[4];
+      bool any_float = false;
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        float q;
+        bool fixed;
+        fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iq[cj], fixed);
+        if (!fixed) {
+          iq[cj] = 0.0f;
+          any_float = true;
+        }
+      }
+      const float4* Tq = T4 + (size_t)cq * G;
+      int* accq = acc + (size_t)(cq * 4) * G;
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        if (u > 0) {
+          int n0r = n0c[u];
+          asm volatile("" : "+v"(n0r));      // a real second load: keeps the compiler from carrying the first one's 16 values
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj) {
+            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            const float4 t = *(const float4*)(row + n0r);
+            fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x = HAS_PAD ? fv[cj][i] * pv[u][i] : fv[cj][i];
+              fv[cj][i] = active[u] ? x : 0.0f;
+            }
+          }
+        }
+        // keys are re-read per (group, quad) — L2 hits — rather than held in 8 registers per quad
+        const float4 tx = *(const float4*)(keyx + n0c[u]), ty = *(const float4*)(keyy + n0c[u]);
+        const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Pt2 p;
+          pt2_from_keys(kx[i], ky[i], g, W1, p);
+          float4 cv[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[v]];
+          float gw[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float s = cv[v].x * fv[0][i];
+            s = __builtin_fmaf(cv[v].y, fv[1][i], s);
+            s = __builtin_fmaf(cv[v].z, fv[2][i], s);
+            s = __builtin_fmaf(cv[v].w, fv[3][i], s);
+            gw[v] = s;
+          }
+          gs[u][i][0] += (gw[1] - gw[0]) * p.w0y + (gw[3] - gw[2]) * p.w1y;
+          gs[u][i][1] += (gw[2] - gw[0]) * p.w0x + (gw[3] - gw[1]) * p.w1x;
+          // pin the two sums here: without it the compiler sinks the whole gather -> g_keys chain of a point past the
+          // following points' work and spills the 16 gathered values meanwhile
+          asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]));
+          // (threads past the end of the cloud hold zeros: they add 0 to the cells of the cloud's first quad — no
+          //  branch here, so that the point's work stays one basic block in source order)
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj) {
+            int* Tc = accq + cj * G + p.base;
+            const float fq = fv[cj][i] * iq[cj];          // power-of-two scale: exact
+#pragma unroll
+            for (int v = 0; v < 4; ++v) atomicAdd(Tc + off[v], __float2int_rn(fq * p.cw[v]));
+          }
+          __builtin_amdgcn_sched_barrier(0);     // one point at a time: keeps the live set inside the register budget
+        }
+      }
+      if (any_float) {         // block-uniform, rare
+#pragma unroll 1
+        for (int cj = 0; cj < 4; ++cj) {
+          float q, iqd;
+          bool fixed;
+          fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iqd, fixed);
+          if (!fixed) scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + cj * G));
+        }
+      }
+    }
+    __syncthreads();
+    // write the chunk out (and clear the accumulators for the next chunk in the same sweep)
+    const bool more = chunk + 1 < a.nchunks;
+    for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) {
+      const int ch = (t << 2) / G;                 // G % 4 == 0: a float4 never straddles channels
+      float q, iqd;
+      bool fixed;
+      fx_quantum(__uint_as_float(s_max[c0 + ch]) * Kf, q, iqd, fixed);
+      const int4 r = ((const int4*)acc)[t];
+      float4 o;
+      if (fixed) o = make_float4((float)r.x * q, (float)r.y * q, (float)r.z * q, (float)r.w * q);
+      else o = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+      ((float4*)gout)[t] = o;
+      if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
+    }
+    // (the next chunk's staging overwrites T4 only: every gather of this chunk is behind the barrier above)
+  }
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    if (active[u]) {
+      const float4 tx = *(const float4*)(keyx + n0[u]), ty = *(const float4*)(keyy + n0[u]);
+      float4 ox, oy;
+      ox.x = gs[u][0][0] * ct_key_mask(tx.x); ox.y = gs[u][1][0] * ct_key_mask(tx.y);
+      ox.z = gs[u][2][0] * ct_key_mask(tx.z); ox.w = gs[u][3][0] * ct_key_mask(tx.w);
+      oy.x = gs[u][0][1] * ct_key_mask(ty.x); oy.y = gs[u][1][1] * ct_key_mask(ty.y);
+      oy.z = gs[u][2][1] * ct_key_mask(ty.z); oy.w = gs[u][3][1] * ct_key_mask(ty.w);
+      *(float4*)(a.g_pos + (bh * 2 + 0) * N + n0[u]) = ox;
+      *(float4*)(a.g_pos + (bh * 2 + 1) * N + n0[u]) = oy;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KB: Splat(max0) backward, hot form.  One 512-thread workgroup per (b, h) plane; chunks of CC channels:
+//   LDS: [CC/2][G] x float4 {z(c), z(c+1), g_z(c), g_z(c+1)}.
+//   CLAIMS = false: a contribution whose product is bit-equal to a non-zero z receives g_z (no claim); the
+//     kernel counts such matches and the non-zero cells of z.  On a tie-free plane the counts agree and every
+//     cell had exactly one match.  Otherwise (duplicated points ...) the plane is redone with CLAIMS = true:
+//     the first tied contribution to compare-and-swap the cell's z word to 0 wins (single winner, as
+//     torch_scatter's backward; which of the tied contributions is unspecified).
+//   QPT > 0: every thread owns at most QPT quads (N <= 4*QPT*blockDim): g_keys stays in registers across the
+//     chunks and may be ACCUMULATED into the destination (a.accumulate) — a block's keys feed Splat and Slice.
+//   QPT == 0: any N; the partial g_keys of the chunks go through memory.
+//   grid = (1, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD, bool CLAIMS, int WT>
+__device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
+                                               int c0, int cc, int n0, const float (&kx)[4], const float (&ky)[4],
+                                               float (&gs)[4][2], int& nm) {
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
+  const int off[4] = {0, W1, 1, W1 + 1};
+  float pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+  for (int cg0 = 0; cg0 < cc; cg0 += 2) {
+    float fa[4], fb[4];
+    {
+      const float4 ta = *(const float4*)(a.src + (bh * a.C + c0 + cg0) * (size_t)N + n0);
+      const float4 tb = *(const float4*)(a.src + (bh * a.C + c0 + cg0 + 1) * (size_t)N + n0);
+      fa[0] = ta.x; fa[1] = ta.y; fa[2] = ta.z; fa[3] = ta.w;
+      fb[0] = tb.x; fb[1] = tb.y; fb[2] = tb.z; fb[3] = tb.w;
+    }
+    float4* Zc = ZG + (size_t)(cg0 >> 1) * G;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pt2 p;
+      pt2_from_keys(kx[i], ky[i], g, W1, p);
+      float4* Zp = Zc + p.base;
+      const float xa = HAS_PAD ? fa[i] * pv[i] : fa[i];
+      const float xb = HAS_PAD ? fb[i] * pv[i] : fb[i];
+      float4 zg[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) zg[v] = Zp[off[v]];
+      float gfa = 0.0f, gfb = 0.0f;
+      float gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!CLAIMS) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const unsigned ba = __float_as_uint(xa * p.cw[v]), bb = __float_as_uint(xb * p.cw[v]);
+          const unsigned za = __float_as_uint(zg[v].x), zb = __float_as_uint(zg[v].y);
+          // a non-positive product has its sign bit set or is zero: never bit-equal to a positive z
+          const bool ma = (ba == za) & (za != 0u), mb = (bb == zb) & (zb != 0u);
+          nm += (int)ma + (int)mb;
+          const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
+          gfa += ga * p.cw[v];
+          gfb += gb * p.cw[v];
+          gw[v] += ga * xa;
+          gw[v] += gb * xb;
+        }
+      } else {
+        unsigned ba[4], bb[4];
+        bool ma[4], mb[4];
+        bool any = false;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          ba[v] = __float_as_uint(xa * p.cw[v]);
+          bb[v] = __float_as_uint(xb * p.cw[v]);
+          const unsigned za = __float_as_uint(zg[v].x), zb = __float_as_uint(zg[v].y);
+          ma[v] = (ba[v] == za) & (za != 0u);
+          mb[v] = (bb[v] == zb) & (zb != 0u);
+          any = any | ma[v] | mb[v];
+        }
+        if (any) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            unsigned* zw = (unsigned*)(Zp + off[v]);
+            const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : 0xFFFFFFFFu, 0u);
+            const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : 0xFFFFFFFFu, 0u);
+            const float ga = (ma[v] & (oa == ba[v])) ? zg[v].z : 0.0f;
+            const float gb = (mb[v] & (ob == bb[v])) ? zg[v].w : 0.0f;
+            gfa += ga * p.cw[v];
+            gfb += gb * p.cw[v];
+            gw[v] += ga * xa;
+            gw[v] += gb * xb;
+          }
+        }
+      }
+      fa[i] = HAS_PAD ? gfa * pv[i] : gfa;
+      fb[i] = HAS_PAD ? gfb * pv[i] : gfb;
+      gs[i][0] += (gw[1] - gw[0]) * p.w0y + (gw[3] - gw[2]) * p.w1y;
+      gs[i][1] += (gw[2] - gw[0]) * p.w0x + (gw[3] - gw[1]) * p.w1x;
+      // pin the point's results here (see slice_bwd_fused_kernel): one point at a time keeps the live set small
+      asm volatile("" : "+v"(gs[i][0]), "+v"(gs[i][1]), "+v"(fa[i]), "+v"(fb[i]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    *(float4*)(a.dst + (bh * a.C + c0 + cg0) * (size_t)N + n0) = make_float4(fa[0], fa[1], fa[2], fa[3]);
+    *(float4*)(a.dst + (bh * a.C + c0 + cg0 + 1) * (size_t)N + n0) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+  }
+}
+
+template <bool HAS_PAD, bool CLAIMS, int WT, int QPT>
+__device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const GridW<2>& g, float4* ZG, int* s_cnt,
+                                                    size_t bh, int b, float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
+  const int G = WT ? WT * WT : g.G, CC = a.CC, N = a.N;
+  const int tid = threadIdx.x;
+  const int nq = N >> 2;
+  int nz = 0, nm = 0;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const int c0 = chunk * CC;
+    const int cc = min(CC, a.C - c0);            // multiple of 4
+    const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+    const float* gin = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
+    __syncthreads();                              // readers of the previous chunk (or pass) are done
+    for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
+      const int cp = t / G, cell = t - cp * G;
+      const size_t o = (size_t)(cp * 2) * G + cell;
+      const float z0 = zin[o], z1 = zin[o + G];
+      ZG[t] = make_float4(z0, z1, gin[o], gin[o + G]);
+      if (!CLAIMS) nz += (__float_as_uint(z0) != 0u) + (__float_as_uint(z1) != 0u);
+    }
+    __syncthreads();
+    if constexpr (QPT > 0) {
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        const int q = tid + u * (int)blockDim.x;
+        if (q < nq) {
+          const int n0 = q << 2;
+          const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+          const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+          const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, kx, ky, gs_reg[u], nm);
+        }
+      }
+    } else {
+      for (int q = tid; q < nq; q += blockDim.x) {
+        const int n0 = q << 2;
+        const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+        const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+        const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+        float gs[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, kx, ky, gs, nm);
+        // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns
+        // these addresses)
+        float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
+                                gs[2][0] * ct_key_mask(kx[2]), gs[3][0] * ct_key_mask(kx[3]));
+        float4 oy = make_float4(gs[0][1] * ct_key_mask(ky[0]), gs[1][1] * ct_key_mask(ky[1]),
+                                gs[2][1] * ct_key_mask(ky[2]), gs[3][1] * ct_key_mask(ky[3]));
+        float* px = a.g_pos + (bh * 2 + 0) * N + n0;
+        float* py = a.g_pos + (bh * 2 + 1) * N + n0;
+        if (chunk > 0) {
+          const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+          ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
+          oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
+        }
+        *(float4*)px = ox;
+        *(float4*)py = oy;
+      }
+    }
+  }
+  if (!CLAIMS) {
+    nz = wave_sum_i32(nz);
+    nm = wave_sum_i32(nm);
+    if ((tid & 63) == 0) {
+      atomicAdd(&s_cnt[0], nz);
+      atomicAdd(&s_cnt[1], nm);
+    }
+    __syncthreads();
+    tie = s_cnt[0] != s_cnt[1];
+  }
+}
+
+template <bool HAS_PAD, int WT, int QPT>
+__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g) {
+  extern __shared__ __align__(16) float lds[];
+  float4* ZG = (float4*)lds;
+  int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int N = a.N;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;       // ordered before use by the barriers of the pass
+  float gs[QPT ? QPT : 1][4][2];
+#pragma unroll
+  for (int u = 0; u < (QPT ? QPT : 1); ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
+  bool tie = false;
+  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, gs, tie);
+  if (tie) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
+#pragma unroll
+    for (int u = 0; u < (QPT ? QPT : 1); ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
+    splat_bwd_plane_pass<HAS_PAD, true, WT, QPT>(a, g, ZG, s_cnt, bh, b, gs, tie);
+  }
+  if constexpr (QPT > 0) {
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+      const int n0 = ((int)threadIdx.x + u * (int)blockDim.x) << 2;
+      if (n0 < N) {
+        const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+        const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+        float4 ox = make_float4(gs[u][0][0] * ct_key_mask(tx.x), gs[u][1][0] * ct_key_mask(tx.y),
+                                gs[u][2][0] * ct_key_mask(tx.z), gs[u][3][0] * ct_key_mask(tx.w));
+        float4 oy = make_float4(gs[u][0][1] * ct_key_mask(ty.x), gs[u][1][1] * ct_key_mask(ty.y),
+                                gs[u][2][1] * ct_key_mask(ty.z), gs[u][3][1] * ct_key_mask(ty.w));
+        float* px = a.g_pos + (bh * 2 + 0) * N + n0;
+        float* py = a.g_pos + (bh * 2 + 1) * N + n0;
+        if (a.accumulate) {
+          const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+          ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
+          oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
+        }
+        *(float4*)px = ox;
+        *(float4*)py = oy;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KG: Slice forward (and the g_feat half of Splat(sum) backward) with the channel-interleaved tile:
+//   one ds_read_b128 per (point, corner, 4 channels).   grid = (nchunks * nsplit, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD, int WT>
+__global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a, GridW<2> g) {
+  extern __shared__ __align__(16) float lds[];
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
+  float4* T4 = (float4*)lds;
+  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);            // multiple of 4
+  const int tid = threadIdx.x;
+  const int off[4] = {0, W1, 1, W1 + 1};
+  const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+  for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
+    const int cq = t / G, cell = t - cq * G;
+    const float* p = gin + (size_t)(cq * 4) * G + cell;
+    T4[t] = make_float4(p[0], p[G], p[2 * (size_t)G], p[3 * (size_t)G]);
+  }
+  __syncthreads();
+  const int nq = N >> 2;
+  const int per = (nq + a.nsplit - 1) / a.nsplit;
+  const int q_beg = sp * per, q_end = min(nq, q_beg + per);
+  float* dst = a.dst + (bh * a.C + c0) * (size_t)N;
+  for (int q = q_beg + tid; q < q_end; q += blockDim.x) {
+    const int n0 = q << 2;
+    float cw[4][4], pv[4];
+    int base[4];
+    {
+      const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+      const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+      const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Pt2 p;
+        pt2_from_keys(kx[i], ky[i], g, W1, p);
+        base[i] = p.base;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cw[i][v] = p.cw[v];
+        pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+      }
+    }
+    for (int cq = 0; cq < (cc >> 2); ++cq) {
+      const float4* Tq = T4 + (size_t)cq * G;
+      float o[4][4];       // [channel][point]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 cv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cv[v] = Tq[base[i] + off[v]];
+        // same order as the reference's sum over corners: ((v0 + v1) + v2) + v3
+        float s0 = cv[0].x * cw[i][0], s1 = cv[0].y * cw[i][0], s2 = cv[0].z * cw[i][0], s3 = cv[0].w * cw[i][0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) {
+          s0 += cv[v].x * cw[i][v];
+          s1 += cv[v].y * cw[i][v];
+          s2 += cv[v].z * cw[i][v];
+          s3 += cv[v].w * cw[i][v];
+        }
+        o[0][i] = HAS_PAD ? s0 * pv[i] : s0;
+        o[1][i] = HAS_PAD ? s1 * pv[i] : s1;
+        o[2][i] = HAS_PAD ? s2 * pv[i] : s2;
+        o[3][i] = HAS_PAD ? s3 * pv[i] : s3;
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj)
+        *(float4*)(dst + (size_t)(cq * 4 + cj) * N + n0) = make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]);
+    }
+  }
+}

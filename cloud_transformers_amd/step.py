@@ -14,8 +14,10 @@ class SplatSliceStep:
     """out = Slice(keys, Splat(keys, feat)); backward from the cotangent `cot`.
 
     forward : z = ct_splat_fwd(keys, feat);  out = ct_slice_fwd(keys, z)
-    backward: g_z, g_keys_b = ct_slice_bwd(keys, z, cot)
-              g_feat, g_keys_a = ct_splat_bwd(keys, feat, z, g_z)
+    backward: g_z, g_keys  = ct_slice_bwd(keys, z, cot)
+              g_feat, g_keys += ct_splat_bwd_ex(keys, feat, z, g_z, CT_BWD_ACCUMULATE_KEYS)
+    The keys feed both ops, so their two key cotangents are summed (what autograd does in the module path); the
+    second backward accumulates into the first one's result inside its own store.
     """
 
     def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max"):
@@ -30,12 +32,12 @@ class SplatSliceStep:
         self.out = torch.empty_like(self.feat)
         self.g_z = torch.empty_like(self.z)
         self.g_feat = torch.empty_like(self.feat)
-        self.g_keys_a = torch.empty_like(self.keys)
-        self.g_keys_b = torch.empty_like(self.keys)
+        self.g_keys_buf = torch.empty_like(self.keys)
         self.lib = _lib.load()
         self.Wa = _lib.int_array(self.W)
         self.red = _lib.REDUCE[reduce]
-        nws = self.lib.ct_splat_bwd_workspace_bytes(self.B, self.H, self.C, self.N, dim, self.Wa, self.red)
+        nws = self.lib.ct_splat_bwd_ex_workspace_bytes(self.B, self.H, self.C, self.N, dim, self.Wa, self.red,
+                                                       _lib.BWD_ACCUMULATE_KEYS)
         self.ws = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
         self.nws = nws
 
@@ -57,33 +59,45 @@ class SplatSliceStep:
 
     def slice_bwd_keys(self):
         _lib.check(self.lib.ct_slice_bwd_keys(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
-                                              _ptr(self.g_keys_b),
+                                              _ptr(self.g_keys_buf),
                                               self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
                    "ct_slice_bwd_keys")
 
     def slice_bwd(self):
         _lib.check(self.lib.ct_slice_bwd(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
-                                         _ptr(self.g_z), _ptr(self.g_keys_b),
+                                         _ptr(self.g_z), _ptr(self.g_keys_buf),
                                          self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
                    "ct_slice_bwd")
 
     def splat_bwd(self):
-        _lib.check(self.lib.ct_splat_bwd(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
-                                         _ptr(self.g_feat), _ptr(self.g_keys_a), _ptr(self.ws), self.nws,
-                                         self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red, _stream()),
-                   "ct_splat_bwd")
+        """accumulates its key cotangent into g_keys_buf (call after slice_bwd, which overwrites it)"""
+        _lib.check(self.lib.ct_splat_bwd_ex(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
+                                            _ptr(self.g_feat), _ptr(self.g_keys_buf), _ptr(self.ws), self.nws,
+                                            self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red,
+                                            _lib.BWD_ACCUMULATE_KEYS, _stream()),
+                   "ct_splat_bwd_ex")
 
-    # one entry per ABI call; each is ONE kernel launch for reduce="max" on the headline shape
+    # one entry per ABI call
     PASSES = ("splat_fwd", "slice_fwd", "slice_bwd", "splat_bwd")
-    # HIP kernel behind each pass on the headline shape (name as rocprofv3 prints it)
-    KERNELS = {
-        "splat_fwd": "scatter_quad_kernel<2, false, false>",
-        "slice_fwd": "quad_kernel<2, 0, 4, 512, false, false>",
-        "slice_bwd": "quad_kernel<2, 1, 4, 512, true, false> + scatter_quad_kernel<2, true, false>",
-        "splat_bwd": "quad_kernel<2, 2, 4, 1024, false, false>",
+
+    # kernel-family tag (ct_debug_last_launch) -> kernel name as rocprofv3 prints it (substring)
+    KERNEL_OF = {
+        "scatter_quad_max": "scatter_quad_kernel<2, false, false>",
+        "scatter_add_fx_reg": "scatter_add_fx_reg_kernel",
+        "gather_ci": "gather_ci_kernel",
+        "gather_quad": "quad_kernel<2, 0,",
+        "slice_bwd_fused": "slice_bwd_fused_kernel",
+        "splat_max_bwd_hot": "splat_max_bwd_hot_kernel",
+        "splat_max_bwd_whole_head": "quad_kernel<2, 2, 4, 1024,",
     }
-    # passes that are exactly one kernel launch (slice_bwd is two: ~47 us + ~42 us on the headline shape)
-    SINGLE_KERNEL = ("splat_fwd", "slice_fwd", "splat_bwd")
+
+    def launch_tags(self):
+        """{pass: kernel-family tags of the launches behind it} for this shape (runs every pass once)."""
+        tags = {}
+        for name in self.PASSES:
+            getattr(self, name)()
+            tags[name] = self.lib.ct_debug_last_launch().decode()
+        return tags
 
     def run(self):
         self.splat_fwd()
@@ -92,7 +106,8 @@ class SplatSliceStep:
         self.splat_bwd()
 
     def g_keys(self):
-        return self.g_keys_a + self.g_keys_b
+        """d(out . cot)/d(keys) after run(): Slice's and Splat's key cotangents, already summed"""
+        return self.g_keys_buf
 
     # algorithmic (compulsory) HBM bytes of the fused formulation, SURVEY.md §8(d)
     def algorithmic_bytes(self):

@@ -89,6 +89,25 @@ int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_
                  void* workspace, size_t workspace_bytes,
                  int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s);
 
+/* ct_splat_bwd with options.  CT_BWD_ACCUMULATE_KEYS: g_keys += result instead of g_keys = result — the
+ * keys of a block feed both Splat and Slice (layers/multihead_ct.py:99-107), so their two key cotangents are
+ * summed by autograd; accumulating in the second backward saves that extra pass over (B,H*dim,N).
+ * workspace: ct_splat_bwd_ex_workspace_bytes(..., flags) bytes. */
+#define CT_BWD_ACCUMULATE_KEYS 1
+size_t ct_splat_bwd_ex_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce, int flags);
+int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int pad_dtype,
+                    const float* grid, const float* g_grid, float* g_feat, float* g_keys,
+                    void* workspace, size_t workspace_bytes,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s);
+
+/* Test hooks (process-wide host state, never read by a kernel): flags select kernel families so that the
+ * parity tests can compare them on identical inputs; the tag string names the kernels the last Splat / Slice
+ * entry point launched (not synchronised: single-stream tests only). */
+#define CT_DEBUG_NO_HOT 1      /* keep the hot-shape kernels (csrc/ct_raster_hot.h) off */
+#define CT_DEBUG_FORCE_HOT 2   /* use them for every eligible layout, however few (b,h) planes there are */
+void ct_debug_set_flags(unsigned flags);
+const char* ct_debug_last_launch(void);
+
 /* Slice.forward  (layers/cloud_transform.py:190-227): out f32[B,H*C,N].
  * Slice backward (autograd of torch.gather = scatter-add, :216-221):
  *   g_grid f32[B,H*C,G] and g_keys f32[B,H*dim,N], both overwritten. */
