@@ -1411,9 +1411,9 @@ struct HotPlan {
 };
 
 // channels per chunk: a multiple of 4 such that `fixed + CC * per_ch` bytes fit half a CU's LDS (else a whole CU's)
-bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp) {
+bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budget = kHalfCuLdsBytes) {
   if ((C & 3) != 0) return false;
-  long long cc = ((long long)kHalfCuLdsBytes - (long long)fixed) / (long long)per_ch;
+  long long cc = (budget - (long long)fixed) / (long long)per_ch;
   cc &= ~3ll;
   if (cc < 4) {
     cc = ((long long)kBigLdsBytes - (long long)fixed) / (long long)per_ch;
@@ -1472,7 +1472,10 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
   HotPlan hp;
-  if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp)) return CT_EINVAL;
+#ifndef CT_FUSED_LDS_BUDGET
+#define CT_FUSED_LDS_BUDGET kHalfCuLdsBytes
+#endif
+  if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
   a.tile_in = grid; a.g_pos = g_pos;
   a.CC = hp.CC; a.nchunks = hp.nchunks;
   dim3 wgrid(1, a.H, a.B);

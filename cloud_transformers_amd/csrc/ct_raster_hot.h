@@ -58,6 +58,32 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// float -> int, rounded to nearest (floor(x + 0.5): ties up) in ONE instruction; __float2int_rn is v_rndne_f32 +
+// v_cvt_i32_f32.  The fixed-point scatter rounds every product once to the quantum; which way an exact tie goes
+// does not matter.
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+typedef float ct_f2 __attribute__((ext_vector_type(2)));
+typedef float ct_f4 __attribute__((ext_vector_type(4)));
+
+// Streaming (read-once / write-once) global accesses carry the non-temporal hint, so that what IS re-read inside a
+// kernel — keys, and the second quad's g_out rows of the fused Slice backward — stays in the XCD's 4 MiB L2 instead
+// of being pushed out by the streams (the re-reads then never reach the memory-side counters, nor HBM).
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+  const ct_f4 v = __builtin_nontemporal_load((const ct_f4*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream4(float* p, float4 v) {
+  const ct_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (ct_f4*)p);
+}
+__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+
+
 // per-axis terms and corner weights of one 2D point
 struct Pt2 {
   float w0x, w1x, w0y, w1y;
@@ -86,7 +112,13 @@ __device__ __forceinline__ void pt2_from_keys(float kx, float ky, const GridW<2>
 //     corners, 4 channels each) -> corner cotangents, and 16 ds_add_u32 of the rounded products.
 //   grid = (1, H, B)
 // ---------------------------------------------------------------------------
-constexpr int kHotThreads = 512;
+#ifndef CT_HOT_THREADS
+#define CT_HOT_THREADS 512
+#endif
+constexpr int kHotThreads = CT_HOT_THREADS;
+#ifndef CT_FUSED_WAVES
+#define CT_FUSED_WAVES 4
+#endif
 
 // IEEE float scatter-add of one channel of a plane into its LDS accumulator row (the channel holds inf / NaN or
 // would overflow the fixed-point bound): re-reads the channel's src row; rare.
@@ -115,7 +147,7 @@ __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const
 }
 
 template <bool HAS_PAD, int WT, int QPT>
-__global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g) {
   extern __shared__ __align__(16) float lds[];
   // WT > 0: square WT x WT grid known at compile time (corner offsets become instruction immediates)
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], CC = a.CC, N = a.N;
@@ -191,7 +223,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
     for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
       const int cq = t / G, cell = t - cq * G;
       const float* p = gin + (size_t)(cq * 4) * G + cell;
-      T4[t] = make_float4(p[0], p[G], p[2 * (size_t)G], p[3 * (size_t)G]);
+      T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
     }
     if (chunk == 0)
       for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
@@ -207,7 +239,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
 #pragma unroll
       for (int cj = 0; cj < 4; ++cj) {
         const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;      // wave-uniform
-        const float4 t = *(const float4*)(row + n0c[0]);
+        const float4 t = ld_stream4(row + n0c[0]);                         // read once
         fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
       }
 #pragma unroll
@@ -270,7 +302,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
             const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
-            const float4 t = *(const float4*)(row + n0r);
+            const float4 t = ld_stream4(row + n0r);                        // second and last read
             fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -298,19 +330,24 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
             s = __builtin_fmaf(cv[v].w, fv[3][i], s);
             gw[v] = s;
           }
-          gs[u][i][0] += (gw[1] - gw[0]) * p.w0y + (gw[3] - gw[2]) * p.w1y;
-          gs[u][i][1] += (gw[2] - gw[0]) * p.w0x + (gw[3] - gw[1]) * p.w1x;
+          gs[u][i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[u][i][0]));
+          gs[u][i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[u][i][1]));
           // pin the two sums here: without it the compiler sinks the whole gather -> g_keys chain of a point past the
           // following points' work and spills the 16 gathered values meanwhile
           asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]));
           // (threads past the end of the cloud hold zeros: they add 0 to the cells of the cloud's first quad — no
-          //  branch here, so that the point's work stays one basic block in source order)
+          //  branch here, so that the point's work stays one basic block in source order.  Issuing the next point's
+          //  gathers ahead of these atomics was measured: no gain.)
+          const ct_f2 cw01 = {p.cw[0], p.cw[1]}, cw23 = {p.cw[2], p.cw[3]};
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
             int* Tc = accq + cj * G + p.base;
             const float fq = fv[cj][i] * iq[cj];          // power-of-two scale: exact
-#pragma unroll
-            for (int v = 0; v < 4; ++v) atomicAdd(Tc + off[v], __float2int_rn(fq * p.cw[v]));
+            const ct_f2 p01 = cw01 * fq, p23 = cw23 * fq; // v_pk_mul_f32
+            atomicAdd(Tc + off[0], cvt_rpi(p01.x));
+            atomicAdd(Tc + off[1], cvt_rpi(p01.y));
+            atomicAdd(Tc + off[2], cvt_rpi(p23.x));
+            atomicAdd(Tc + off[3], cvt_rpi(p23.y));
           }
           __builtin_amdgcn_sched_barrier(0);     // one point at a time: keeps the live set inside the register budget
         }
@@ -337,7 +374,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
       float4 o;
       if (fixed) o = make_float4((float)r.x * q, (float)r.y * q, (float)r.z * q, (float)r.w * q);
       else o = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
-      ((float4*)gout)[t] = o;
+      st_stream4(gout + ((size_t)t << 2), o);
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
     // (the next chunk's staging overwrites T4 only: every gather of this chunk is behind the barrier above)
@@ -351,8 +388,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
       ox.z = gs[u][2][0] * ct_key_mask(tx.z); ox.w = gs[u][3][0] * ct_key_mask(tx.w);
       oy.x = gs[u][0][1] * ct_key_mask(ty.x); oy.y = gs[u][1][1] * ct_key_mask(ty.y);
       oy.z = gs[u][2][1] * ct_key_mask(ty.z); oy.w = gs[u][3][1] * ct_key_mask(ty.w);
-      *(float4*)(a.g_pos + (bh * 2 + 0) * N + n0[u]) = ox;
-      *(float4*)(a.g_pos + (bh * 2 + 1) * N + n0[u]) = oy;
+      st_stream4(a.g_pos + (bh * 2 + 0) * N + n0[u], ox);
+      st_stream4(a.g_pos + (bh * 2 + 1) * N + n0[u], oy);
     }
   }
 }
@@ -370,6 +407,11 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused_kernel(RasterA
 //   QPT == 0: any N; the partial g_keys of the chunks go through memory.
 //   grid = (1, H, B)
 // ---------------------------------------------------------------------------
+// bit pattern of an empty / already claimed cell in the staged z tile: a NaN with an all-ones payload.  z itself is
+// never NaN (a NaN product does not beat the zero floor in the forward), and a product equals this pattern only if
+// a feature is that very NaN.
+constexpr unsigned kNoMatch = 0x7FFFFFFFu;
+
 template <bool HAS_PAD, bool CLAIMS, int WT>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
                                                int c0, int cc, int n0, const float (&kx)[4], const float (&ky)[4],
@@ -379,79 +421,89 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
   float pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
-  for (int cg0 = 0; cg0 < cc; cg0 += 2) {
-    float fa[4], fb[4];
-    {
-      const float4 ta = *(const float4*)(a.src + (bh * a.C + c0 + cg0) * (size_t)N + n0);
-      const float4 tb = *(const float4*)(a.src + (bh * a.C + c0 + cg0 + 1) * (size_t)N + n0);
-      fa[0] = ta.x; fa[1] = ta.y; fa[2] = ta.z; fa[3] = ta.w;
-      fb[0] = tb.x; fb[1] = tb.y; fb[2] = tb.z; fb[3] = tb.w;
+  // 4 channels (two {z,z,g,g} pairs) per step: the corner weights of a point are computed once per 4 channels.
+  // (Requesting the next step's rows before this step is processed was measured: the 16 extra registers spill, 73 -> 102 us.)
+  for (int cg0 = 0; cg0 < cc; cg0 += 4) {
+    float fv[4][4];          // [channel][point]
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)N;      // wave-uniform
+      const float4 t = ld_stream4(row + n0);
+      fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
     }
     float4* Zc = ZG + (size_t)(cg0 >> 1) * G;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       Pt2 p;
       pt2_from_keys(kx[i], ky[i], g, W1, p);
-      float4* Zp = Zc + p.base;
-      const float xa = HAS_PAD ? fa[i] * pv[i] : fa[i];
-      const float xb = HAS_PAD ? fb[i] * pv[i] : fb[i];
-      float4 zg[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) zg[v] = Zp[off[v]];
-      float gfa = 0.0f, gfb = 0.0f;
       float gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (!CLAIMS) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float4* Zp = Zc + (size_t)pr * G + p.base;
+        const float xa = HAS_PAD ? fv[2 * pr][i] * pv[i] : fv[2 * pr][i];
+        const float xb = HAS_PAD ? fv[2 * pr + 1][i] * pv[i] : fv[2 * pr + 1][i];
+        float4 zg[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const unsigned ba = __float_as_uint(xa * p.cw[v]), bb = __float_as_uint(xb * p.cw[v]);
-          const unsigned za = __float_as_uint(zg[v].x), zb = __float_as_uint(zg[v].y);
-          // a non-positive product has its sign bit set or is zero: never bit-equal to a positive z
-          const bool ma = (ba == za) & (za != 0u), mb = (bb == zb) & (zb != 0u);
-          nm += (int)ma + (int)mb;
-          const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
-          gfa += ga * p.cw[v];
-          gfb += gb * p.cw[v];
-          gw[v] += ga * xa;
-          gw[v] += gb * xb;
+          zg[v] = Zp[off[v]];
+          // (whole 16-byte reads: keeps the compiler from splitting them into a narrow read plus conditional ones)
+          asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
         }
-      } else {
-        unsigned ba[4], bb[4];
-        bool ma[4], mb[4];
-        bool any = false;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          ba[v] = __float_as_uint(xa * p.cw[v]);
-          bb[v] = __float_as_uint(xb * p.cw[v]);
-          const unsigned za = __float_as_uint(zg[v].x), zb = __float_as_uint(zg[v].y);
-          ma[v] = (ba[v] == za) & (za != 0u);
-          mb[v] = (bb[v] == zb) & (zb != 0u);
-          any = any | ma[v] | mb[v];
-        }
-        if (any) {
+        float gfa = 0.0f, gfb = 0.0f;
+        if (!CLAIMS) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            unsigned* zw = (unsigned*)(Zp + off[v]);
-            const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : 0xFFFFFFFFu, 0u);
-            const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : 0xFFFFFFFFu, 0u);
-            const float ga = (ma[v] & (oa == ba[v])) ? zg[v].z : 0.0f;
-            const float gb = (mb[v] & (ob == bb[v])) ? zg[v].w : 0.0f;
-            gfa += ga * p.cw[v];
-            gfb += gb * p.cw[v];
-            gw[v] += ga * xa;
-            gw[v] += gb * xb;
+            // the products are formed exactly as the forward formed them (one rounding: no fma).  Empty cells were
+            // staged as kNoMatch, so bit-equality alone is the winner test.
+            const unsigned ba = __float_as_uint(xa * p.cw[v]), bb = __float_as_uint(xb * p.cw[v]);
+            const bool ma = ba == __float_as_uint(zg[v].x), mb = bb == __float_as_uint(zg[v].y);
+            nm += (int)ma;       // (add-with-carry of the compare mask: one instruction each ...
+            nm += (int)mb;
+            asm volatile("" : "+v"(nm));      //  ... issued here: otherwise all 32 masks of a point are kept for a final sum)
+            const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
+            gfa = __builtin_fmaf(ga, p.cw[v], gfa);
+            gfb = __builtin_fmaf(gb, p.cw[v], gfb);
+            gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
+          }
+        } else {
+          unsigned ba[4], bb[4];
+          bool ma[4], mb[4];
+          bool any = false;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            ba[v] = __float_as_uint(xa * p.cw[v]);
+            bb[v] = __float_as_uint(xb * p.cw[v]);
+            ma[v] = ba[v] == __float_as_uint(zg[v].x);
+            mb[v] = bb[v] == __float_as_uint(zg[v].y);
+            any = any | ma[v] | mb[v];
+          }
+          if (any) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              // claim: the first tied contribution to swap the cell's z word to kNoMatch wins it
+              unsigned* zw = (unsigned*)(Zp + off[v]);
+              const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : kNoMatch, kNoMatch);
+              const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : kNoMatch, kNoMatch);
+              const float ga = (ma[v] & (oa == ba[v])) ? zg[v].z : 0.0f;
+              const float gb = (mb[v] & (ob == bb[v])) ? zg[v].w : 0.0f;
+              gfa = __builtin_fmaf(ga, p.cw[v], gfa);
+              gfb = __builtin_fmaf(gb, p.cw[v], gfb);
+              gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
+            }
           }
         }
+        fv[2 * pr][i] = HAS_PAD ? gfa * pv[i] : gfa;
+        fv[2 * pr + 1][i] = HAS_PAD ? gfb * pv[i] : gfb;
       }
-      fa[i] = HAS_PAD ? gfa * pv[i] : gfa;
-      fb[i] = HAS_PAD ? gfb * pv[i] : gfb;
-      gs[i][0] += (gw[1] - gw[0]) * p.w0y + (gw[3] - gw[2]) * p.w1y;
-      gs[i][1] += (gw[2] - gw[0]) * p.w0x + (gw[3] - gw[1]) * p.w1x;
+      gs[i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[i][0]));
+      gs[i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[i][1]));
       // pin the point's results here (see slice_bwd_fused_kernel): one point at a time keeps the live set small
-      asm volatile("" : "+v"(gs[i][0]), "+v"(gs[i][1]), "+v"(fa[i]), "+v"(fb[i]));
+      asm volatile("" : "+v"(gs[i][0]), "+v"(gs[i][1]), "+v"(fv[0][i]), "+v"(fv[1][i]), "+v"(fv[2][i]), "+v"(fv[3][i]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    *(float4*)(a.dst + (bh * a.C + c0 + cg0) * (size_t)N + n0) = make_float4(fa[0], fa[1], fa[2], fa[3]);
-    *(float4*)(a.dst + (bh * a.C + c0 + cg0 + 1) * (size_t)N + n0) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+      st_stream4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)N + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]));
   }
 }
 
@@ -471,9 +523,12 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
       const int cp = t / G, cell = t - cp * G;
       const size_t o = (size_t)(cp * 2) * G + cell;
-      const float z0 = zin[o], z1 = zin[o + G];
-      ZG[t] = make_float4(z0, z1, gin[o], gin[o + G]);
-      if (!CLAIMS) nz += (__float_as_uint(z0) != 0u) + (__float_as_uint(z1) != 0u);
+      // an empty cell (z = 0: nothing beat the zero floor) is staged as kNoMatch, a bit pattern no product of finite
+      // inputs has, so that the winner test in the loop is one compare
+      const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
+      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
+                          ld_stream(gin + o + G));
+      if (!CLAIMS) nz += (z0 != 0u) + (z1 != 0u);
     }
     __syncthreads();
     if constexpr (QPT > 0) {
@@ -596,7 +651,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
   for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
     const int cq = t / G, cell = t - cq * G;
     const float* p = gin + (size_t)(cq * 4) * G + cell;
-    T4[t] = make_float4(p[0], p[G], p[2 * (size_t)G], p[3 * (size_t)G]);
+    T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
   }
   __syncthreads();
   const int nq = N >> 2;
@@ -645,7 +700,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
       }
 #pragma unroll
       for (int cj = 0; cj < 4; ++cj)
-        *(float4*)(dst + (size_t)(cq * 4 + cj) * N + n0) = make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]);
+        st_stream4(dst + (size_t)(cq * 4 + cj) * N + n0, make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]));
     }
   }
 }

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import subprocess, re, sys
 from cloud_transformers_amd import _lib
-_lib.HIPCC_FLAGS.append('-Rpass-analysis=kernel-resource-usage')
+_lib.HIPCC_FLAGS.append("-Rpass-analysis=kernel-resource-usage"); _lib.HIPCC_FLAGS.extend(os.environ.get("CT_EXTRA", "").split())
 import io, contextlib
 try:
     r = subprocess.run([_lib._hipcc()] + _lib.HIPCC_FLAGS + ["-I", _lib.INCLUDE, _lib.CSRC + "/ct_raster.hip", "-o", "/tmp/raster_only.so"], capture_output=True, text=True)
