@@ -104,6 +104,21 @@ __device__ __forceinline__ float ct_load_pad(const void* pad, int pad_dtype, siz
   return 1.0f;
 }
 
+typedef float ct_f4 __attribute__((ext_vector_type(4)));
+
+// Streaming (read-once / write-once) global accesses carry the non-temporal hint, so that what IS re-read inside a
+// kernel — keys, and the second quad's g_out rows of the fused Slice backward — stays in the XCD's 4 MiB L2 instead
+// of being pushed out by the streams (the re-reads then never reach the memory-side counters, nor HBM).
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+  const ct_f4 v = __builtin_nontemporal_load((const ct_f4*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream4(float* p, float4 v) {
+  const ct_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (ct_f4*)p);
+}
+__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+
 // hipGetLastError() is sticky across unrelated runtime calls of the host
 // framework (e.g. a hipEventQuery that returned hipErrorNotReady), so every
 // entry point clears it first (CT_CLEAR_ERROR) and checks after its launches.

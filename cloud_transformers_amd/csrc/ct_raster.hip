@@ -1341,6 +1341,10 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
   dim3 grid(p.nchunks, a.H, a.B);
   if (p.lds_tile) {
     if (sum) {
+      if constexpr (DIM == 2 && FROM_KEYS) {
+        const int r = run_scatter_add_hot(a, g, st);
+        if (r != CT_EINVAL) return r;
+      }
       constexpr int kRegCh = 8;
       const bool aligned = ((((uintptr_t)a.src) | ((uintptr_t)a.pos.keys) | ((uintptr_t)a.tile_out)) & 15) == 0;
       if (FROM_KEYS && aligned && (a.N & 3) == 0 && a.N <= 4096 && (g.G & 3) == 0) {
@@ -1480,10 +1484,41 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   a.CC = hp.CC; a.nchunks = hp.nchunks;
   dim3 wgrid(1, a.H, a.B);
   const int nq = a.N >> 2;
-#define CT_MK_SLICE_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(slice_bwd_fused_kernel, PADV, WTV, QPTV)
+#define CT_MK_SLICE_BWD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true>
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   note("slice_bwd_fused");
+  return CT_OK;
+}
+
+// The scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid) on the fused kernel without its gather side.
+int run_scatter_add_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
+  if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  HotPlan hp;
+  if (!hot_chunks(a.C, (size_t)g.G * 4, (size_t)(g.G + a.C + 1) * 4, hp)) return CT_EINVAL;
+  a.CC = hp.CC; a.nchunks = hp.nchunks;
+  dim3 wgrid(1, a.H, a.B);
+  const int nq = a.N >> 2;
+#define CT_MK_SCATTER_ADD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, false>
+  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SCATTER_ADD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  else CT_LAUNCH_HOT_(CT_MK_SCATTER_ADD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
+  note("scatter_add_fused");
+  return CT_OK;
+}
+
+// Splat(sum) backward in one pass.  CT_EINVAL: not eligible.
+int run_splat_sum_bwd_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos | (uintptr_t)a.tile_in;
+  if (!hot_shape_ok(a, g.G, bits)) return CT_EINVAL;
+  const size_t lds = (size_t)a.C * g.G * 4;
+  if (lds > (size_t)kBigLdsBytes) return CT_EINVAL;
+  a.nsplit = pick_nsplit(a.B, a.H, 1, a.N);
+  const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
+  dim3 grid(a.nsplit, a.H, a.B);
+#define CT_MK_SPLAT_SUM_BWD(PADV, WTV) CT_HOT_KERNEL0(splat_sum_bwd_kernel, PADV, WTV)
+  CT_LAUNCH_HOT_(CT_MK_SPLAT_SUM_BWD, grid, hot_threads(nq), lds, st, a, g);
+  note("splat_sum_bwd_hot");
   return CT_OK;
 }
 
@@ -1776,6 +1811,15 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
       const int r = run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st);
       if (r != CT_EINVAL) return r;
     }
+    if constexpr (FROM_KEYS) {
+      if (reduce == CT_REDUCE_SUM && dim == 2) {
+        RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
+        a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = g_grid;
+        a.accumulate = 1;
+        const int r = run_splat_sum_bwd_hot(a, make_grid<2>(W), st);
+        if (r != CT_EINVAL) return r;
+      }
+    }
     float* tmp = (float*)((char*)ws + head);
     const int r = splat_bwd_impl<FROM_KEYS>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, tmp, ws, head, B, H, C, N, dim, W,
                                             reduce, st, 0);
@@ -1796,6 +1840,12 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
   } else if (reduce == CT_REDUCE_SUM) {
     // linear op: g_feat = Slice(g_grid), gw = sum_c g_grid * feat
     a.tile_in = g_grid;
+    if constexpr (FROM_KEYS) {
+      if (dim == 2) {
+        const int r = run_splat_sum_bwd_hot(a, make_grid<2>(W), st);
+        if (r != CT_EINVAL) return r;
+      }
+    }
     int r = dim == 2 ? run_gather<2, FROM_KEYS>(a, W, st) : run_gather<3, FROM_KEYS>(a, W, st);
     if (r != CT_OK) return r;
     return dim == 2 ? run_gather_gw<2, FROM_KEYS>(a, W, st) : run_gather_gw<3, FROM_KEYS>(a, W, st);

@@ -68,20 +68,6 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 }
 
 typedef float ct_f2 __attribute__((ext_vector_type(2)));
-typedef float ct_f4 __attribute__((ext_vector_type(4)));
-
-// Streaming (read-once / write-once) global accesses carry the non-temporal hint, so that what IS re-read inside a
-// kernel — keys, and the second quad's g_out rows of the fused Slice backward — stays in the XCD's 4 MiB L2 instead
-// of being pushed out by the streams (the re-reads then never reach the memory-side counters, nor HBM).
-__device__ __forceinline__ float4 ld_stream4(const float* p) {
-  const ct_f4 v = __builtin_nontemporal_load((const ct_f4*)p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_stream4(float* p, float4 v) {
-  const ct_f4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, (ct_f4*)p);
-}
-__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
 
 
 // per-axis terms and corner weights of one 2D point
@@ -146,13 +132,14 @@ __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const
   }
 }
 
-template <bool HAS_PAD, int WT, int QPT>
+// GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
+template <bool HAS_PAD, int WT, int QPT, bool GATHER>
 __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g) {
   extern __shared__ __align__(16) float lds[];
   // WT > 0: square WT x WT grid known at compile time (corner offsets become instruction immediates)
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], CC = a.CC, N = a.N;
   float4* T4 = (float4*)lds;
-  int* acc = (int*)(lds + (size_t)CC * G);
+  int* acc = (int*)(lds + (GATHER ? (size_t)CC * G : 0));
   int* cnt = acc + (size_t)CC * G;
   unsigned* s_max = (unsigned*)(cnt + G);
   unsigned* s_k = s_max + a.C;
@@ -220,10 +207,12 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
     const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
     float* gout = a.tile_out + (bh * a.C + c0) * (size_t)G;
     // stage the conv chunk channel-interleaved (4 coalesced dword loads -> one conflict-free ds_write_b128)
-    for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
-      const int cq = t / G, cell = t - cq * G;
-      const float* p = gin + (size_t)(cq * 4) * G + cell;
-      T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+    if (GATHER) {
+      for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
+        const int cq = t / G, cell = t - cq * G;
+        const float* p = gin + (size_t)(cq * 4) * G + cell;
+        T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+      }
     }
     if (chunk == 0)
       for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
@@ -318,23 +307,25 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
         for (int i = 0; i < 4; ++i) {
           Pt2 p;
           pt2_from_keys(kx[i], ky[i], g, W1, p);
-          float4 cv[4];
+          if (GATHER) {
+            float4 cv[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[v]];
-          float gw[4];
+            for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[v]];
+            float gw[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            float s = cv[v].x * fv[0][i];
-            s = __builtin_fmaf(cv[v].y, fv[1][i], s);
-            s = __builtin_fmaf(cv[v].z, fv[2][i], s);
-            s = __builtin_fmaf(cv[v].w, fv[3][i], s);
-            gw[v] = s;
+            for (int v = 0; v < 4; ++v) {
+              float s = cv[v].x * fv[0][i];
+              s = __builtin_fmaf(cv[v].y, fv[1][i], s);
+              s = __builtin_fmaf(cv[v].z, fv[2][i], s);
+              s = __builtin_fmaf(cv[v].w, fv[3][i], s);
+              gw[v] = s;
+            }
+            gs[u][i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[u][i][0]));
+            gs[u][i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[u][i][1]));
+            // pin the two sums here: without it the compiler sinks the whole gather -> g_keys chain of a point past
+            // the following points' work and spills the 16 gathered values meanwhile
+            asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]));
           }
-          gs[u][i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[u][i][0]));
-          gs[u][i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[u][i][1]));
-          // pin the two sums here: without it the compiler sinks the whole gather -> g_keys chain of a point past the
-          // following points' work and spills the 16 gathered values meanwhile
-          asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]));
           // (threads past the end of the cloud hold zeros: they add 0 to the cells of the cloud's first quad — no
           //  branch here, so that the point's work stays one basic block in source order.  Issuing the next point's
           //  gathers ahead of these atomics was measured: no gain.)
@@ -381,7 +372,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
   }
 #pragma unroll
   for (int u = 0; u < QPT; ++u) {
-    if (active[u]) {
+    if (GATHER && active[u]) {
       const float4 tx = *(const float4*)(keyx + n0[u]), ty = *(const float4*)(keyy + n0[u]);
       float4 ox, oy;
       ox.x = gs[u][0][0] * ct_key_mask(tx.x); ox.y = gs[u][1][0] * ct_key_mask(tx.y);
@@ -702,5 +693,108 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
       for (int cj = 0; cj < 4; ++cj)
         st_stream4(dst + (size_t)(cq * 4 + cj) * N + n0, make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]));
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KS: Splat(sum) backward in one pass (linear op: g_feat = Slice(g_grid), corner cotangents gw = sum_c g_grid * feat):
+//   the g_grid tile of ALL channels of the plane channel-interleaved in LDS, one ds_read_b128 per (point, corner,
+//   4 channels) feeds both results; g_keys is written once (or accumulated, a.accumulate).
+//   grid = (nsplit, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD, int WT>
+__global__ void __launch_bounds__(kHotThreads, 4) splat_sum_bwd_kernel(RasterArgs a, GridW<2> g) {
+  extern __shared__ __align__(16) float lds[];
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
+  float4* T4 = (float4*)lds;
+  const int sp = blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int tid = threadIdx.x;
+  const int off[4] = {0, W1, 1, W1 + 1};
+  const float* gin = a.tile_in + bh * C * (size_t)G;
+  for (int t = tid; t < (C >> 2) * G; t += blockDim.x) {
+    const int cq = t / G, cell = t - cq * G;
+    const float* p = gin + (size_t)(cq * 4) * G + cell;
+    T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+  }
+  __syncthreads();
+  const int nq = N >> 2;
+  const int per = (nq + a.nsplit - 1) / a.nsplit;
+  const int q_beg = sp * per, q_end = min(nq, q_beg + per);
+  for (int q = q_beg + tid; q < q_end; q += blockDim.x) {
+    const int n0 = q << 2;
+    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+    const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+    float pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+    float gs[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
+    for (int cq = 0; cq < (C >> 2); ++cq) {
+      const float4* Tq = T4 + (size_t)cq * G;
+      float fv[4][4];       // [channel][point]: feat in, g_feat out
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const float* row = a.src + (bh * C + cq * 4 + cj) * (size_t)N;
+        const float4 t = ld_stream4(row + n0);
+        fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Pt2 p;
+        pt2_from_keys(kx[i], ky[i], g, W1, p);
+        float4 cv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[v]];
+        float f[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) f[cj] = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+        float gw[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float s = cv[v].x * f[0];
+          s = __builtin_fmaf(cv[v].y, f[1], s);
+          s = __builtin_fmaf(cv[v].z, f[2], s);
+          s = __builtin_fmaf(cv[v].w, f[3], s);
+          gw[v] = s;
+        }
+        gs[i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[i][0]));
+        gs[i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[i][1]));
+        // g_feat: the reference's sum over corners, ((v0 + v1) + v2) + v3
+        float s0 = cv[0].x * p.cw[0], s1 = cv[0].y * p.cw[0], s2 = cv[0].z * p.cw[0], s3 = cv[0].w * p.cw[0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) {
+          s0 += cv[v].x * p.cw[v];
+          s1 += cv[v].y * p.cw[v];
+          s2 += cv[v].z * p.cw[v];
+          s3 += cv[v].w * p.cw[v];
+        }
+        fv[0][i] = HAS_PAD ? s0 * pv[i] : s0;
+        fv[1][i] = HAS_PAD ? s1 * pv[i] : s1;
+        fv[2][i] = HAS_PAD ? s2 * pv[i] : s2;
+        fv[3][i] = HAS_PAD ? s3 * pv[i] : s3;
+        asm volatile("" : "+v"(gs[i][0]), "+v"(gs[i][1]), "+v"(fv[0][i]), "+v"(fv[1][i]), "+v"(fv[2][i]), "+v"(fv[3][i]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj)
+        st_stream4(a.dst + (bh * C + cq * 4 + cj) * (size_t)N + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]));
+    }
+    float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
+                            gs[2][0] * ct_key_mask(kx[2]), gs[3][0] * ct_key_mask(kx[3]));
+    float4 oy = make_float4(gs[0][1] * ct_key_mask(ky[0]), gs[1][1] * ct_key_mask(ky[1]),
+                            gs[2][1] * ct_key_mask(ky[2]), gs[3][1] * ct_key_mask(ky[3]));
+    float* px = a.g_pos + (bh * 2 + 0) * N + n0;
+    float* py = a.g_pos + (bh * 2 + 1) * N + n0;
+    if (a.accumulate) {
+      const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+      ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
+      oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
+    }
+    *(float4*)px = ox;
+    *(float4*)py = oy;
   }
 }

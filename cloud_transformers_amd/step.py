@@ -84,6 +84,8 @@ class SplatSliceStep:
     KERNEL_OF = {
         "scatter_quad_max": "scatter_quad_kernel<2, false, false>",
         "scatter_add_fx_reg": "scatter_add_fx_reg_kernel",
+        "scatter_add_fused": "slice_bwd_fused_kernel<false, 32, 2, false>",
+        "splat_sum_bwd_hot": "splat_sum_bwd_kernel",
         "gather_ci": "gather_ci_kernel",
         "gather_quad": "quad_kernel<2, 0,",
         "slice_bwd_fused": "slice_bwd_fused_kernel",

@@ -83,8 +83,8 @@ def test_headline_shape_fwd_bwd_against_oracle_planes(C, reduce, flags):
     tags = step.launch_tags()
     assert tags["slice_fwd"] == "gather_ci", tags
     assert tags["slice_bwd"] == "slice_bwd_fused", tags
-    assert tags["splat_fwd"] == ("scatter_quad_max" if reduce == "max" else "scatter_add_fx_reg"), tags
-    assert tags["splat_bwd"] == ("splat_max_bwd_hot" if reduce == "max" else "gather_ci+gather_gw_quad+add_inplace"), tags
+    assert tags["splat_fwd"] == ("scatter_quad_max" if reduce == "max" else "scatter_add_fused"), tags
+    assert tags["splat_bwd"] == ("splat_max_bwd_hot" if reduce == "max" else "splat_sum_bwd_hot"), tags
     step.run()                                    # (launch_tags re-ran the passes: g_keys was accumulated twice)
     torch.cuda.synchronize()
     got = (step.z, step.out, step.g_z, step.g_feat, step.g_keys())
