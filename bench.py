@@ -322,6 +322,8 @@ def run_ddp_step(args):
 
     for _ in range(max(1, args.warmup)):
         one()
+    from cloud_transformers_amd import ops
+    coll0 = ops.sync_stats_collectives()
     barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -332,7 +334,6 @@ def run_ddp_step(args):
     dt = max_over_ranks(dist, time.perf_counter() - t0)
     if rank == 0:
         nbytes = sum(p.numel() for p in net.parameters()) * 4
-        from cloud_transformers_amd import ops
         out = {
             "metric": METRIC, "value": world * B * N / (dt / args.steps), "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -342,8 +343,8 @@ def run_ddp_step(args):
                                    % (nbytes / 4e6, B, N),
                        "per_gpu_batch": B, "parallelism": "dp%d" % world, "world_size_seen": world,
                        "gradient_allreduce_MB_per_step": nbytes / 1e6,
-                       "sync_bn_collectives_per_step": getattr(ops, "sync_stats_collectives", lambda: None)(),
-                       "loss": float(loss)},
+                       "norm_statistics_collectives_per_step": (ops.sync_stats_collectives() - coll0) / args.steps,
+                       "loss": float(loss.detach())},
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

@@ -58,7 +58,40 @@ struct BnArgs {
   const float* residual; // nullable: added after the ReLU (the union block's skip connection)
   long long rbs;
   long long* num_batches_tracked;   // nullable: incremented once per launch, as nn.BatchNorm1d.forward does
+  // Synchronised statistics (SyncBatchNorm under data parallelism) split the pass around the exchange between ranks:
+  //   mode 1: local statistics only — save_mean[c] = mean, save_rstd[c] = sum (x - mean)^2 — nothing else is written;
+  //   mode 2: normalise with the statistics of the whole job: every rank's (mean, sum of squares, count) as gathered
+  //           by ONE all_gather — g_mean[r * g_stride + c], g_m2[r * g_stride + c], g_count[r * g_stride], r < world —
+  //           merged here, per channel, by the parallel-variance rule (no host arithmetic between the collective and
+  //           this launch); save_mean / save_rstd receive the merged mean and rsqrt(var + eps), count_out[0] the
+  //           job's number of values per channel;
+  //   mode 0: both in one pass over this rank's batch (the channel stays in registers in between).
+  int mode;
+  float* count_out;      // mode 1: this rank's B*N (written by channel 0); mode 2: the job's total (nullable)
+  const float* g_mean;
+  const float* g_m2;
+  const float* g_count;
+  int world;
+  long long g_stride;
 };
+
+// mode 2: merge the ranks' statistics of channel c (Chan et al.: M2 = sum M2_r + sum n_r (mean_r - mean)^2)
+__device__ __forceinline__ void merge_rank_stats(const BnArgs& a, int c, float& mu, float& var, float& M) {
+  float total = 0.f, acc = 0.f;
+  for (int r = 0; r < a.world; ++r) {
+    const float n = a.g_count[r * a.g_stride];
+    total += n;
+    acc += a.g_mean[r * a.g_stride + c] * n;
+  }
+  mu = acc / total;
+  float m2 = 0.f;
+  for (int r = 0; r < a.world; ++r) {
+    const float d = a.g_mean[r * a.g_stride + c] - mu;
+    m2 += a.g_m2[r * a.g_stride + c] + a.g_count[r * a.g_stride] * d * d;
+  }
+  var = m2 / total;
+  M = total;
+}
 
 // float offset of quad q (over the B rows of channel c, N/4 quads each) in a tensor whose batch stride is bs floats
 __device__ __forceinline__ size_t quad_offset(int q, int nq, int c, long long bs, int N) {
@@ -77,23 +110,37 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* _
     const int q = threadIdx.x + k * kThreads;
     v[k] = q < total ? *reinterpret_cast<const float4*>(a.x + quad_offset(q, nq, c, a.xbs, a.N)) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float s[1] = {0.f};
+  float M = (float)a.B * (float)a.N;
+  float mu, var;
+  if (a.mode != 2) {
+    float s[1] = {0.f};
 #pragma unroll
-  for (int k = 0; k < NV; ++k) s[0] += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-  block_sum<1>(s, red);
-  const float M = (float)a.B * (float)a.N;
-  const float mu = s[0] / M;
-  float ss[1] = {0.f};
+    for (int k = 0; k < NV; ++k) s[0] += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    block_sum<1>(s, red);
+    mu = s[0] / M;
+    float ss[1] = {0.f};
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int q = threadIdx.x + k * kThreads;
-    if (q < total) {
-      const float dx = v[k].x - mu, dy = v[k].y - mu, dz = v[k].z - mu, dw = v[k].w - mu;
-      ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    for (int k = 0; k < NV; ++k) {
+      const int q = threadIdx.x + k * kThreads;
+      if (q < total) {
+        const float dx = v[k].x - mu, dy = v[k].y - mu, dz = v[k].z - mu, dw = v[k].w - mu;
+        ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
     }
+    block_sum<1>(ss, red);
+    if (a.mode == 1) {          // local statistics for the exchange
+      if (threadIdx.x == 0) {
+        a.save_mean[c] = mu;
+        a.save_rstd[c] = ss[0];
+        if (c == 0 && a.count_out) a.count_out[0] = M;
+      }
+      return;
+    }
+    var = ss[0] / M;
+  } else {
+    merge_rank_stats(a, c, mu, var, M);
+    if (threadIdx.x == 0 && c == 0 && a.count_out) a.count_out[0] = M;
   }
-  block_sum<1>(ss, red);
-  const float var = ss[0] / M;
   const float rs = rsqrtf(var + a.eps);
   if (threadIdx.x == 0) {
     a.save_mean[c] = mu;
@@ -138,6 +185,14 @@ struct BnBwdArgs {
   int B, C, N;
   int relu;
   long long xbs, gybs, gxbs;   // batch strides in floats
+  // mode 1: the two per-channel sums only (g_bias = sum g', g_weight = sum g' * xhat over THIS rank's batch);
+  // mode 2: gx from the job-wide sums sum0[c] / sum1[c] (this rank's sums all-reduced in ONE collective) over count[0]
+  //         values per channel (g_weight / g_bias not written);
+  // mode 0: both in one pass.
+  int mode;
+  const float* sum0;
+  const float* sum1;
+  const float* count;
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * (weight * rstd) + bias, same operation
@@ -169,17 +224,24 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdArgs a) {
                        masked(gv.z, xv.z - mu, gfw, be, a.relu), masked(gv.w, xv.w - mu, gfw, be, a.relu));
   }
   float s[2] = {0.f, 0.f};
+  float M = (float)a.B * (float)a.N;
+  if (a.mode != 2) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    s[0] += (g[k].x + g[k].y) + (g[k].z + g[k].w);
-    s[1] += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+    for (int k = 0; k < NV; ++k) {
+      s[0] += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+      s[1] += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+    }
+    block_sum<2>(s, red);
+    if (threadIdx.x == 0) {
+      a.g_bias[c] = s[0];
+      a.g_weight[c] = s[1];
+    }
+    if (a.mode == 1) return;      // this rank's sums for the exchange
+  } else {
+    s[0] = a.sum0[c];
+    s[1] = a.sum1[c];
+    M = a.count[0];
   }
-  block_sum<2>(s, red);
-  if (threadIdx.x == 0) {
-    a.g_bias[c] = s[0];
-    a.g_weight[c] = s[1];
-  }
-  const float M = (float)a.B * (float)a.N;
   const float m0 = s[0] / M, m1 = s[1] / M;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -209,29 +271,43 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* 
   __shared__ float red[1][kWaves];
   const int c = blockIdx.x;
   const int total = chan_items<VEC>(a.B, a.N);
-  float s[1] = {0.f};
-  for (int i = threadIdx.x; i < total; i += kThreads) {
-    const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
-    if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p); s[0] += (v.x + v.y) + (v.z + v.w); }
-    else s[0] += p[0];
-  }
-  block_sum<1>(s, red);
-  const float M = (float)a.B * (float)a.N;
-  const float mu = s[0] / M;
-  float ss[1] = {0.f};
-  for (int i = threadIdx.x; i < total; i += kThreads) {
-    const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
-    if (VEC) {
-      const float4 v = *reinterpret_cast<const float4*>(p);
-      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-      ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    } else {
-      const float d = p[0] - mu;
-      ss[0] += d * d;
+  float M = (float)a.B * (float)a.N;
+  float mu, var;
+  if (a.mode != 2) {
+    float s[1] = {0.f};
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+      const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+      if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p); s[0] += (v.x + v.y) + (v.z + v.w); }
+      else s[0] += p[0];
     }
+    block_sum<1>(s, red);
+    mu = s[0] / M;
+    float ss[1] = {0.f};
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+      const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+        ss[0] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      } else {
+        const float d = p[0] - mu;
+        ss[0] += d * d;
+      }
+    }
+    block_sum<1>(ss, red);
+    if (a.mode == 1) {          // local statistics for the exchange
+      if (threadIdx.x == 0) {
+        a.save_mean[c] = mu;
+        a.save_rstd[c] = ss[0];
+        if (c == 0 && a.count_out) a.count_out[0] = M;
+      }
+      return;
+    }
+    var = ss[0] / M;
+  } else {
+    merge_rank_stats(a, c, mu, var, M);
+    if (threadIdx.x == 0 && c == 0 && a.count_out) a.count_out[0] = M;
   }
-  block_sum<1>(ss, red);
-  const float var = ss[0] / M;
   const float rs = rsqrtf(var + a.eps);
   if (threadIdx.x == 0) {
     a.save_mean[c] = mu;
@@ -273,27 +349,34 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
   const float gfw = a.weight[c] * rs;
   const float be = a.bias[c];
   float s[2] = {0.f, 0.f};
-  for (int i = threadIdx.x; i < total; i += kThreads) {
-    const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
-    const float* pg = a.gy + item_offset<VEC>(i, a.N, c, a.gybs);
-    if (VEC) {
-      const float4 xv = *reinterpret_cast<const float4*>(px), gv = *reinterpret_cast<const float4*>(pg);
-      const float g0 = masked(gv.x, xv.x - mu, gfw, be, a.relu), g1 = masked(gv.y, xv.y - mu, gfw, be, a.relu);
-      const float g2 = masked(gv.z, xv.z - mu, gfw, be, a.relu), g3 = masked(gv.w, xv.w - mu, gfw, be, a.relu);
-      s[0] += (g0 + g1) + (g2 + g3);
-      s[1] += (g0 * ((xv.x - mu) * rs) + g1 * ((xv.y - mu) * rs)) + (g2 * ((xv.z - mu) * rs) + g3 * ((xv.w - mu) * rs));
-    } else {
-      const float g0 = masked(pg[0], px[0] - mu, gfw, be, a.relu);
-      s[0] += g0;
-      s[1] += g0 * ((px[0] - mu) * rs);
+  float M = (float)a.B * (float)a.N;
+  if (a.mode != 2) {
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+      const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
+      const float* pg = a.gy + item_offset<VEC>(i, a.N, c, a.gybs);
+      if (VEC) {
+        const float4 xv = *reinterpret_cast<const float4*>(px), gv = *reinterpret_cast<const float4*>(pg);
+        const float g0 = masked(gv.x, xv.x - mu, gfw, be, a.relu), g1 = masked(gv.y, xv.y - mu, gfw, be, a.relu);
+        const float g2 = masked(gv.z, xv.z - mu, gfw, be, a.relu), g3 = masked(gv.w, xv.w - mu, gfw, be, a.relu);
+        s[0] += (g0 + g1) + (g2 + g3);
+        s[1] += (g0 * ((xv.x - mu) * rs) + g1 * ((xv.y - mu) * rs)) + (g2 * ((xv.z - mu) * rs) + g3 * ((xv.w - mu) * rs));
+      } else {
+        const float g0 = masked(pg[0], px[0] - mu, gfw, be, a.relu);
+        s[0] += g0;
+        s[1] += g0 * ((px[0] - mu) * rs);
+      }
     }
+    block_sum<2>(s, red);
+    if (threadIdx.x == 0) {
+      a.g_bias[c] = s[0];
+      a.g_weight[c] = s[1];
+    }
+    if (a.mode == 1) return;      // this rank's sums for the exchange
+  } else {
+    s[0] = a.sum0[c];
+    s[1] = a.sum1[c];
+    M = a.count[0];
   }
-  block_sum<2>(s, red);
-  if (threadIdx.x == 0) {
-    a.g_bias[c] = s[0];
-    a.g_weight[c] = s[1];
-  }
-  const float M = (float)a.B * (float)a.N;
   const float m0 = s[0] / M, m1 = s[1] / M;
   for (int i = threadIdx.x; i < total; i += kThreads) {
     const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
@@ -353,22 +436,15 @@ static bool stride_ok(long long bs, int C, int N, long long& out) {
   return true;
 }
 
-extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
-                              float* running_mean, float* running_var, long long* num_batches_tracked,
-                              const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
-                              float* save_mean, float* save_rstd, int B, int C, int N, float eps, float momentum,
-                              int relu, ct_stream_t s) {
-  hipStream_t stream = (hipStream_t)s;
-  if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
-  if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
+static int bn_fwd_launch(BnArgs a, float* y, long long x_batch_stride, long long y_batch_stride, long long residual_batch_stride,
+                         hipStream_t stream) {
+  const int B = a.B, C = a.C, N = a.N;
   if (!shape_ok(B, C, N)) return CT_EINVAL;
-  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
-           residual, 0, num_batches_tracked};
   if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs) ||
       !stride_ok(residual_batch_stride, C, N, a.rbs))
     return CT_EINVAL;
   const bool vec = (N & 3) == 0 && ((a.xbs | a.ybs | a.rbs) & 3) == 0 &&
-                   ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0;
+                   ((((uintptr_t)a.x) | ((uintptr_t)y) | ((uintptr_t)a.residual)) & 15) == 0;
   CT_CLEAR_ERROR();
   if (vec && reg_ok(B, N)) {
     CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
@@ -381,19 +457,15 @@ extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const fl
   return CT_OK;
 }
 
-extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
-                              const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
-                              float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N,
-                              int relu, ct_stream_t s) {
-  hipStream_t stream = (hipStream_t)s;
-  if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
+static int bn_bwd_launch(BnBwdArgs a, long long x_batch_stride, long long gy_batch_stride, long long gx_batch_stride,
+                         hipStream_t stream) {
+  const int B = a.B, C = a.C, N = a.N;
   if (!shape_ok(B, C, N)) return CT_EINVAL;
-  BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0};
   if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(gy_batch_stride, C, N, a.gybs) ||
       !stride_ok(gx_batch_stride, C, N, a.gxbs))
     return CT_EINVAL;
   const bool vec = (N & 3) == 0 && ((a.xbs | a.gybs | a.gxbs) & 3) == 0 &&
-                   ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0;
+                   ((((uintptr_t)a.x) | ((uintptr_t)a.gy) | ((uintptr_t)a.gx)) & 15) == 0;
   CT_CLEAR_ERROR();
   if (vec && reg_ok(B, N)) {
     CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, a)
@@ -404,4 +476,68 @@ extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const fl
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
+}
+
+extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                              float* save_mean, float* save_rstd, int B, int C, int N, float eps, float momentum,
+                              int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
+  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
+           residual, 0, num_batches_tracked, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  return bn_fwd_launch(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                              const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
+                              float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N,
+                              int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
+  BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+  return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, gx_batch_stride, (hipStream_t)s);
+}
+
+// ---- the same norm split around a statistics exchange between ranks (SyncBatchNorm under data parallelism) ----
+
+extern "C" int ct_bn_stats_fwd(const float* x, long long x_batch_stride, float* mean, float* m2, float* count, int B, int C,
+                               int N, ct_stream_t s) {
+  if (!x || !mean || !m2) return CT_EINVAL;
+  BnArgs a{x, nullptr, nullptr, nullptr, nullptr, mean, m2, B, C, N, 0.0f, 0.0f, 0, 0, 0, nullptr, 0, nullptr,
+           1, count, nullptr, nullptr, nullptr, 0, 0};
+  return bn_fwd_launch(a, const_cast<float*>(x), x_batch_stride, x_batch_stride, 0, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_apply_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                               const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
+                               float* running_mean, float* running_var, long long* num_batches_tracked,
+                               const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                               float* save_mean, float* save_rstd, float* count_total, int B, int C, int N, float eps,
+                               float momentum, int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !y || !g_mean || !g_m2 || !g_count || !save_mean || !save_rstd || !(eps >= 0.0f) ||
+      world < 1 || g_stride < 1)
+    return CT_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
+  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
+           residual, 0, num_batches_tracked, 2, count_total, g_mean, g_m2, g_count, world, g_stride};
+  return bn_fwd_launch(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_reduce_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                                const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                                float* sum_g, float* sum_gxhat, int B, int C, int N, int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !mean || !rstd || !gy || !sum_g || !sum_gxhat) return CT_EINVAL;
+  BnBwdArgs a{x, weight, bias, mean, rstd, gy, const_cast<float*>(x), sum_gxhat, sum_g, B, C, N, relu, 0, 0, 0,
+              1, nullptr, nullptr, nullptr};
+  return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, x_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_apply_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                               const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                               const float* sum_g, const float* sum_gxhat, const float* count, float* gx,
+                               long long gx_batch_stride, int B, int C, int N, int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !mean || !rstd || !gy || !gx || !sum_g || !sum_gxhat || !count) return CT_EINVAL;
+  BnBwdArgs a{x, weight, bias, mean, rstd, gy, gx, nullptr, nullptr, B, C, N, relu, 0, 0, 0, 2, sum_g, sum_gxhat, count};
+  return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, gx_batch_stride, (hipStream_t)s);
 }

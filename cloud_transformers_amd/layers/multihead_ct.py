@@ -55,8 +55,8 @@ def forward_style(module_list, input, z, residual=None):
 def run_after(module_list, input, residual=None):
     """Apply an `after` Sequential (and add `residual` to its result); a training-mode nn.BatchNorm1d directly followed by
     nn.ReLU runs as the fused ct_bn_relu kernels when the shape qualifies (ops.bn_relu_eligible), the skip connection
-    added in the same pass when that pair ends the stack — SyncBatchNorm, eval mode and every other layer go through
-    their own forward."""
+    added in the same pass when that pair ends the stack (an nn.SyncBatchNorm too: ops exchanges the group's statistics
+    over its process group) — eval mode and every other layer go through their own forward."""
     layers = list(module_list)
     i = 0
     while i < len(layers):
@@ -114,7 +114,7 @@ class _MHCTCore(nn.Module):
 
     def _norm_keys_values(self, key_values):
         """key_bn on the first 3H channels, values_bn on the rest (multihead_ct.py:89-91): fused kernels on the slices
-        where they lie when both norms qualify, the modules on split views otherwise (SyncBatchNorm, eval mode, ...)."""
+        where they lie when both norms qualify, the modules on split views otherwise (eval mode, ...)."""
         Ck = self.heads * 3
         Cv = key_values.size(1) - Ck
         if ops.bn_relu_eligible(self.key_bn, key_values, Ck) and ops.bn_relu_eligible(self.values_bn, key_values, Cv):

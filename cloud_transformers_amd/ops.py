@@ -552,51 +552,157 @@ class JoinAdaInReluFn(torch.autograd.Function):
         return tuple(grads)
 
 
+# ---------------------------------------------------------------------------
+# training-mode BatchNorm1d (+ ReLU, + skip) groups, with or without an exchange of statistics between ranks
+# ---------------------------------------------------------------------------
+_sync_stats_collectives = 0
+
+
+def sync_stats_collectives():
+    """Number of statistics collectives (one all_gather per norm group in forward, one all_reduce in backward) issued
+    by this process so far — bench.py reports the per-step figure."""
+    return _sync_stats_collectives
+
+
+def _sync_group(bn):
+    """The process group a norm module exchanges its batch statistics over, or None: a plain BatchNorm1d, no process
+    group initialised, or a SyncBatchNorm whose group has a single rank (torch's own SyncBatchNorm then runs the plain
+    batch norm too: nn/modules/batchnorm.py `need_sync`)."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm):
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    pg = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return pg if dist.get_world_size(pg) > 1 else None
+
+
+def _bn_group_fwd(items, B, N, device, group):
+    """Run the norms of one group.  items: dicts with x (data_ptr), xbs, C, w, b, rm, rv, nbt, eps, mom, relu, res (ptr or
+    None), rbs, y (ptr), ybs.  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
+    device tensor with the job's values per channel.  With a group: local statistics of ALL items into one buffer, ONE
+    all_gather, then the normalising kernels merge the ranks' statistics themselves (csrc/ct_bnorm.hip mode 1 / 2)."""
+    global _sync_stats_collectives
+    lib = _lib.load()
+    stats = []
+    if group is None:
+        for it in items:
+            mean = torch.empty(it["C"], device=device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            _lib.check(lib.ct_bn_relu_fwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["rm"]), _ptr(it["rv"]),
+                                          _ptr(it["nbt"]), it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
+                                          B, it["C"], N, float(it["eps"]), float(it["mom"]), int(it["relu"]), _stream()),
+                       "ct_bn_relu_fwd")
+            stats.append((mean, rstd))
+        return stats, None
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    Ct = sum(it["C"] for it in items)
+    stride = 2 * Ct + 1
+    local = torch.empty(stride, device=device, dtype=torch.float32)
+    base, c0 = local.data_ptr(), 0
+    for i, it in enumerate(items):
+        _lib.check(lib.ct_bn_stats_fwd(it["x"], it["xbs"], base + 4 * c0, base + 4 * (Ct + c0),
+                                       base + 4 * (stride - 1) if i == 0 else None, B, it["C"], N, _stream()), "ct_bn_stats_fwd")
+        c0 += it["C"]
+    gathered = torch.empty(world * stride, device=device, dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    _sync_stats_collectives += 1
+    count = torch.empty(1, device=device, dtype=torch.float32)
+    gb, c0 = gathered.data_ptr(), 0
+    for i, it in enumerate(items):
+        mean = torch.empty(it["C"], device=device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.check(lib.ct_bn_apply_fwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), gb + 4 * c0, gb + 4 * (Ct + c0),
+                                       gb + 4 * (stride - 1), world, stride, _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"]),
+                                       it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
+                                       _ptr(count) if i == 0 else None, B, it["C"], N, float(it["eps"]), float(it["mom"]),
+                                       int(it["relu"]), _stream()), "ct_bn_apply_fwd")
+        stats.append((mean, rstd))
+        c0 += it["C"]
+    # (`gathered` is read by the kernels just enqueued: torch's caching allocator keeps it alive on this stream)
+    return stats, count
+
+
+def _bn_group_bwd(items, B, N, device, group, count):
+    """Backward of a norm group.  items: dicts with x, xbs, C, w, b, mean, rstd, gy (ptr), gybs, gx (ptr), gxbs, relu.
+    Returns [(g_weight, g_bias)] per item (this rank's sums: DDP averages parameter gradients itself).  With a group:
+    the two per-channel sums of ALL items into one buffer, ONE all_reduce, then the input-gradient kernels."""
+    global _sync_stats_collectives
+    lib = _lib.load()
+    out = []
+    if group is None:
+        for it in items:
+            g_w = torch.empty(it["C"], device=device, dtype=torch.float32)
+            g_b = torch.empty_like(g_w)
+            _lib.check(lib.ct_bn_relu_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
+                                          it["gy"], it["gybs"], it["gx"], it["gxbs"], _ptr(g_w), _ptr(g_b), B, it["C"], N,
+                                          int(it["relu"]), _stream()), "ct_bn_relu_bwd")
+            out.append((g_w, g_b))
+        return out
+    import torch.distributed as dist
+    Ct = sum(it["C"] for it in items)
+    sums = torch.empty(2 * Ct, device=device, dtype=torch.float32)       # [sum g' | sum g' * xhat]
+    sb, c0 = sums.data_ptr(), 0
+    for it in items:
+        _lib.check(lib.ct_bn_reduce_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
+                                        it["gy"], it["gybs"], sb + 4 * c0, sb + 4 * (Ct + c0), B, it["C"], N, int(it["relu"]),
+                                        _stream()), "ct_bn_reduce_bwd")
+        c0 += it["C"]
+    local = sums.clone()                                                  # this rank's g_bias / g_weight
+    dist.all_reduce(sums, group=group)
+    _sync_stats_collectives += 1
+    c0 = 0
+    for it in items:
+        _lib.check(lib.ct_bn_apply_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
+                                       it["gy"], it["gybs"], sb + 4 * c0, sb + 4 * (Ct + c0), _ptr(count), it["gx"], it["gxbs"],
+                                       B, it["C"], N, int(it["relu"]), _stream()), "ct_bn_apply_bwd")
+        out.append((local[Ct + c0:Ct + c0 + it["C"]], local[c0:c0 + it["C"]]))
+        c0 += it["C"]
+    return out
+
+
 class BnReluFn(torch.autograd.Function):
     """relu?(batch_norm(x)) [+ residual] in training mode (batch statistics; running statistics and num_batches_tracked
     updated in place by the kernel): the nn.Sequential(BatchNorm1d, ReLU) tail of the blocks' `after` stacks and the
-    union's skip connection (layers/multihead_ct.py:67-68,149-153,198)."""
+    union's skip connection (layers/multihead_ct.py:67-68,149-153,198).  `group`: the process group of a SyncBatchNorm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, residual):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, residual, group=None):
         _dev(x, weight, bias)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         B, C, N = x.shape
         y = torch.empty_like(x)
-        mean = torch.empty(C, device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
         rbs = 0
         if residual is not None:
             rbs = _batch_stride(residual, C, N)
             if rbs is None:
                 residual = _f32c(residual)
                 rbs = 0
-        lib = _lib.load()
         with _on(x.device):
-            _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                          _ptr(nbt), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd), B, C, N,
-                                          float(eps), float(momentum), int(bool(relu)), _stream()), "ct_bn_relu_fwd")
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
+            stats, count = _bn_group_fwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, rm=running_mean, rv=running_var, nbt=nbt,
+                                               eps=eps, mom=momentum, relu=relu, res=_ptr(residual), rbs=rbs, y=_ptr(y), ybs=0)],
+                                         B, N, x.device, group)
+        mean, rstd = stats[0]
+        ctx.save_for_backward(x, weight, bias, mean, rstd, count)
         ctx.relu = int(bool(relu))
         ctx.has_residual = residual is not None
+        ctx.group = group
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
+        x, weight, bias, mean, rstd, count = ctx.saved_tensors
         B, C, N = x.shape
         gybs = _batch_stride(gy, C, N)          # a slice of the concatenation's cotangent is read where it lies
         if gybs is None:
             gy = _f32c(gy)
             gybs = 0
         gx = torch.empty_like(x)
-        g_w = torch.empty_like(weight)
-        g_b = torch.empty_like(bias)
-        lib = _lib.load()
         with _on(x.device):
-            _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
-                                          _ptr(gx), 0, _ptr(g_w), _ptr(g_b), B, C, N, ctx.relu, _stream()), "ct_bn_relu_bwd")
-        return gx, g_w, g_b, None, None, None, None, None, None, (gy if ctx.has_residual else None)
+            ((g_w, g_b),) = _bn_group_bwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, mean=mean, rstd=rstd, gy=_ptr(gy),
+                                                gybs=gybs, gx=_ptr(gx), gxbs=0, relu=ctx.relu)], B, N, x.device, ctx.group, count)
+        return gx, g_w, g_b, None, None, None, None, None, None, (gy if ctx.has_residual else None), None
 
 
 class SplitBnFn(torch.autograd.Function):
@@ -606,105 +712,103 @@ class SplitBnFn(torch.autograd.Function):
     neither the contiguous copies of the slices nor the concatenation of their cotangents exist."""
 
     @staticmethod
-    def forward(ctx, x, wk, bk, rmk, rvk, nbk, epsk, momk, wv, bv, rmv, rvv, nbv, epsv, momv):
+    def forward(ctx, x, wk, bk, rmk, rvk, nbk, epsk, momk, wv, bv, rmv, rvv, nbv, epsv, momv, group=None):
         _dev(x, wk, wv)
         x = _f32c(x)
         B, C, N = x.shape
         Ck = wk.numel()
         Cv = C - Ck
         assert wv.numel() == Cv
-        lib = _lib.load()
-        outs, saved = [], []
+        items, outs = [], []
+        for c0, Cs, w, b, rm, rv, nb, eps, mom in ((0, Ck, wk, bk, rmk, rvk, nbk, epsk, momk),
+                                                   (Ck, Cv, wv, bv, rmv, rvv, nbv, epsv, momv)):
+            y = torch.empty(B, Cs, N, device=x.device, dtype=torch.float32)
+            items.append(dict(x=_ptr(x) + c0 * N * 4, xbs=C * N, C=Cs, w=_f32c(w), b=_f32c(b), rm=rm, rv=rv, nbt=nb, eps=eps,
+                              mom=mom, relu=0, res=None, rbs=0, y=_ptr(y), ybs=0))
+            outs.append(y)
         with _on(x.device):
-            for c0, Cs, w, b, rm, rv, nb, eps, mom in ((0, Ck, wk, bk, rmk, rvk, nbk, epsk, momk),
-                                                       (Ck, Cv, wv, bv, rmv, rvv, nbv, epsv, momv)):
-                w, b = _f32c(w), _f32c(b)
-                y = torch.empty(B, Cs, N, device=x.device, dtype=torch.float32)
-                mean = torch.empty(Cs, device=x.device, dtype=torch.float32)
-                rstd = torch.empty_like(mean)
-                _lib.check(lib.ct_bn_relu_fwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nb),
-                                              None, 0, _ptr(y), 0, _ptr(mean), _ptr(rstd), B, Cs, N, float(eps), float(mom),
-                                              0, _stream()), "ct_bn_relu_fwd")
-                outs.append(y)
-                saved += [w, b, mean, rstd]
-        ctx.save_for_backward(x, *saved)
+            stats, count = _bn_group_fwd(items, B, N, x.device, group)
+        saved = []
+        for it, (mean, rstd) in zip(items, stats):
+            saved += [it["w"], it["b"], mean, rstd]
+        ctx.save_for_backward(x, count, *saved)
         ctx.Ck = Ck
+        ctx.group = group
         return outs[0], outs[1]
 
     @staticmethod
     def backward(ctx, gk, gv):
-        x, wk, bk, mk, rk, wv, bv, mv, rv = ctx.saved_tensors
+        x, count, wk, bk, mk, rk, wv, bv, mv, rv = ctx.saved_tensors
         B, C, N = x.shape
         Ck = ctx.Ck
         gx = torch.empty_like(x)
-        grads = []
-        lib = _lib.load()
+        items = []
+        for c0, Cs, w, b, mean, rstd, gy in ((0, Ck, wk, bk, mk, rk, gk), (Ck, C - Ck, wv, bv, mv, rv, gv)):
+            if gy is None:
+                gy = torch.zeros(B, Cs, N, device=x.device, dtype=torch.float32)
+            gybs = _batch_stride(gy, Cs, N)
+            if gybs is None:
+                gy, gybs = _f32c(gy), 0
+            items.append(dict(x=_ptr(x) + c0 * N * 4, xbs=C * N, C=Cs, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
+                              gx=_ptr(gx) + c0 * N * 4, gxbs=C * N, relu=0, keep=gy))
         with _on(x.device):
-            for c0, Cs, w, b, mean, rstd, gy in ((0, Ck, wk, bk, mk, rk, gk), (Ck, C - Ck, wv, bv, mv, rv, gv)):
-                if gy is None:
-                    gy = torch.zeros(B, Cs, N, device=x.device, dtype=torch.float32)
-                gybs = _batch_stride(gy, Cs, N)
-                if gybs is None:
-                    gy, gybs = _f32c(gy), 0
-                g_w, g_b = torch.empty_like(w), torch.empty_like(b)
-                _lib.check(lib.ct_bn_relu_bwd(_ptr(x) + c0 * N * 4, C * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
-                                              _ptr(gx) + c0 * N * 4, C * N, _ptr(g_w), _ptr(g_b), B, Cs, N, 0, _stream()),
-                           "ct_bn_relu_bwd")
-                grads.append((g_w, g_b))
-        (gwk, gbk), (gwv, gbv) = grads
-        return gx, gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None
+            (gwk, gbk), (gwv, gbv) = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
+        return gx, gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None, None
 
 
 class JoinBnReluFn(torch.autograd.Function):
     """cat([relu(bn_i(x_i)) for i], dim=1) — the heads' `after` stacks of a union block followed by its concatenation
     (layers/multihead_ct.py:67-68,187-196): every head's kernel writes its channel range of the result where it belongs
     and, in backward, reads its range of the cotangent where it lies; the separate outputs and their copy never exist.
-    Arguments: n, then per head (x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum)."""
+    Arguments: n, group, then per head (x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum)."""
 
     @staticmethod
-    def forward(ctx, n, *args):
+    def forward(ctx, n, group, *args):
         heads = [args[i * 8:(i + 1) * 8] for i in range(n)]
         xs = [_f32c(h[0]) for h in heads]
         _dev(*xs)
         B, _, N = xs[0].shape
         Ct = sum(x.size(1) for x in xs)
         y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
-        lib = _lib.load()
-        saved, c0 = [], 0
+        items, c0 = [], 0
+        for x, (_, w, b, rm, rv, nbt, eps, mom) in zip(xs, heads):
+            C = x.size(1)
+            items.append(dict(x=_ptr(x), xbs=0, C=C, w=_f32c(w), b=_f32c(b), rm=rm, rv=rv, nbt=nbt, eps=eps, mom=mom, relu=1,
+                              res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N))
+            c0 += C
         with _on(y.device):
-            for x, (_, w, b, rm, rv, nbt, eps, mom) in zip(xs, heads):
-                w, b = _f32c(w), _f32c(b)
-                C = x.size(1)
-                mean = torch.empty(C, device=y.device, dtype=torch.float32)
-                rstd = torch.empty_like(mean)
-                _lib.check(lib.ct_bn_relu_fwd(_ptr(x), 0, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nbt), None, 0,
-                                              _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd), B, C, N, float(eps),
-                                              float(mom), 1, _stream()), "ct_bn_relu_fwd")
-                saved += [x, w, b, mean, rstd]
-                c0 += C
-        ctx.save_for_backward(*saved)
+            stats, count = _bn_group_fwd(items, B, N, y.device, group)
+        saved = []
+        for x, it, (mean, rstd) in zip(xs, items, stats):
+            saved += [x, it["w"], it["b"], mean, rstd]
+        ctx.save_for_backward(count, *saved)
         ctx.n = n
+        ctx.group = group
         return y
 
     @staticmethod
     def backward(ctx, gy):
         n = ctx.n
-        saved = ctx.saved_tensors
+        count = ctx.saved_tensors[0]
+        saved = ctx.saved_tensors[1:]
         B, Ct, N = gy.shape
         gybs = _batch_stride(gy, Ct, N)
         if gybs is None:
             gy, gybs = _f32c(gy), Ct * N
-        lib = _lib.load()
-        grads, c0 = [None], 0
+        items, gxs, c0 = [], [], 0
+        for i in range(n):
+            x, w, b, mean, rstd = saved[i * 5:(i + 1) * 5]
+            C = x.size(1)
+            gx = torch.empty_like(x)
+            gxs.append(gx)
+            items.append(dict(x=_ptr(x), xbs=0, C=C, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs,
+                              gx=_ptr(gx), gxbs=0, relu=1))
+            c0 += C
         with _on(gy.device):
-            for i in range(n):
-                x, w, b, mean, rstd = saved[i * 5:(i + 1) * 5]
-                C = x.size(1)
-                gx, g_w, g_b = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
-                _lib.check(lib.ct_bn_relu_bwd(_ptr(x), 0, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs,
-                                              _ptr(gx), 0, _ptr(g_w), _ptr(g_b), B, C, N, 1, _stream()), "ct_bn_relu_bwd")
-                grads += [gx, g_w, g_b, None, None, None, None, None]
-                c0 += C
+            wb = _bn_group_bwd(items, B, N, gy.device, ctx.group, count)
+        grads = [None, None]
+        for gx, (g_w, g_b) in zip(gxs, wb):
+            grads += [gx, g_w, g_b, None, None, None, None, None]
         return tuple(grads)
 
 
@@ -714,7 +818,7 @@ def join_bn_relu(xs, bns):
     args = []
     for x, bn in zip(xs, bns):
         args += [x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum]
-    return JoinBnReluFn.apply(len(xs), *args)
+    return JoinBnReluFn.apply(len(xs), _sync_group(bns[0]), *args)
 
 
 class UnionKeysValuesFn(torch.autograd.Function):
@@ -723,14 +827,15 @@ class UnionKeysValuesFn(torch.autograd.Function):
     so forward is one [sum Co, Cin] x [Cin, N] product per cloud instead of one per head, the data gradient one product
     with K = sum Co instead of one per head plus autograd's accumulation of their results, the weight gradient one
     product.  The norms read their channel ranges of the GEMM output where they lie and write their input cotangents
-    into the ranges of ONE tensor, which is the data / weight gradient GEMMs' operand.
-    Arguments: n, x, then per head: weight [Co,Cin,1], key_bn (w, b, rm, rv, nbt, eps, mom), values_bn (same 7).
+    into the ranges of ONE tensor, which is the data / weight gradient GEMMs' operand.  Under SyncBatchNorm the 2n norms
+    share ONE statistics all_gather in forward and ONE all_reduce in backward.
+    Arguments: n, group, x, then per head: weight [Co,Cin,1], key_bn (w, b, rm, rv, nbt, eps, mom), values_bn (same 7).
     Returns (keys_res_0, values_0, keys_res_1, values_1, ...)."""
 
     PER_HEAD = 15
 
     @staticmethod
-    def forward(ctx, n, x, *args):
+    def forward(ctx, n, group, x, *args):
         P = UnionKeysValuesFn.PER_HEAD
         heads = [args[i * P:(i + 1) * P] for i in range(n)]
         x = _f32c(x)
@@ -739,56 +844,52 @@ class UnionKeysValuesFn(torch.autograd.Function):
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)               # [sum Co, Cin]
         Ct = Wc.size(0)
         y = torch.bmm(Wc.unsqueeze(0).expand(B, -1, -1), x)                 # [B, sum Co, N]
-        lib = _lib.load()
-        outs, saved, meta, c0 = [], [], [], 0
-        with _on(x.device):
-            for h in heads:
-                Co = h[0].size(0)
-                for (w, b, rm, rv, nbt, eps, mom) in (h[1:8], h[8:15]):
-                    w, b = _f32c(w), _f32c(b)
-                    C = w.numel()
-                    o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
-                    mean = torch.empty(C, device=x.device, dtype=torch.float32)
-                    rstd = torch.empty_like(mean)
-                    _lib.check(lib.ct_bn_relu_fwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(w), _ptr(b), _ptr(rm), _ptr(rv), _ptr(nbt),
-                                                  None, 0, _ptr(o), 0, _ptr(mean), _ptr(rstd), B, C, N, float(eps), float(mom),
-                                                  0, _stream()), "ct_bn_relu_fwd")
-                    outs.append(o)
-                    saved += [w, b, mean, rstd]
-                    meta.append((c0, C))
-                    c0 += C
+        outs, items, meta, c0 = [], [], [], 0
+        for h in heads:
+            for (w, b, rm, rv, nbt, eps, mom) in (h[1:8], h[8:15]):
+                w, b = _f32c(w), _f32c(b)
+                C = w.numel()
+                o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+                items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, C=C, w=w, b=b, rm=rm, rv=rv, nbt=nbt, eps=eps, mom=mom,
+                                  relu=0, res=None, rbs=0, y=_ptr(o), ybs=0))
+                outs.append(o)
+                meta.append((c0, C))
+                c0 += C
         assert c0 == Ct, "key_bn + values_bn must cover the projections"
-        ctx.save_for_backward(x, y, Wc, *saved)
+        with _on(x.device):
+            stats, count = _bn_group_fwd(items, B, N, x.device, group)
+        saved = []
+        for it, (mean, rstd) in zip(items, stats):
+            saved += [it["w"], it["b"], mean, rstd]
+        ctx.save_for_backward(x, y, Wc, count, *saved)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
+        ctx.group = group
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
-        x, y, Wc = ctx.saved_tensors[:3]
-        saved = ctx.saved_tensors[3:]
+        x, y, Wc, count = ctx.saved_tensors[:4]
+        saved = ctx.saved_tensors[4:]
         B, Cin, N = x.shape
         Ct = Wc.size(0)
         g_y = torch.empty_like(y)
-        lib = _lib.load()
-        bn_grads = []
+        items = []
+        for i, (c0, C) in enumerate(ctx.meta):
+            w, b, mean, rstd = saved[i * 4:(i + 1) * 4]
+            gy = gouts[i]
+            if gy is None:
+                gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
+            gybs = _batch_stride(gy, C, N)
+            if gybs is None:
+                gy, gybs = _f32c(gy), 0
+            items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, C=C, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
+                              gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, relu=0, keep=gy))
         with _on(x.device):
-            for i, (c0, C) in enumerate(ctx.meta):
-                w, b, mean, rstd = saved[i * 4:(i + 1) * 4]
-                gy = gouts[i]
-                if gy is None:
-                    gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
-                gybs = _batch_stride(gy, C, N)
-                if gybs is None:
-                    gy, gybs = _f32c(gy), 0
-                g_w, g_b = torch.empty_like(w), torch.empty_like(b)
-                _lib.check(lib.ct_bn_relu_bwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
-                                              _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_w), _ptr(g_b), B, C, N, 0, _stream()),
-                           "ct_bn_relu_bwd")
-                bn_grads.append((g_w, g_b))
-        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[1] else None
+            bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
+        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[2] else None
         g_Wc = torch.bmm(g_y, x.transpose(1, 2)).sum(0)                     # [sum Co, Cin]
-        grads, r0 = [None, g_x], 0
+        grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), gwk, gbk, None, None, None, None, None, gwv, gbv, None, None, None, None, None]
@@ -804,7 +905,7 @@ def union_keys_values(x, convs, key_bns, values_bns):
         args.append(conv.weight)
         for bn in (kb, vb):
             args += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum]
-    outs = UnionKeysValuesFn.apply(len(convs), x, *args)
+    outs = UnionKeysValuesFn.apply(len(convs), _sync_group(key_bns[0]), x, *args)
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(convs))]
 
 
@@ -819,7 +920,7 @@ def union_keys_values_eligible(x, convs, key_bns, values_bns):
             return False
         probe = (x.size(0), x.size(2))
         for bn in (kb, vb):
-            if not (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+            if not (type(bn) in _BN_TYPES and bn.training and bn.affine and bn.track_running_stats
                     and bn.momentum is not None):
                 return False
             key = (probe[0], bn.num_features, probe[1])
@@ -832,6 +933,9 @@ def union_keys_values_eligible(x, convs, key_bns, values_bns):
 
 
 _bn_supported = {}
+# nn.BatchNorm1d, and nn.SyncBatchNorm (what parallel.data_parallel / the reference's DDP recipe turns every norm into:
+# train_segmentation.py:128): same parameters and buffers, statistics exchanged over its process group
+_BN_TYPES = (torch.nn.BatchNorm1d, torch.nn.SyncBatchNorm)
 
 
 def bn_relu_eligible(bn, x, channels=None):
@@ -839,7 +943,7 @@ def bn_relu_eligible(bn, x, channels=None):
     channels) can run as ct_bn_relu_*: training mode with running statistics and a fixed momentum, affine, CUDA fp32
     [B,C,N] contiguous, and a shape the register-resident kernels take (ct_bn_relu_supported)."""
     C = x.size(1) if channels is None and x.dim() == 3 else channels
-    if not (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+    if not (type(bn) in _BN_TYPES and bn.training and bn.affine and bn.track_running_stats
             and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
             and x.is_contiguous() and x.data_ptr() % 16 == 0 and C == bn.num_features):
         return False
@@ -856,14 +960,14 @@ def split_bn(x, bn_a, bn_b):
     return SplitBnFn.apply(x, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, bn_a.num_batches_tracked,
                            bn_a.eps, bn_a.momentum,
                            bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var, bn_b.num_batches_tracked,
-                           bn_b.eps, bn_b.momentum)
+                           bn_b.eps, bn_b.momentum, _sync_group(bn_a))
 
 
 def bn_relu(x, bn, relu=True, residual=None):
     """relu?(bn(x)) [+ residual] through the fused kernels; the caller checked bn_relu_eligible(bn, x).  Updates the
     module's running statistics and num_batches_tracked exactly as nn.BatchNorm1d.forward does in training mode."""
     return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                          bn.momentum, relu, residual)
+                          bn.momentum, relu, residual, _sync_group(bn))
 
 
 # ---------------------------------------------------------------------------

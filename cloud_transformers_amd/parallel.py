@@ -83,17 +83,22 @@ def all_gather(dist, data):
 
 def data_parallel(model, device_index, sync_bn=True, **ddp_kwargs):
     """The reference's wrap (train_segmentation.py:128-130: SyncBatchNorm.convert_sync_batchnorm, then
-    DistributedDataParallel on the rank's device) with the two settings that matter on RCCL over xGMI:
-    gradients are views into the all-reduce buckets (no copy into and out of them), and the module buffers are
-    not re-broadcast from rank 0 before every forward — under SyncBatchNorm every rank computes the same running
-    statistics anyway, and the ~180 per-step broadcasts of a 12-block network are pure latency (measured on one
-    MI355X at world size 1: 35-40 ms per step with them, 30-34 ms without, 31 ms without DDP; eager steps spread +-2 ms between runs).
+    DistributedDataParallel on the rank's device) with the settings that matter on RCCL over xGMI:
+    * gradients are views into the all-reduce buckets (no copy into and out of them);
+    * under SyncBatchNorm the module buffers are not re-broadcast from rank 0 before every forward — every rank computes
+      the same running statistics from the exchanged batch statistics, and the ~180 per-step broadcasts of a 12-block
+      network are pure latency (one MI355X, world size 1: 35-40 ms per step with them, 30-34 ms without).  With plain
+      BatchNorm (`sync_bn=False`) each rank's running statistics follow its own shard, so DDP's default re-broadcast
+      stays on — otherwise the ranks' buffers drift apart silently and a checkpoint holds rank 0's shard statistics;
+    * the converted norms keep the fused kernels: the blocks' norm groups exchange their statistics in ONE all_gather
+      (forward) / ONE all_reduce (backward) per group (ops._bn_group_fwd / _bn_group_bwd), 6 collectives per
+      MultiHeadUnion block and step instead of 2 per norm.
     `device_index=None` wraps a CPU module (gloo)."""
     import torch
     if sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     kw = dict(device_ids=None if device_index is None else [device_index], gradient_as_bucket_view=True,
-              broadcast_buffers=False)
+              broadcast_buffers=not sync_bn)
     kw.update(ddp_kwargs)
     return torch.nn.parallel.DistributedDataParallel(model, **kw)
 

@@ -210,6 +210,29 @@ int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight
                    float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N, int relu,
                    ct_stream_t s);
 
+/* The same norm split around an exchange of statistics between ranks — nn.SyncBatchNorm under data parallelism
+ * (train_segmentation.py:128-130 converts every BatchNorm of the model).  Forward: ct_bn_stats_fwd on every norm of a
+ * block into ONE buffer (mean[C], sum of squared deviations[C] per norm, this rank's count), one all_gather of that
+ * buffer, then ct_bn_apply_fwd per norm, which merges the ranks' statistics itself (parallel-variance rule) and
+ * normalises (+ ReLU, + skip).  Backward: ct_bn_reduce_bwd per norm into one buffer (these are also this rank's weight /
+ * bias gradients), one all_reduce(sum), ct_bn_apply_bwd.  g_mean / g_m2 point at rank 0's entries of the norm's channels
+ * inside the gathered buffer, g_count at rank 0's count; rank r's are g_stride floats further. */
+int ct_bn_stats_fwd(const float* x, long long x_batch_stride, float* mean, float* m2, float* count /* nullable */,
+                    int B, int C, int N, ct_stream_t s);
+int ct_bn_apply_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                    const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, const float* residual,
+                    long long residual_batch_stride, float* y, long long y_batch_stride, float* save_mean,
+                    float* save_rstd, float* count_total /* nullable */, int B, int C, int N, float eps, float momentum,
+                    int relu, ct_stream_t s);
+int ct_bn_reduce_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                     const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                     float* sum_g, float* sum_gxhat, int B, int C, int N, int relu, ct_stream_t s);
+int ct_bn_apply_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                    const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                    const float* sum_g, const float* sum_gxhat, const float* count, float* gx, long long gx_batch_stride,
+                    int B, int C, int N, int relu, ct_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Adaptive instance normalisation of the AdaIN blocks (AdaIn1dUpd: layers/utils.py:82-97 =
  * InstanceNorm1d(affine=False, eps) -> * (gamma + 1) -> + beta; followed by ReLU in `after`,

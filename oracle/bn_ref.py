@@ -1,0 +1,93 @@
+"""CPU stand-ins for the four statistics-exchange norm kernels of csrc/ct_bnorm.hip (ct_bn_stats_fwd, ct_bn_apply_fwd,
+ct_bn_reduce_bwd, ct_bn_apply_bwd), in float64 on the same raw pointers and strides.
+
+TEST INFRASTRUCTURE ONLY (tests/test_syncbn_gloo.py): they let the product's HOST logic — buffer layout, offsets,
+the one-all_gather / one-all_reduce exchange of cloud_transformers_amd/ops._bn_group_fwd / _bn_group_bwd — run on
+gloo at world size 2 without a GPU.  The kernels themselves are checked on the GPU (tests/test_syncbn_gpu.py,
+tests/test_bnorm_gpu.py).  Semantics follow nn.SyncBatchNorm (the reference converts every norm with
+SyncBatchNorm.convert_sync_batchnorm: train_segmentation.py:128)."""
+import ctypes
+
+import numpy as np
+
+
+def _vec(ptr, n):
+    return np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ctypes.c_float)), shape=(int(n),))
+
+
+def _bcn(ptr, bs, B, C, N):
+    """[B,C,N] float32 view at `ptr` with batch stride bs floats (0 = dense)"""
+    bs = int(bs) or C * N
+    flat = _vec(ptr, (B - 1) * bs + C * N)
+    return np.lib.stride_tricks.as_strided(flat, shape=(B, C, N), strides=(bs * 4, N * 4, 4))
+
+
+class FakeLib:
+    """the subset of libcloudct's ABI the norm groups call when a process group is present"""
+
+    def ct_bn_stats_fwd(self, x, xbs, mean, m2, count, B, C, N, stream):
+        xv = _bcn(x, xbs, B, C, N).astype(np.float64)
+        mu = xv.mean(axis=(0, 2))
+        _vec(mean, C)[:] = mu
+        _vec(m2, C)[:] = ((xv - mu[None, :, None]) ** 2).sum(axis=(0, 2))
+        if count:
+            _vec(count, 1)[0] = B * N
+        return 0
+
+    def _merge(self, g_mean, g_m2, g_count, world, stride, C):
+        cnt = np.array([_vec(g_count + 4 * r * stride, 1)[0] for r in range(world)], dtype=np.float64)
+        means = np.stack([_vec(g_mean + 4 * r * stride, C).astype(np.float64) for r in range(world)])
+        m2s = np.stack([_vec(g_m2 + 4 * r * stride, C).astype(np.float64) for r in range(world)])
+        total = cnt.sum()
+        mu = (means * cnt[:, None]).sum(0) / total
+        m2 = (m2s + cnt[:, None] * (means - mu) ** 2).sum(0)
+        return mu, m2 / total, total
+
+    def ct_bn_apply_fwd(self, x, xbs, w, b, g_mean, g_m2, g_count, world, stride, rm, rv, nbt, res, rbs, y, ybs,
+                        save_mean, save_rstd, count_total, B, C, N, eps, mom, relu, stream):
+        mu, var, total = self._merge(g_mean, g_m2, g_count, world, stride, C)
+        rs = 1.0 / np.sqrt(var + eps)
+        xv = _bcn(x, xbs, B, C, N).astype(np.float64)
+        out = (xv - mu[None, :, None]) * (_vec(w, C) * rs)[None, :, None] + _vec(b, C)[None, :, None]
+        if relu:
+            out = np.maximum(out, 0.0)
+        if res:
+            out = out + _bcn(res, rbs, B, C, N)
+        _bcn(y, ybs, B, C, N)[:] = out
+        _vec(save_mean, C)[:] = mu
+        _vec(save_rstd, C)[:] = rs
+        if count_total:
+            _vec(count_total, 1)[0] = total
+        if rm:
+            _vec(rm, C)[:] = (1 - mom) * _vec(rm, C) + mom * mu
+            _vec(rv, C)[:] = (1 - mom) * _vec(rv, C) + mom * var * total / (total - 1)
+        if nbt:
+            np.ctypeslib.as_array(ctypes.cast(int(nbt), ctypes.POINTER(ctypes.c_longlong)), shape=(1,))[0] += 1
+        return 0
+
+    def _masked(self, x, xbs, w, b, mean, rstd, gy, gybs, B, C, N, relu):
+        xv = _bcn(x, xbs, B, C, N).astype(np.float64)
+        g = _bcn(gy, gybs, B, C, N).astype(np.float64).copy()
+        mu, rs = _vec(mean, C).astype(np.float64), _vec(rstd, C).astype(np.float64)
+        xh = (xv - mu[None, :, None]) * rs[None, :, None]
+        if relu:
+            pre = (xv - mu[None, :, None]) * (_vec(w, C) * rs)[None, :, None] + _vec(b, C)[None, :, None]
+            g[~(pre > 0)] = 0.0
+        return g, xh, rs
+
+    def ct_bn_reduce_bwd(self, x, xbs, w, b, mean, rstd, gy, gybs, sum_g, sum_gx, B, C, N, relu, stream):
+        g, xh, _ = self._masked(x, xbs, w, b, mean, rstd, gy, gybs, B, C, N, relu)
+        _vec(sum_g, C)[:] = g.sum(axis=(0, 2))
+        _vec(sum_gx, C)[:] = (g * xh).sum(axis=(0, 2))
+        return 0
+
+    def ct_bn_apply_bwd(self, x, xbs, w, b, mean, rstd, gy, gybs, sum_g, sum_gx, count, gx, gxbs, B, C, N, relu, stream):
+        g, xh, rs = self._masked(x, xbs, w, b, mean, rstd, gy, gybs, B, C, N, relu)
+        M = float(_vec(count, 1)[0])
+        m0 = _vec(sum_g, C).astype(np.float64) / M
+        m1 = _vec(sum_gx, C).astype(np.float64) / M
+        _bcn(gx, gxbs, B, C, N)[:] = (_vec(w, C) * rs)[None, :, None] * (g - m0[None, :, None] - xh * m1[None, :, None])
+        return 0
+
+    def ct_strerror(self, status):
+        return b"fake"

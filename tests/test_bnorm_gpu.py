@@ -80,8 +80,11 @@ def test_run_after_dispatch():
         assert torch.allclose(run_after(seq, big.clone()), ref(big), rtol=1e-4, atol=1e-5) and calls == [1]
         assert torch.allclose(seq[0].running_var, ref[0].running_var, rtol=1e-5, atol=1e-6)
         del calls[:]
+        # SyncBatchNorm (what DDP training converts every norm into) takes the fused kernels too: without a process group
+        # there is nothing to exchange (tests/test_syncbn_gpu.py covers the two-rank exchange)
         sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU())).cuda()
-        assert not ops.bn_relu_eligible(sync[0], x)
+        assert ops.bn_relu_eligible(sync[0], x)
+        assert torch.allclose(run_after(sync, x.clone()), ref(x), rtol=1e-4, atol=1e-5) and calls == [1]
     finally:
         ops.bn_relu = real
 
