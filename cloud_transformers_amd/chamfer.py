@@ -17,7 +17,10 @@ from . import _lib
 from .ops import _dev, _ptr, _stream, _on
 
 
-class ChamferFunction(Function):
+class ChamferWithIndicesFunction(Function):
+    """(dist1, dist2, idx1, idx2): the nearest-neighbour indices too (int32, lowest index on ties) — what metrics.py and
+    chamfer_with_indices use.  `ChamferFunction` below keeps the reference's two outputs."""
+
     @staticmethod
     def forward(ctx, xyz1, xyz2):
         assert xyz1.device == xyz2.device
@@ -58,17 +61,26 @@ class ChamferFunction(Function):
         return gradxyz1, gradxyz2
 
 
+class ChamferFunction:
+    """The reference's interface (chamfer_extension/dist_chamfer.py:10-56): `dist1, dist2 = ChamferFunction.apply(xyz1, xyz2)`
+    — TWO outputs, as its own callers unpack them (utils/grdnet_utils.py:22, dist_chamfer.py:62)."""
+
+    @staticmethod
+    def apply(xyz1, xyz2):
+        d1, d2, _, _ = ChamferWithIndicesFunction.apply(xyz1, xyz2)
+        return d1, d2
+
+
 class ChamferDist(nn.Module):
     """forward(input1 [B,n,3], input2 [B,m,3]) -> (dist1 [B,n], dist2 [B,m]) squared NN distances."""
 
     def forward(self, input1, input2):
-        d1, d2, _, _ = ChamferFunction.apply(input1, input2)
-        return d1, d2
+        return ChamferFunction.apply(input1, input2)
 
 
 def chamfer_with_indices(xyz1, xyz2):
     """(dist1, dist2, idx1, idx2) — indices are int32, lowest index on ties."""
-    return ChamferFunction.apply(xyz1, xyz2)
+    return ChamferWithIndicesFunction.apply(xyz1, xyz2)
 
 
 def _to_bn3(pc):

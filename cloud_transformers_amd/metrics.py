@@ -22,7 +22,7 @@ def nn_distances(xyz1, xyz2):
     """Euclidean distance from every point of xyz1 [B,n,3] to its nearest neighbour in
     xyz2 [B,m,3] and vice versa -> ([B,n], [B,m]).  No gradient (evaluation only)."""
     with torch.no_grad():
-        d1, d2, _, _ = ChamferFunction.apply(xyz1.contiguous().float(), xyz2.contiguous().float())
+        d1, d2 = ChamferFunction.apply(xyz1.contiguous().float(), xyz2.contiguous().float())
         return torch.sqrt(d1), torch.sqrt(d2)
 
 
@@ -92,7 +92,7 @@ class ChamferDistance(torch.nn.Module):
         if xyz1.size(0) == 1 and self.ignore_zeros:
             xyz1 = xyz1[torch.sum(xyz1, dim=2).ne(0)].unsqueeze(dim=0)
             xyz2 = xyz2[torch.sum(xyz2, dim=2).ne(0)].unsqueeze(dim=0)
-        dist1, dist2, _, _ = ChamferFunction.apply(xyz1.contiguous(), xyz2.contiguous())
+        dist1, dist2 = ChamferFunction.apply(xyz1.contiguous(), xyz2.contiguous())
         return torch.mean(dist1) + torch.mean(dist2)
 
 

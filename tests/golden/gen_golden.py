@@ -351,12 +351,17 @@ def gen_chamfer():
     cp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cp)
     g = torch.Generator().manual_seed(505)
-    a = torch.rand(2, 256, 3, generator=g)
-    b = torch.rand(2, 256, 3, generator=g)
+    a = torch.rand(2, 256, 3, generator=g).requires_grad_(True)
+    b = torch.rand(2, 256, 3, generator=g).requires_grad_(True)
     res = cp.dist_chamfer(a, b)
-    d = dict(xyz1=_np(a), xyz2=_np(b))
-    for i, r in enumerate(res):
+    # autograd through the reference's own formulation: the cotangent of a min goes to its arg-min element, so these
+    # gradients pin the nearest-neighbour INDICES and the gradient formula of the native kernels (chamfer.cu:155-174)
+    cots = [torch.randn(r.shape, generator=g) for r in res]
+    sum((r * c).sum() for r, c in zip(res, cots)).backward()
+    d = dict(xyz1=_np(a), xyz2=_np(b), g_xyz1=_np(a.grad), g_xyz2=_np(b.grad))
+    for i, (r, c) in enumerate(zip(res, cots)):
         d[f"ret{i}"] = _np(r)
+        d[f"cot{i}"] = _np(c)
     np.savez_compressed(os.path.join(OUT, "chamfer.npz"), **d)
     print("chamfer: returns", [tuple(r.shape) for r in res])
 
@@ -366,6 +371,8 @@ def main():
     sys.dont_write_bytecode = True
     torch.set_num_threads(1)
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "chamfer":      # regenerate this fixture alone
+        return gen_chamfer()
     from layers import cloud_transform as ct
     from layers import utils as lu
     gen_positions(ct)

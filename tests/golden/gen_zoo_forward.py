@@ -7,7 +7,8 @@ same order (checked by tests/test_zoo_cpu.py::test_same_seed_same_weights), so t
 Saved to tests/golden/zoo_segmenter_forward.npz: the input cloud, the logits in eval mode and in training mode (batch
 statistics), and d(sum of logits * cot)/d(cloud) in eval mode.  tests/golden/zoo_classifier_forward.npz: the same for the
 ScanObjectNN classifier (model_zoo/scanobject/classifier.py: MultiHeadPool, Res2D/3D blocks, class + mask heads), eval mode;
-tests/golden/zoo_inpainter_forward.npz: the completion inpainter (encoder, style mapping, twelve AdaIN decoder blocks), eval mode.
+tests/golden/zoo_inpainter_forward.npz: the completion inpainter (encoder, style mapping, twelve AdaIN decoder blocks), eval mode;
+tests/golden/zoo_reconstructor_decoder.npz: the What3D reconstruction decoder from a given style vector + its Chamfer loss.
 
 usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_zoo_forward.py
 """
@@ -121,7 +122,69 @@ def main():
                         z=taps["z"].numpy(), dec1=taps["dec1"].numpy(), dec2=taps["dec2"].numpy(),
                         g_dec12=taps["g_dec12"].numpy(), g_dec11=taps["g_dec11"].numpy())
     print("saved", rec.shape, float(rec.abs().max()), float(nz.grad.abs().max()), float(pt.grad.abs().max()))
+    gen_reconstructor_decoder(g)
+
+
+def gen_reconstructor_decoder(g):
+    """What3D single-view reconstruction (model_zoo/image_reconstruction/reconstructor.py:26-92), DECODER ONLY: the image
+    encoder is torchvision's pretrained ResNet-50 (not in this image, no network), so the fixture starts from a given
+    style vector z — what `mapping` hands to the decoder (:84) — and runs the reference's own start / twelve
+    MultiHeadUnionAdaIn / final stack on its own layers, then the training loss's Chamfer term (PCN-style
+    loss_chamfer_adj, dist_chamfer.py:80-89, with the reference's pure-torch distances chamfer_pytorch.py:4-14 since the
+    CUDA extension cannot run here).  `torchvision.models` is a stand-in that only lets the class construct: nothing of
+    it is executed.  Besides the outputs the fixture keeps the INPUT of the last decoder block and the cotangent at its
+    output, so that the block's gradients can be compared on identical inputs (whole-model gradients drift, see
+    tests/test_zoo_gpu.py)."""
+    import types
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tvm.resnet50 = lambda pretrained=False: torch.nn.Sequential(torch.nn.Identity(), torch.nn.Identity(), torch.nn.Identity())
+    tv.models = tvm
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tvm
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_chamfer_pytorch", os.path.join(G.REF, "chamfer_extension", "chamfer_pytorch.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    ns = {"__name__": "zoo_model"}
+    with open(os.path.join(G.REF, "model_zoo/image_reconstruction/reconstructor.py")) as f:
+        exec(compile(f.read(), "reconstructor.py", "exec"), ns)
+    torch.manual_seed(SEED)
+    model = ns["Model"]()
+    perturb(model, SEED + 2)
+    model.eval()
+    Bd, Nd = 2, 256
+    z = torch.relu(torch.randn(Bd, 512, generator=g)).requires_grad_(True)                  # post-ReLU style vector
+    noise = torch.nn.functional.normalize(torch.randn(Bd, 3, Nd, generator=g), dim=1).requires_grad_(True)   # utils/pcd_utils.py:5-13
+    target = torch.rand(Bd, 3, 1, Nd, generator=g)
+    fs = ns["forward_style"]
+    taps = {}
+    last = model.attentions_decoder[11]
+    hooks = [model.attentions_decoder[0].register_forward_hook(lambda m, a, o: taps.__setitem__("dec1", o[0][:, :64].detach().clone())),
+             last.register_forward_pre_hook(lambda m, a: taps.__setitem__("x11", a[0].detach().clone())),
+             last.register_forward_hook(lambda m, a, o: taps.__setitem__("x12", o[0])),
+             last.register_full_backward_hook(lambda m, gi, go: (taps.__setitem__("g_x11", gi[0].detach().clone()),
+                                                                  taps.__setitem__("g_x12", go[0].detach().clone())) and None)]
+    x = fs(model.start, noise, z)
+    for blk in model.attentions_decoder:
+        x, _ = blk(x, z, noise)
+    rec = fs(model.final, x, z).unsqueeze(2)                                                 # [B,3,1,N], sigmoid output
+    d0, d1 = cp.dist_chamfer(rec[:, :, 0].permute(0, 2, 1), target[:, :, 0].permute(0, 2, 1))
+    loss = (torch.sqrt(d0.clamp_min(0)).mean() + torch.sqrt(d1.clamp_min(0)).mean()) / 2    # loss_chamfer_adj
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "zoo_reconstructor_decoder.npz"), seed=SEED, z=z.detach().numpy(), noise=noise.detach().numpy(),
+                        target=target.numpy(), rec=rec.detach().numpy(), loss=float(loss), dec1=taps["dec1"].numpy(),
+                        # (AdaIN blocks normalise per cloud: cloud 0 alone is a self-contained block-level case)
+                        x11=taps["x11"][:1].numpy(), g_x12=taps["g_x12"][:1].numpy(), g_x11=taps["g_x11"][:1].numpy(),
+                        g_z=z.grad.numpy(), g_noise=noise.grad.numpy())
+    print("saved reconstructor decoder", rec.shape, float(loss), float(z.grad.abs().max()))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "reconstructor":        # this fixture alone
+        G._install_shims()
+        if G.REF not in sys.path:
+            sys.path.insert(0, G.REF)
+        gen_reconstructor_decoder(torch.Generator().manual_seed(SEED + 7))
+    else:
+        main()

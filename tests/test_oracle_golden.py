@@ -133,3 +133,8 @@ def test_chamfer_against_reference_torch_restatement():
     g = ((a[:, :, None] - b[:, None]) ** 2).sum(-1)
     assert torch.equal(g.gather(2, i1.long()[..., None])[..., 0], d1)
     assert torch.equal(g.gather(1, i2.long()[:, None])[:, 0], d2)
+    # gradients of the reference's formulation under autograd: the cotangent of a min flows to its arg-min element, so
+    # these pin the oracle's INDICES and its gradient formula (chamfer.cu:155-174) at once
+    ga, gb = R.chamfer_bwd(a, b, T(raw["cot1"]), T(raw["cot0"]), i1, i2)
+    np.testing.assert_allclose(ga.numpy(), raw["g_xyz1"], atol=2e-5)
+    np.testing.assert_allclose(gb.numpy(), raw["g_xyz2"], atol=2e-5)

@@ -245,3 +245,64 @@ def test_inpainter_eval_forward_and_gradients_match_the_reference():
         err = np.abs(got.cpu().double().numpy() - ref)
         scale = np.abs(ref).max()
         assert np.median(err) <= 3e-2 * scale and err.max() <= 0.3 * scale, (name, np.median(err), err.max(), scale)
+
+
+class ReconstructorDecoder(nn.Module):
+    """What3D single-view reconstruction (model_zoo/image_reconstruction/reconstructor.py:26-92) without its image
+    encoder (torchvision's pretrained ResNet-50): `mapping` is kept so that parameters are drawn in the reference's
+    order, the decoder — Conv1d(3) + AdaIN + ReLU stem, twelve MultiHeadUnionAdaIn, Conv + AdaIN + ReLU + Conv + Sigmoid
+    head — starts from a given style vector."""
+
+    def __init__(self, num_latent=512, dim=512):
+        super().__init__()
+        from cloud_transformers_amd.layers.multihead_ct import MultiHeadUnionAdaIn
+        from cloud_transformers_amd.layers.utils import AdaIn1dUpd
+        self.mapping = nn.Sequential(nn.Linear(2048, num_latent), nn.ReLU(inplace=True))
+        self.start = nn.Sequential(nn.Conv1d(3, dim, kernel_size=1, bias=False), AdaIn1dUpd(dim, num_latent=num_latent), nn.ReLU(True))
+        self.attentions_decoder = nn.ModuleList([MultiHeadUnionAdaIn(model_dim=dim, features_dims=f, heads=[16, 16], tensor_sizes=s,
+                                                                     model_dim_out=dim, n_latent=num_latent, tensor_dims=[2, 3])
+                                                 for _ in range(4) for f, s in ZOO])
+        self.final = nn.Sequential(nn.Conv1d(dim, dim, kernel_size=1, bias=False), AdaIn1dUpd(dim, num_latent=num_latent),
+                                   nn.ReLU(inplace=True), nn.Conv1d(dim, 3, kernel_size=1), nn.Sigmoid())
+
+    def forward(self, noise, z):
+        from cloud_transformers_amd.layers.multihead_ct import forward_style
+        x = forward_style(self.start, noise, z)
+        for blk in self.attentions_decoder:
+            x, _ = blk(x, z, noise)
+        return forward_style(self.final, x, z).unsqueeze(2)
+
+
+def test_reconstructor_decoder_and_chamfer_loss_match_the_reference():
+    """BASELINE configs[4] at model level: the AdaIN decoder from a style vector and the PCN-style Chamfer term of its
+    training loss (train_image_reconstruction.py:173-178) on the HIP Chamfer kernels; and — on the reference's OWN input
+    of the last decoder block and the cotangent at its output — that block's input gradient, tightly."""
+    from cloud_transformers_amd.chamfer import loss_chamfer_adj
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_reconstructor_decoder.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    net = ReconstructorDecoder()
+    _perturb(net, int(gold["seed"]) + 2)
+    net = net.cuda().eval()
+    z = torch.from_numpy(gold["z"]).cuda().requires_grad_(True)
+    noise = torch.from_numpy(gold["noise"]).cuda().requires_grad_(True)
+    taps = {}
+    h = net.attentions_decoder[0].register_forward_hook(lambda m, a, o: taps.__setitem__("dec1", o[0][:, :64].detach().clone()))
+    rec = net(noise, z)
+    h.remove()
+    _close(taps["dec1"], gold["dec1"], "after decoder block 1", 1e-4)
+    err = np.abs(rec.detach().cpu().double().numpy() - gold["rec"].astype(np.float64))
+    assert np.median(err) <= 2e-3 and err.max() <= 5e-2, ("reconstruction (sigmoid output in [0,1])", np.median(err), err.max())
+    loss = loss_chamfer_adj(rec, torch.from_numpy(gold["target"]).cuda())
+    assert abs(float(loss) - float(gold["loss"])) <= 2e-3 * float(gold["loss"]), (float(loss), float(gold["loss"]))
+    loss.backward()
+    assert torch.isfinite(z.grad).all() and torch.isfinite(noise.grad).all()
+    # the Chamfer term alone on the reference's reconstruction: value within 1e-5
+    ref_rec = torch.from_numpy(gold["rec"]).cuda()
+    lc = loss_chamfer_adj(ref_rec, torch.from_numpy(gold["target"]).cuda())
+    assert abs(float(lc) - float(gold["loss"])) <= 1e-5 * max(1.0, float(gold["loss"])), (float(lc), float(gold["loss"]))
+    # block 12 on identical inputs: d/d(input) within 1e-4 of the reference's (per-cloud norms: cloud 0 alone)
+    blk = net.attentions_decoder[11]
+    x11 = torch.from_numpy(gold["x11"]).cuda().requires_grad_(True)
+    out, _ = blk(x11, z.detach()[:1], noise.detach()[:1])
+    out.backward(torch.from_numpy(gold["g_x12"]).cuda())
+    _close(x11.grad, gold["g_x11"], "d/d(input of decoder block 12) on the reference's own input", 1e-4)
