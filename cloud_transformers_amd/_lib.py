@@ -85,6 +85,8 @@ SIGNATURES = {
     "ct_debug_last_launch": (ctypes.c_char_p, []),
     "ct_slice_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
+    "ct_slice_bwd_ws": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_keys": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),

@@ -1403,11 +1403,23 @@ int pick_nsplit(int B, int H, int nchunks, int N) {
 }
 
 
+// out[i] = sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
+__global__ void __launch_bounds__(256) sum_parts_kernel(const float* parts, float* out, size_t n, size_t stride, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = parts[i];
+  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
+  out[i] = s;
+}
+
 // ---------------------------------------------------------------------------
 // hot-shape dispatch (ct_raster_hot.h): 2D, corners from keys, N % 4 == 0, C % 4 == 0, G % 4 == 0, 16-byte
 // aligned rows, enough (b,h) planes to fill the chip with one workgroup per plane
 // ---------------------------------------------------------------------------
 constexpr int kHalfCuLdsBytes = 80 * 1024;     // two workgroups per CU
+#ifndef CT_FUSED_LDS_BUDGET
+#define CT_FUSED_LDS_BUDGET kHalfCuLdsBytes
+#endif
 
 struct HotPlan {
   int CC, nchunks;
@@ -1432,9 +1444,29 @@ bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budge
   return true;
 }
 
+// Backward hot kernels: chunks of a plane may be dealt to `ncg` workgroups when there are too few (b,h) planes to fill
+// the chip with one workgroup per plane (the zoo's B8 x H16 blocks: 128 planes) — thinner chunks, more workgroups;
+// each group's partial g_keys goes to the workspace.  Pure shape arithmetic: the workspace queries use it too.
+bool hot_bwd_plan(int B, int H, int C, int G, size_t per_ch, size_t fixed, long long budget, HotPlan& hp, int& ncg) {
+  if (!hot_chunks(C, per_ch, fixed, hp, budget)) return false;
+  ncg = 1;
+  const long long planes = (long long)B * H;
+  if (planes >= 256 || C <= 4) return true;
+  const int want = (int)((512 + planes - 1) / planes);          // chunk groups that would give ~512 workgroups
+  int cc = (((C + want - 1) / want) + 3) & ~3;
+  if (cc < 4) cc = 4;
+  if (cc < hp.CC) {
+    hp.CC = cc;
+    hp.nchunks = (C + cc - 1) / cc;
+    hp.lds = fixed + (size_t)cc * per_ch;
+  }
+  ncg = hp.nchunks < want ? hp.nchunks : want;
+  return true;
+}
+
 bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
   return hot_enabled() && (a.N & 3) == 0 && (G & 3) == 0 && (a.C & 3) == 0 && (ptr_bits & 15) == 0 &&
-         ((long long)a.B * a.H >= 128 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
+         ((long long)a.B * a.H >= 32 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
 }
 
 // kernels are instantiated for the 32 x 32 grid of the headline shape (immediate corner offsets) and for any grid
@@ -1471,23 +1503,45 @@ int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   return CT_OK;
 }
 
-// Slice backward, fused.  CT_EINVAL: not eligible.
-int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, hipStream_t st) {
-  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos;
+// Slice backward, fused.  CT_EINVAL: not eligible.  ws: scratch for the chunk groups' partial g_keys (may be null: then
+// only shapes that need a single group per plane qualify).
+size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
+  HotPlan hp;
+  int ncg = 1;
+  if ((C & 3) || (N & 3) || (g.G & 3) || N > 8 * kHotThreads) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
+}
+
+int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, void* ws, size_t ws_bytes, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
+                         (uintptr_t)ws;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
   HotPlan hp;
-#ifndef CT_FUSED_LDS_BUDGET
-#define CT_FUSED_LDS_BUDGET kHalfCuLdsBytes
-#endif
-  if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
-  a.tile_in = grid; a.g_pos = g_pos;
-  a.CC = hp.CC; a.nchunks = hp.nchunks;
-  dim3 wgrid(1, a.H, a.B);
+  int ncg = 1;
+  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+  if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
+    // no scratch for the partial sums: one group per plane if there are planes enough to be worth it
+    if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
+    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
+    ncg = 1;
+  }
+  a.tile_in = grid;
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  a.g_pos = ncg > 1 ? (float*)ws : g_pos;
+  a.gpos_stride = ncg > 1 ? gpos_n : 0;
+  dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
 #define CT_MK_SLICE_BWD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true>
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
-  note("slice_bwd_fused");
+  note(ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
+  if (ncg > 1) {
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos, gpos_n, gpos_n, ncg);
+    CT_CHECK_LAUNCH();
+  }
   return CT_OK;
 }
 
@@ -1497,8 +1551,10 @@ int run_scatter_add_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
   HotPlan hp;
   if (!hot_chunks(a.C, (size_t)g.G * 4, (size_t)(g.G + a.C + 1) * 4, hp)) return CT_EINVAL;
-  a.CC = hp.CC; a.nchunks = hp.nchunks;
-  dim3 wgrid(1, a.H, a.B);
+  int ncg = 1;
+  hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 4, (size_t)(g.G + a.C + 1) * 4, kHalfCuLdsBytes, hp, ncg);   // no g_keys: groups are free
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
 #define CT_MK_SCATTER_ADD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, false>
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SCATTER_ADD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
@@ -1523,24 +1579,55 @@ int run_splat_sum_bwd_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
 }
 
 // can the hot Splat(max) backward take this call, and does it keep g_keys in registers (may accumulate)?
-bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<2>& g, HotPlan& hp, bool& single) {
+bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<2>& g, HotPlan& hp, int& ncg, bool& single) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
                          (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
   if (!hot_shape_ok(a, g.G, bits)) return false;
-  if (!hot_chunks(a.C, (size_t)g.G * 8, 16, hp)) return false;
+  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
   single = (a.N >> 2) <= 2 * kHotThreads;
   return true;
 }
 
-int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, hipStream_t st) {
-  a.CC = hp.CC; a.nchunks = hp.nchunks;
-  dim3 wgrid(1, a.H, a.B);
+size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
+  HotPlan hp;
+  int ncg = 1;
+  if ((C & 3) || (N & 3) || (g.G & 3)) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return 0;
+  return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
+}
+
+// y (+)= sum_k parts[k*stride + i] (ascending k)
+__global__ void __launch_bounds__(256) sum_parts_acc_kernel(const float* parts, float* out, size_t n, size_t stride, int k, int acc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = parts[i];
+  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
+  out[i] = acc ? out[i] + s : s;
+}
+
+int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, int ncg, void* ws, hipStream_t st) {
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  float* const out = a.g_pos;
+  const int accumulate = a.accumulate;
+  const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+  if (ncg > 1) {
+    a.g_pos = (float*)ws;
+    a.gpos_stride = gpos_n;
+    a.accumulate = 0;
+  }
+  dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
 #define CT_MK_SPLAT_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
-  note("splat_max_bwd_hot");
+  note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");
+  if (ncg > 1) {
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(sum_parts_acc_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, out, gpos_n,
+                       gpos_n, ncg, accumulate);
+    CT_CHECK_LAUNCH();
+  }
   return CT_OK;
 }
 
@@ -1606,15 +1693,6 @@ int run_gather_gw(RasterArgs a, const int* W, hipStream_t st) {
   return CT_OK;
 }
 
-// out[i] = sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
-__global__ void __launch_bounds__(256) sum_parts_kernel(const float* parts, float* out, size_t n, size_t stride, int k) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = parts[i];
-  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
-  out[i] = s;
-}
-
 // channel-chunk groups a Splat(max) backward launch is split into (more workgroups for few (b,h) planes)
 inline int splat_bwd_ncg(int B, int H, int nchunks) {
   int ncg = 1;
@@ -1671,7 +1749,14 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if constexpr (DIM == 2 && FROM_KEYS) {
     HotPlan hp;
     bool single = false;
-    if (splat_bwd_hot_plan(a, g, hp, single) && (single || !a.accumulate)) return run_splat_max_bwd_hot(a, g, hp, st);
+    int ncg = 1;
+    if (splat_bwd_hot_plan(a, g, hp, ncg, single)) {
+      const size_t need = ncg > 1 ? (size_t)ncg * a.B * a.H * 2 * a.N * 4 : 0;
+      // several groups: the partial sums go through the workspace and the final sum may accumulate; one group: the
+      // kernel accumulates in its own store when every thread owns its quads (`single`)
+      if (need <= ws_bytes && (ws || !need) && (ncg > 1 || single || !a.accumulate) && ((uintptr_t)ws & 15) == 0)
+        return run_splat_max_bwd_hot(a, g, hp, ncg, ws, st);
+    }
   }
   if (a.accumulate) return CT_EINVAL;     // the caller redirects g_pos to scratch and adds (splat_bwd_impl)
   // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
@@ -1705,11 +1790,11 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
 
 // Slice backward, hot path: returns CT_EINVAL when the shape is not eligible.
 template <int DIM>
-int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, hipStream_t st) {
+int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
   if ((g.G & 3) != 0) return CT_EINVAL;
   if constexpr (DIM == 2) {
-    const int r = run_slice_bwd_hot(a, grid, g_pos, g, st);
+    const int r = run_slice_bwd_hot(a, grid, g_pos, g, ws, ws_bytes, st);
     if (r != CT_EINVAL) return r;
   }
   // gather side: tile + [CC] maxima + [G] counters in LDS
@@ -1865,7 +1950,8 @@ int slice_fwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
 
 template <bool FROM_KEYS>
 int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, const float* g_out,
-                   float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st) {
+                   float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st,
+                   void* ws = nullptr, size_t ws_bytes = 0) {
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
@@ -1877,7 +1963,7 @@ int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
   if (FROM_KEYS && (N & 3) == 0) {
     // fast path: g_keys first (its kernel also leaves the scatter's quantum statistics in g_grid),
     // then the streaming fixed-point scatter-add
-    int r = dim == 2 ? run_slice_bwd_fast<2>(a, grid, g_pos, W, st) : run_slice_bwd_fast<3>(a, grid, g_pos, W, st);
+    int r = dim == 2 ? run_slice_bwd_fast<2>(a, grid, g_pos, W, ws, ws_bytes, st) : run_slice_bwd_fast<3>(a, grid, g_pos, W, ws, ws_bytes, st);
     if (r != CT_EINVAL) return r;       // CT_EINVAL: shape not eligible, use the generic pair below
   }
   int r = dim == 2 ? run_scatter<2, FROM_KEYS>(a, W, true, st) : run_scatter<3, FROM_KEYS>(a, W, true, st);
@@ -1937,8 +2023,7 @@ int ct_splat_fwd(const float* keys, const float* feat, const void* pad, int pad_
   return splat_fwd_impl<true>(pos, feat, pad, pad_dtype, grid, B, H, C, N, dim, W, reduce, (hipStream_t)s);
 }
 
-size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce) {
-  if (!valid_common(B, H, C, N, dim, W) || reduce != CT_REDUCE_MAX0) return 0;
+static size_t splat_bwd_workspace_generic(int B, int H, int C, int N, int dim, const int* W) {
   size_t G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
   if (G * 4 > (size_t)kBigLdsBytes) return (size_t)B * H * C * G * 4;   // claim copy of z (tile does not fit LDS)
@@ -1947,6 +2032,16 @@ size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const i
   const Plan p = make_plan(B, H, C, N, (int)G, two ? 2 : 1);
   const int ncg = splat_bwd_ncg(B, H, p.nchunks);
   return ncg > 1 ? (size_t)ncg * B * H * ((size_t)1 << dim) * N * 4 : 0;
+}
+
+size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce) {
+  if (!valid_common(B, H, C, N, dim, W) || reduce != CT_REDUCE_MAX0) return 0;
+  size_t n = splat_bwd_workspace_generic(B, H, C, N, dim, W);
+  if (dim == 2) {       // the hot kernels' chunk groups (whichever family a call ends up on, the scratch is enough)
+    const size_t hot = splat_bwd_hot_workspace(B, H, C, N, make_grid<2>(W));
+    if (hot > n) n = hot;
+  }
+  return n;
 }
 
 int ct_splat_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,
@@ -1989,6 +2084,19 @@ int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_
   if (!keys) return CT_EINVAL;
   PosSrc pos = {keys, nullptr, nullptr};
   return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s);
+}
+
+size_t ct_slice_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
+  if (!valid_common(B, H, C, N, dim, W) || dim != 2) return 0;
+  return slice_bwd_hot_workspace(B, H, C, N, make_grid<2>(W));
+}
+
+int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                    float* g_grid, float* g_keys, void* ws, size_t ws_bytes, int B, int H, int C, int N, int dim,
+                    const int* W, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes);
 }
 
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out, float* g_grid,

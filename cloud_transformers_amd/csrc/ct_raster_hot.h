@@ -201,7 +201,10 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
 
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+  // Few (b,h) planes (the zoo's H16 blocks): the chunks of a plane are dealt to a.ncg workgroups (blockIdx.x), each
+  // writing its partial g_keys to its own slice of the workspace (summed afterwards in a fixed order).
+  const int cgi = blockIdx.x;
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);            // multiple of 4
     const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
         T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
       }
     }
-    if (chunk == 0)
+    if (chunk == cgi)
       for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     __syncthreads();
     const float Kf = (float)(*s_k);
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
     }
     __syncthreads();
     // write the chunk out (and clear the accumulators for the next chunk in the same sweep)
-    const bool more = chunk + 1 < a.nchunks;
+    const bool more = chunk + a.ncg < a.nchunks;
     for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) {
       const int ch = (t << 2) / G;                 // G % 4 == 0: a float4 never straddles channels
       float q, iqd;
@@ -379,8 +382,9 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       ox.z = gs[u][2][0] * ct_key_mask(tx.z); ox.w = gs[u][3][0] * ct_key_mask(tx.w);
       oy.x = gs[u][0][1] * ct_key_mask(ty.x); oy.y = gs[u][1][1] * ct_key_mask(ty.y);
       oy.z = gs[u][2][1] * ct_key_mask(ty.z); oy.w = gs[u][3][1] * ct_key_mask(ty.w);
-      st_stream4(a.g_pos + (bh * 2 + 0) * N + n0[u], ox);
-      st_stream4(a.g_pos + (bh * 2 + 1) * N + n0[u], oy);
+      float* gp = a.g_pos + (size_t)cgi * a.gpos_stride;
+      st_stream4(gp + (bh * 2 + 0) * N + n0[u], ox);
+      st_stream4(gp + (bh * 2 + 1) * N + n0[u], oy);
     }
   }
 }
@@ -505,7 +509,9 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
   const int tid = threadIdx.x;
   const int nq = N >> 2;
   int nz = 0, nm = 0;
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+  const int cgi = blockIdx.x;                     // chunk group (see slice_bwd_fused_kernel)
+  float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);            // multiple of 4
     const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
@@ -550,9 +556,9 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
                                 gs[2][0] * ct_key_mask(kx[2]), gs[3][0] * ct_key_mask(kx[3]));
         float4 oy = make_float4(gs[0][1] * ct_key_mask(ky[0]), gs[1][1] * ct_key_mask(ky[1]),
                                 gs[2][1] * ct_key_mask(ky[2]), gs[3][1] * ct_key_mask(ky[3]));
-        float* px = a.g_pos + (bh * 2 + 0) * N + n0;
-        float* py = a.g_pos + (bh * 2 + 1) * N + n0;
-        if (chunk > 0) {
+        float* px = gpos + (bh * 2 + 0) * N + n0;
+        float* py = gpos + (bh * 2 + 1) * N + n0;
+        if (chunk > cgi) {
           const float4 qx = *(const float4*)px, qy = *(const float4*)py;
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
           oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
@@ -608,8 +614,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
                                 gs[u][2][0] * ct_key_mask(tx.z), gs[u][3][0] * ct_key_mask(tx.w));
         float4 oy = make_float4(gs[u][0][1] * ct_key_mask(ty.x), gs[u][1][1] * ct_key_mask(ty.y),
                                 gs[u][2][1] * ct_key_mask(ty.z), gs[u][3][1] * ct_key_mask(ty.w));
-        float* px = a.g_pos + (bh * 2 + 0) * N + n0;
-        float* py = a.g_pos + (bh * 2 + 1) * N + n0;
+        float* px = a.g_pos + (size_t)blockIdx.x * a.gpos_stride + (bh * 2 + 0) * N + n0;
+        float* py = a.g_pos + (size_t)blockIdx.x * a.gpos_stride + (bh * 2 + 1) * N + n0;
         if (a.accumulate) {
           const float4 qx = *(const float4*)px, qy = *(const float4*)py;
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;

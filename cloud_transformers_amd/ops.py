@@ -183,10 +183,13 @@ class SliceKeysFn(torch.autograd.Function):
         g_grid = torch.empty_like(grid)
         g_keys = torch.empty_like(keys)
         lib = _lib.load()
+        Wa = _lib.int_array(W)
+        ws_bytes = lib.ct_slice_bwd_workspace_bytes(B, H, C, N, dim, Wa)
+        ws = torch.empty(ws_bytes, device=grid.device, dtype=torch.uint8) if ws_bytes else None
         with _on(grid.device):
-            _lib.check(lib.ct_slice_bwd(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
-                                        _ptr(g_grid), _ptr(g_keys), B, H, C, N, dim, _lib.int_array(W), _stream()),
-                       "ct_slice_bwd")
+            _lib.check(lib.ct_slice_bwd_ws(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
+                                           _ptr(g_grid), _ptr(g_keys), _ptr(ws), ws_bytes, B, H, C, N, dim, Wa, _stream()),
+                       "ct_slice_bwd_ws")
         return g_keys, g_grid, None, None, None
 
 

@@ -40,6 +40,9 @@ class SplatSliceStep:
                                                        _lib.BWD_ACCUMULATE_KEYS)
         self.ws = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
         self.nws = nws
+        nws2 = self.lib.ct_slice_bwd_workspace_bytes(self.B, self.H, self.C, self.N, dim, self.Wa)
+        self.ws2 = torch.empty(nws2, device=dev, dtype=torch.uint8) if nws2 else None
+        self.nws2 = nws2
 
     # the four passes, individually callable (bench.py times them one by one)
     def splat_fwd(self):
@@ -64,10 +67,10 @@ class SplatSliceStep:
                    "ct_slice_bwd_keys")
 
     def slice_bwd(self):
-        _lib.check(self.lib.ct_slice_bwd(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
-                                         _ptr(self.g_z), _ptr(self.g_keys_buf),
-                                         self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
-                   "ct_slice_bwd")
+        _lib.check(self.lib.ct_slice_bwd_ws(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
+                                            _ptr(self.g_z), _ptr(self.g_keys_buf), _ptr(self.ws2), self.nws2,
+                                            self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
+                   "ct_slice_bwd_ws")
 
     def splat_bwd(self):
         """accumulates its key cotangent into g_keys_buf (call after slice_bwd, which overwrites it)"""

@@ -116,6 +116,13 @@ int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_
 int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_dtype,
                  const float* g_out, float* g_grid, float* g_keys,
                  int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+/* ct_slice_bwd with scratch: with few (b,h) planes (the zoo's H = 16 blocks) the channel chunks of a plane are dealt to
+ * several workgroups, whose partial g_keys go through `workspace` (ct_slice_bwd_workspace_bytes(...) bytes, may be 0).
+ * Same results as ct_slice_bwd, which has to keep one workgroup per plane there. */
+size_t ct_slice_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W);
+int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                    const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
+                    int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
 /* The two halves of ct_slice_bwd, for callers that need only one cotangent
  * (autograd's needs_input_grad) and for per-kernel timing: each is one launch. */
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out,

@@ -210,7 +210,8 @@ def test_fixed_point_scatter_add_keeps_every_channels_precision(family, flags):
         grid = torch.zeros(B, H * C, *W, device="cuda", requires_grad=True)
         ops.slice_keys(kc, grid, None, W, H, dim).backward(sc)
         tag = lib.ct_debug_last_launch().decode()
-        assert tag == ("slice_bwd_fused" if family == "hot" else "slice_bwd_gw_stats_nsplit+scatter_quad_add"), tag
+        # (few planes: the channel chunks of a plane are dealt to several workgroups — "..._groups")
+        assert tag == ("slice_bwd_fused_groups" if family == "hot" else "slice_bwd_gw_stats_nsplit+scatter_quad_add"), tag
     flags(0)
     assert _per_channel_err(z, ref, C) <= 1e-4, _per_channel_err(z, ref, C)
     assert _per_channel_err(grid.grad, ref, C) <= 1e-4, _per_channel_err(grid.grad, ref, C)
@@ -245,7 +246,7 @@ def test_splat_bwd_accumulates_into_g_keys(flags):
                                       _ptr(ws1), n1, B, H, C, N, 2, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()), "bwd_ex")
         tag = lib.ct_debug_last_launch().decode()
         flags(0)
-        assert ("splat_max_bwd_hot" == tag) == force, tag
+        assert tag.startswith("splat_max_bwd_hot") == force, tag
         assert relerr(gk_acc, base + gk_plain) <= 1e-6
         assert relerr(gf_b, gf_a) <= 1e-6
         # too small a workspace is refused
