@@ -1114,6 +1114,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
 }
 
 #include "ct_raster_hot.h"
+#include "ct_raster_hot3d.h"
 
 // ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
@@ -1631,6 +1632,123 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   return CT_OK;
 }
 
+
+// ---- 3D forms (ct_raster_hot3d.h) ----
+#define CT_LAUNCH_HOT3_(KPAD, KNOPAD, GRID, NT, LDS, STREAM, ARGS, GW)                    \
+  do {                                                                                   \
+    if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((KPAD), GRID, NT, LDS, STREAM, ARGS, GW); \
+    else CT_LAUNCH((KNOPAD), GRID, NT, LDS, STREAM, ARGS, GW);                             \
+  } while (0)
+
+int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.dst | (uintptr_t)a.tile_in;
+  if (!hot_shape_ok(a, g.G, bits)) return CT_EINVAL;
+  HotPlan hp;
+  if (!hot_chunks(a.C, (size_t)g.G * 4, 0, hp)) return CT_EINVAL;
+  // few planes: thinner chunks give more workgroups (the tile is staged once per chunk either way)
+  while ((long long)a.B * a.H * hp.nchunks < 256 && hp.CC > 4) {
+    hp.CC = ((hp.CC / 2) + 3) & ~3;
+    hp.nchunks = (a.C + hp.CC - 1) / hp.CC;
+    hp.lds = (size_t)hp.CC * g.G * 4;
+  }
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = hp.nchunks;
+  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N);
+  const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
+  dim3 grid(hp.nchunks * a.nsplit, a.H, a.B);
+  CT_LAUNCH_HOT3_((gather_ci3_kernel<true>), (gather_ci3_kernel<false>), grid, hot_threads(nq), hp.lds, st, a, g);
+  note("gather_ci3");
+  return CT_OK;
+}
+
+size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
+  HotPlan hp;
+  int ncg = 1;
+  if ((C & 3) || (N & 3) || (g.G & 3) || N > 8 * kHotThreads) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  return ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0;
+}
+
+int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
+                         (uintptr_t)ws;
+  if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  HotPlan hp;
+  int ncg = 1;
+  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
+    if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
+    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
+    ncg = 1;
+  }
+  a.tile_in = grid;
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  a.g_pos = ncg > 1 ? (float*)ws : g_pos;
+  a.gpos_stride = ncg > 1 ? gpos_n : 0;
+  dim3 wgrid(ncg, a.H, a.B);
+  const int nq = a.N >> 2;
+  if (nq <= kHotThreads)
+    CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 1>), (slice_bwd_fused3_kernel<false, 1>), wgrid, hot_threads(nq), hp.lds, st, a, g);
+  else
+    CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 2>), (slice_bwd_fused3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
+  note(ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
+  if (ncg > 1) {
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos, gpos_n, gpos_n, ncg);
+    CT_CHECK_LAUNCH();
+  }
+  return CT_OK;
+}
+
+// The 3D hot Splat(max) backward is parity-green but SLOWER than the generic kernel today (8 corners x {z, g_z} reads keep
+// ~20 more values live than the 2D form: the compiler spills; 16^3 C16 B8 N4096: 118 us vs 72 us), so it only runs when a
+// test forces the hot kernels.
+bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<3>& g, HotPlan& hp, int& ncg, bool& single) {
+  if (!(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return false;
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
+                         (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
+  if (!hot_shape_ok(a, g.G, bits)) return false;
+  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
+  single = (a.N >> 2) <= 2 * kHotThreads;
+  return true;
+}
+
+size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
+  HotPlan hp;
+  int ncg = 1;
+  if ((C & 3) || (N & 3) || (g.G & 3)) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return 0;
+  return ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0;
+}
+
+int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, int ncg, void* ws, hipStream_t st) {
+  a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  float* const out = a.g_pos;
+  const int accumulate = a.accumulate;
+  const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  if (ncg > 1) {
+    a.g_pos = (float*)ws;
+    a.gpos_stride = gpos_n;
+    a.accumulate = 0;
+  }
+  dim3 wgrid(ncg, a.H, a.B);
+  const int nq = a.N >> 2;
+  if (nq <= kHotThreads)
+    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 1>), (splat_max_bwd_hot3_kernel<false, 1>), wgrid, hot_threads(nq), hp.lds, st, a, g);
+  else if (nq <= 2 * kHotThreads)
+    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 2>), (splat_max_bwd_hot3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
+  else
+    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, kHotThreads, hp.lds, st, a, g);
+  note(ncg > 1 ? "splat_max_bwd_hot3_groups" : "splat_max_bwd_hot3");
+  if (ncg > 1) {
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(sum_parts_acc_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, out, gpos_n,
+                       gpos_n, ncg, accumulate);
+    CT_CHECK_LAUNCH();
+  }
+  return CT_OK;
+}
+
 // y += x
 __global__ void __launch_bounds__(256) add_inplace_kernel(float* y, const float* x, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1646,7 +1764,7 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N);
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(p.nchunks * a.nsplit, a.H, a.B);
-  if constexpr (DIM == 2 && FROM_KEYS) {
+  if constexpr (FROM_KEYS) {
     const int r = run_gather_hot(a, g, st);
     if (r != CT_EINVAL) return r;
   }
@@ -1746,12 +1864,12 @@ int launch_splat_max_bwd(RasterArgs a, const GridW<DIM>& g, const Plan& p, bool 
 template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
-  if constexpr (DIM == 2 && FROM_KEYS) {
+  if constexpr (FROM_KEYS) {
     HotPlan hp;
     bool single = false;
     int ncg = 1;
     if (splat_bwd_hot_plan(a, g, hp, ncg, single)) {
-      const size_t need = ncg > 1 ? (size_t)ncg * a.B * a.H * 2 * a.N * 4 : 0;
+      const size_t need = ncg > 1 ? (size_t)ncg * a.B * a.H * DIM * a.N * 4 : 0;
       // several groups: the partial sums go through the workspace and the final sum may accumulate; one group: the
       // kernel accumulates in its own store when every thread owns its quads (`single`)
       if (need <= ws_bytes && (ws || !need) && (ncg > 1 || single || !a.accumulate) && ((uintptr_t)ws & 15) == 0)
@@ -1793,7 +1911,7 @@ template <int DIM>
 int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
   if ((g.G & 3) != 0) return CT_EINVAL;
-  if constexpr (DIM == 2) {
+  {
     const int r = run_slice_bwd_hot(a, grid, g_pos, g, ws, ws_bytes, st);
     if (r != CT_EINVAL) return r;
   }
@@ -1889,11 +2007,11 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
     const size_t gpos_n = (size_t)B * H * (FROM_KEYS ? dim : (1 << dim)) * N;
     if (!ws || ws_bytes < gpos_n * 4) return CT_EWORKSPACE;
     const size_t head = ws_bytes - gpos_n * 4;
-    if (reduce == CT_REDUCE_MAX0 && dim == 2 && FROM_KEYS && grid) {
+    if (reduce == CT_REDUCE_MAX0 && FROM_KEYS && grid) {
       RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
       a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = grid; a.tile_in2 = g_grid;
       a.accumulate = 1;
-      const int r = run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st);
+      const int r = dim == 2 ? run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st) : run_splat_max_bwd<3, FROM_KEYS>(a, W, ws, head, st);
       if (r != CT_EINVAL) return r;
     }
     if constexpr (FROM_KEYS) {
@@ -2037,8 +2155,8 @@ static size_t splat_bwd_workspace_generic(int B, int H, int C, int N, int dim, c
 size_t ct_splat_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W, int reduce) {
   if (!valid_common(B, H, C, N, dim, W) || reduce != CT_REDUCE_MAX0) return 0;
   size_t n = splat_bwd_workspace_generic(B, H, C, N, dim, W);
-  if (dim == 2) {       // the hot kernels' chunk groups (whichever family a call ends up on, the scratch is enough)
-    const size_t hot = splat_bwd_hot_workspace(B, H, C, N, make_grid<2>(W));
+  {                     // the hot kernels' chunk groups (whichever family a call ends up on, the scratch is enough)
+    const size_t hot = dim == 2 ? splat_bwd_hot_workspace(B, H, C, N, make_grid<2>(W)) : splat_bwd_hot_workspace(B, H, C, N, make_grid<3>(W));
     if (hot > n) n = hot;
   }
   return n;
@@ -2087,8 +2205,8 @@ int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_
 }
 
 size_t ct_slice_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
-  if (!valid_common(B, H, C, N, dim, W) || dim != 2) return 0;
-  return slice_bwd_hot_workspace(B, H, C, N, make_grid<2>(W));
+  if (!valid_common(B, H, C, N, dim, W)) return 0;
+  return dim == 2 ? slice_bwd_hot_workspace(B, H, C, N, make_grid<2>(W)) : slice_bwd_hot_workspace(B, H, C, N, make_grid<3>(W));
 }
 
 int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,

@@ -1,0 +1,565 @@
+// 3D (trilinear, 8 corners) forms of the hot-shape kernels of ct_raster_hot.h — the zoo's volume heads (16^3 C16,
+// 8^3 C32; model_zoo/s3dis/segmenter.py:28-45).  Same design: channel-interleaved LDS tiles read with ds_read_b128,
+// the fused Slice backward with a per-channel fixed-point quantum, the branch-free Splat(max) backward with its
+// match-count tie detection.  A point's 8 corner reads are issued in two halves of 4 to stay inside 128 registers.
+// Included by ct_raster.hip after ct_raster_hot.h (uses its helpers).
+#pragma once
+
+struct Pt3 {
+  float w0[3], w1[3];
+  float cw[8];          // corner v = dx + 2 dy + 4 dz, weight (wx * wy) * wz  (ct_corners<3>)
+  int base;
+};
+
+__device__ __forceinline__ void pt3_from_keys(float kx, float ky, float kz, const GridW<3>& g, Pt3& p) {
+  int f[3];
+  ct_axis(kx, g.hw[0], g.W[0], p.w0[0], p.w1[0], f[0]);
+  ct_axis(ky, g.hw[1], g.W[1], p.w0[1], p.w1[1], f[1]);
+  ct_axis(kz, g.hw[2], g.W[2], p.w0[2], p.w1[2], f[2]);
+  p.base = (f[0] * g.W[1] + f[1]) * g.W[2] + f[2];
+  const float xy00 = p.w0[0] * p.w0[1], xy10 = p.w1[0] * p.w0[1], xy01 = p.w0[0] * p.w1[1], xy11 = p.w1[0] * p.w1[1];
+  p.cw[0] = xy00 * p.w0[2]; p.cw[1] = xy10 * p.w0[2]; p.cw[2] = xy01 * p.w0[2]; p.cw[3] = xy11 * p.w0[2];
+  p.cw[4] = xy00 * p.w1[2]; p.cw[5] = xy10 * p.w1[2]; p.cw[6] = xy01 * p.w1[2]; p.cw[7] = xy11 * p.w1[2];
+}
+
+// cell offsets of the 8 corners relative to the base cell
+__device__ __forceinline__ void corner_offsets3(const GridW<3>& g, int (&off)[8]) {
+  const int sx = g.W[1] * g.W[2], sy = g.W[2];
+  off[0] = 0; off[1] = sx; off[2] = sy; off[3] = sx + sy;
+  off[4] = 1; off[5] = sx + 1; off[6] = sy + 1; off[7] = sx + sy + 1;
+}
+
+__device__ __forceinline__ void load_keys3(const float* keys, size_t bh, int N, int n0, float (&k)[3][4]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float4 t = *(const float4*)(keys + (bh * 3 + j) * N + n0);
+    k[j][0] = t.x; k[j][1] = t.y; k[j][2] = t.z; k[j][3] = t.w;
+  }
+}
+
+__device__ __forceinline__ void store_gkeys3(float* gpos, size_t bh, int N, int n0, const float (&gs)[4][3], const float (&k)[3][4],
+                                             bool accumulate) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float4 o = make_float4(gs[0][j] * ct_key_mask(k[j][0]), gs[1][j] * ct_key_mask(k[j][1]),
+                           gs[2][j] * ct_key_mask(k[j][2]), gs[3][j] * ct_key_mask(k[j][3]));
+    float* p = gpos + (bh * 3 + j) * N + n0;
+    if (accumulate) {
+      const float4 q = *(const float4*)p;
+      o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    }
+    *(float4*)p = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KF3: Slice backward, fused (see slice_bwd_fused_kernel).  grid = (ncg, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD, int QPT>
+__global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(RasterArgs a, GridW<3> g) {
+  extern __shared__ __align__(16) float lds[];
+  const int G = g.G, CC = a.CC, N = a.N;
+  float4* T4 = (float4*)lds;
+  int* acc = (int*)(lds + (size_t)CC * G);
+  int* cnt = acc + (size_t)CC * G;
+  unsigned* s_max = (unsigned*)(cnt + G);
+  unsigned* s_k = s_max + a.C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int tid = threadIdx.x;
+  int off[8];
+  corner_offsets3(g, off);
+  int n0[QPT], n0c[QPT];
+  bool active[QPT];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    n0[u] = (tid + u * (int)blockDim.x) << 2;
+    active[u] = n0[u] < N;
+    n0c[u] = active[u] ? n0[u] : 0;
+  }
+  float pv[QPT][4];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0[u] + i) : 1.0f;
+  for (int i = tid; i < G + a.C + 1; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    if (active[u]) {
+      float k[3][4];
+      load_keys3(a.pos.keys, bh, N, n0[u], k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Pt3 p;
+        pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+        atomicAdd(&cnt[p.base], 1);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // contributions per cell = points based at the cell and at its 7 lower neighbours (a wrapped neighbour index lands
+    // on a cell of the last row / column / slice, which is never a base: it reads zero)
+    unsigned kloc = 0;
+    for (int X = tid; X < G; X += blockDim.x) {
+      unsigned c = 0;
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+        if (X >= off[v]) c += (unsigned)cnt[X - off[v]];
+      kloc = max(kloc, c);
+    }
+    kloc = wave_max_u32(kloc);
+    if ((tid & 63) == 0) atomicMax(s_k, kloc);
+  }
+  float gs[QPT][4][3];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
+
+  const int cgi = blockIdx.x;
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * CC;
+    const int cc = min(CC, a.C - c0);
+    const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+    float* gout = a.tile_out + (bh * a.C + c0) * (size_t)G;
+    for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
+      const int cq = t / G, cell = t - cq * G;
+      const float* p = gin + (size_t)(cq * 4) * G + cell;
+      T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+    }
+    if (chunk == cgi)
+      for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const float Kf = (float)(*s_k);
+    for (int cq = 0; cq < (cc >> 2); ++cq) {
+      const int ch0 = c0 + cq * 4;
+      float fv[4][4];
+      float mx[4];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+        const float4 t = ld_stream4(row + n0c[0]);
+        fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = HAS_PAD ? fv[cj][i] * pv[0][i] : fv[cj][i];
+          x = active[0] ? x : 0.0f;
+          fv[cj][i] = x;
+          x = fabsf(x);
+          m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());
+        }
+        mx[cj] = m;
+      }
+#pragma unroll
+      for (int u = 1; u < QPT; ++u) {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+          const float4 t = *(const float4*)(row + n0c[u]);
+          const float tv[4] = {t.x, t.y, t.z, t.w};
+          float m = mx[cj];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float x = fabsf(HAS_PAD ? tv[i] * pv[u][i] : tv[i]);
+            x = active[u] ? x : 0.0f;
+            m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());
+          }
+          mx[cj] = m;
+        }
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const unsigned mb = wave_max_u32(__float_as_uint(mx[cj]));
+        if ((tid & 63) == 0) atomicMax(&s_max[ch0 + cj], mb);
+      }
+      __syncthreads();
+      float iq[4];
+      bool any_float = false;
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        float q;
+        bool fixed;
+        fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iq[cj], fixed);
+        if (!fixed) {
+          iq[cj] = 0.0f;
+          any_float = true;
+        }
+      }
+      const float4* Tq = T4 + (size_t)cq * G;
+      int* accq = acc + (size_t)(cq * 4) * G;
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        if (u > 0) {
+          int n0r = n0c[u];
+          asm volatile("" : "+v"(n0r));
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj) {
+            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            const float4 t = ld_stream4(row + n0r);
+            fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x = HAS_PAD ? fv[cj][i] * pv[u][i] : fv[cj][i];
+              fv[cj][i] = active[u] ? x : 0.0f;
+            }
+          }
+        }
+        float k[3][4];
+        load_keys3(a.pos.keys, bh, N, n0c[u], k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Pt3 p;
+          pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+          float gw[8];
+#pragma unroll
+          for (int hv = 0; hv < 2; ++hv) {
+            float4 cv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[hv * 4 + v]];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              float s = cv[v].x * fv[0][i];
+              s = __builtin_fmaf(cv[v].y, fv[1][i], s);
+              s = __builtin_fmaf(cv[v].z, fv[2][i], s);
+              s = __builtin_fmaf(cv[v].w, fv[3][i], s);
+              gw[hv * 4 + v] = s;
+            }
+          }
+          float gd[3];
+          ct_corner_grad<3>(p.w0, p.w1, gw, gd);
+          gs[u][i][0] += gd[0];
+          gs[u][i][1] += gd[1];
+          gs[u][i][2] += gd[2];
+          asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]), "+v"(gs[u][i][2]));
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj) {
+            int* Tc = accq + cj * G + p.base;
+            const float fq = fv[cj][i] * iq[cj];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) atomicAdd(Tc + off[v], cvt_rpi(fq * p.cw[v]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (any_float) {
+#pragma unroll 1
+        for (int cj = 0; cj < 4; ++cj) {
+          float q, iqd;
+          bool fixed;
+          fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iqd, fixed);
+          if (!fixed) {
+            float* row_acc = (float*)(accq + cj * G);
+            const float* src = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            for (int qd = tid; qd < (N >> 2); qd += blockDim.x) {
+              const int nn = qd << 2;
+              float k[3][4];
+              load_keys3(a.pos.keys, bh, N, nn, k);
+              const float4 tf = *(const float4*)(src + nn);
+              const float f[4] = {tf.x, tf.y, tf.z, tf.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                Pt3 p;
+                pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+                const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + nn + i) : f[i];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) atomicAdd(row_acc + p.base + off[v], x * p.cw[v]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const bool more = chunk + a.ncg < a.nchunks;
+    for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) {
+      const int ch = (t << 2) / G;
+      float q, iqd;
+      bool fixed;
+      fx_quantum(__uint_as_float(s_max[c0 + ch]) * Kf, q, iqd, fixed);
+      const int4 r = ((const int4*)acc)[t];
+      float4 o;
+      if (fixed) o = make_float4((float)r.x * q, (float)r.y * q, (float)r.z * q, (float)r.w * q);
+      else o = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+      st_stream4(gout + ((size_t)t << 2), o);
+      if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    if (active[u]) {
+      float k[3][4];
+      load_keys3(a.pos.keys, bh, N, n0[u], k);
+      store_gkeys3(a.g_pos + (size_t)cgi * a.gpos_stride, bh, N, n0[u], gs[u], k, false);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KB3: Splat(max0) backward (see splat_max_bwd_hot_kernel).  grid = (ncg, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD, bool CLAIMS>
+__device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW<3>& g, float4* ZG, size_t bh, int b, int c0,
+                                                int cc, int n0, const float (&k)[3][4], const int (&off)[8], float (&gs)[4][3],
+                                                int& nm) {
+  const int G = g.G, N = a.N;
+  float pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+  for (int cg0 = 0; cg0 < cc; cg0 += 4) {
+    float fv[4][4];
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)N;
+      const float4 t = ld_stream4(row + n0);
+      fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+    }
+    float4* Zc = ZG + (size_t)(cg0 >> 1) * G;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pt3 p;
+      pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+      float gw[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float4* Zp = Zc + (size_t)pr * G + p.base;
+        const float xa = HAS_PAD ? fv[2 * pr][i] * pv[i] : fv[2 * pr][i];
+        const float xb = HAS_PAD ? fv[2 * pr + 1][i] * pv[i] : fv[2 * pr + 1][i];
+        float gfa = 0.0f, gfb = 0.0f;
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+          float4 zg[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            zg[v] = Zp[off[hv * 4 + v]];
+            asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
+          }
+          if (!CLAIMS) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float w = p.cw[hv * 4 + v];
+              const unsigned ba = __float_as_uint(xa * w), bb = __float_as_uint(xb * w);
+              const bool ma = ba == __float_as_uint(zg[v].x), mb = bb == __float_as_uint(zg[v].y);
+              nm += (int)ma;
+              nm += (int)mb;
+              asm volatile("" : "+v"(nm));
+              const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
+              gfa = __builtin_fmaf(ga, w, gfa);
+              gfb = __builtin_fmaf(gb, w, gfb);
+              gw[hv * 4 + v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[hv * 4 + v]));
+            }
+          } else {
+            unsigned ba[4], bb[4];
+            bool ma[4], mb[4];
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float w = p.cw[hv * 4 + v];
+              ba[v] = __float_as_uint(xa * w);
+              bb[v] = __float_as_uint(xb * w);
+              ma[v] = ba[v] == __float_as_uint(zg[v].x);
+              mb[v] = bb[v] == __float_as_uint(zg[v].y);
+              any = any | ma[v] | mb[v];
+            }
+            if (any) {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float w = p.cw[hv * 4 + v];
+                unsigned* zw = (unsigned*)(Zp + off[hv * 4 + v]);
+                const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : kNoMatch, kNoMatch);
+                const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : kNoMatch, kNoMatch);
+                const float ga = (ma[v] & (oa == ba[v])) ? zg[v].z : 0.0f;
+                const float gb = (mb[v] & (ob == bb[v])) ? zg[v].w : 0.0f;
+                gfa = __builtin_fmaf(ga, w, gfa);
+                gfb = __builtin_fmaf(gb, w, gfb);
+                gw[hv * 4 + v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[hv * 4 + v]));
+              }
+            }
+          }
+        }
+        fv[2 * pr][i] = HAS_PAD ? gfa * pv[i] : gfa;
+        fv[2 * pr + 1][i] = HAS_PAD ? gfb * pv[i] : gfb;
+      }
+      float gd[3];
+      ct_corner_grad<3>(p.w0, p.w1, gw, gd);
+      gs[i][0] += gd[0];
+      gs[i][1] += gd[1];
+      gs[i][2] += gd[2];
+      asm volatile("" : "+v"(gs[i][0]), "+v"(gs[i][1]), "+v"(gs[i][2]), "+v"(fv[0][i]), "+v"(fv[1][i]), "+v"(fv[2][i]), "+v"(fv[3][i]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+      st_stream4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)N + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]));
+  }
+}
+
+template <bool HAS_PAD, bool CLAIMS, int QPT>
+__device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const GridW<3>& g, float4* ZG, int* s_cnt, size_t bh,
+                                                     int b, const int (&off)[8], float (&gs_reg)[QPT ? QPT : 1][4][3], bool& tie) {
+  const int G = g.G, CC = a.CC, N = a.N;
+  const int tid = threadIdx.x;
+  const int nq = N >> 2;
+  int nz = 0, nm = 0;
+  const int cgi = blockIdx.x;
+  float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * CC;
+    const int cc = min(CC, a.C - c0);
+    const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+    const float* gin = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
+    __syncthreads();
+    for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
+      const int cp = t / G, cell = t - cp * G;
+      const size_t o = (size_t)(cp * 2) * G + cell;
+      const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
+      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
+                          ld_stream(gin + o + G));
+      if (!CLAIMS) nz += (z0 != 0u) + (z1 != 0u);
+    }
+    __syncthreads();
+    if constexpr (QPT > 0) {
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        const int q = tid + u * (int)blockDim.x;
+        if (q < nq) {
+          float k[3][4];
+          load_keys3(a.pos.keys, bh, N, q << 2, k);
+          splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, k, off, gs_reg[u], nm);
+        }
+      }
+    } else {
+      for (int q = tid; q < nq; q += blockDim.x) {
+        float k[3][4];
+        load_keys3(a.pos.keys, bh, N, q << 2, k);
+        float gs[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
+        splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, k, off, gs, nm);
+        store_gkeys3(gpos, bh, N, q << 2, gs, k, chunk > cgi);
+      }
+    }
+  }
+  if (!CLAIMS) {
+    nz = wave_sum_i32(nz);
+    nm = wave_sum_i32(nm);
+    if ((tid & 63) == 0) {
+      atomicAdd(&s_cnt[0], nz);
+      atomicAdd(&s_cnt[1], nm);
+    }
+    __syncthreads();
+    tie = s_cnt[0] != s_cnt[1];
+  }
+}
+
+template <bool HAS_PAD, int QPT>
+__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(RasterArgs a, GridW<3> g) {
+  extern __shared__ __align__(16) float lds[];
+  float4* ZG = (float4*)lds;
+  int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int N = a.N;
+  int off[8];
+  corner_offsets3(g, off);
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  float gs[QPT ? QPT : 1][4][3];
+#pragma unroll
+  for (int u = 0; u < (QPT ? QPT : 1); ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
+  bool tie = false;
+  splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, off, gs, tie);
+  if (tie) {
+#pragma unroll
+    for (int u = 0; u < (QPT ? QPT : 1); ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
+    splat_bwd_plane_pass3<HAS_PAD, true, QPT>(a, g, ZG, s_cnt, bh, b, off, gs, tie);
+  }
+  if constexpr (QPT > 0) {
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+      const int n0 = ((int)threadIdx.x + u * (int)blockDim.x) << 2;
+      if (n0 < N) {
+        float k[3][4];
+        load_keys3(a.pos.keys, bh, N, n0, k);
+        store_gkeys3(a.g_pos + (size_t)blockIdx.x * a.gpos_stride, bh, N, n0, gs[u], k, a.accumulate != 0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KG3: Slice forward / gather with the channel-interleaved tile.  grid = (nchunks * nsplit, H, B)
+// ---------------------------------------------------------------------------
+template <bool HAS_PAD>
+__global__ void __launch_bounds__(kHotThreads, 4) gather_ci3_kernel(RasterArgs a, GridW<3> g) {
+  extern __shared__ __align__(16) float lds[];
+  const int G = g.G, N = a.N;
+  float4* T4 = (float4*)lds;
+  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int c0 = chunk * a.CC;
+  const int cc = min(a.CC, a.C - c0);
+  const int tid = threadIdx.x;
+  int off[8];
+  corner_offsets3(g, off);
+  const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
+  for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
+    const int cq = t / G, cell = t - cq * G;
+    const float* p = gin + (size_t)(cq * 4) * G + cell;
+    T4[t] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+  }
+  __syncthreads();
+  const int nq = N >> 2;
+  const int per = (nq + a.nsplit - 1) / a.nsplit;
+  const int q_beg = sp * per, q_end = min(nq, q_beg + per);
+  float* dst = a.dst + (bh * a.C + c0) * (size_t)N;
+  for (int q = q_beg + tid; q < q_end; q += blockDim.x) {
+    const int n0 = q << 2;
+    float k[3][4], pv[4];
+    load_keys3(a.pos.keys, bh, N, n0, k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+    for (int cq = 0; cq < (cc >> 2); ++cq) {
+      const float4* Tq = T4 + (size_t)cq * G;
+      float o[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Pt3 p;
+        pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+          float4 cv[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) cv[v] = Tq[p.base + off[hv * 4 + v]];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float w = p.cw[hv * 4 + v];
+            // the reference's sum over corners in corner order (the first product initialises the sum)
+            if (hv == 0 && v == 0) { s0 = cv[0].x * w; s1 = cv[0].y * w; s2 = cv[0].z * w; s3 = cv[0].w * w; }
+            else { s0 += cv[v].x * w; s1 += cv[v].y * w; s2 += cv[v].z * w; s3 += cv[v].w * w; }
+          }
+        }
+        o[0][i] = HAS_PAD ? s0 * pv[i] : s0;
+        o[1][i] = HAS_PAD ? s1 * pv[i] : s1;
+        o[2][i] = HAS_PAD ? s2 * pv[i] : s2;
+        o[3][i] = HAS_PAD ? s3 * pv[i] : s3;
+        asm volatile("" : "+v"(o[0][i]), "+v"(o[1][i]), "+v"(o[2][i]), "+v"(o[3][i]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj)
+        st_stream4(dst + (size_t)(cq * 4 + cj) * N + n0, make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]));
+    }
+  }
+}

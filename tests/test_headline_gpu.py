@@ -123,6 +123,12 @@ SMALL = [
     (1, 1, 20, 2048, (16, 16), True, False),
     (1, 2, 8, 2052, (32, 32), False, False),      # ragged tail of the second quad
     (1, 1, 32, 4096, (48, 40), False, False),     # several chunks, whole-CU LDS
+    # 3D (trilinear) forms: the zoo's volume heads
+    (2, 2, 16, 1024, (16, 16, 16), False, False),
+    (1, 2, 32, 4096, (8, 8, 8), False, False),    # two quads per thread, 32 channels
+    (1, 2, 8, 8192, (8, 8, 8), False, False),     # g_keys through memory
+    (2, 2, 12, 516, (6, 8, 10), True, False),     # non-cubic, padding mask, ragged tail
+    (1, 2, 8, 256, (4, 4, 4), False, True),       # exact ties in 3D
 ]
 
 
@@ -132,7 +138,7 @@ def test_hot_kernels_forced_on_small_shapes(cfg, reduce, flags):
     """The hot-shape kernels on shapes the oracle handles whole (they are normally reserved for >= 128 planes)."""
     mod, lib = _lib()
     B, H, C, N, W, use_pad, dup = cfg
-    dim = 2
+    dim = len(W)
     g = torch.Generator().manual_seed(B * 131 + C * 7 + N)
     keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
     feat = torch.randn(B, H * C, N, generator=g)
@@ -145,7 +151,7 @@ def test_hot_kernels_forced_on_small_shapes(cfg, reduce, flags):
     flags(mod.DEBUG_FORCE_HOT)
     got, tags = hip_chain(keys.cuda(), feat.cuda(), cot.cuda(), list(W), H, dim, reduce, None if pad is None else pad.cuda())
     flags(0)
-    assert tags["slice_fwd"] == "gather_ci", tags
+    assert tags["slice_fwd"] == ("gather_ci" if dim == 2 else "gather_ci3"), tags
     if reduce == "max":
         assert torch.equal(got[0].cpu(), ref[0])
     if dup and reduce == "max":
