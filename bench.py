@@ -162,6 +162,18 @@ def cpu_baseline(args):
                                         "median of %d after a warm-up" % r1}}
 
 
+def emit(line):
+    """Print the result as the LAST line of stdout: RCCL writes its version banner through C stdio, which — when stdout
+    is a file or a pipe — sits in libc's buffer until exit and would land after a Python print; flush it first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
 def init_rank():
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -281,7 +293,13 @@ def run_op(args):
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()             # every rank's banners are out (they flush below before this barrier completes)
+        emit(json.dumps(out))
+    elif dist is not None:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -346,7 +364,12 @@ def run_ddp_step(args):
                        "norm_statistics_collectives_per_step": (ops.sync_stats_collectives() - coll0) / args.steps,
                        "loss": float(loss.detach())},
         }
-        print(json.dumps(out), flush=True)
+        dist.barrier()
+        emit(json.dumps(out))
+    else:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
     dist.barrier()
     dist.destroy_process_group()
 
