@@ -315,6 +315,118 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4_kernel(GconvArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// K-split form of the quad MFMA kernel for WIDE groups (more than 32 input channels per group: the grouped Res2D /
+// Res3D stacks of the classifier / inpainter encoders, 64 channels per group on 8^3 .. 2^3 volumes;
+// model_zoo/scanobject/classifier.py:74-92).  gconv_fwd4_kernel keeps a group's whole input tile and the whole filter
+// bank of a 16-row block in LDS — 147 KiB of bank alone at 64 input channels in 3D.  Here the contraction runs over
+// blocks of 16 input channels: per block the workgroup stages 16 input planes and the bank slice of ITS 16-row output
+// blocks ([mt][row][4 kb][4 kq][16 co][4 dx]), and the accumulators of every (span of 16 quads, 16-row block) item a
+// wave owns stay in registers across the blocks (MAXI items per wave).  Backward-data = the same kernel on the
+// transposed + flipped bank.  grid = (tiles * msplit, groups, B)
+// ---------------------------------------------------------------------------
+constexpr int kKBlk = 16;       // input channels per contraction block (4 MFMA k-groups)
+
+template <int DIM, int MAXI>
+__global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a) {
+  constexpr int NR = DIM == 3 ? 9 : 3;
+  constexpr int KBB = kKBlk / 4;
+  extern __shared__ __align__(16) float lds[];
+  const int tile = blockIdx.x / a.msplit, ms = blockIdx.x % a.msplit, grp = blockIdx.y, b = blockIdx.z;
+  const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
+  const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
+  float* xs = lds + kSlack;                                              // [16][plane]
+  float* ws = lds + kSlack + (size_t)kKBlk * a.plane + kSlack;           // [nmt][NR][KBB][4 kq][16 co][4]
+  const size_t vol = (size_t)a.D * a.H * a.W;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int wq = a.W >> 2;
+  const int nquads = td * th * wq;
+  const int nspans = (nquads + 15) >> 4;
+  const int MT = (a.Cout + 15) >> 4;
+  const int nmt = (MT - ms + a.msplit - 1) / a.msplit;                    // 16-row blocks of this workgroup: ms, ms + msplit, ...
+  const int nitems = nspans * nmt;
+  float* yg = a.y + ((size_t)b * a.groups + grp) * a.Cout * vol;
+
+  floatx4 acc[MAXI][4];
+  int it_sp[MAXI], it_mt[MAXI];
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    const int item = wave + u * nwaves;
+    it_sp[u] = item < nitems ? item / nmt : -1;
+    it_mt[u] = item < nitems ? item % nmt : 0;
+    const int mt = ms + it_mt[u] * a.msplit;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = mt * 16 + kq * 4 + r;
+      const float bv = (a.bias != nullptr && co < a.Cout && item < nitems) ? a.bias[grp * a.Cout + co] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[u][j][r] = bv;
+    }
+  }
+
+  for (int k0 = 0; k0 < a.Cin; k0 += kKBlk) {
+    __syncthreads();                                   // the previous block's operands are consumed
+    GconvArgs ab = a;
+    ab.Cin = min(kKBlk, a.Cin - k0);                   // channels of this block (the rest of the 16 planes stays zero)
+    stage_halo_tile<DIM>(xs, a.x + (((size_t)b * a.groups + grp) * a.Cin + k0) * vol, ab, kKBlk, td0, th0, lane, wave, nwaves);
+    for (int i = threadIdx.x; i < nmt * NR * KBB * 256; i += blockDim.x) {
+      const int dx = i & 3, m = (i >> 2) & 15, k = (i >> 6) & 3, rk = i >> 8;
+      const int kb = rk % KBB, r = (rk / KBB) % NR, mtl = rk / (KBB * NR);
+      const int co = (ms + mtl * a.msplit) * 16 + m, ci = k0 + kb * 4 + k, tap = r * 3 + dx;
+      float v = 0.0f;
+      if (dx < 3 && co < a.Cout && ci < a.Cin)
+        v = a.transposed ? a.w[((size_t)(grp * a.Cin + ci) * a.Cout + co) * a.taps + (a.taps - 1 - tap)]
+                         : a.w[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + tap];
+      ws[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      if (it_sp[u] < 0) continue;                      // wave-uniform
+      const int q = min(it_sp[u] * 16 + col, nquads - 1);
+      const int xq = q % wq, y = (q / wq) % th, z = q / (wq * th);
+      const int x0 = xq * 4;
+      const bool bl = x0 == 0, br = x0 + 4 == a.W;
+      const int off = (z * a.Hs + y) * a.W + x0;
+      const float* wm = ws + (size_t)it_mt[u] * NR * KBB * 256;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int roff = ((r / 3) * a.Hs + (r % 3)) * a.W;
+#pragma unroll
+        for (int kb = 0; kb < KBB; ++kb) {
+          const float4 a4 = *(const float4*)__builtin_assume_aligned(wm + ((size_t)(r * KBB + kb) * 4 + kq) * 64 + col * 4, 16);
+          const float* rp = xs + (size_t)(kb * 4 + kq) * a.plane + off + roff;
+          const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+          const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+          const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+          const float av[3] = {a4.x, a4.y, a4.z};
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dx], v[j + dx], acc[u][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    if (it_sp[u] < 0) continue;
+    const int qi = it_sp[u] * 16 + col;
+    if (qi < nquads) {
+      const int xq = qi % wq, y = (qi / wq) % th, z = qi / (wq * th);
+      const size_t o = ((size_t)(td0 + z) * a.H + (th0 + y)) * a.W + xq * 4;
+      const int mt = ms + it_mt[u] * a.msplit;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = mt * 16 + kq * 4 + r;
+        if (co < a.Cout) *(float4*)(yg + (size_t)co * vol + o) = make_float4(acc[u][0][r], acc[u][1][r], acc[u][2][r], acc[u][3][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Four-channel groups (the zoo's C=4 heads: 128^2 planes, 32^3 volumes) on the vector ALU.
 // A 16x16x4 MFMA carries 4 useful rows and 4 useful K slots out of 16 for these filters; the op is
@@ -839,6 +951,89 @@ __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, siz
 }
 
 // second stage of the ring kernel's reduction: g_w[grp, co, ci, t] = sum over chunks (ascending) of the stored partials
+// ---------------------------------------------------------------------------
+// Backward-weight for SMALL volumes with many channels (the pooled 8^3 .. 2^3 volumes and 16^2 .. 4^2 planes of the
+// Res3D / Res2D stacks: <= 512 positions, 32-64 channels per group).  There the ring kernel's per-unit pipeline never
+// fills (its tiles are the whole volume) and its workspace reduction moves more bytes than the op: 300-800 us for
+// 0.2-14 GFLOP.  This form is a plain register-tiled correlation on the vector ALU: one 256-thread workgroup per
+// (group, 16 output channels, 16 input channels), thread = one (co, ci) pair holding its 3^d filter taps; per batch
+// element the zero-padded input block and the g_y block sit in LDS, a thread walks the rows with g_y's row and the
+// three shifted input rows in registers (W + 2 + W reads per 3 W multiply-adds per (dz, dy)).  Lanes of a wave differ
+// in ci (16) and co (4): every LDS read is a 16- or 4-address broadcast.  No atomics, no workspace: bitwise
+// reproducible.  The bias gradient rides along (ci block 0, lanes with ci == 0).   grid = (ci_blocks * co_blocks, groups)
+// ---------------------------------------------------------------------------
+template <int DIM, int WT>
+__global__ void __launch_bounds__(256) gconv_wrw_small_kernel(GconvArgs a, const float* __restrict__ gy, float* __restrict__ gw,
+                                                             float* __restrict__ gbias) {
+  constexpr int NR = DIM == 3 ? 9 : 3;
+  extern __shared__ __align__(16) float lds[];
+  const int D = a.D, H = a.H;
+  const int Hp = H + 2, Wp = WT + 2, Dp = DIM == 3 ? D + 2 : 1;
+  int plane = Dp * Hp * Wp;
+  plane |= 1;                                            // odd stride between input channels: conflict-free broadcasts
+  const int P = D * H * WT;
+  float* xs = lds;                                       // [16][plane], zero halo
+  float* gs = lds + 16 * plane;                          // [16][P]
+  const int cib = (a.Cin + 15) / 16;
+  const int cb = blockIdx.x % cib, ob = blockIdx.x / cib, grp = blockIdx.y;
+  const int ci = threadIdx.x & 15, co = threadIdx.x >> 4;
+  const int ci_g = cb * 16 + ci, co_g = ob * 16 + co;
+  const size_t vol = (size_t)P;
+  float acc[NR * 3];
+#pragma unroll
+  for (int t = 0; t < NR * 3; ++t) acc[t] = 0.0f;
+  float bsum = 0.0f;
+  for (int i = threadIdx.x; i < 16 * plane; i += 256) xs[i] = 0.0f;      // the halo stays zero for every batch element
+  for (int b = 0; b < a.B; ++b) {
+    __syncthreads();
+    const float* xg = a.x + ((size_t)b * a.groups + grp) * a.Cin * vol;
+    const float* gg = gy + ((size_t)b * a.groups + grp) * a.Cout * vol;
+    for (int i = threadIdx.x; i < 16 * P; i += 256) {
+      const int c = i / P, p = i - c * P;
+      const int x = p % WT, y = (p / WT) % H, z = p / (WT * H);
+      const int cin = cb * 16 + c, cout = ob * 16 + c;
+      xs[c * plane + ((DIM == 3 ? z + 1 : 0) * Hp + y + 1) * Wp + x + 1] = cin < a.Cin ? xg[(size_t)cin * vol + p] : 0.0f;
+      gs[i] = cout < a.Cout ? gg[(size_t)cout * vol + p] : 0.0f;
+    }
+    __syncthreads();
+    const float* xc = xs + ci * plane;
+    const float* gc = gs + co * P;
+    for (int z = 0; z < D; ++z) {
+      for (int y = 0; y < H; ++y) {
+        float g[WT];
+#pragma unroll
+        for (int x = 0; x < WT; ++x) g[x] = gc[(z * H + y) * WT + x];
+        if (cb == 0) {
+#pragma unroll
+          for (int x = 0; x < WT; ++x) bsum += g[x];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int dz = DIM == 3 ? r / 3 : 0, dy = r % 3;
+          const float* row = xc + ((z + dz) * Hp + y + dy) * Wp;       // padded coordinates: (z + dz - 1) + 1, ...
+          float xr[WT + 2];
+#pragma unroll
+          for (int x = 0; x < WT + 2; ++x) xr[x] = row[x];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            float s = acc[r * 3 + dx];
+#pragma unroll
+            for (int x = 0; x < WT; ++x) s = __builtin_fmaf(g[x], xr[x + dx], s);
+            acc[r * 3 + dx] = s;
+          }
+        }
+      }
+    }
+  }
+  if (co_g < a.Cout && ci_g < a.Cin) {
+    float* o = gw + ((size_t)(grp * a.Cout + co_g) * a.Cin + ci_g) * a.taps;
+#pragma unroll
+    for (int t = 0; t < NR * 3; ++t) o[t] = acc[t];
+  }
+  if (gbias != nullptr && cb == 0 && ci == 0 && co_g < a.Cout) gbias[grp * a.Cout + co_g] = bsum;
+}
+
+
 __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int Cin,
                                                                int Cout, int taps) {
   __shared__ float red[4][64];
@@ -1043,12 +1238,57 @@ int launch_fwd4(GconvArgs a, int dim, hipStream_t st) {
   return CT_OK;
 }
 
+
+// K-split form for wide groups (> 32 input channels per group): see gconv_fwd4k_kernel
+int launch_fwd4k(GconvArgs a, int dim, hipStream_t st) {
+  const int NR = dim == 3 ? 9 : 3;
+  const int MT = (a.Cout + 15) / 16;
+  constexpr int kWaves = kThreadsBig / 64;
+  // Pass 0: the smallest split of the 16-row output blocks over workgroups (msplit) for which ONE tile covers the whole
+  // volume next to the bank slice (the pooled 8^3 .. 2^3 volumes: no halo re-staging at all); pass 1: any tiling, the
+  // thinnest bank first.  Items = (span of 16 quads, 16-row block) pairs a wave keeps in registers: <= 4 per wave.
+  for (int pass = 0; pass < 2; ++pass)
+  for (int step = 0; step < MT; ++step) {
+    const int msplit = pass == 0 ? step + 1 : MT - step;
+    const int nmt = (MT + msplit - 1) / msplit;
+    const size_t wbytes = (size_t)nmt * NR * (kKBlk / 4) * 256 * 4;
+    GconvArgs t = a;
+    if (!plan_tiles_min_halo(t, dim, 0, wbytes, kKBlk, 16, kLdsBudgetMax)) continue;
+    if (pass == 0 && t.nD * t.nH != 1) continue;
+    const int nquads = t.TD * t.TH * (a.W >> 2);
+    const int items = ((nquads + 15) / 16) * nmt;
+    const long long wgs = (long long)t.nD * t.nH * a.groups * a.B * msplit;
+    if (items > 4 * kWaves) continue;                        // thinner blocks per workgroup
+    if (pass == 0 && wgs < 256 && msplit < MT && items > kWaves / 2) continue;   // cover the chip while the waves still have work
+    t.msplit = msplit;
+    const size_t lds = (size_t)kKBlk * t.plane * 4 + wbytes + 2 * kSlack * 4;
+    dim3 grid(t.nD * t.nH * msplit, a.groups, a.B);
+    const int maxi = items <= kWaves ? 1 : (items <= 2 * kWaves ? 2 : 4);
+    CT_CLEAR_ERROR();
+#define CT_F4K_LAUNCH(DIMV, MAXIV)                                                              \
+    do {                                                                                        \
+      if (set_lds_attr(gconv_fwd4k_kernel<DIMV, MAXIV>, lds) != CT_OK) return CT_ELAUNCH;       \
+      hipLaunchKernelGGL((gconv_fwd4k_kernel<DIMV, MAXIV>), grid, dim3(kThreadsBig), lds, st, t); \
+    } while (0)
+    if (dim == 2) { if (maxi == 1) CT_F4K_LAUNCH(2, 1); else if (maxi == 2) CT_F4K_LAUNCH(2, 2); else CT_F4K_LAUNCH(2, 4); }
+    else { if (maxi == 1) CT_F4K_LAUNCH(3, 1); else if (maxi == 2) CT_F4K_LAUNCH(3, 2); else CT_F4K_LAUNCH(3, 4); }
+#undef CT_F4K_LAUNCH
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+  }
+  return CT_EINVAL;
+}
+
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
+  if (rows16 && a.Cin > 32) {      // wide groups: contraction in blocks of 16 input channels
+    const int r = launch_fwd4k(a, dim, st);
+    if (r != CT_EINVAL) return r;
+  }
   if (rows16) {
     // the quad form keeps the whole filter bank of a 16-row block in LDS ([rows][KB][4][16][4] floats): with 64 input
-    // channels per group in 3D that alone is 147 KiB — such shapes take the one-position form below (27 % smaller bank)
+    // channels per group in 3D that alone is 147 KiB — such shapes take the K-split form above
     const int r = launch_fwd4(a, dim, st);
     if (r != CT_EINVAL) return r;
   }
@@ -1201,6 +1441,38 @@ int launch_wrw_tiles(GconvArgs a, int dim, const float* g_y, float* g_w, hipStre
 }
 
 // plan-only checks behind ct_gconv_supported
+// small volumes, many channels: the register-tiled vector-ALU form (see gconv_wrw_small_kernel)
+bool wrw_small_eligible(const GconvArgs& a, int dim) {
+  const int P = a.D * a.H * a.W;
+  if (!(a.W == 2 || a.W == 4 || a.W == 8 || a.W == 16)) return false;
+  // (the walk over the batch is serial per workgroup: beyond ~2048 positions x batch the MFMA ring kernel wins —
+  //  8^3 B8: 563 vs 400 us; 8^3 B2: 133 vs 305 us)
+  if (P > 512 || (long long)P * a.B > 2048 || (a.Cin < 32 && a.Cout < 32)) return false;
+  const int plane = ((dim == 3 ? a.D + 2 : 1) * (a.H + 2) * (a.W + 2)) | 1;
+  return (size_t)(16 * plane + 16 * P) * 4 <= (size_t)kLdsBudgetMax;
+}
+
+int launch_wrw_small(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_bias, hipStream_t st) {
+  const int P = a.D * a.H * a.W;
+  const int plane = ((dim == 3 ? a.D + 2 : 1) * (a.H + 2) * (a.W + 2)) | 1;
+  const size_t lds = (size_t)(16 * plane + 16 * P) * 4;
+  dim3 grid(((a.Cin + 15) / 16) * ((a.Cout + 15) / 16), a.groups);
+  CT_CLEAR_ERROR();
+#define CT_WS_LAUNCH(DIMV, WTV)                                                                    \
+  do {                                                                                             \
+    if (set_lds_attr(gconv_wrw_small_kernel<DIMV, WTV>, lds) != CT_OK) return CT_ELAUNCH;          \
+    hipLaunchKernelGGL((gconv_wrw_small_kernel<DIMV, WTV>), grid, dim3(256), lds, st, a, g_y, g_w, g_bias); \
+  } while (0)
+  if (dim == 2) {
+    if (a.W == 2) CT_WS_LAUNCH(2, 2); else if (a.W == 4) CT_WS_LAUNCH(2, 4); else if (a.W == 8) CT_WS_LAUNCH(2, 8); else CT_WS_LAUNCH(2, 16);
+  } else {
+    if (a.W == 2) CT_WS_LAUNCH(3, 2); else if (a.W == 4) CT_WS_LAUNCH(3, 4); else if (a.W == 8) CT_WS_LAUNCH(3, 8); else CT_WS_LAUNCH(3, 16);
+  }
+#undef CT_WS_LAUNCH
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 bool fwd_plan_ok(GconvArgs a, int dim) {
   if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 &&
       (plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudget) || plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudgetMax))) return true;
@@ -1209,6 +1481,7 @@ bool fwd_plan_ok(GconvArgs a, int dim) {
 }
 
 bool wrw_plan_ok(GconvArgs a, int dim) {
+  if (wrw_small_eligible(a, dim)) return true;
   WrwRingPlan p;
   if ((a.W & 3) == 0 && plan_wrw_ring(a, dim, p, c4_wrw_eligible(a) ? 4 : 16)) return true;
   const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
@@ -1270,6 +1543,12 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   CT_CLEAR_ERROR();
   const bool aligned = ((((uintptr_t)x) | ((uintptr_t)g_y)) & 15) == 0;
   bool ring_bias = (a.W & 3) == 0 && workspace != nullptr;        // the ring kernels' workspace path produces g_bias itself
+  if (wrw_small_eligible(a, dim)) {
+    r = launch_wrw_small(a, dim, g_y, g_w, g_bias, st);
+    if (r != CT_OK) return r;
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+  }
   if (workspace && aligned && c4_wrw_eligible(a)) {
     r = launch_c4_wrw(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
   } else {

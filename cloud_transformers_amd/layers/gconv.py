@@ -67,11 +67,12 @@ def _eligible(mod, x):
             and mod.padding_mode == "zeros"):
         return False
     # More than 32 channels per group (the grouped Res2D / Res3D stacks on the pooled 8^3 .. 2^3 volumes and 16^2 .. 4^2
-    # planes of the classifier / inpainter encoders): these kernels keep a group's filter bank and input tile in LDS and
-    # were built for the MultiHead convolutions (<= 32 channels per group on large grids); with 64 channels per group the
-    # bank alone is 110-147 KiB and is re-staged per tile, and the library convolution is 2-4x faster (B8 3D 1024->1024,
-    # groups 16, 8^3: 5.0 ms vs 1.5 ms fwd+bwd; 512->1024: 1.5 vs 0.9 ms; 2^3: 1.1 vs 0.28 ms) — it takes those layers.
-    if max(mod.in_channels, mod.out_channels) // mod.groups > 32:
+    # planes of the classifier / inpainter encoders) run on the K-split MFMA kernel (gconv_fwd4k_kernel: contraction in
+    # blocks of 16 input channels) and the small-volume weight-gradient kernel; measured fwd+bwd at B8, groups 16, vs the
+    # library: 3D 1024->1024 8^3 0.71 vs 1.46 ms, 512->1024 8^3 0.42 vs 0.90, 4^3 0.22 vs 0.46, 2D 8^2 0.10 vs 0.13,
+    # 4^2 0.08 vs 0.13.  One exception: rows that are not 16-byte multiples (the 2^3 volumes, W = 2) with wide groups —
+    # the quad MFMA kernels need float4 rows and the one-position form loses to the library there (0.33 vs 0.30 ms).
+    if max(mod.in_channels, mod.out_channels) // mod.groups > 32 and x.shape[-1] % 4 != 0:
         return False
     # shapes whose tiles do not fit LDS (very wide rows with many channels per group) take the library convolution
     W = tuple(x.shape[2:])

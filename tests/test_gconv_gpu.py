@@ -25,6 +25,11 @@ CASES = [
     (1, 2, 64, 64, 2, (4, 4), False),         # classifier Res2DBlock(1024, 1024, groups=16) on 4^2
     (1, 3, 16, 48, 2, (8, 8), True),          # few workgroups: the 3 output-channel blocks of a tile go to different workgroups
     (2, 16, 64, 64, 3, (8, 8, 8), False),     # inpainter Res3DBlock(1024, 1024, groups=16) at batch 2
+    # wide groups on the K-split kernel (contraction in blocks of 16 input channels)
+    (1, 2, 64, 64, 3, (8, 8, 8), True),
+    (1, 2, 48, 64, 2, (8, 8), True),          # input channels not a multiple of the block
+    (1, 2, 72, 40, 3, (4, 4, 4), True),       # ragged input block and ragged 16-row output block
+    (1, 1, 64, 64, 2, (16, 16), False),       # several spans per wave
 ]
 
 
@@ -63,10 +68,10 @@ def test_gconv_fwd_bwd(cfg):
         close(m.bias.grad, br.grad, "g_bias", 5e-5)
 
 
-def test_wide_groups_take_the_library_convolution():
-    """More than 32 channels per group (the Res2D / Res3D stacks of the classifier and the inpainter on 8^3 .. 2^3
-    volumes): the library convolution is 2-4x faster there than these kernels (built for the MultiHead convs: <= 32
-    channels per group on large grids), so the modules route such layers to it — same results."""
+def test_wide_groups_run_on_the_k_split_kernels():
+    """More than 32 channels per group (the Res2D / Res3D stacks of the classifier and the inpainter on the pooled 8^3 ..
+    4^3 volumes and 8^2 .. 4^2 planes) run on this package's kernels too (K-split MFMA forward / backward-data, small-volume
+    weight gradient); only wide groups on rows that are not 16-byte multiples (the 2^3 volumes) go to the library."""
     from cloud_transformers_amd.layers import gconv as G
     calls = []
     real = G.GroupedConvFn.apply
@@ -78,9 +83,13 @@ def test_wide_groups_take_the_library_convolution():
         narrow(torch.randn(1, 64, 4, 4, 4, device="cuda"))
         assert calls == [1]
         xw = torch.randn(1, 128, 4, 4, 4, device="cuda")
-        assert torch.allclose(wide(xw), torch.nn.functional.conv3d(xw, wide.weight, None, padding=1, groups=2), atol=1e-5)
+        assert torch.allclose(wide(xw), torch.nn.functional.conv3d(xw, wide.weight, None, padding=1, groups=2), atol=1e-4)
+        assert calls == [1, 1]
         mixed(torch.randn(1, 64, 8, 8, device="cuda"))
-        assert calls == [1]
+        assert calls == [1, 1, 1]
+        x2 = torch.randn(1, 128, 2, 2, 2, device="cuda")                                   # 2^3: rows of 2 floats
+        assert torch.allclose(wide(x2), torch.nn.functional.conv3d(x2, wide.weight, None, padding=1, groups=2), atol=1e-4)
+        assert calls == [1, 1, 1]
     finally:
         G.GroupedConvFn.apply = real
 
