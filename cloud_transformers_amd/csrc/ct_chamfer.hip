@@ -2,10 +2,10 @@
 // its gradient (replaces chamfer_extension/chamfer.cu:12-195 of the reference).
 //
 // Forward is O(n*m) fp32 VALU work.  One 1024-thread workgroup owns 64*Q query
-// points (Q per lane, in registers); each of its 4 waves scans one quarter of
-// the target cloud.  Target coordinates are wave-uniform, so they are fetched
+// points (Q per lane, in registers); each of its 16 waves scans one sixteenth
+// of the target cloud.  Target coordinates are wave-uniform, so they are fetched
 // with scalar loads (s_load_dwordx*) straight into SGPRs — no LDS staging and
-// no barriers in the scan loop.  The four partial (min, argmin) pairs are
+// no barriers in the scan loop.  The 16 partial (min, argmin) pairs are
 // merged through LDS in ascending target order, which preserves the
 // reference's tie rule (strict '<' while scanning ascending: lowest index
 // wins, chamfer.cu:36,46,126).
@@ -13,11 +13,14 @@
 
 namespace {
 
-constexpr int kQ = 4;          // queries per lane
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 constexpr int kUnroll = 8;     // targets per scalar-load batch
 constexpr int kWaves = 16;     // waves per workgroup = target slices (B*n/256 query groups alone would
                                // leave most of the 256 CUs idle: 16 slices give ~2k waves at n = 16k)
 
+// kQ = queries per lane (4, or 2 when 256-query workgroups would leave CUs without one).
+template <int kQ>
 __global__ void __launch_bounds__(64 * kWaves)
 nn_kernel(const float* __restrict__ q, const float* __restrict__ t, float* __restrict__ dist,
           int* __restrict__ idx, int n, int m) {
@@ -30,29 +33,40 @@ nn_kernel(const float* __restrict__ q, const float* __restrict__ t, float* __res
   q += (size_t)b * n * 3;
   t += (size_t)b * m * 3;
 
-  float qx[kQ], qy[kQ], qz[kQ], best[kQ];
-  int bi[kQ];
+  // Queries sit in registers as float pairs so the distance arithmetic runs on the packed fp32 pipe
+  // (v_pk_add/mul/fma_f32: two queries per issue slot).  The scan only tracks, per query, the running minimum and
+  // the 8-target block it came from (one compare per block instead of one per target); the index inside the block
+  // is recovered afterwards by recomputing those 8 distances with the same expression.
+  f2 qx[kQ / 2], qy[kQ / 2], qz[kQ / 2];
+  float best[kQ];
+  int blk[kQ];
 #pragma unroll
   for (int k = 0; k < kQ; ++k) {
     int i = min(q0 + k * 64 + lane, n - 1);
-    qx[k] = q[i * 3 + 0];
-    qy[k] = q[i * 3 + 1];
-    qz[k] = q[i * 3 + 2];
+    qx[k >> 1][k & 1] = q[i * 3 + 0];
+    qy[k >> 1][k & 1] = q[i * 3 + 1];
+    qz[k >> 1][k & 1] = q[i * 3 + 2];
     best[k] = __builtin_inff();
-    bi[k] = 0;
+    blk[k] = 0;
   }
   const int per = (m + kWaves - 1) / kWaves;
-  const int j_beg = wave * per;
+  const int j_beg = min(wave * per, m);
   const int j_end = min(m, j_beg + per);
-  auto visit = [&](int j, float tx, float ty, float tz) {
+  auto dist2 = [&](int p, float tx, float ty, float tz) -> f2 {
+    const f2 dx = f2{tx, tx} - qx[p], dy = f2{ty, ty} - qy[p], dz = f2{tz, tz} - qz[p];
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  };
+  auto scan_block = [&](int j, const float* buf) {
 #pragma unroll
-    for (int k = 0; k < kQ; ++k) {
-      float dx = tx - qx[k], dy = ty - qy[k], dz = tz - qz[k];
-      float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      if (d < best[k]) {
-        best[k] = d;
-        bi[k] = j;
+    for (int p = 0; p < kQ / 2; ++p) {
+      f2 mn = dist2(p, buf[0], buf[1], buf[2]);
+#pragma unroll
+      for (int u = 1; u < kUnroll; ++u) {
+        const f2 d = dist2(p, buf[3 * u], buf[3 * u + 1], buf[3 * u + 2]);
+        mn.x = fminf(mn.x, d.x), mn.y = fminf(mn.y, d.y);
       }
+      if (mn.x < best[2 * p]) best[2 * p] = mn.x, blk[2 * p] = j;          // strict: the earlier block keeps a tie
+      if (mn.y < best[2 * p + 1]) best[2 * p + 1] = mn.y, blk[2 * p + 1] = j;
     }
   };
   int j = j_beg;
@@ -61,10 +75,31 @@ nn_kernel(const float* __restrict__ q, const float* __restrict__ t, float* __res
     float buf[3 * kUnroll];
 #pragma unroll
     for (int u = 0; u < 3 * kUnroll; ++u) buf[u] = tp[u];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) visit(j + u, buf[3 * u], buf[3 * u + 1], buf[3 * u + 2]);
+    scan_block(j, buf);
   }
-  for (; j < j_end; ++j, tp += 3) visit(j, tp[0], tp[1], tp[2]);
+  if (j < j_end) {                           // ragged last block: repeat the slice's last target
+    float buf[3 * kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int o = 3 * (min(j + u, j_end - 1) - j);
+      buf[3 * u] = tp[o], buf[3 * u + 1] = tp[o + 1], buf[3 * u + 2] = tp[o + 2];
+    }
+    scan_block(j, buf);
+  }
+  int bi[kQ];
+#pragma unroll
+  for (int k = 0; k < kQ; ++k) {
+    bi[k] = 0;
+    if (j_beg < j_end) {
+#pragma unroll
+      for (int u = kUnroll - 1; u >= 0; --u) {   // descending, so the lowest index among equal distances wins
+        const int jj = min(blk[k] + u, j_end - 1);
+        const float dx = t[jj * 3 + 0] - qx[k >> 1][k & 1], dy = t[jj * 3 + 1] - qy[k >> 1][k & 1],
+                    dz = t[jj * 3 + 2] - qz[k >> 1][k & 1];
+        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) == best[k]) bi[k] = jj;
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kQ; ++k) {
     s_best[wave][k * 64 + lane] = best[k];
@@ -120,10 +155,15 @@ int ct_chamfer_fwd(const float* xyz1, const float* xyz2, float* dist1, float* di
                    int B, int n, int m, ct_stream_t s) {
   if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || B <= 0 || n <= 0 || m <= 0 || B > 65535) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
-  const int per = 64 * kQ;
   CT_CLEAR_ERROR();
-  hipLaunchKernelGGL(nn_kernel, dim3((n + per - 1) / per, B), dim3(64 * kWaves), 0, st, xyz1, xyz2, dist1, idx1, n, m);
-  hipLaunchKernelGGL(nn_kernel, dim3((m + per - 1) / per, B), dim3(64 * kWaves), 0, st, xyz2, xyz1, dist2, idx2, m, n);
+  auto launch = [&](const float* q, const float* t, float* d, int32_t* i, int nq, int nt) {
+    if ((size_t)B * ((nq + 255) / 256) >= 256 /* CUs on MI355X */)
+      hipLaunchKernelGGL(nn_kernel<4>, dim3((nq + 255) / 256, B), dim3(64 * kWaves), 0, st, q, t, d, i, nq, nt);
+    else
+      hipLaunchKernelGGL(nn_kernel<2>, dim3((nq + 127) / 128, B), dim3(64 * kWaves), 0, st, q, t, d, i, nq, nt);
+  };
+  launch(xyz1, xyz2, dist1, idx1, n, m);
+  launch(xyz2, xyz1, dist2, idx2, m, n);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

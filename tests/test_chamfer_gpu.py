@@ -49,6 +49,21 @@ def test_chamfer_ties_lowest_index():
     assert (i1.cpu() == 700).all()
 
 
+@pytest.mark.parametrize("n,m", [(300, 1003), (64, 7), (513, 129), (1024, 4096), (5, 17)])
+def test_chamfer_exact_ties_on_a_lattice(n, m):
+    """Lattice coordinates make every distance exact and ties abundant: the indices must equal the reference's
+    (lowest target index among equals) for every query — inside one 8-target scan block, across blocks, across the
+    16 per-wave target slices and in the ragged last block of a slice."""
+    from cloud_transformers_amd.chamfer import chamfer_with_indices
+    g = torch.Generator().manual_seed(n * 7 + m)
+    a = torch.randint(0, 6, (2, n, 3), generator=g).float() / 4
+    b = torch.randint(0, 6, (2, m, 3), generator=g).float() / 4
+    d1r, d2r, i1r, i2r = R.chamfer_fwd(a, b)
+    d1, d2, i1, i2 = chamfer_with_indices(a.cuda(), b.cuda())
+    assert torch.equal(i1.cpu(), i1r.int()) and torch.equal(i2.cpu(), i2r.int())
+    assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r)
+
+
 def test_losses_match_oracle():
     from cloud_transformers_amd.chamfer import loss_chamfer, loss_chamfer_adj, loss_chamder_2d
     g = torch.Generator().manual_seed(11)
