@@ -436,6 +436,101 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a) {
 // (scalar loads of the group's 4x4x3^d bank).  Same halo tile, staging and border masking as the MFMA kernel;
 // backward-data reads the bank transposed + flipped.  grid = (nD*nH, groups, B)
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// 2^d volumes (the last stage of the Res3D / Res2D stacks: 1024 channels on 2x2x2): with padding 1 every output
+// position sees every input position, so the layer is a small dense contraction whose cost is reading the filter bank
+// once (7 MB at 1024 -> 1024, groups 16).  One 256-thread workgroup owns COB output channels of one group for the whole
+// batch: their filters (a contiguous block, or COB x taps runs for the transposed pass) and the group's inputs sit in LDS;
+// lane = (output channel, cloud) keeps the P outputs of its row in registers and reads a filter (7 x b128) and the input
+// row (P floats) per input channel — P*P multiply-adds per 7 + P/4 LDS reads; the four waves split the input channels
+// and their partial rows meet in LDS.   grid = (ceil(Cout / COB), groups)
+// ---------------------------------------------------------------------------
+constexpr int kTinyTapStride = 28;     // 27 taps padded to whole b128 reads (2D: 9 -> 12)
+
+template <int DIM>
+__global__ void __launch_bounds__(256) gconv_tiny_kernel(GconvArgs a, int COB) {
+  constexpr int P = DIM == 3 ? 8 : 4;
+  constexpr int TAPS = DIM == 3 ? 27 : 9;
+  constexpr int TS = DIM == 3 ? kTinyTapStride : 12;
+  extern __shared__ __align__(16) float lds[];
+  const int Cin = a.Cin, B = a.B;
+  const int wrow = Cin * TS + 4;                       // +4: the COB filter rows start in different bank quads
+  const int xrow = Cin * P + 4;
+  float* ws = lds;                                     // [COB][Cin][TS]
+  float* xs = ws + COB * wrow;                         // [B][Cin][P]
+  float* part = xs + B * xrow;                         // [4 waves][items][P]
+  const int grp = blockIdx.y, co0 = blockIdx.x * COB;
+  const int nco = min(COB, a.Cout - co0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // filters: ws[co][ci][tap] (taps flipped for the transposed pass)
+  if (!a.transposed) {
+    const float* wg = a.w + ((size_t)(grp * a.Cout + co0) * Cin) * TAPS;          // nco*Cin*TAPS contiguous floats
+    for (int i = tid; i < nco * Cin * TAPS; i += 256) {
+      const int tap = i % TAPS, r = i / TAPS, ci = r % Cin, co = r / Cin;
+      ws[co * wrow + ci * TS + tap] = wg[i];
+    }
+  } else {
+    // a.w is (groups * Cin_here, Cout_here, taps): runs of nco * TAPS floats per input channel of this pass
+    for (int i = tid; i < Cin * nco * TAPS; i += 256) {
+      const int tap = i % TAPS, r = i / TAPS, co = r % nco, ci = r / nco;
+      ws[co * wrow + ci * TS + (TAPS - 1 - tap)] = a.w[((size_t)(grp * Cin + ci) * a.Cout + co0 + co) * TAPS + tap];
+    }
+  }
+  for (int i = tid; i < B * Cin * P; i += 256) {
+    const int b = i / (Cin * P), r = i - b * (Cin * P);
+    xs[b * xrow + r] = a.x[((size_t)b * a.groups + grp) * Cin * P + r];
+  }
+  __syncthreads();
+  const int items = nco * B;
+  for (int it0 = 0; it0 < items; it0 += 64) {
+    const int it = it0 + lane;
+    const bool live = it < items;
+    const int co = live ? it / B : 0, b = live ? it - (it / B) * B : 0;
+    float acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+    const float* wr = ws + co * wrow;
+    const float* xr = xs + b * xrow;
+    for (int ci = wave; ci < Cin; ci += 4) {
+      float w[TS], x[P];
+#pragma unroll
+      for (int t = 0; t < TS; t += 4) *(float4*)(w + t) = *(const float4*)(wr + ci * TS + t);
+#pragma unroll
+      for (int q = 0; q < P; q += 4) *(float4*)(x + q) = *(const float4*)(xr + ci * P + q);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          // position index = (z*2 + y)*2 + x; tap = the offset q - p + 1 per axis
+          const int dx = (q & 1) - (p & 1) + 1, dy = ((q >> 1) & 1) - ((p >> 1) & 1) + 1;
+          const int dz = DIM == 3 ? ((q >> 2) & 1) - ((p >> 2) & 1) + 1 : 0;
+          acc[p] = __builtin_fmaf(w[(dz * 3 + dy) * 3 + dx], x[q], acc[p]);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int p = 0; p < P; p += 4) *(float4*)(part + ((size_t)wave * items + it) * P + p) = *(float4*)(acc + p);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < items * (P / 4); i += 256) {
+    const int it = i / (P / 4), h = i - it * (P / 4);
+    const int co = it / B, b = it - co * B;
+    float4 s = *(const float4*)(part + (size_t)it * P + h * 4);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 o = *(const float4*)(part + ((size_t)k * items + it) * P + h * 4);
+      s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+    }
+    if (a.bias) {
+      const float bv = a.bias[grp * a.Cout + co0 + co];
+      s.x += bv, s.y += bv, s.z += bv, s.w += bv;
+    }
+    *(float4*)(a.y + (((size_t)b * a.groups + grp) * a.Cout + co0 + co) * P + h * 4) = s;
+  }
+}
+
 template <int DIM, bool TRANSPOSED>
 __global__ void __launch_bounds__(kThreads) gconv_c4_kernel(GconvArgs a) {
   constexpr int C = 4;
@@ -1279,7 +1374,39 @@ int launch_fwd4k(GconvArgs a, int dim, hipStream_t st) {
   return CT_EINVAL;
 }
 
+// 2^d volumes: the dense small-volume form
+size_t tiny_lds(const GconvArgs& a, int dim, int cob) {
+  const int P = dim == 3 ? 8 : 4, TS = dim == 3 ? kTinyTapStride : 12;
+  return ((size_t)cob * (a.Cin * TS + 4) + (size_t)a.B * (a.Cin * P + 4) + (size_t)4 * cob * a.B * P) * 4;
+}
+
+int tiny_cob(const GconvArgs& a, int dim) {
+  if (a.W != 2 || a.H != 2 || (dim == 3 && a.D != 2)) return 0;
+  if ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) return 0;
+  int cob = 64 / a.B;                                   // one lane per (output channel, cloud)
+  if (cob < 4) cob = 4;
+  if (cob > a.Cout) cob = a.Cout;
+  while (cob > 1 && tiny_lds(a, dim, cob) > (size_t)84 * 1024) cob >>= 1;      // two workgroups per CU when it can
+  return tiny_lds(a, dim, cob) <= (size_t)kLdsBudgetMax ? cob : 0;
+}
+
+int launch_tiny(GconvArgs a, int dim, int cob, hipStream_t st) {
+  const size_t lds = tiny_lds(a, dim, cob);
+  dim3 grid((a.Cout + cob - 1) / cob, a.groups);
+  CT_CLEAR_ERROR();
+  if (dim == 2) {
+    if (set_lds_attr(gconv_tiny_kernel<2>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_tiny_kernel<2>, grid, dim3(256), lds, st, a, cob);
+  } else {
+    if (set_lds_attr(gconv_tiny_kernel<3>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_tiny_kernel<3>, grid, dim3(256), lds, st, a, cob);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
+  if (const int cob = tiny_cob(a, dim)) return launch_tiny(a, dim, cob, st);
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
   if (rows16 && a.Cin > 32) {      // wide groups: contraction in blocks of 16 input channels
@@ -1474,6 +1601,7 @@ int launch_wrw_small(GconvArgs a, int dim, const float* g_y, float* g_w, float* 
 }
 
 bool fwd_plan_ok(GconvArgs a, int dim) {
+  if (tiny_cob(a, dim)) return true;
   if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 &&
       (plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudget) || plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudgetMax))) return true;
   const size_t wbytes = (size_t)a.taps * a.KB * 64 * 4;          // the one-position form: what the quad form falls back to

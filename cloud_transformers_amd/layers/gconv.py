@@ -5,8 +5,10 @@ shapes, initialisation and state dicts are exactly those of the `nn.Conv{2,3}d(.
 groups=heads)` layers the reference builds (layers/multihead_ct.py:50-65,
 unet2d/unet_parts.py:13-16, layers/v2v_groups.py:26-29).  The forward/backward run on the
 hand-written kernels whenever the layer is the shape the MHCT path uses — kernel 3, stride 1,
-padding 1, dilation 1, zero padding, fp32 on a HIP device; any other configuration (e.g. the
-1x1 skip convolutions) goes to the stock PyTorch/MIOpen implementation of the parent class.
+padding 1, dilation 1, zero padding, fp32 on a HIP device.  The grouped 1x1 skip projections of the Res stacks
+(layers/v2v_groups.py:40-44) are one batched GEMM per (cloud, group) on the BLAS library — the library's grouped
+convolution spends ~0.4 ms per weight gradient on these few-kFLOP layers; any other configuration goes to the
+stock PyTorch/MIOpen implementation of the parent class.
 """
 import torch
 from torch import nn
@@ -70,9 +72,11 @@ def _eligible(mod, x):
     # planes of the classifier / inpainter encoders) run on the K-split MFMA kernel (gconv_fwd4k_kernel: contraction in
     # blocks of 16 input channels) and the small-volume weight-gradient kernel; measured fwd+bwd at B8, groups 16, vs the
     # library: 3D 1024->1024 8^3 0.71 vs 1.46 ms, 512->1024 8^3 0.42 vs 0.90, 4^3 0.22 vs 0.46, 2D 8^2 0.10 vs 0.13,
-    # 4^2 0.08 vs 0.13.  One exception: rows that are not 16-byte multiples (the 2^3 volumes, W = 2) with wide groups —
-    # the quad MFMA kernels need float4 rows and the one-position form loses to the library there (0.33 vs 0.30 ms).
-    if max(mod.in_channels, mod.out_channels) // mod.groups > 32 and x.shape[-1] % 4 != 0:
+    # 4^2 0.08 vs 0.13; 2^d volumes have their own dense kernel (gconv_tiny_kernel).  One exception: other rows that are
+    # not 16-byte multiples with wide groups — the quad MFMA kernels need float4 rows and the one-position form loses to
+    # the library there.
+    if (max(mod.in_channels, mod.out_channels) // mod.groups > 32 and x.shape[-1] % 4 != 0
+            and tuple(x.shape[2:]) != (2,) * nd):
         return False
     # shapes whose tiles do not fit LDS (very wide rows with many channels per group) take the library convolution
     W = tuple(x.shape[2:])
@@ -87,10 +91,31 @@ def _eligible(mod, x):
 _SUPPORTED = {}
 
 
+def _pointwise(mod, x):
+    nd = x.dim() - 2
+    return (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32
+            and tuple(mod.kernel_size) == (1,) * nd and tuple(mod.stride) == (1,) * nd
+            and tuple(mod.padding) == (0,) * nd and tuple(mod.dilation) == (1,) * nd)
+
+
+def _pointwise_grouped(mod, x):
+    """y[b, g, :, p] = W[g] @ x[b, g, :, p] (+ bias): batch of groups x clouds plain GEMMs; autograd supplies the two
+    transposed products of the backward."""
+    B, G = x.shape[0], mod.groups
+    sp = x.shape[2:]
+    co, ci = mod.out_channels // G, mod.in_channels // G
+    y = torch.matmul(mod.weight.reshape(1, G, co, ci), x.reshape(B, G, ci, -1)).reshape(B, G * co, *sp)
+    if mod.bias is not None:
+        y = y + mod.bias.reshape(1, -1, *([1] * len(sp)))
+    return y
+
+
 class GroupedConv2d(nn.Conv2d):
     def forward(self, x):
         if _eligible(self, x):
             return GroupedConvFn.apply(x, self.weight, self.bias, self.groups)
+        if _pointwise(self, x):
+            return _pointwise_grouped(self, x)
         return super().forward(x)
 
 
@@ -98,4 +123,6 @@ class GroupedConv3d(nn.Conv3d):
     def forward(self, x):
         if _eligible(self, x):
             return GroupedConvFn.apply(x, self.weight, self.bias, self.groups)
+        if _pointwise(self, x):
+            return _pointwise_grouped(self, x)
         return super().forward(x)

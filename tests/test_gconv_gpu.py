@@ -30,6 +30,12 @@ CASES = [
     (1, 2, 48, 64, 2, (8, 8), True),          # input channels not a multiple of the block
     (1, 2, 72, 40, 3, (4, 4, 4), True),       # ragged input block and ragged 16-row output block
     (1, 1, 64, 64, 2, (16, 16), False),       # several spans per wave
+    # 2^d volumes on the dense small-volume kernel
+    (8, 16, 64, 64, 3, (2, 2, 2), True),      # classifier Res3DBlock(1024, 1024, groups=16) after the second pool
+    (2, 3, 40, 24, 3, (2, 2, 2), False),      # ragged channel counts, few clouds
+    (3, 2, 5, 7, 2, (2, 2), True),
+    (70, 1, 8, 8, 3, (2, 2, 2), True),        # more clouds than lanes per output channel
+    (1, 2, 160, 16, 2, (2, 2), False),
 ]
 
 
@@ -71,7 +77,8 @@ def test_gconv_fwd_bwd(cfg):
 def test_wide_groups_run_on_the_k_split_kernels():
     """More than 32 channels per group (the Res2D / Res3D stacks of the classifier and the inpainter on the pooled 8^3 ..
     4^3 volumes and 8^2 .. 4^2 planes) run on this package's kernels too (K-split MFMA forward / backward-data, small-volume
-    weight gradient); only wide groups on rows that are not 16-byte multiples (the 2^3 volumes) go to the library."""
+    weight gradient), and so do the 2^3 volumes (dense small-volume kernel); only wide groups on other rows that are not
+    16-byte multiples go to the library."""
     from cloud_transformers_amd.layers import gconv as G
     calls = []
     real = G.GroupedConvFn.apply
@@ -89,17 +96,45 @@ def test_wide_groups_run_on_the_k_split_kernels():
         assert calls == [1, 1, 1]
         x2 = torch.randn(1, 128, 2, 2, 2, device="cuda")                                   # 2^3: rows of 2 floats
         assert torch.allclose(wide(x2), torch.nn.functional.conv3d(x2, wide.weight, None, padding=1, groups=2), atol=1e-4)
-        assert calls == [1, 1, 1]
+        assert calls == [1, 1, 1, 1]
+        x3 = torch.randn(1, 128, 3, 3, 3, device="cuda")                                   # rows of 3 floats, wide groups
+        assert torch.allclose(wide(x3), torch.nn.functional.conv3d(x3, wide.weight, None, padding=1, groups=2), atol=1e-4)
+        assert calls == [1, 1, 1, 1]
     finally:
         G.GroupedConvFn.apply = real
 
 
+@pytest.mark.parametrize("dim,B,G,ci,co,sp,bias", [(2, 1, 2, 4, 4, (5, 5), False), (2, 8, 16, 16, 32, (16, 16), True),
+                                                     (3, 8, 16, 32, 64, (8, 8, 8), True), (3, 2, 1, 6, 3, (2, 3, 4), False)])
+def test_pointwise_skip_projections_are_batched_gemms(dim, B, G, ci, co, sp, bias):
+    """The grouped 1x1 projections of the Res stacks (layers/v2v_groups.py:40-44): forward and all three gradients
+    against the stock grouped convolution."""
+    from cloud_transformers_amd.layers.gconv import GroupedConv2d, GroupedConv3d
+    torch.manual_seed(dim * 100 + G)
+    m = (GroupedConv2d if dim == 2 else GroupedConv3d)(G * ci, G * co, kernel_size=1, groups=G, bias=bias).cuda()
+    x = torch.randn(B, G * ci, *sp, device="cuda", requires_grad=True)
+    go = torch.randn(B, G * co, *sp, device="cuda")
+    y = m(x)
+    y.backward(go)
+    got = [y.detach(), x.grad.clone(), m.weight.grad.clone()] + ([m.bias.grad.clone()] if bias else [])
+    xr = x.detach().clone().requires_grad_(True)
+    w = m.weight.detach().clone().requires_grad_(True)
+    b = m.bias.detach().clone().requires_grad_(True) if bias else None
+    conv = torch.nn.functional.conv2d if dim == 2 else torch.nn.functional.conv3d
+    yr = conv(xr, w, b, groups=G)
+    yr.backward(go)
+    want = [yr.detach(), xr.grad, w.grad] + ([b.grad] if bias else [])
+    for a, r in zip(got, want):
+        assert a.shape == r.shape
+        assert torch.allclose(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+
+
 def test_ineligible_configs_use_parent_class():
     from cloud_transformers_amd.layers.gconv import GroupedConv2d
-    m = GroupedConv2d(8, 8, kernel_size=1, groups=2, bias=False).cuda()       # 1x1 skip conv
-    x = torch.randn(1, 8, 5, 5, device="cuda")
-    ref = torch.nn.functional.conv2d(x, m.weight, None, groups=2)
-    assert torch.allclose(m(x), ref, atol=1e-6)
+    m = GroupedConv2d(8, 8, kernel_size=3, stride=2, padding=1, groups=2, bias=False).cuda()       # strided
+    x = torch.randn(1, 8, 6, 6, device="cuda")
+    ref = torch.nn.functional.conv2d(x, m.weight, None, stride=2, padding=1, groups=2)
+    assert torch.allclose(m(x), ref, atol=1e-5)
 
 
 def test_state_dict_is_plain_conv():
