@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_gw_kernel(Raste
 #pragma unroll
         for (int v = 0; v < V; ++v) gw[v] += Tc[c.cell[v]] * s;
       }
-      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first, atomic);
+      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first && !a.accumulate, atomic);
     }
     first = false;
   }
@@ -831,7 +831,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(R
         if (has_pad) gf = gf * p;
         dst[(size_t)ch * a.N + n] = gf;
       }
-      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first, atomic);
+      store_gpos<DIM, FROM_KEYS>(a.g_pos + (size_t)cg * a.gpos_stride, bh, a.N, n, pp, gw, first && !a.accumulate, atomic);
     }
     first = false;
   }
@@ -1064,7 +1064,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
             for (int i = 0; i < 4; ++i) atomicAdd(pk + i, gs[i][j]);
           } else {
             float4 o = make_float4(gs[0][j], gs[1][j], gs[2][j], gs[3][j]);
-            if (!first) {
+            if (!first || a.accumulate) {
               const float4 prev = *(const float4*)pk;
               o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
             }
@@ -1404,13 +1404,32 @@ int pick_nsplit(int B, int H, int nchunks, int N) {
 }
 
 
-// out[i] = sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
-__global__ void __launch_bounds__(256) sum_parts_kernel(const float* parts, float* out, size_t n, size_t stride, int k) {
+// out[i] (+)= sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
+template <typename V>
+__global__ void __launch_bounds__(256) sum_parts_kernel(const V* parts, V* out, size_t n, size_t stride, int k, int acc) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = parts[i];
-  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
+  V s = parts[i];
+  for (int j = 1; j < k; ++j) {
+    const V t = parts[(size_t)j * stride + i];
+    if constexpr (sizeof(V) == 16) { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; } else { s += t; }
+  }
+  if (acc) {
+    const V o = out[i];
+    if constexpr (sizeof(V) == 16) { s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w; } else { s = o + s; }
+  }
   out[i] = s;
+}
+
+int launch_sum_parts(const float* parts, float* out, size_t n, size_t stride, int k, int acc, hipStream_t st) {
+  CT_CLEAR_ERROR();
+  if (((n | stride) & 3) == 0 && ((((uintptr_t)parts) | ((uintptr_t)out)) & 15) == 0)
+    hipLaunchKernelGGL(sum_parts_kernel<float4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float4*)parts,
+                       (float4*)out, n / 4, stride / 4, k, acc);
+  else
+    hipLaunchKernelGGL(sum_parts_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, parts, out, n, stride, k, acc);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1453,7 +1472,10 @@ bool hot_bwd_plan(int B, int H, int C, int G, size_t per_ch, size_t fixed, long 
   ncg = 1;
   const long long planes = (long long)B * H;
   if (planes >= 256 || C <= 4) return true;
-  const int want = (int)((512 + planes - 1) / planes);          // chunk groups that would give ~512 workgroups
+  // chunk groups that would give ~512 workgroups (two per CU) — or ~256 when even a four-channel chunk takes more than
+  // half a CU's LDS: a second round of workgroups would repeat the per-plane setup and double the partial g_keys
+  const long long wgs = (fixed + 4 * per_ch > (size_t)kHalfCuLdsBytes) ? 256 : 512;
+  const int want = (int)((wgs + planes - 1) / planes);
   int cc = (((C + want - 1) / want) + 3) & ~3;
   if (cc < 4) cc = 4;
   if (cc < hp.CC) {
@@ -1518,6 +1540,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  // 32 planes (B2 H16 of the completion heads): one or two workgroups per plane walking 16k points lose to the
+  // split-N scatter + gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16)
+  if ((long long)a.B * a.H < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
   if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
@@ -1540,7 +1565,7 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   note(ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos, gpos_n, gpos_n, ncg);
+    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1597,15 +1622,6 @@ size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
 }
 
-// y (+)= sum_k parts[k*stride + i] (ascending k)
-__global__ void __launch_bounds__(256) sum_parts_acc_kernel(const float* parts, float* out, size_t n, size_t stride, int k, int acc) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = parts[i];
-  for (int j = 1; j < k; ++j) s += parts[(size_t)j * stride + i];
-  out[i] = acc ? out[i] + s : s;
-}
-
 int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, int ncg, void* ws, hipStream_t st) {
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
   float* const out = a.g_pos;
@@ -1625,8 +1641,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(sum_parts_acc_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, out, gpos_n,
-                       gpos_n, ncg, accumulate);
+    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1672,6 +1687,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  // 32 planes (B2 H16 of the completion heads): one or two workgroups per plane walking 16k points lose to the
+  // split-N scatter + gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16)
+  if ((long long)a.B * a.H < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
   if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
@@ -1694,22 +1712,25 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   note(ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos, gpos_n, gpos_n, ncg);
+    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
 }
 
-// The 3D hot Splat(max) backward is parity-green but SLOWER than the generic kernel today (8 corners x {z, g_z} reads keep
-// ~20 more values live than the 2D form: the compiler spills; 16^3 C16 B8 N4096: 118 us vs 72 us), so it only runs when a
-// test forces the hot kernels.
+// The 3D hot Splat(max) backward runs in its loop form only (a quad's g_keys share is added to the workgroup's rows per
+// chunk): with the 12 values of a quad kept in registers across chunks — and the corner setup of all four points hoisted
+// out of the channel loop by the compiler — it spilled 170-450 registers and lost to the generic kernel (118 vs 72 us on
+// 16^3 C16 B8 N4096); now 53 us.
 bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<3>& g, HotPlan& hp, int& ncg, bool& single) {
-  if (!(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return false;
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
                          (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
   if (!hot_shape_ok(a, g.G, bits)) return false;
   if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
-  single = (a.N >> 2) <= 2 * kHotThreads;
+  // a workgroup walks all N points of its plane: with fewer workgroups than CUs (16^3 at B2 H16: 128) the generic
+  // kernel's thinner single-channel chunks win (72 vs 147 us)
+  if ((long long)a.B * a.H * ncg < 256 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return false;
+  single = false;
   return true;
 }
 
@@ -1733,17 +1754,13 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
-  if (nq <= kHotThreads)
-    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 1>), (splat_max_bwd_hot3_kernel<false, 1>), wgrid, hot_threads(nq), hp.lds, st, a, g);
-  else if (nq <= 2 * kHotThreads)
-    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 2>), (splat_max_bwd_hot3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
-  else
-    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, kHotThreads, hp.lds, st, a, g);
+  // always the loop form (g_keys partials stored per chunk): keeping a quad's 12 g_keys values in registers across the
+  // chunks makes the 3D kernel spill
+  CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, hot_threads(nq), hp.lds, st, a, g);
   note(ncg > 1 ? "splat_max_bwd_hot3_groups" : "splat_max_bwd_hot3");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(sum_parts_acc_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, out, gpos_n,
-                       gpos_n, ncg, accumulate);
+    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1822,7 +1839,7 @@ inline int splat_bwd_ncg(int B, int H, int nchunks) {
 // g_keys that still have to be summed — the whole-head form clears it
 template <int DIM, bool FROM_KEYS>
 int launch_splat_max_bwd(RasterArgs a, const GridW<DIM>& g, const Plan& p, bool two, float* g_pos_out, bool& parts, void* ws,
-                         size_t ws_bytes, hipStream_t st) {
+                         size_t ws_bytes, int accumulate, hipStream_t st) {
   dim3 grid(a.ncg, a.H, a.B);
   if (!p.lds_tile) {
     size_t need = (size_t)a.B * a.H * a.C * g.G * 4;
@@ -1841,6 +1858,7 @@ int launch_splat_max_bwd(RasterArgs a, const GridW<DIM>& g, const Plan& p, bool 
         quad_ok(a, FROM_KEYS, true) && (g.G & 3) == 0) {
       a.CC = a.C; a.nchunks = 1; a.ncg = 1; a.atomic_gpos = 0;
       a.g_pos = g_pos_out; a.gpos_stride = 0; parts = false;
+      a.accumulate = accumulate;
       int t = round_threads(a.N >> 2);
       dim3 wgrid(1, a.H, a.B);
       if (t > 512) CT_LAUNCH_QUAD((2, QM_SPLAT_MAX_BWD, CT_QUAD_CG, 1024, false), wgrid, 1024, wh_bytes, st, a, g);
@@ -1876,7 +1894,6 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
         return run_splat_max_bwd_hot(a, g, hp, ncg, ws, st);
     }
   }
-  if (a.accumulate) return CT_EINVAL;     // the caller redirects g_pos to scratch and adds (splat_bwd_impl)
   // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
   const bool two = (size_t)g.G * 8 <= (size_t)kMaxLdsBytes;
   Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, two ? 2 : 1);
@@ -1887,19 +1904,21 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   // g_keys sums over the channel chunks.  Across chunk GROUPS (different workgroups) that sum went through
   // device-scope float atomics — a third of this kernel's time on the 64^2 C16 zoo head.  With the caller's
   // workspace each group stores its partial and sum_parts_kernel adds them in a fixed order.
+  // a.accumulate (g_keys += result): a workgroup that owns its points adds in its own store, the atomic form skips
+  // the zero fill, the partial-sum form accumulates in the final sum.
   float* const g_pos_out = a.g_pos;
+  const int accumulate = a.accumulate;
   const size_t gpos_n = gpos_bytes<DIM, FROM_KEYS>(a) / 4;
   bool parts = a.ncg > 1 && p.lds_tile && ws && ws_bytes >= (size_t)a.ncg * gpos_n * 4;
-  if (parts) { a.g_pos = (float*)ws; a.gpos_stride = gpos_n; }
+  if (parts) { a.g_pos = (float*)ws; a.gpos_stride = gpos_n; a.accumulate = 0; }
   a.atomic_gpos = a.ncg > 1 && !parts;
-  if (a.atomic_gpos && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
+  if (a.atomic_gpos && !accumulate && hipMemsetAsync(a.g_pos, 0, gpos_bytes<DIM, FROM_KEYS>(a), st) != hipSuccess) return CT_ELAUNCH;
   const int ncg = a.ncg;
-  const int r = launch_splat_max_bwd<DIM, FROM_KEYS>(a, g, p, two, g_pos_out, parts, ws, ws_bytes, st);
+  const int r = launch_splat_max_bwd<DIM, FROM_KEYS>(a, g, p, two, g_pos_out, parts, ws, ws_bytes, accumulate, st);
   if (r != CT_OK) return r;
   if (parts) {
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, (const float*)ws, g_pos_out, gpos_n,
-                       gpos_n, ncg);
+    if (launch_sum_parts((const float*)ws, g_pos_out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -2007,7 +2026,7 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
     const size_t gpos_n = (size_t)B * H * (FROM_KEYS ? dim : (1 << dim)) * N;
     if (!ws || ws_bytes < gpos_n * 4) return CT_EWORKSPACE;
     const size_t head = ws_bytes - gpos_n * 4;
-    if (reduce == CT_REDUCE_MAX0 && FROM_KEYS && grid) {
+    if (reduce == CT_REDUCE_MAX0 && grid) {
       RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
       a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = grid; a.tile_in2 = g_grid;
       a.accumulate = 1;

@@ -113,13 +113,15 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
     kloc = wave_max_u32(kloc);
     if ((tid & 63) == 0) atomicMax(s_k, kloc);
   }
-  float gs[QPT][4][3];
+  // one quad per thread: its 12 g_keys values stay in registers over all channels; more quads: each (channel group, quad)
+  // adds its share to the workgroup's own g_keys rows (read-modify-write, L2-resident) — 24 live values would spill
+  constexpr bool kKeepGs = QPT == 1;
+  float gs[1][4][3];
 #pragma unroll
-  for (int u = 0; u < QPT; ++u)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
+  for (int i = 0; i < 4; ++i) gs[0][i][0] = gs[0][i][1] = gs[0][i][2] = 0.0f;
 
   const int cgi = blockIdx.x;
+  float* const gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);
@@ -213,10 +215,16 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
         }
         float k[3][4];
         load_keys3(a.pos.keys, bh, N, n0c[u], k);
+        if (!kKeepGs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gs[0][i][0] = gs[0][i][1] = gs[0][i][2] = 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          float kx = k[0][i], ky = k[1][i], kz = k[2][i];
+          asm volatile("" : "+v"(kx), "+v"(ky), "+v"(kz));        // one point's corner setup live at a time
           Pt3 p;
-          pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+          pt3_from_keys(kx, ky, kz, g, p);
           float gw[8];
 #pragma unroll
           for (int hv = 0; hv < 2; ++hv) {
@@ -234,10 +242,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           }
           float gd[3];
           ct_corner_grad<3>(p.w0, p.w1, gw, gd);
-          gs[u][i][0] += gd[0];
-          gs[u][i][1] += gd[1];
-          gs[u][i][2] += gd[2];
-          asm volatile("" : "+v"(gs[u][i][0]), "+v"(gs[u][i][1]), "+v"(gs[u][i][2]));
+          gs[0][i][0] += gd[0];
+          gs[0][i][1] += gd[1];
+          gs[0][i][2] += gd[2];
+          asm volatile("" : "+v"(gs[0][i][0]), "+v"(gs[0][i][1]), "+v"(gs[0][i][2]));
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
             int* Tc = accq + cj * G + p.base;
@@ -247,6 +255,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (!kKeepGs && active[u]) store_gkeys3(gpos, bh, N, n0c[u], gs[0], k, chunk > cgi || cq > 0);
       }
       if (any_float) {
 #pragma unroll 1
@@ -291,12 +300,11 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
   }
-#pragma unroll
-  for (int u = 0; u < QPT; ++u) {
-    if (active[u]) {
+  if (kKeepGs) {
+    if (active[0]) {
       float k[3][4];
-      load_keys3(a.pos.keys, bh, N, n0[u], k);
-      store_gkeys3(a.g_pos + (size_t)cgi * a.gpos_stride, bh, N, n0[u], gs[u], k, false);
+      load_keys3(a.pos.keys, bh, N, n0[0], k);
+      store_gkeys3(gpos, bh, N, n0[0], gs[0], k, false);
     }
   }
 }
@@ -323,8 +331,12 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
     float4* Zc = ZG + (size_t)(cg0 >> 1) * G;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      // the corner cells / weights are recomputed per channel group: hoisted out of the channel loop they would keep
+      // 4 x 15 registers alive (the opaque copies stop the hoisting)
+      float kx = k[0][i], ky = k[1][i], kz = k[2][i];
+      asm volatile("" : "+v"(kx), "+v"(ky), "+v"(kz));
       Pt3 p;
-      pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
+      pt3_from_keys(kx, ky, kz, g, p);
       float gw[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {

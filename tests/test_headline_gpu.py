@@ -224,37 +224,47 @@ def test_fixed_point_scatter_add_keeps_every_channels_precision(family, flags):
 
 
 def test_splat_bwd_accumulates_into_g_keys(flags):
-    """ct_splat_bwd_ex(CT_BWD_ACCUMULATE_KEYS): g_keys += result, on the hot kernel (in its own store) and on the
-    generic path (scratch + add)."""
+    """ct_splat_bwd_ex(CT_BWD_ACCUMULATE_KEYS): g_keys += result in every form of the Splat(max) backward — the hot
+    kernel and the whole-plane / quad / generic kernels add in their own store, chunk groups accumulate in the ordered
+    sum of their partials (or with atomics when the workspace has no room for them)."""
     from cloud_transformers_amd.ops import _ptr, _stream
     mod, lib = _lib()
-    for (B, H, C, N, W, force) in ((2, 2, 8, 1024, 32, True), (2, 2, 8, 1024, 32, False), (1, 2, 5, 333, 16, False)):
+    HOT, NOHOT = mod.DEBUG_FORCE_HOT, mod.DEBUG_NO_HOT
+    cases = ((2, 2, 8, 1024, 32, 2, HOT, "splat_max_bwd_hot"), (2, 2, 8, 1024, 32, 2, 0, "splat_max_bwd_quad"),
+             (1, 2, 5, 333, 16, 2, 0, "splat_max_bwd_generic"), (1, 2, 32, 2048, 64, 2, NOHOT, "splat_max_bwd_quad"),
+             (16, 16, 16, 512, 32, 2, NOHOT, "splat_max_bwd_whole_head"), (2, 2, 8, 1024, 16, 3, 0, "splat_max_bwd_generic"),
+             (1, 2, 16, 512, 16, 3, NOHOT, "splat_max_bwd_generic"))
+    for (B, H, C, N, W, dim, dbg, want_tag) in cases:
         g = torch.Generator().manual_seed(N + C)
-        keys = torch.tanh(torch.randn(B, H * 2, N, generator=g)).cuda()
+        Ws = [W] * dim
+        keys = torch.tanh(torch.randn(B, H * dim, N, generator=g)).cuda()
         feat = torch.randn(B, H * C, N, generator=g).cuda()
-        gz = torch.randn(B, H * C, W, W, generator=g).cuda()
-        Wa = mod.int_array([W, W])
-        z = torch.empty(B, H * C, W, W, device="cuda")
-        mod.check(lib.ct_splat_fwd(_ptr(keys), _ptr(feat), None, 0, _ptr(z), B, H, C, N, 2, Wa, 0, _stream()), "fwd")
-        base = torch.randn(B, H * 2, N, generator=g).cuda()
+        gz = torch.randn(B, H * C, *Ws, generator=g).cuda()
+        Wa = mod.int_array(Ws)
+        z = torch.empty(B, H * C, *Ws, device="cuda")
+        mod.check(lib.ct_splat_fwd(_ptr(keys), _ptr(feat), None, 0, _ptr(z), B, H, C, N, dim, Wa, 0, _stream()), "fwd")
+        base = torch.randn(B, H * dim, N, generator=g).cuda()
         gk_plain = torch.empty_like(keys)
         gf_a, gf_b = torch.empty_like(feat), torch.empty_like(feat)
-        n0 = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, 2, Wa, 0)
+        n0 = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, 0)
         ws0 = torch.empty(max(n0, 1), device="cuda", dtype=torch.uint8)
         mod.check(lib.ct_splat_bwd(_ptr(keys), _ptr(feat), None, 0, _ptr(z), _ptr(gz), _ptr(gf_a), _ptr(gk_plain),
-                                   _ptr(ws0), n0, B, H, C, N, 2, Wa, 0, _stream()), "bwd")
-        flags(mod.DEBUG_FORCE_HOT if force else 0)
-        n1 = lib.ct_splat_bwd_ex_workspace_bytes(B, H, C, N, 2, Wa, 0, mod.BWD_ACCUMULATE_KEYS)
+                                   _ptr(ws0), n0, B, H, C, N, dim, Wa, 0, _stream()), "bwd")
+        n1 = lib.ct_splat_bwd_ex_workspace_bytes(B, H, C, N, dim, Wa, 0, mod.BWD_ACCUMULATE_KEYS)
         assert n1 == n0 + keys.numel() * 4
-        ws1 = torch.empty(n1, device="cuda", dtype=torch.uint8)
-        gk_acc = base.clone()
-        mod.check(lib.ct_splat_bwd_ex(_ptr(keys), _ptr(feat), None, 0, _ptr(z), _ptr(gz), _ptr(gf_b), _ptr(gk_acc),
-                                      _ptr(ws1), n1, B, H, C, N, 2, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()), "bwd_ex")
-        tag = lib.ct_debug_last_launch().decode()
-        flags(0)
-        assert tag.startswith("splat_max_bwd_hot") == force, tag
-        assert relerr(gk_acc, base + gk_plain) <= 1e-6
-        assert relerr(gf_b, gf_a) <= 1e-6
+        for nws in (n1, keys.numel() * 4):         # full workspace; only the mandatory tail (no room for partial sums)
+            ws1 = torch.empty(nws, device="cuda", dtype=torch.uint8)
+            gk_acc = base.clone()
+            flags(dbg)
+            mod.check(lib.ct_splat_bwd_ex(_ptr(keys), _ptr(feat), None, 0, _ptr(z), _ptr(gz), _ptr(gf_b), _ptr(gk_acc),
+                                          _ptr(ws1), nws, B, H, C, N, dim, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()), "bwd_ex")
+            tag = lib.ct_debug_last_launch().decode()
+            flags(0)
+            if nws == n1:
+                assert tag.startswith(want_tag), (tag, want_tag)
+            assert "add_inplace" not in tag, tag
+            assert relerr(gk_acc, base + gk_plain) <= 2e-6, (B, H, C, N, W, dim, tag)
+            assert relerr(gf_b, gf_a) <= 1e-6
         # too small a workspace is refused
         assert lib.ct_splat_bwd_ex(_ptr(keys), _ptr(feat), None, 0, _ptr(z), _ptr(gz), _ptr(gf_b), _ptr(gk_acc),
-                                   _ptr(ws1), 16, B, H, C, N, 2, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()) == -3
+                                   _ptr(ws1), 16, B, H, C, N, dim, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()) == -3
