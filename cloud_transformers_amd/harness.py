@@ -1,0 +1,264 @@
+"""YAML-driven training harness around the hot path: the reference's experiment plumbing
+(utils/train_util.py:19-134) and the skeleton of its training scripts (train_segmentation.py:64-230,
+train_classification.py) with synthetic loaders, so that a reference config + model file runs end to end on this
+package's layers and checkpoints stay interchangeable.
+
+* config: the reference's YAML schema — `experiment.{root,writer_root}`, `data.{batch_size,num_points,...}`,
+  `model.generator` (a python file defining `Model`; the remaining `model.*` keys are its kwargs),
+  `train.{optimizer,scheduler,num_epochs,save_each,...}`, optional `restore.{generator,optimizer,new_lr}`.
+* checkpoints: `<exp>/<name>_<epoch_name>_<n>.t7` holding a plain `state_dict()` (train_util.py:74-80); parameter names of
+  this package's modules equal the reference's, so released weights load with `strict=True`; `restore_exp_fix` drops the
+  `module.` prefix DistributedDataParallel adds (train_util.py:98-117).
+* data: real dataset readers (h5 / S3DIS rooms / GRNet) are out of scope; `SyntheticClouds` produces batches
+  of the shapes and dtypes those loaders yield.
+"""
+import copy
+import datetime
+import shutil
+import time
+from collections import OrderedDict
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import parallel
+
+
+def worker_init_fn(worker_id):
+    import random
+    import numpy as np
+    seed = int(np.random.get_state()[1][0]) + worker_id
+    np.random.seed(seed % (2 ** 32))
+    random.seed(seed)
+
+
+def get_model(model_file, params_dict, exp_dir=None):
+    """Instantiate `Model(**params_dict)` from a model python file; keep a copy beside the experiment."""
+    env = {"__name__": "model_file"}
+    with open(str(model_file), "r") as f:
+        exec(compile(f.read(), str(model_file), "exec"), env)
+    model = env["Model"](**params_dict)
+    if exp_dir is not None:
+        assert Path(exp_dir).exists()
+        shutil.copy2(str(model_file), str(exp_dir))
+    return model
+
+
+def check_model_paths(*paths):
+    out = []
+    for p in paths:
+        f = Path(p)
+        assert f.exists() and f.suffix == ".py", p
+        out.append((p, f.name[:-3]))
+    return out
+
+
+class NullWriter:
+    """Stands in for tensorboardX.SummaryWriter when it is not installed: keeps the last value of every tag."""
+
+    def __init__(self, logdir=None):
+        self.logdir, self.scalars = logdir, {}
+
+    def add_scalar(self, tag, value, global_step=None):
+        self.scalars[tag] = (float(value), global_step)
+
+    def close(self):
+        pass
+
+
+def _summary_writer(path):
+    try:
+        from tensorboardX import SummaryWriter
+    except ImportError:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+        except ImportError:
+            return NullWriter(str(path))
+    return SummaryWriter(str(path))
+
+
+def create_experiment(*desc, params_dict):
+    exp_path, writer_path = Path(params_dict["exp_root"]), Path(params_dict["writer_root"])
+    assert writer_path.exists(), writer_path
+    full_desc = "_".join([*desc, datetime.datetime.now().strftime("%d_%m_%y_%H_%M_%S")])
+    writer = _summary_writer(writer_path.joinpath(full_desc))
+    exp_dir = exp_path.joinpath(full_desc)
+    exp_dir.mkdir(parents=True)
+    if "config_path" in params_dict:
+        cfg = Path(params_dict["config_path"])
+        assert cfg.exists()
+        shutil.copy2(str(cfg), str(exp_dir))
+    return writer, exp_dir, full_desc
+
+
+def save_exp(objects, names, exp_path, epoch, epoch_name="epoch"):
+    assert len(objects) == len(names)
+    for obj, name in zip(objects, names):
+        with open("{}/{}_{}_{}.t7".format(str(exp_path), name, epoch_name, epoch), "wb") as f:
+            torch.save(obj.state_dict(), f)
+
+
+def restore_exp(objects, names, device, verbose=True, strict=True):
+    assert len(objects) == len(names)
+    for obj, name in zip(objects, names):
+        assert Path(name).exists(), name
+        if verbose:
+            print("restoring from {}".format(name))
+        with open(name, "rb") as f:
+            state = torch.load(f, map_location=device)
+        if isinstance(obj, nn.Module):
+            obj.load_state_dict(state, strict=strict)
+        else:
+            obj.load_state_dict(state)
+
+
+def restore_exp_fix(objects, names, device=None, verbose=True):
+    """Load checkpoints written from a DistributedDataParallel wrapper into plain modules (strict)."""
+    device = device if device is not None else torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+    assert len(objects) == len(names)
+    for obj, name in zip(objects, names):
+        assert Path(name).exists(), name
+        if verbose:
+            print("restoring from {}".format(name))
+        with open(name, "rb") as f:
+            state = torch.load(f, map_location=device)
+        obj.load_state_dict(OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state.items()), strict=True)
+
+
+def make_optimizer(params, opt_cfg):
+    cfg = dict(opt_cfg)                        # (the reference deletes `type` from the caller's dict; a copy keeps cfg reusable)
+    return getattr(torch.optim, cfg.pop("type"))(params, **cfg)
+
+
+def make_scheduler(optimizer, scheduler_cfg):
+    cfg = dict(scheduler_cfg)
+    return getattr(torch.optim.lr_scheduler, cfg.pop("type"))(optimizer, **cfg)
+
+
+class SyntheticClouds(torch.utils.data.Dataset):
+    """Batches shaped like the reference loaders': `segmentation` -> (points f32 [N, 3], labels i64 [N]) as
+    datasets/s3dis_v2.py yields; `classification` -> (points f32 [N, 3], label i64 [], mask f32 [N]) as
+    datasets/scanobjectnn.py yields.  Deterministic per index."""
+
+    def __init__(self, task, num_points, n_classes, length=64, seed=0, channels=3):
+        assert task in ("segmentation", "classification") and channels >= 3
+        self.task, self.n, self.k, self.length, self.seed, self.ch = task, num_points, n_classes, length, seed, channels
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        pts = torch.rand(self.n, self.ch, generator=g) * 2 - 1          # xyz (+ colour / normalised position channels)
+        if self.task == "segmentation":
+            # labels follow the geometry (octants), so a few steps of training move the loss
+            lab = ((pts[:, 0] > 0).long() + 2 * (pts[:, 1] > 0).long() + 4 * (pts[:, 2] > 0).long()) % self.k
+            return pts, lab
+        lab = torch.randint(self.k, (), generator=g)
+        pts = pts * (0.5 + 0.5 * (lab.float() + 1) / self.k)
+        return pts, lab, (pts[:, 2] > 0).float()
+
+
+class Trainer:
+    """The reference scripts' loop: model file + YAML config -> DDP(+SyncBN) model, optimizer, scheduler, steps with
+    loss reduction to rank 0, `.t7` checkpoints every `train.save_each` iterations.
+
+    `task`: "segmentation" (loss = CE(pred[:, :, 0], labels), train_segmentation.py:178) or "classification"
+    (loss = CE(logits, label) + seg_weight * BCE-with-logits(mask), train_classification.py)."""
+
+    def __init__(self, cfg, task, n_classes, device=None, dist=None, exp_name="exp", dataset_length=64, make_dirs=True,
+                 channels=3):
+        self.cfg = cfg = copy.deepcopy(cfg)
+        self.task, self.dist = task, dist
+        self.rank = dist.get_rank() if parallel._active(dist) else 0
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        model_cfg = dict(cfg["model"])
+        model_file, _ = check_model_paths(model_cfg.pop("generator"))[0]
+        self.writer, self.exp_dir = NullWriter(), None
+        if self.rank == 0 and make_dirs:
+            Path(cfg["experiment"]["writer_root"]).mkdir(parents=True, exist_ok=True)
+            params = {"exp_root": cfg["experiment"]["root"], "writer_root": cfg["experiment"]["writer_root"]}
+            if "config_path" in cfg:
+                params["config_path"] = cfg["config_path"]
+            self.writer, self.exp_dir, _ = create_experiment(exp_name, params_dict=params)
+        model = get_model(model_file, model_cfg, exp_dir=self.exp_dir).to(self.device)
+        if "restore" in cfg and "generator" in cfg["restore"]:
+            restore_exp_fix([model], [cfg["restore"]["generator"]], device=self.device, verbose=self.rank == 0)
+        if parallel._active(dist):
+            model = parallel.data_parallel(model, self.device.index if self.device.type == "cuda" else None)
+        self.model = model
+        tr = cfg["train"]
+        if "scale_lr" in tr:      # the learnable residual scales of the AdaIN blocks get their own rate
+            named = list(model.named_parameters())
+            params = [{"params": [p for n, p in named if not n.endswith("scale")]},
+                      {"params": [p for n, p in named if n.endswith("scale")], "lr": tr["scale_lr"]}]
+        else:
+            params = model.parameters()
+        self.optimizer = make_optimizer(params, tr["optimizer"])
+        if "restore" in cfg and "optimizer" in cfg["restore"]:
+            restore_exp([self.optimizer], [cfg["restore"]["optimizer"]], self.device, verbose=self.rank == 0)
+            if "new_lr" in cfg["restore"]:
+                for g in self.optimizer.param_groups:
+                    g["lr"] = cfg["restore"]["new_lr"]
+        self.scheduler = make_scheduler(self.optimizer, tr["scheduler"]) if "scheduler" in tr else None
+        data = SyntheticClouds(task, cfg["data"]["num_points"], n_classes, length=dataset_length, channels=channels)
+        self.sampler = torch.utils.data.distributed.DistributedSampler(data) if parallel._active(dist) else None
+        self.loader = torch.utils.data.DataLoader(data, batch_size=cfg["data"]["batch_size"], shuffle=self.sampler is None,
+                                                  num_workers=0, sampler=self.sampler, drop_last=True)
+        self.ce, self.bce = nn.CrossEntropyLoss(), nn.BCEWithLogitsLoss()
+        self.iters = 0
+
+    def _loss(self, batch):
+        if self.task == "segmentation":
+            pts, labels = batch
+            pcd = pts.permute(0, 2, 1)[:, :, None].to(self.device)                    # (B, channels, 1, N)
+            out = self.model(pcd)
+            pred = out[0] if isinstance(out, (tuple, list)) else out                  # the reference returns (pred, lattice stats)
+            return self.ce(pred[:, :, 0], labels.to(self.device))
+        pts, label, mask = batch
+        logits, mask_pred = self.model(pts.permute(0, 2, 1)[:, :, None].to(self.device))
+        w = float(self.cfg["train"].get("seg_weight", 0.5))
+        return self.ce(logits, label.to(self.device)) + w * self.bce(mask_pred.reshape(mask.shape[0], -1), mask.to(self.device))
+
+    def save(self):
+        if self.rank == 0 and self.exp_dir is not None:
+            parallel.save_exp_parallel([self.model, self.optimizer], ["generator", "g_opt"], exp_path=self.exp_dir,
+                                       epoch=self.iters, epoch_name="iter")
+
+    def fit(self, max_iters=None):
+        """Runs `train.num_epochs` epochs (or `max_iters` steps); returns the rank-0 loss history."""
+        tr = self.cfg["train"]
+        history = []
+        for epoch in range(tr["num_epochs"]):
+            if self.sampler is not None:
+                self.sampler.set_epoch(epoch)
+            self.model.train()
+            end = time.time()
+            for batch in self.loader:
+                loss = self._loss(batch)
+                loss.backward()
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+                if self.scheduler is not None:
+                    self.scheduler.step()
+                reduced = parallel.reduce_loss_dict(self.dist, {"loss": loss})
+                if self.rank == 0:
+                    history.append(float(reduced["loss"].detach()))
+                    self.writer.add_scalar("train/loss", history[-1], global_step=self.iters)
+                    self.writer.add_scalar("train/batch_time", time.time() - end, global_step=self.iters)
+                end = time.time()
+                self.iters += 1
+                if self.iters % tr.get("save_each", 1 << 62) == 0:
+                    self.save()
+                if max_iters is not None and self.iters >= max_iters:
+                    return history
+        return history
+
+
+def load_config(path):
+    import yaml
+    with open(path, "r") as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    cfg["config_path"] = str(path)
+    return cfg
