@@ -1,5 +1,5 @@
 """Soak: many more random cases through the fuzz tests' own generators (tests/test_gconv_gpu.py::test_gconv_fuzz,
-tests/test_raster_gpu.py::test_fuzz_shapes_against_oracle).  `python tools/soak_fuzz.py [n_gconv_seeds] [n_raster_batches] [n_emd_seeds]`.
+tests/test_raster_gpu.py::test_fuzz_shapes_against_oracle).  `python tools/soak_fuzz.py [n_gconv_seeds] [n_raster_batches] [n_emd_seeds] [n_hot_cases]`.
 
 Round-1 runs: 600 grouped-conv seeds clean (after ct_gconv_supported: two shapes without an LDS tile plan used to fail);
 672 raster cases (288, then 384 after the quad scatter kernels) with two expected differences, both the same thing: a feature that randn drew as exactly 0.0 ties with the zero floor of an empty
@@ -13,6 +13,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gconv_gpu as G          # noqa: E402
 import tests.test_raster_gpu as T         # noqa: E402
 import tests.test_emd_gpu as E            # noqa: E402
+import tests.test_headline_gpu as HL      # noqa: E402
+
+
+def hot_fuzz(n_cases, seed=7000):
+    """Random shapes through the hot-shape kernels (forced on: they normally need >= 64-256 workgroups of planes): 2D and 3D,
+    max and sum, padding masks, ragged quads, non-square grids — each against the oracle chain (forward, and all three
+    gradients)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    mod, lib = HL._lib()
+    bad = 0
+    for i in range(n_cases):
+        dim = int(rng.integers(2, 4))
+        if dim == 2:
+            W = (int(rng.choice([8, 12, 16, 24, 32, 40, 48, 64])), int(rng.choice([8, 16, 20, 32, 36, 64])))
+        else:
+            W = tuple(int(v) for v in rng.choice([4, 6, 8, 10, 16], size=3))
+            if (W[0] * W[1] * W[2]) % 4:
+                W = (W[0], W[1], 8)
+        cfg = (int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.choice([4, 8, 12, 16, 20, 32])),
+               4 * int(rng.integers(16, 2300)), W, bool(rng.random() < 0.4), False)
+        for reduce in ("max", "sum"):
+            try:
+                HL.test_hot_kernels_forced_on_small_shapes(cfg, reduce, lambda v: lib.ct_debug_set_flags(v))
+            except Exception as e:         # noqa: BLE001
+                bad += 1
+                lib.ct_debug_set_flags(0)
+                print("hot cfg", cfg, reduce, "FAILED", str(e)[:300].replace("\n", " "))
+    print("hot kernels:", 2 * n_cases, "cases, failures:", bad)
 
 
 def main():
@@ -45,6 +74,8 @@ def main():
             bad += 1
             print("emd seed", seed, "FAILED", str(e)[:300].replace("\n", " "))
     print("emd:", n_e, "seeds, failures:", bad)
+    if len(sys.argv) > 4:
+        hot_fuzz(int(sys.argv[4]))
 
 
 if __name__ == "__main__":
