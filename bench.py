@@ -60,7 +60,7 @@ def parse():
     return p.parse_args()
 
 
-def time_passes(step, iters=30):
+def time_passes(step, iters=200):
     """Average device time (ms) of each of the four ABI passes, measured with HIP
     events on the stream the kernels are launched on (torch's current stream)."""
     import torch
@@ -237,6 +237,12 @@ def run_op(args):
         for _ in range(k):
             run()
 
+    # The per-pass HIP-event timings (the roofline's kernel time) are taken BEFORE the step timing, on every rank: the
+    # driver's short runs (W = 5 warm-up steps = 1 ms, K = 20 steps = 4 ms) otherwise measure the GPU's clock ramp after
+    # the idle seconds of set-up and graph capture — same build, same box: 150-160 M points/s with W = 5, 167 M with
+    # W = 200 (a 20-step burst after idle runs at 0.24 ms per step, tools/dev/lat_probe.py; sustained load: 0.195).  The
+    # line says so (`config.order`).
+    passes = time_passes(step)
     run_steps(args.warmup)
     barrier(dist)
     torch.cuda.synchronize()
@@ -250,7 +256,6 @@ def run_op(args):
 
     if rank == 0:
         alg = step.algorithmic_bytes()
-        passes = time_passes(step)
         tags = step.launch_tags()
         # dominant KERNEL: the longest pass that is a single launch (profiles/*_kernel_stats.csv lists every kernel's
         # average for cross-checking)
@@ -278,7 +283,8 @@ def run_op(args):
                                    % (B, N, H, C, dim, W, args.reduce),
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
                        "world_size_seen": world,
-                       "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1},
+                       "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1,
+                       "order": "per-pass HIP-event timings (203 launches of each pass), then W warm-up steps, then the K timed steps"},
             "roofline": {"bound": "hbm", "kernel": step.KERNEL_OF.get(tags[dom], tags[dom]),
                          "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
