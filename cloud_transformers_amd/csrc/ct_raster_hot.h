@@ -109,7 +109,8 @@ constexpr int kHotThreads = CT_HOT_THREADS;
 // IEEE float scatter-add of one channel of a plane into its LDS accumulator row (the channel holds inf / NaN or
 // would overflow the fixed-point bound): re-reads the channel's src row; rare.
 template <bool HAS_PAD>
-__device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int ch, float* row_acc) {
+__device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int ch, float* row_acc,
+                                                      int es = 1 /* element stride of the channel's cells in row_acc */) {
   const int N = a.N, W1 = g.W[1];
   const float* src = a.src + (bh * a.C + ch) * (size_t)N;
   for (int q = threadIdx.x; q < (N >> 2); q += blockDim.x) {
@@ -123,14 +124,18 @@ __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const
       Pt2 p;
       pt2_from_keys(kx[i], ky[i], g, W1, p);
       const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : f[i];
-      float* T = row_acc + p.base;
+      float* T = row_acc + p.base * es;
       atomicAdd(T, x * p.cw[0]);
-      atomicAdd(T + W1, x * p.cw[1]);
-      atomicAdd(T + 1, x * p.cw[2]);
-      atomicAdd(T + W1 + 1, x * p.cw[3]);
+      atomicAdd(T + W1 * es, x * p.cw[1]);
+      atomicAdd(T + es, x * p.cw[2]);
+      atomicAdd(T + (W1 + 1) * es, x * p.cw[3]);
     }
   }
 }
+
+#ifndef CT_FUSED_PAIR
+#define CT_FUSED_PAIR 1
+#endif
 
 // GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
 template <bool HAS_PAD, int WT, int QPT, bool GATHER>
@@ -284,6 +289,11 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
           any_float = true;
         }
       }
+#if CT_FUSED_PAIR
+      // channel pairs share a 64-bit accumulator word: a pair with a float-path channel takes the float path whole
+      if (iq[0] == 0.0f || iq[1] == 0.0f) iq[0] = iq[1] = 0.0f;
+      if (iq[2] == 0.0f || iq[3] == 0.0f) iq[2] = iq[3] = 0.0f;
+#endif
       const float4* Tq = T4 + (size_t)cq * G;
       int* accq = acc + (size_t)(cq * 4) * G;
 #pragma unroll
@@ -333,6 +343,25 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
           //  branch here, so that the point's work stays one basic block in source order.  Issuing the next point's
           //  gathers ahead of these atomics was measured: no gain.)
           const ct_f2 cw01 = {p.cw[0], p.cw[1]}, cw23 = {p.cw[2], p.cw[3]};
+#if CT_FUSED_PAIR
+          // Two channels per LDS atomic: the pair's fixed-point values go into one 64-bit word {lo = channel 2k, hi =
+          // channel 2k+1} as hi * 2^32 + lo in two's complement (high word = hi + (lo >> 31)), so the word holds
+          // sum(hi) * 2^32 + sum(lo) exactly and the halves are recovered at write-out.  ds_add_u64 5.5 ns against
+          // 2 x 3.3 ns for two ds_add_u32 (tools/microbench/lds_atomics.hip).
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj) {
+            unsigned long long* Tc = (unsigned long long*)accq + (size_t)pj * G + p.base;
+            const float fa = fv[2 * pj][i] * iq[2 * pj], fb = fv[2 * pj + 1][i] * iq[2 * pj + 1];
+            const ct_f2 a01 = cw01 * fa, a23 = cw23 * fa, b01 = cw01 * fb, b23 = cw23 * fb;
+            const int lo[4] = {cvt_rpi(a01.x), cvt_rpi(a01.y), cvt_rpi(a23.x), cvt_rpi(a23.y)};
+            const int hi[4] = {cvt_rpi(b01.x), cvt_rpi(b01.y), cvt_rpi(b23.x), cvt_rpi(b23.y)};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const unsigned long long val = ((unsigned long long)(unsigned)(hi[v] + (lo[v] >> 31)) << 32) | (unsigned)lo[v];
+              atomicAdd(Tc + off[v], val);
+            }
+          }
+#else
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
             int* Tc = accq + cj * G + p.base;
@@ -343,6 +372,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
             atomicAdd(Tc + off[2], cvt_rpi(p23.x));
             atomicAdd(Tc + off[3], cvt_rpi(p23.y));
           }
+#endif
           __builtin_amdgcn_sched_barrier(0);     // one point at a time: keeps the live set inside the register budget
         }
       }
@@ -352,13 +382,44 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
           float q, iqd;
           bool fixed;
           fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iqd, fixed);
+#if CT_FUSED_PAIR
+          if (iq[cj] == 0.0f)      // this channel's pair is on the float path: its half of the pair's words holds a float
+            scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + (size_t)(cj >> 1) * 2 * G) + (cj & 1), 2);
+#else
           if (!fixed) scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + cj * G));
+#endif
         }
       }
     }
     __syncthreads();
     // write the chunk out (and clear the accumulators for the next chunk in the same sweep)
     const bool more = chunk + a.ncg < a.nchunks;
+#if CT_FUSED_PAIR
+    // a thread takes 4 cells of a channel pair: two 16-byte reads of {lo, hi} words -> one float4 per channel
+    for (int t = tid; t < (cc >> 1) * (G >> 2); t += blockDim.x) {
+      const int pr = t / (G >> 2), cell = (t - pr * (G >> 2)) << 2;
+      float qa, qb, iqd;
+      bool fa, fb;
+      fx_quantum(__uint_as_float(s_max[c0 + 2 * pr]) * Kf, qa, iqd, fa);
+      fx_quantum(__uint_as_float(s_max[c0 + 2 * pr + 1]) * Kf, qb, iqd, fb);
+      int4* w = (int4*)(acc + ((size_t)pr * G + cell) * 2);
+      const int4 r0 = w[0], r1 = w[1];
+      const int lo[4] = {r0.x, r0.z, r1.x, r1.z}, hw[4] = {r0.y, r0.w, r1.y, r1.w};
+      float4 oa, ob;
+      if (fa && fb) {
+        // word = hi * 2^32 + lo (two's complement): lo is the low half as it stands, hi = high half + (lo < 0)
+        oa = make_float4((float)lo[0] * qa, (float)lo[1] * qa, (float)lo[2] * qa, (float)lo[3] * qa);
+        ob = make_float4((float)(hw[0] - (lo[0] >> 31)) * qb, (float)(hw[1] - (lo[1] >> 31)) * qb,
+                         (float)(hw[2] - (lo[2] >> 31)) * qb, (float)(hw[3] - (lo[3] >> 31)) * qb);
+      } else {
+        oa = make_float4(__int_as_float(lo[0]), __int_as_float(lo[1]), __int_as_float(lo[2]), __int_as_float(lo[3]));
+        ob = make_float4(__int_as_float(hw[0]), __int_as_float(hw[1]), __int_as_float(hw[2]), __int_as_float(hw[3]));
+      }
+      st_stream4(gout + (size_t)(2 * pr) * G + cell, oa);
+      st_stream4(gout + (size_t)(2 * pr + 1) * G + cell, ob);
+      if (more) w[0] = w[1] = make_int4(0, 0, 0, 0);
+    }
+#else
     for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) {
       const int ch = (t << 2) / G;                 // G % 4 == 0: a float4 never straddles channels
       float q, iqd;
@@ -371,6 +432,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       st_stream4(gout + ((size_t)t << 2), o);
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
+#endif
     // (the next chunk's staging overwrites T4 only: every gather of this chunk is behind the barrier above)
   }
 #pragma unroll

@@ -194,6 +194,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           any_float = true;
         }
       }
+#if CT_FUSED_PAIR
+      if (iq[0] == 0.0f || iq[1] == 0.0f) iq[0] = iq[1] = 0.0f;      // 64-bit {lo, hi} words: see slice_bwd_fused_kernel
+      if (iq[2] == 0.0f || iq[3] == 0.0f) iq[2] = iq[3] = 0.0f;
+#endif
       const float4* Tq = T4 + (size_t)cq * G;
       int* accq = acc + (size_t)(cq * 4) * G;
 #pragma unroll
@@ -246,6 +250,18 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           gs[0][i][1] += gd[1];
           gs[0][i][2] += gd[2];
           asm volatile("" : "+v"(gs[0][i][0]), "+v"(gs[0][i][1]), "+v"(gs[0][i][2]));
+#if CT_FUSED_PAIR
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj) {
+            unsigned long long* Tc = (unsigned long long*)accq + (size_t)pj * G + p.base;
+            const float fa = fv[2 * pj][i] * iq[2 * pj], fb = fv[2 * pj + 1][i] * iq[2 * pj + 1];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+              const int lo = cvt_rpi(fa * p.cw[v]), hi = cvt_rpi(fb * p.cw[v]);
+              atomicAdd(Tc + off[v], ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32) | (unsigned)lo);
+            }
+          }
+#else
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
             int* Tc = accq + cj * G + p.base;
@@ -253,6 +269,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 #pragma unroll
             for (int v = 0; v < 8; ++v) atomicAdd(Tc + off[v], cvt_rpi(fq * p.cw[v]));
           }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         if (!kKeepGs && active[u]) store_gkeys3(gpos, bh, N, n0c[u], gs[0], k, chunk > cgi || cq > 0);
@@ -263,8 +280,15 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           float q, iqd;
           bool fixed;
           fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iqd, fixed);
+#if CT_FUSED_PAIR
+          constexpr int es = 2;
+          if (iq[cj] == 0.0f) {
+            float* row_acc = (float*)(accq + (size_t)(cj >> 1) * 2 * G) + (cj & 1);
+#else
+          constexpr int es = 1;
           if (!fixed) {
             float* row_acc = (float*)(accq + cj * G);
+#endif
             const float* src = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
             for (int qd = tid; qd < (N >> 2); qd += blockDim.x) {
               const int nn = qd << 2;
@@ -278,7 +302,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
                 pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
                 const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + nn + i) : f[i];
 #pragma unroll
-                for (int v = 0; v < 8; ++v) atomicAdd(row_acc + p.base + off[v], x * p.cw[v]);
+                for (int v = 0; v < 8; ++v) atomicAdd(row_acc + (p.base + off[v]) * es, x * p.cw[v]);
               }
             }
           }
@@ -287,6 +311,30 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
     }
     __syncthreads();
     const bool more = chunk + a.ncg < a.nchunks;
+#if CT_FUSED_PAIR
+    for (int t = tid; t < (cc >> 1) * (G >> 2); t += blockDim.x) {
+      const int pr = t / (G >> 2), cell = (t - pr * (G >> 2)) << 2;
+      float qa, qb, iqd;
+      bool fa, fb;
+      fx_quantum(__uint_as_float(s_max[c0 + 2 * pr]) * Kf, qa, iqd, fa);
+      fx_quantum(__uint_as_float(s_max[c0 + 2 * pr + 1]) * Kf, qb, iqd, fb);
+      int4* w = (int4*)(acc + ((size_t)pr * G + cell) * 2);
+      const int4 r0 = w[0], r1 = w[1];
+      const int lo[4] = {r0.x, r0.z, r1.x, r1.z}, hw[4] = {r0.y, r0.w, r1.y, r1.w};
+      float4 oa, ob;
+      if (fa && fb) {
+        oa = make_float4((float)lo[0] * qa, (float)lo[1] * qa, (float)lo[2] * qa, (float)lo[3] * qa);
+        ob = make_float4((float)(hw[0] - (lo[0] >> 31)) * qb, (float)(hw[1] - (lo[1] >> 31)) * qb,
+                         (float)(hw[2] - (lo[2] >> 31)) * qb, (float)(hw[3] - (lo[3] >> 31)) * qb);
+      } else {
+        oa = make_float4(__int_as_float(lo[0]), __int_as_float(lo[1]), __int_as_float(lo[2]), __int_as_float(lo[3]));
+        ob = make_float4(__int_as_float(hw[0]), __int_as_float(hw[1]), __int_as_float(hw[2]), __int_as_float(hw[3]));
+      }
+      st_stream4(gout + (size_t)(2 * pr) * G + cell, oa);
+      st_stream4(gout + (size_t)(2 * pr + 1) * G + cell, ob);
+      if (more) w[0] = w[1] = make_int4(0, 0, 0, 0);
+    }
+#else
     for (int t = tid; t < (cc * G) >> 2; t += blockDim.x) {
       const int ch = (t << 2) / G;
       float q, iqd;
@@ -299,6 +347,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
       st_stream4(gout + ((size_t)t << 2), o);
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
+#endif
   }
   if (kKeepGs) {
     if (active[0]) {

@@ -268,3 +268,42 @@ def test_splat_bwd_accumulates_into_g_keys(flags):
         # too small a workspace is refused
         assert lib.ct_splat_bwd_ex(_ptr(keys), _ptr(feat), None, 0, _ptr(z), _ptr(gz), _ptr(gf_b), _ptr(gk_acc),
                                    _ptr(ws1), 16, B, H, C, N, dim, Wa, 0, mod.BWD_ACCUMULATE_KEYS, _stream()) == -3
+
+
+@pytest.mark.parametrize("W", [(32, 32), (8, 8, 8)], ids=["2d", "3d"])
+def test_fused_slice_backward_with_non_finite_channels(W, flags):
+    """The fused Slice backward accumulates channel PAIRS in 64-bit fixed-point words; a channel that holds inf / NaN (or
+    would overflow the bound) takes IEEE float atomics — and so does its pair partner, which must stay exact to float
+    accuracy, as must every other channel."""
+    from cloud_transformers_amd import ops
+    mod, lib = _lib()
+    dim = len(W)
+    B, H, C, N = 1, 2, 8, 1024
+    g = torch.Generator().manual_seed(5 + dim)
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    grid = torch.randn(B, H * C, *W, generator=g)
+    cot = torch.randn(B, H * C, N, generator=g)
+    cot[0, 1, 7] = float("inf")                 # head 0, channel 1: partner of channel 0
+    cot[0, 4, 100] = float("nan")               # head 0, channel 4: partner of channel 5
+    cot[0, C + 6] *= 1e30                        # head 1, channel 6: finite, but a sum of it could overflow
+    lc, idx = R.positions(keys, list(W), H, dim)
+    ref = torch.zeros(B, H * C, *W)
+    gr = grid.clone().requires_grad_(True)
+    R.slice_(lc, idx, gr, None, list(W), H, dim).backward(cot)
+    ref = gr.grad
+    flags(mod.DEBUG_FORCE_HOT)
+    gk = grid.cuda().requires_grad_(True)
+    ops.slice_keys(keys.cuda(), gk, None, list(W), H, dim).backward(cot.cuda())
+    tag = lib.ct_debug_last_launch().decode()
+    flags(0)
+    assert tag.startswith("slice_bwd_fused"), tag
+    got = gk.grad.cpu()
+    for ch in range(H * C):
+        a, r = got[0, ch].double(), ref[0, ch].double()
+        if ch in (1, 4):
+            # the same cells are inf / NaN, every other cell of the channel agrees
+            assert torch.equal(torch.isfinite(a), torch.isfinite(r)), ch
+            fin = torch.isfinite(r)
+            assert float((a[fin] - r[fin]).abs().max()) <= 1e-4 * float(r[fin].abs().max()), ch
+        else:
+            assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), ch

@@ -16,8 +16,10 @@ for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
         feat = torch.randn(B, H * C, N, device="cuda")
         cot = torch.randn(B, H * C, N, device="cuda")
         st = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
-        st.run(); torch.cuda.synchronize()
-        p = time_passes(st, iters=20)
+        for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks
+            st.run()
+        torch.cuda.synchronize()
+        p = time_passes(st, iters=100)
         tot = sum(p.values()) * 1e3
         alg = st.algorithmic_bytes()["total"]
         print(C, W, dim, "|", B, N, "|", {k: round(v * 1e3, 1) for k, v in p.items()}, "|", round(tot, 1), "|",
