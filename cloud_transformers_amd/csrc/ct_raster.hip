@@ -1965,9 +1965,12 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   // that fits beside the tile, otherwise several cells share a counter — the maximum over the table is then still
   // an upper bound of the per-cell maximum, which is all K has to be (a looser bound costs log2 of the slack in
   // the 30-bit fixed-point resolution)
+  // The table is also kept small enough for TWO workgroups per CU: a full-resolution table for 128^2 cells (64 KiB beside
+  // the 64 KiB tile) left one workgroup per CU that spent its time zeroing and scanning counters (a 16x looser K costs 4 of
+  // the 30 bits).
   int cnt = 1024;
   while (cnt < g.G) cnt *= 2;
-  while (cnt > 1024 && pg.lds_bytes + (size_t)(pg.CC * 32 + cnt) * 4 > (size_t)kBigLdsBytes) cnt /= 2;
+  while (cnt > 1024 && pg.lds_bytes + (size_t)(pg.CC * 32 + cnt) * 4 > (size_t)kHalfCuLdsBytes) cnt /= 2;
   const size_t extra = (size_t)(pg.CC * 32 + cnt) * 4;
   if (pg.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
   ga.cnt_mask = cnt - 1;
