@@ -307,3 +307,46 @@ def test_fused_slice_backward_with_non_finite_channels(W, flags):
             assert float((a[fin] - r[fin]).abs().max()) <= 1e-4 * float(r[fin].abs().max()), ch
         else:
             assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), ch
+
+
+ZOO_SHAPES = [
+    # C, W, dim, B, N  — the six zoo head shapes at the S3DIS batch (model_zoo/s3dis/segmenter.py:28-45) and two decoder
+    # shapes of the completion model (B2 N16384, model_zoo/completion/inpainter.py:135-155)
+    (4, 128, 2, 8, 4096), (4, 32, 3, 8, 4096), (16, 64, 2, 8, 4096), (16, 16, 3, 8, 4096), (16, 16, 2, 8, 4096),
+    (32, 8, 3, 8, 4096), (16, 64, 2, 2, 16384), (32, 8, 3, 2, 16384),
+]
+
+
+@pytest.mark.parametrize("cfg", ZOO_SHAPES, ids=[str(c) for c in ZOO_SHAPES])
+def test_zoo_head_shapes_at_full_size_against_oracle_planes(cfg, flags):
+    """The kernels the zoo's heads actually run (H = 16: chunk groups, partial g_keys sums, 3D hot kernels, split-N
+    statistics kernels) at full size in the default dispatch: the whole fwd+bwd step against the oracle on sampled (b, h)
+    planes, and the other kernel family on full tensors."""
+    from cloud_transformers_amd.step import SplatSliceStep
+    mod, lib = _lib()
+    C, Wn, dim, B, N = cfg
+    H, W = 16, [Wn] * dim
+    torch.manual_seed(77 + C + Wn)
+    keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
+    feat = torch.randn(B, H * C, N, device="cuda")
+    cot = torch.randn(B, H * C, N, device="cuda")
+    step = SplatSliceStep(keys, feat, cot, Wn, H, dim, "max")
+    step.run()
+    torch.cuda.synchronize()
+    got = (step.z, step.out, step.g_z, step.g_feat, step.g_keys())
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, 5)):
+        ref = oracle_chain(keys[b:b + 1, h * dim:(h + 1) * dim].cpu(), feat[b:b + 1, h * C:(h + 1) * C].cpu(),
+                           cot[b:b + 1, h * C:(h + 1) * C].cpu(), W, 1, dim, "max")
+        sl = slice(h * C, (h + 1) * C)
+        mine = (got[0][b:b + 1, sl], got[1][b:b + 1, sl], got[2][b:b + 1, sl], got[3][b:b + 1, sl],
+                got[4][b:b + 1, h * dim:(h + 1) * dim])
+        assert torch.equal(mine[0].cpu(), ref[0]), "z plane (%d,%d)" % (b, h)
+        for name, a, r in zip(NAMES, mine, ref):
+            assert relerr(a, r) <= 1e-4, "%s plane (%d,%d): %.2e" % (name, b, h, relerr(a, r))
+    # the other kernel family on the full tensors (module path: separate g_keys of Splat and Slice summed by autograd)
+    flags(mod.DEBUG_NO_HOT)
+    gen, _ = hip_chain(keys, feat, cot, W, H, dim, "max")
+    flags(0)
+    assert torch.equal(got[0], gen[0])
+    for name, a, b_ in zip(NAMES[1:], got[1:], gen[1:]):
+        assert relerr(a, b_) <= 1e-5, name
