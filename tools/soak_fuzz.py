@@ -5,7 +5,10 @@ Round-1 runs: 600 grouped-conv seeds clean (after ct_gconv_supported: two shapes
 672 raster cases (288, then 384 after the quad scatter kernels) with two expected differences, both the same thing: a feature that randn drew as exactly 0.0 ties with the zero floor of an empty
 cell, where the oracle's scatter_reduce stand-in gives the candidate half the cotangent and torch_scatter's CPU rule (strict >)
 and this implementation give it none (backward differs on exact ties only).
-60 EMD fuzz seeds (sizes 1024-5120, clustered / duplicated / shared clouds): assignments and distances equal the oracle's exactly."""
+60 EMD fuzz seeds (sizes 1024-5120, clustered / duplicated / shared clouds): assignments and distances equal the oracle's exactly.
+Round-2 run (after the hot kernels, channel-pair accumulators, 3D backward kernels): 600 grouped-conv seeds, 288 raster cases (one
+expected difference of the kind above: a zero feature against the zero floor, tools/dev/fuzz_case_probe.py prints the cells),
+40 EMD seeds, 800 forced-hot-kernel cases (2D/3D, max/sum, masks): clean."""
 import os
 import sys
 
