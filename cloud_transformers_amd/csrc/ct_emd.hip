@@ -288,6 +288,15 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   if (kDepth < ntiles) fetch(kDepth, stage[0]);
   __syncthreads();
   Top2 t2 = {-1e9f, -1e9f, 0x7fffffff};
+  // Candidate filter.  Only the bidder's two largest values matter, so a candidate below the second-best value the
+  // bidder's lanes (of this wave) have seen so far can be dropped before its sqrt and its double-precision tail (2/3 of the
+  // work): with thr that value, value = 3 - sqrt(d2) - price < thr  <=>  sqrt(d2) > 3 - thr - price, tested on the squared
+  // distance as d2 > tt*|tt|, tt = (3 - thr + 1e-5) - price (the margin covers the roundings of the test; tt <= 0 means the
+  // price alone rules the target out).  thr only uses earlier, lower-indexed targets, so a tie with it can never win the
+  // lowest-index rule either: the result is bit-identical.  The slow path runs when ANY lane of the wave has a candidate
+  // (wave-uniform branch); thr is refreshed from the lanes' running pairs after such a batch.
+  float cthr = 2e9f;                 // 3 - thr + margin; thr = -1e9 at the start: nothing is dropped
+  const int Tw = T < 64 ? T : 64;    // lanes of this wave that work for the same bidder
   for (int t0 = 0; t0 < ntiles; t0 += kDepth) {
 #pragma unroll
     for (int r = 0; r < kDepth; ++r) {
@@ -298,18 +307,33 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
           const int k0 = t * kTile;
           for (int k = sub; k < kTile; k += 4 * T) {           // kTile / T is a multiple of 4 (T <= 256)
             float4 q[4];
-            float d[4];
+            float d2[4];
+            bool keep = false;
 #pragma unroll
             for (int u = 0; u < 4; ++u) q[u] = tl[k + u * T];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const float x2 = q[u].x - x1, y2 = q[u].y - y1, z2 = q[u].z - z1;
-              const float d2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
-              // evaluated in double like the reference (its literal 3.0 is a double), rounded once
-              d[u] = (float)(3.0 - (double)sqrtf(d2) - (double)q[u].w);
+              d2[u] = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+              const float tt = cthr - q[u].w;
+              keep |= !(d2[u] > tt * fabsf(tt));
             }
+            if (__builtin_amdgcn_ballot_w64(keep) != 0ull) {   // wave-uniform
+              float d[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) top2_push(t2, d[u], k0 + k + u * T);
+              for (int u = 0; u < 4; ++u)      // evaluated in double like the reference (its literal 3.0 is a double), rounded once
+                d[u] = (float)(3.0 - (double)sqrtf(d2[u]) - (double)q[u].w);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) top2_push(t2, d[u], k0 + k + u * T);
+              // second-best value over the bidder's lanes in this wave (values only; the lanes keep their own pairs)
+              float gb = t2.best, g2 = t2.better;
+              for (int m = 1; m < Tw; m <<= 1) {
+                const float ob = __shfl_xor(gb, m, 64), o2 = __shfl_xor(g2, m, 64);
+                g2 = fmaxf(fminf(gb, ob), fmaxf(g2, o2));
+                gb = fmaxf(gb, ob);
+              }
+              cthr = 3.0f - g2 + 1e-5f;
+            }
           }
         }
         if (t + 1 < ntiles) {
@@ -322,7 +346,6 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
     }
   }
   // butterfly over the lanes of a bidder inside its wave (inactive lanes hold the identity)
-  const int Tw = T < 64 ? T : 64;
   for (int m = 1; m < Tw; m <<= 1) {
     Top2 o;
     o.best = __shfl_xor(t2.best, m, 64);
