@@ -59,6 +59,30 @@ __global__ void __launch_bounds__(256) scan(const float* __restrict__ pts, const
   out[blockIdx.x * 256 + threadIdx.x] = t2.best + t2.better + (float)t2.idx;
 }
 
+__global__ void touch(float* prc, int n) {      // another kernel writes the prices between two scans, as emd_update_kernel does
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) prc[i] += 1e-9f;
+}
+
+template <int VAR, int KB>
+float run_after_writer(const float* pts, float* prc, const float* q, float* out, int n, int U) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int reps = 50;
+  float tot = 0;
+  for (int i = 0; i < reps + 5; ++i) {
+    hipLaunchKernelGGL(touch, dim3(n / 256), dim3(256), 0, 0, prc, n);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((scan<VAR, KB>), dim3(U), dim3(256), 0, 0, pts, prc, q, out, n);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (i >= 5) tot += ms;
+  }
+  return tot / reps * 1e3f;
+}
+
 template <int VAR, int KB>
 float run(const float* pts, const float* prc, const float* q, float* out, int n, int U) {
   hipEvent_t e0, e1;
@@ -92,6 +116,8 @@ int main() {
     printf("U=%4d bidders, n=%d: double %.1f us | float %.1f | no sqrt %.1f | loads only %.1f   (8 per batch)\n", U, n,
            run<0, 8>(dp, dprc, dq, dout, n, U), run<1, 8>(dp, dprc, dq, dout, n, U), run<2, 8>(dp, dprc, dq, dout, n, U),
            run<3, 8>(dp, dprc, dq, dout, n, U));
+    printf("                             after a writer kernel, timed alone between events: double %.1f us | loads only %.1f\n",
+           run_after_writer<0, 8>(dp, dprc, dq, dout, n, U), run_after_writer<3, 8>(dp, dprc, dq, dout, n, U));
     printf("                             double %.1f us | float %.1f | no sqrt %.1f | loads only %.1f   (4 per batch)\n",
            run<0, 4>(dp, dprc, dq, dout, n, U), run<1, 4>(dp, dprc, dq, dout, n, U), run<2, 4>(dp, dprc, dq, dout, n, U),
            run<3, 4>(dp, dprc, dq, dout, n, U));
