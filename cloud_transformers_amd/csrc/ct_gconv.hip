@@ -1057,10 +1057,16 @@ __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, siz
 // in ci (16) and co (4): every LDS read is a 16- or 4-address broadcast.  No atomics, no workspace: bitwise
 // reproducible.  The bias gradient rides along (ci block 0, lanes with ci == 0).   grid = (ci_blocks * co_blocks, groups)
 // ---------------------------------------------------------------------------
+// kWsSplit thread groups of 256 (co, ci) pairs walk disjoint row ranges of the volume (depth slices in 3D, rows in 2D) and
+// their partial filters meet in LDS: one workgroup per CU then runs 4 waves per SIMD instead of 1 — the walk is a chain of
+// LDS reads and dependent multiply-adds (8^3 B2 1024->1024: 147 -> see DESIGN).
+constexpr int kWsSplit = 4;
+
 template <int DIM, int WT>
-__global__ void __launch_bounds__(256) gconv_wrw_small_kernel(GconvArgs a, const float* __restrict__ gy, float* __restrict__ gw,
-                                                             float* __restrict__ gbias) {
+__global__ void __launch_bounds__(256 * kWsSplit) gconv_wrw_small_kernel(GconvArgs a, const float* __restrict__ gy, float* __restrict__ gw,
+                                                                        float* __restrict__ gbias) {
   constexpr int NR = DIM == 3 ? 9 : 3;
+  constexpr int NT = 256 * kWsSplit;
   extern __shared__ __align__(16) float lds[];
   const int D = a.D, H = a.H;
   const int Hp = H + 2, Wp = WT + 2, Dp = DIM == 3 ? D + 2 : 1;
@@ -1071,19 +1077,24 @@ __global__ void __launch_bounds__(256) gconv_wrw_small_kernel(GconvArgs a, const
   float* gs = lds + 16 * plane;                          // [16][P]
   const int cib = (a.Cin + 15) / 16;
   const int cb = blockIdx.x % cib, ob = blockIdx.x / cib, grp = blockIdx.y;
-  const int ci = threadIdx.x & 15, co = threadIdx.x >> 4;
+  const int pair = threadIdx.x & 255, slice = threadIdx.x >> 8;
+  const int ci = pair & 15, co = pair >> 4;
   const int ci_g = cb * 16 + ci, co_g = ob * 16 + co;
   const size_t vol = (size_t)P;
+  // this slice's rows: (z, y) pairs in row-major order, rows = D * H
+  const int rows = D * H;
+  const int per = (rows + kWsSplit - 1) / kWsSplit;
+  const int r_beg = min(rows, slice * per), r_end = min(rows, r_beg + per);
   float acc[NR * 3];
 #pragma unroll
   for (int t = 0; t < NR * 3; ++t) acc[t] = 0.0f;
   float bsum = 0.0f;
-  for (int i = threadIdx.x; i < 16 * plane; i += 256) xs[i] = 0.0f;      // the halo stays zero for every batch element
+  for (int i = threadIdx.x; i < 16 * plane; i += NT) xs[i] = 0.0f;      // the halo stays zero for every batch element
   for (int b = 0; b < a.B; ++b) {
     __syncthreads();
     const float* xg = a.x + ((size_t)b * a.groups + grp) * a.Cin * vol;
     const float* gg = gy + ((size_t)b * a.groups + grp) * a.Cout * vol;
-    for (int i = threadIdx.x; i < 16 * P; i += 256) {
+    for (int i = threadIdx.x; i < 16 * P; i += NT) {
       const int c = i / P, p = i - c * P;
       const int x = p % WT, y = (p / WT) % H, z = p / (WT * H);
       const int cin = cb * 16 + c, cout = ob * 16 + c;
@@ -1093,39 +1104,55 @@ __global__ void __launch_bounds__(256) gconv_wrw_small_kernel(GconvArgs a, const
     __syncthreads();
     const float* xc = xs + ci * plane;
     const float* gc = gs + co * P;
-    for (int z = 0; z < D; ++z) {
-      for (int y = 0; y < H; ++y) {
-        float g[WT];
+    for (int zy = r_beg; zy < r_end; ++zy) {
+      const int z = zy / H, y = zy - z * H;
+      float g[WT];
 #pragma unroll
-        for (int x = 0; x < WT; ++x) g[x] = gc[(z * H + y) * WT + x];
-        if (cb == 0) {
+      for (int x = 0; x < WT; ++x) g[x] = gc[zy * WT + x];
+      if (cb == 0) {
 #pragma unroll
-          for (int x = 0; x < WT; ++x) bsum += g[x];
-        }
+        for (int x = 0; x < WT; ++x) bsum += g[x];
+      }
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const int dz = DIM == 3 ? r / 3 : 0, dy = r % 3;
-          const float* row = xc + ((z + dz) * Hp + y + dy) * Wp;       // padded coordinates: (z + dz - 1) + 1, ...
-          float xr[WT + 2];
+      for (int r = 0; r < NR; ++r) {
+        const int dz = DIM == 3 ? r / 3 : 0, dy = r % 3;
+        const float* row = xc + ((z + dz) * Hp + y + dy) * Wp;       // padded coordinates: (z + dz - 1) + 1, ...
+        float xr[WT + 2];
 #pragma unroll
-          for (int x = 0; x < WT + 2; ++x) xr[x] = row[x];
+        for (int x = 0; x < WT + 2; ++x) xr[x] = row[x];
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            float s = acc[r * 3 + dx];
+        for (int dx = 0; dx < 3; ++dx) {
+          float s = acc[r * 3 + dx];
 #pragma unroll
-            for (int x = 0; x < WT; ++x) s = __builtin_fmaf(g[x], xr[x + dx], s);
-            acc[r * 3 + dx] = s;
-          }
+          for (int x = 0; x < WT; ++x) s = __builtin_fmaf(g[x], xr[x + dx], s);
+          acc[r * 3 + dx] = s;
         }
       }
     }
   }
-  if (co_g < a.Cout && ci_g < a.Cin) {
-    float* o = gw + ((size_t)(grp * a.Cout + co_g) * a.Cin + ci_g) * a.taps;
+  // partial filters of slices 1.. -> LDS [slice - 1][tap (+ bias)][pair], summed by slice 0 in slice order
+  __syncthreads();
+  float* red = lds;
+  constexpr int NV = NR * 3 + 1;
+  if (slice > 0) {
 #pragma unroll
-    for (int t = 0; t < NR * 3; ++t) o[t] = acc[t];
+    for (int t = 0; t < NR * 3; ++t) red[((slice - 1) * NV + t) * 256 + pair] = acc[t];
+    red[((slice - 1) * NV + NR * 3) * 256 + pair] = bsum;
   }
-  if (gbias != nullptr && cb == 0 && ci == 0 && co_g < a.Cout) gbias[grp * a.Cout + co_g] = bsum;
+  __syncthreads();
+  if (slice == 0) {
+    for (int sl = 0; sl < kWsSplit - 1; ++sl) {
+#pragma unroll
+      for (int t = 0; t < NR * 3; ++t) acc[t] += red[(sl * NV + t) * 256 + pair];
+      bsum += red[(sl * NV + NR * 3) * 256 + pair];
+    }
+    if (co_g < a.Cout && ci_g < a.Cin) {
+      float* o = gw + ((size_t)(grp * a.Cout + co_g) * a.Cin + ci_g) * a.taps;
+#pragma unroll
+      for (int t = 0; t < NR * 3; ++t) o[t] = acc[t];
+    }
+    if (gbias != nullptr && cb == 0 && ci == 0 && co_g < a.Cout) gbias[grp * a.Cout + co_g] = bsum;
+  }
 }
 
 
@@ -1568,27 +1595,35 @@ int launch_wrw_tiles(GconvArgs a, int dim, const float* g_y, float* g_w, hipStre
 }
 
 // plan-only checks behind ct_gconv_supported
+// LDS of the small-volume weight gradient: the two operand tiles, or the partial filters of the row slices if larger
+size_t wrw_small_lds(const GconvArgs& a, int dim) {
+  const int P = a.D * a.H * a.W;
+  const int plane = ((dim == 3 ? a.D + 2 : 1) * (a.H + 2) * (a.W + 2)) | 1;
+  const size_t tiles = (size_t)(16 * plane + 16 * P) * 4;
+  const size_t red = (size_t)(kWsSplit - 1) * (a.taps + 1) * 256 * 4;
+  return tiles > red ? tiles : red;
+}
+
 // small volumes, many channels: the register-tiled vector-ALU form (see gconv_wrw_small_kernel)
 bool wrw_small_eligible(const GconvArgs& a, int dim) {
   const int P = a.D * a.H * a.W;
   if (!(a.W == 2 || a.W == 4 || a.W == 8 || a.W == 16)) return false;
-  // (the walk over the batch is serial per workgroup: beyond ~2048 positions x batch the MFMA ring kernel wins —
-  //  8^3 B8: 563 vs 400 us; 8^3 B2: 133 vs 305 us)
-  if (P > 512 || (long long)P * a.B > 2048 || (a.Cin < 32 && a.Cout < 32)) return false;
-  const int plane = ((dim == 3 ? a.D + 2 : 1) * (a.H + 2) * (a.W + 2)) | 1;
-  return (size_t)(16 * plane + 16 * P) * 4 <= (size_t)kLdsBudgetMax;
+  // (the walk over the batch is serial per workgroup: beyond a few thousand positions x batch the MFMA ring kernel wins)
+  if (P > 512 || (a.Cin < 32 && a.Cout < 32)) return false;
+  const long long wgs = (long long)((a.Cin + 15) / 16) * ((a.Cout + 15) / 16) * a.groups;
+  if ((long long)P * a.B > (wgs >= 256 ? 4096 : 2048)) return false;      // 8^3 B8 64->64 (256 workgroups): 327 vs 403 us ring;
+                                                                          // 32->64 (128 workgroups): 326 vs 211 us
+  return wrw_small_lds(a, dim) <= (size_t)kLdsBudgetMax;
 }
 
 int launch_wrw_small(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_bias, hipStream_t st) {
-  const int P = a.D * a.H * a.W;
-  const int plane = ((dim == 3 ? a.D + 2 : 1) * (a.H + 2) * (a.W + 2)) | 1;
-  const size_t lds = (size_t)(16 * plane + 16 * P) * 4;
+  const size_t lds = wrw_small_lds(a, dim);
   dim3 grid(((a.Cin + 15) / 16) * ((a.Cout + 15) / 16), a.groups);
   CT_CLEAR_ERROR();
 #define CT_WS_LAUNCH(DIMV, WTV)                                                                    \
   do {                                                                                             \
     if (set_lds_attr(gconv_wrw_small_kernel<DIMV, WTV>, lds) != CT_OK) return CT_ELAUNCH;          \
-    hipLaunchKernelGGL((gconv_wrw_small_kernel<DIMV, WTV>), grid, dim3(256), lds, st, a, g_y, g_w, g_bias); \
+    hipLaunchKernelGGL((gconv_wrw_small_kernel<DIMV, WTV>), grid, dim3(256 * kWsSplit), lds, st, a, g_y, g_w, g_bias); \
   } while (0)
   if (dim == 2) {
     if (a.W == 2) CT_WS_LAUNCH(2, 2); else if (a.W == 4) CT_WS_LAUNCH(2, 4); else if (a.W == 8) CT_WS_LAUNCH(2, 8); else CT_WS_LAUNCH(2, 16);
