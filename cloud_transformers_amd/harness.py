@@ -139,10 +139,12 @@ def make_scheduler(optimizer, scheduler_cfg):
 class SyntheticClouds(torch.utils.data.Dataset):
     """Batches shaped like the reference loaders': `segmentation` -> (points f32 [N, 3], labels i64 [N]) as
     datasets/s3dis_v2.py yields; `classification` -> (points f32 [N, 3], label i64 [], mask f32 [N]) as
-    datasets/scanobjectnn.py yields.  Deterministic per index."""
+    datasets/scanobjectnn.py yields; `completion` -> (noise f32 [4, N]: points on the unit sphere + the "is a real point"
+    label, partial cloud f32 [n_classes, 3] (n_classes = its size), ground truth f32 [N, 3]) — what train_inpainter.py:178-185
+    hands to the generator and the losses after `partial_postproces`.  Deterministic per index."""
 
     def __init__(self, task, num_points, n_classes, length=64, seed=0, channels=3):
-        assert task in ("segmentation", "classification") and channels >= 3
+        assert task in ("segmentation", "classification", "completion") and channels >= 3
         self.task, self.n, self.k, self.length, self.seed, self.ch = task, num_points, n_classes, length, seed, channels
 
     def __len__(self):
@@ -150,6 +152,12 @@ class SyntheticClouds(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        if self.task == "completion":
+            gt = torch.nn.functional.normalize(torch.randn(self.n, 3, generator=g), dim=1) * (0.5 + 0.4 * torch.rand((), generator=g))
+            part = gt[torch.randperm(self.n, generator=g)[: self.k]] + 0.01 * torch.randn(self.k, 3, generator=g)
+            sphere = torch.nn.functional.normalize(torch.randn(3, self.n, generator=g), dim=0)
+            noise = torch.cat([sphere, (torch.rand(1, self.n, generator=g) > 0.5).float()], dim=0)
+            return noise, part, gt
         pts = torch.rand(self.n, self.ch, generator=g) * 2 - 1          # xyz (+ colour / normalised position channels)
         if self.task == "segmentation":
             # labels follow the geometry (octants), so a few steps of training move the loss
@@ -164,8 +172,10 @@ class Trainer:
     """The reference scripts' loop: model file + YAML config -> DDP(+SyncBN) model, optimizer, scheduler, steps with
     loss reduction to rank 0, `.t7` checkpoints every `train.save_each` iterations.
 
-    `task`: "segmentation" (loss = CE(pred[:, :, 0], labels), train_segmentation.py:178) or "classification"
-    (loss = CE(logits, label) + seg_weight * BCE-with-logits(mask), train_classification.py)."""
+    `task`: "segmentation" (loss = CE(pred[:, :, 0], labels), train_segmentation.py:178), "classification"
+    (loss = CE(logits, label) + seg_weight * BCE-with-logits(mask), train_classification.py) or "completion"
+    (loss = mean sqrt(EMD(rec, gt, 0.005, 50)) + chamfer_weight * loss_chamfer(rec, gt), train_inpainter.py:186-192;
+    `n_classes` is then the size of the partial cloud)."""
 
     def __init__(self, cfg, task, n_classes, device=None, dist=None, exp_name="exp", dataset_length=64, make_dirs=True,
                  channels=3):
@@ -216,6 +226,17 @@ class Trainer:
             out = self.model(pcd)
             pred = out[0] if isinstance(out, (tuple, list)) else out                  # the reference returns (pred, lattice stats)
             return self.ce(pred[:, :, 0], labels.to(self.device))
+        if self.task == "completion":
+            from .chamfer import loss_chamfer
+            from .emd import emdModule
+            noise, part, gt = batch
+            out = self.model(noise.to(self.device), part.permute(0, 2, 1)[:, :, None].to(self.device))
+            rec = out[0] if isinstance(out, (tuple, list)) else out                   # (B, 3, 1, N)
+            gt4 = gt.permute(0, 2, 1)[:, :, None].to(self.device)
+            tr = self.cfg["train"]
+            dist, _ = emdModule()(rec[:, :, 0].permute(0, 2, 1), gt4[:, :, 0].permute(0, 2, 1),
+                                  float(tr.get("emd_eps", 0.005)), int(tr.get("emd_iters", 50)))
+            return torch.sqrt(dist).mean(1).mean() + float(tr.get("chamfer_weight", 1.0)) * loss_chamfer(rec, gt4)
         pts, label, mask = batch
         logits, mask_pred = self.model(pts.permute(0, 2, 1)[:, :, None].to(self.device))
         w = float(self.cfg["train"].get("seg_weight", 0.5))

@@ -125,3 +125,7 @@ def test_synthetic_batches_have_the_loaders_shapes():
     cls = H.SyntheticClouds("classification", 64, 15, length=4)
     pts, lab, mask = cls[0]
     assert pts.shape == (64, 3) and lab.shape == () and mask.shape == (64,) and mask.dtype == torch.float32
+    comp = H.SyntheticClouds("completion", 1024, 256, length=2)
+    noise, part, gt = comp[1]
+    assert noise.shape == (4, 1024) and part.shape == (256, 3) and gt.shape == (1024, 3)
+    assert torch.allclose(noise[:3].norm(dim=0), torch.ones(1024), atol=1e-5) and set(noise[3].unique().tolist()) <= {0.0, 1.0}

@@ -51,3 +51,39 @@ def test_segmenter_trains_from_a_yaml_config_and_round_trips_its_checkpoint(tmp_
     H.restore_exp_fix([fresh], [ckpt], device=torch.device("cuda", 0), verbose=False)
     state = torch.load(ckpt)
     assert list(state) == list(fresh.state_dict())
+
+
+COMPLETION = '''
+experiment:
+    root: '{root}/exp'
+    writer_root: '{root}/runs'
+data:
+    batch_size: 2
+    num_workers: 0
+    num_points: 1024
+model:
+    generator: '{root}/inpainter.py'
+train:
+    num_epochs: 1
+    chamfer_weight: !!float 1.0
+    scale_lr: !!float 1e-2
+    optimizer:
+        type: 'Adam'
+        lr: !!float 1e-4
+        betas: [!!float 0.9, !!float 0.999]
+        weight_decay: !!float 0.0
+'''
+
+
+def test_completion_task_steps_the_inpainter_with_emd_and_chamfer(tmp_path):
+    """train_inpainter.py's step (186-195): EMD (auction, 50 iterations) + Chamfer loss through the AdaIN decoder; the
+    residual scales of the AdaIN blocks get their own learning rate (`train.scale_lr`)."""
+    from cloud_transformers_amd import harness as H
+    (tmp_path / "inpainter.py").write_text("from tests.test_zoo_gpu import Inpainter as Model\n")
+    cfg_path = tmp_path / "inpainting.yaml"
+    cfg_path.write_text(COMPLETION.format(root=str(tmp_path)))
+    torch.manual_seed(0)
+    tr = H.Trainer(H.load_config(cfg_path), "completion", n_classes=256, device=torch.device("cuda", 0), dataset_length=4)
+    assert len(tr.optimizer.param_groups) == 2 and len(tr.optimizer.param_groups[1]["params"]) > 0
+    hist = tr.fit(max_iters=2)
+    assert len(hist) == 2 and all(v == v and 0.0 < v < 10.0 for v in hist)
