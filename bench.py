@@ -181,6 +181,8 @@ def init_rank():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible to this rank" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -384,10 +386,12 @@ def main():
     args = parse()
     from cloud_transformers_amd import launch
     if args.gpus > 1 and not launch.under_launcher():
-        # parent: start one rank per GPU before anything here touches the GPU, return their exit code
-        import torch
-        have = torch.cuda.device_count()               # (does not initialise HIP)
-        if have < args.gpus:
+        # parent: start one rank per GPU before anything here touches the GPU, return their exit code.  The library is
+        # built HERE, once (compile only, no GPU call): N ranks finding it missing would all run hipcc at the same time.
+        from cloud_transformers_amd import _lib
+        _lib.build()
+        have = launch.visible_gpus()                   # KFD topology + *_VISIBLE_DEVICES: no HIP runtime in the parent
+        if have is not None and have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
         raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

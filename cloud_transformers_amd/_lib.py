@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("CLOUDCT_LIB") or os.path.join(LIB_DIR, "libcloudct.so")   # override: A/B builds
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-HIP_SOURCES = ["ct_raster.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip",
+HIP_SOURCES = ["ct_raster.hip", "ct_mhct.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip",
                "ct_adain.hip", "ct_bnorm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # index/weight math must round exactly like the reference's fp32 op sequence
@@ -53,16 +53,33 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into lib/libcloudct.so (cross-compiles without a GPU)."""
+    """Compile every HIP source into lib/libcloudct.so (cross-compiles without a GPU).
+
+    Safe when several processes call it at once (the ranks `launch.spawn_ranks` / torchrun start on a fresh checkout):
+    the compile runs under an exclusive file lock into a per-process temporary name, staleness is re-checked under the
+    lock (a rank that waited finds the library its sibling built), and the finished file is renamed into place."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE] + srcs + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH
+            srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+            tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+            cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE] + srcs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -115,6 +132,13 @@ SIGNATURES = {
     "ct_gconv_supported": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_gconv_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_gconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_mhct_core_supported": (_i, [_i, _i, _i, _i, _i, _ip]),
+    "ct_mhct_core_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
+    "ct_mhct_core_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_mhct_core_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
+    "ct_mhct_core_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_debug_set_core": (None, [ctypes.c_uint]),
+    "ct_mhct_core_status": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _ip, ctypes.POINTER(ctypes.c_int), _vp]),
     "ct_chamfer_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ct_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ct_emd_workspace_bytes": (_sz, [_i, _i]),

@@ -332,7 +332,11 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
                 g2 = fmaxf(fminf(gb, ob), fmaxf(g2, o2));
                 gb = fmaxf(gb, ob);
               }
-              cthr = 3.0f - g2 + 1e-5f;
+              // safety margin of the filter: a candidate whose exact value reaches g2 must survive the float test.  The
+              // roundings of 3 - g2, of + margin, of - price and of tt^2 add up to < 1.6e-5 while |g2| <= 32 (values of
+              // interest then have |price| <= 37: ulp(64) = 7.6e-6); beyond that (large eps, late iterations: prices in
+              // the hundreds) an absolute margin sinks below one ulp, so the filter is switched off (cthr = inf keeps all)
+              cthr = fabsf(g2) <= 32.0f ? 3.0f - g2 + 4e-5f : __builtin_inff();
             }
           }
         }

@@ -1,0 +1,630 @@
+// Plane-resident MHCT core: positions -> Splat(max, zero floor) -> grouped 3^d convolution (+bias)
+// -> Slice of one (batch, head) plane in ONE kernel; the rasterised grid z and the convolved grid y live in LDS only
+// (reference op sequence: layers/multihead_ct.py:99-107 = DifferentiablePositions -> Splat -> conv -> Slice,
+//  layers/cloud_transform.py:72-227).  Built for the three grids of the zoo / headline whose two tiles fit one CU's
+// 160 KiB beside the filter bank: 2D 32^2 C16 (147 KiB), 2D 16^2 C16 (48 KiB), 3D 8^3 C32 (150 KiB).
+//
+// Phases of a workgroup (1024 threads):
+//   A  scatter-max of its share of the plane's points into the z tile (ds_max_u32 on the bit patterns of the
+//      positive products: positive IEEE floats order like unsigned integers, and only positive products beat the
+//      zero floor).  The tile is laid out as the convolution's zero-padded input: [C][halo rows][W], channel stride
+//      == 16 mod 32 floats (conflict-free B-operand reads of the matrix instruction).
+//   X  (clusters only) a plane handled by S workgroups: every workgroup publishes its partial tile through the
+//      workspace, arrives on the plane's counter and merges the partners' tiles (element-wise max) — agent-scope
+//      release / acquire as MI355X_MICROARCH.md "Valid forms" prescribes; partners sit on one XCD (block index
+//      congruent mod 8), which is a speed matter only.  Few planes (the zoo's B8 x H16 = 128, the decoders' 32) would
+//      otherwise leave half or seven eighths of the chip idle.
+//   B  per block of 16 output channels: implicit-GEMM convolution on the matrix cores (v_mfma_f32_16x16x4_f32, exact
+//      fp32: the quad formulation of gconv_fwd4_kernel, ct_gconv.hip), filter bank streamed through LDS one window
+//      row ahead; the result is written to the channel-interleaved gather tile [4][cell] x float4;
+//   C  gather (ds_read_b128 per point, corner and 4 channels) for the workgroup's share of the points -> out.
+// Optional side outputs: z and y as tensors (training: the backward passes read them), the occupancy count
+// |z| > 1e-9 (layers/multihead_ct.py:104-105).
+#include "ct_common.h"
+#include <atomic>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCoreThreads = 1024;
+constexpr int kCoreSlack = 4;                  // floats in front of the z tile: the left neighbour of its first element
+constexpr int kSpinLimit = 1 << 22;            // polls of ~0.5 us before a workgroup gives up on its partners
+
+struct CoreArgs {
+  const float* keys;     // (B, H*DIM, N)   the lattice (post-tanh keys)
+  const float* feat;     // (B, H*C, N)
+  const void* pad;       // (B, N) | null
+  int pad_dtype;
+  const float* w;        // (H*C, C, 3^DIM)
+  const float* bias;     // (H*C) | null
+  float* out;            // (B, H*C, N)
+  float* z_save;         // (B, H*C, G) | null
+  float* y_save;         // (B, H*C, G) | null
+  long long* occ;        // [1] | null
+  float* xch;            // [planes][S][C*G]   partial tiles of a cluster
+  unsigned* flags;       // [planes] arrival counters, then {occ sum (2 words), done counter}: zeroed before the launch
+  int* status;           // [1] set to 1 when a cluster gave up waiting (never in a correct run)
+  int B, H, N;
+  int S, SC, SN;         // workgroups per plane = SC (blocks of output channels) x SN (point ranges)
+  int planes, xcd_map;
+};
+
+template <int DIM, int WT, int C>
+struct CoreGeom {
+  static constexpr int V = 1 << DIM;
+  static constexpr int G = DIM == 2 ? WT * WT : WT * WT * WT;
+  static constexpr int HS = WT + 2;                                    // halo'd extent of every axis but the fastest
+  static constexpr int PLANE0 = DIM == 2 ? HS * WT : HS * HS * WT;
+  static constexpr int PLANE = PLANE0 + ((48 - (PLANE0 % 32)) % 32);   // == 16 (mod 32)
+  static constexpr int NR = DIM == 2 ? 3 : 9;                          // window rows (every tap axis but the fastest)
+  static constexpr int TAPS = NR * 3;
+  static constexpr int KB = C / 4;
+  static constexpr int NRB = DIM == 2 ? 3 : 1;                         // window rows per staged slice of the bank
+  static constexpr int NST = NR / NRB;
+  static constexpr int SLICE = NRB * KB * 256;                         // floats: [NRB][KB][4 k][16 co][4 dx]
+  static constexpr int NBUF = NST > 1 ? 2 : 1;
+  static constexpr int NLD = (SLICE + kCoreThreads - 1) / kCoreThreads;
+  static constexpr int Z_FLOATS = kCoreSlack + C * PLANE + 4;
+  static constexpr size_t LDS_BYTES = (size_t)(Z_FLOATS + 16 * G + NBUF * SLICE) * 4;
+  static_assert(PLANE % 32 == 16 && PLANE >= PLANE0, "channel stride");
+  static_assert(C % 16 == 0 && WT % 4 == 0, "16-row blocks, quads");
+};
+
+// halo-layout address of compact cell index `cell` (x slowest)
+template <int DIM, int WT>
+__device__ __forceinline__ int halo_of(int cell) {
+  if constexpr (DIM == 2) {
+    return cell + WT;                                      // one halo row in front, rows keep their width
+  } else {
+    const int z = cell % WT, y = (cell / WT) % WT, x = cell / (WT * WT);
+    return ((x + 1) * (WT + 2) + (y + 1)) * WT + z;
+  }
+}
+
+template <int DIM>
+struct CorePt {
+  float cw[1 << DIM];
+  int hb, cb;             // base cell in the halo layout / compact
+};
+
+// corner weights and base cell of one point: the op sequence of ct_axis / ct_corners (ct_common.h), which follow
+// layers/cloud_transform.py:91-99 and layers/utils.py:100-186 rounding for rounding
+template <int DIM, int WT>
+__device__ __forceinline__ void core_pt(const float (&k)[DIM], CorePt<DIM>& p) {
+  constexpr float hw = (float)(WT - 1) * 0.5f;
+  float w0[DIM], w1[DIM];
+  int f[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) ct_axis(k[j], hw, WT, w0[j], w1[j], f[j]);
+  if constexpr (DIM == 2) {
+    p.cb = f[0] * WT + f[1];
+    p.hb = p.cb + WT;
+    p.cw[0] = w0[0] * w0[1];
+    p.cw[1] = w1[0] * w0[1];
+    p.cw[2] = w0[0] * w1[1];
+    p.cw[3] = w1[0] * w1[1];
+  } else {
+    p.cb = (f[0] * WT + f[1]) * WT + f[2];
+    p.hb = ((f[0] + 1) * (WT + 2) + (f[1] + 1)) * WT + f[2];
+    const float xy00 = w0[0] * w0[1], xy10 = w1[0] * w0[1], xy01 = w0[0] * w1[1], xy11 = w1[0] * w1[1];
+    p.cw[0] = xy00 * w0[2]; p.cw[1] = xy10 * w0[2]; p.cw[2] = xy01 * w0[2]; p.cw[3] = xy11 * w0[2];
+    p.cw[4] = xy00 * w1[2]; p.cw[5] = xy10 * w1[2]; p.cw[6] = xy01 * w1[2]; p.cw[7] = xy11 * w1[2];
+  }
+}
+
+// corner v = dx + 2 dy (+ 4 dz): offsets relative to the base cell, halo layout and compact
+template <int DIM, int WT>
+__device__ __forceinline__ constexpr int off_halo(int v) {
+  return DIM == 2 ? (v & 1) * WT + (v >> 1) : (v & 1) * (WT + 2) * WT + ((v >> 1) & 1) * WT + (v >> 2);
+}
+template <int DIM, int WT>
+__device__ __forceinline__ constexpr int off_compact(int v) {
+  return DIM == 2 ? (v & 1) * WT + (v >> 1) : (v & 1) * WT * WT + ((v >> 1) & 1) * WT + (v >> 2);
+}
+
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// slice `st` of the filter bank of output channels co0..co0+15 of head h:
+//   ws[((rl*KB + kb)*4 + k)*64 + m*4 + dx] = W[co0 + m][ci = kb*4 + k][tap = (st*NRB + rl)*3 + dx]     (dx == 3: 0)
+template <int DIM, int WT, int C>
+__device__ __forceinline__ void load_wslice(const float* wh, int co0, int st, float (&r)[CoreGeom<DIM, WT, C>::NLD]) {
+  using Gm = CoreGeom<DIM, WT, C>;
+#pragma unroll
+  for (int u = 0; u < Gm::NLD; ++u) {
+    const int i = (int)threadIdx.x + u * kCoreThreads;
+    const int dx = i & 3, m = (i >> 2) & 15, k = (i >> 6) & 3, rk = i >> 8;
+    const int kb = rk % Gm::KB, rl = rk / Gm::KB;
+    const int tap = (st * Gm::NRB + rl) * 3 + dx;
+    r[u] = (i < Gm::SLICE && dx < 3) ? wh[((size_t)(co0 + m) * C + kb * 4 + k) * Gm::TAPS + tap] : 0.0f;
+  }
+}
+template <int DIM, int WT, int C>
+__device__ __forceinline__ void store_wslice(float* ws, const float (&r)[CoreGeom<DIM, WT, C>::NLD]) {
+  using Gm = CoreGeom<DIM, WT, C>;
+#pragma unroll
+  for (int u = 0; u < Gm::NLD; ++u) {
+    const int i = (int)threadIdx.x + u * kCoreThreads;
+    if (i < Gm::SLICE) ws[i] = r[u];
+  }
+}
+
+// grid = (planes * S)
+template <int DIM, int WT, int C, bool HAS_PAD>
+__global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a) {
+  using Gm = CoreGeom<DIM, WT, C>;
+  constexpr int V = Gm::V, G = Gm::G, PLANE = Gm::PLANE, HS = Gm::HS, KB = Gm::KB;
+  constexpr int CG = DIM == 2 ? 4 : 2;           // channel rows requested together in the scatter
+  extern __shared__ __align__(16) float lds[];
+  __shared__ int s_flag[2];                      // [0] abort, [1] occupancy partial
+  float* const Zf = lds + kCoreSlack;
+  unsigned* const Zu = (unsigned*)Zf;
+  float4* const Y4 = (float4*)(lds + Gm::Z_FLOATS);
+  float* const WS = lds + Gm::Z_FLOATS + 16 * G;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, N = a.N;
+  int plane, s;
+  {
+    const int i = blockIdx.x;
+    if (a.xcd_map) {                             // the S workgroups of a plane share i % 8: one XCD (speed only)
+      const int x = i & 7, j = i >> 3;
+      plane = (j / S) * 8 + x;
+      s = j % S;
+    } else {
+      plane = i / S;
+      s = i % S;
+    }
+  }
+  const int b = plane / a.H, h = plane - b * a.H;
+  const size_t bh = (size_t)plane;
+  const int sc = s / a.SN, sn = s - sc * a.SN;
+
+  // ---- zero the z tile (halo included)
+  for (int t = tid; t < (Gm::Z_FLOATS >> 2); t += kCoreThreads) ((float4*)lds)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 2) s_flag[tid] = 0;
+  __syncthreads();
+
+  // ---- A: scatter-max of this workgroup's point range
+  const int nq = N >> 2;
+  {
+    const int per = (nq + S - 1) / S;
+    const int q0 = s * per, q1 = min(nq, q0 + per);
+    const float* src = a.feat + bh * C * (size_t)N;
+    for (int q = q0 + tid; q < q1; q += kCoreThreads) {
+      const int n0 = q << 2;
+      float cw[4][V];
+      int hb[4];
+      {
+        float kk[DIM][4];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          const float4 t = *(const float4*)(a.keys + (bh * DIM + j) * N + n0);
+          kk[j][0] = t.x; kk[j][1] = t.y; kk[j][2] = t.z; kk[j][3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float k1[DIM];
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) k1[j] = kk[j][i];
+          CorePt<DIM> p;
+          core_pt<DIM, WT>(k1, p);
+          hb[i] = p.hb;
+#pragma unroll
+          for (int v = 0; v < V; ++v) cw[i][v] = p.cw[v];
+        }
+      }
+      float pv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+      for (int cg0 = 0; cg0 < C; cg0 += CG) {
+        float fv[CG][4];
+#pragma unroll
+        for (int cj = 0; cj < CG; ++cj) {
+          const float4 t = *(const float4*)(src + (size_t)(cg0 + cj) * N + n0);
+          fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+        }
+#pragma unroll
+        for (int cj = 0; cj < CG; ++cj) {
+          unsigned* Tc = Zu + (size_t)(cg0 + cj) * PLANE;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float f = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const float prod = f * cw[i][v];
+              if (prod > 0.0f) atomicMax(Tc + hb[i] + off_halo<DIM, WT>(v), __float_as_uint(prod));
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- X: merge the partial tiles of the plane's workgroups
+  if (S > 1) {
+    float* mine = a.xch + ((size_t)plane * S + s) * (size_t)(C * G);
+    for (int t = tid; t < (C * G) >> 2; t += kCoreThreads) {
+      const int c = t / (G >> 2), cell = (t - c * (G >> 2)) << 2;
+      *(float4*)(mine + (size_t)c * G + cell) = *(const float4*)(Zf + (size_t)c * PLANE + halo_of<DIM, WT>(cell));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(a.flags + plane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int it = 0;
+      bool ok = true;
+      while (__hip_atomic_load(a.flags + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++it > kSpinLimit) {
+          ok = false;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!ok) {
+        s_flag[0] = 1;
+        atomicExch(a.status, 1);
+      }
+    }
+    __syncthreads();
+    if (s_flag[0]) return;                       // block-uniform
+    for (int o = 1; o < S; ++o) {
+      const int so = (s + o) % S;
+      const float* other = a.xch + ((size_t)plane * S + so) * (size_t)(C * G);
+      for (int t = tid; t < (C * G) >> 2; t += kCoreThreads) {
+        const int c = t / (G >> 2), cell = (t - c * (G >> 2)) << 2;
+        const float4 v = *(const float4*)(other + (size_t)c * G + cell);
+        float4* zp = (float4*)(Zf + (size_t)c * PLANE + halo_of<DIM, WT>(cell));
+        const float4 m = *zp;                    // all values are >= 0: float max == the scatter's unsigned max
+        *zp = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- side outputs of the merged tile: z (training) and the occupancy count; workgroup s takes C/S channels
+  if (a.z_save != nullptr || a.occ != nullptr) {
+    const int cper = C / S, c_lo = s * cper;
+    int cnt = 0;
+    for (int t = tid; t < (cper * G) >> 2; t += kCoreThreads) {
+      const int cl = t / (G >> 2), cell = (t - cl * (G >> 2)) << 2;
+      const int c = c_lo + cl;
+      const float4 v = *(const float4*)(Zf + (size_t)c * PLANE + halo_of<DIM, WT>(cell));
+      cnt += (int)(v.x > 1e-9f) + (int)(v.y > 1e-9f) + (int)(v.z > 1e-9f) + (int)(v.w > 1e-9f);   // z >= 0
+      if (a.z_save != nullptr) *(float4*)(a.z_save + (bh * C + c) * (size_t)G + cell) = v;
+    }
+    if (a.occ != nullptr) {
+      cnt = wave_sum_int(cnt);
+      if (lane == 0 && cnt) atomicAdd(&s_flag[1], cnt);
+      __syncthreads();
+      if (tid == 0) {
+        // sum over all workgroups, written by the last one to arrive (device-scope atomics at the memory side)
+        unsigned long long* acc = (unsigned long long*)(a.flags + ((a.planes + 1) & ~1));
+        unsigned* done = a.flags + ((a.planes + 1) & ~1) + 2;
+        (void)__hip_atomic_fetch_add(acc, (unsigned long long)s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(a.planes * S) - 1u)
+          *a.occ = (long long)__hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+
+  // ---- B + C per block of 16 output channels
+  const int nmt = (C / 16) / a.SC;
+  const int col = lane & 15, kq = lane >> 4;
+  constexpr int wq = WT >> 2;
+  constexpr int nspans = G >> 6;                 // spans of 16 quads = 64 cells
+  const float* wh = a.w + (size_t)h * C * C * Gm::TAPS;
+  for (int mi = 0; mi < nmt; ++mi) {
+    const int co0 = (sc * nmt + mi) * 16;
+    float wr[Gm::NLD];
+    load_wslice<DIM, WT, C>(wh, co0, 0, wr);
+    __syncthreads();                             // previous block: gathers done with Y4, bank consumed
+    store_wslice<DIM, WT, C>(WS, wr);
+    __syncthreads();
+    // span of this wave (waves beyond the spans only help staging)
+    const bool has_item = wave < nspans;
+    const int q = (has_item ? wave : 0) * 16 + col;
+    int off;
+    bool bl, br;
+    {
+      const int xq = q % wq;
+      const int x0 = xq * 4;
+      bl = x0 == 0;
+      br = x0 + 4 == WT;
+      if constexpr (DIM == 2) {
+        off = (q / wq) * WT + x0;
+      } else {
+        const int y = (q / wq) % WT, z = q / (wq * WT);
+        off = (z * HS + y) * WT + x0;
+      }
+    }
+    floatx4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float bv = a.bias != nullptr ? a.bias[(size_t)h * C + co0 + kq * 4 + r] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j][r] = bv;
+    }
+    for (int st = 0; st < Gm::NST; ++st) {
+      if (st + 1 < Gm::NST) load_wslice<DIM, WT, C>(wh, co0, st + 1, wr);
+      const float* ws = WS + (size_t)(st & (Gm::NBUF - 1)) * Gm::SLICE;
+      if (has_item) {
+#pragma unroll
+        for (int rl = 0; rl < Gm::NRB; ++rl) {
+          const int r = st * Gm::NRB + rl;
+          const int roff = DIM == 2 ? r * WT : ((r / 3) * HS + (r % 3)) * WT;
+#pragma unroll 2
+          for (int kb = 0; kb < KB; ++kb) {
+            const float4 a4 = *(const float4*)__builtin_assume_aligned(ws + ((size_t)(rl * KB + kb) * 4 + kq) * 64 + col * 4, 16);
+            const float* rp = Zf + (size_t)(kb * 4 + kq) * PLANE + off + roff;
+            const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+            const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+            const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+            const float av[3] = {a4.x, a4.y, a4.z};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dx], v[j + dx], acc[j], 0, 0, 0);
+          }
+        }
+      }
+      if (st + 1 < Gm::NST) {
+        store_wslice<DIM, WT, C>(WS + (size_t)((st + 1) & (Gm::NBUF - 1)) * Gm::SLICE, wr);
+        __syncthreads();
+      }
+    }
+    if (has_item) {
+      // D_j: row (output channel) = kq*4 + r, column = quad col, element j  ->  Y4[kq][cell] = 4 channels of a cell
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Y4[(size_t)kq * G + q * 4 + j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      if (a.y_save != nullptr && sn == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *(float4*)(a.y_save + (bh * C + co0 + kq * 4 + r) * (size_t)G + q * 4) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      }
+    }
+    __syncthreads();
+
+    // ---- C: gather this block's 16 channels for the workgroup's point range
+    {
+      const int per = (nq + a.SN - 1) / a.SN;
+      const int q0 = sn * per, q1 = min(nq, q0 + per);
+      float* dst = a.out + (bh * C + co0) * (size_t)N;
+      for (int qd = q0 + tid; qd < q1; qd += kCoreThreads) {
+        const int n0 = qd << 2;
+        float kk[DIM][4];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          const float4 t = *(const float4*)(a.keys + (bh * DIM + j) * N + n0);
+          kk[j][0] = t.x; kk[j][1] = t.y; kk[j][2] = t.z; kk[j][3] = t.w;
+        }
+        float pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+#pragma unroll 1
+        for (int cq = 0; cq < 4; ++cq) {
+          const float4* Tq = Y4 + (size_t)cq * G;
+          float o[4][4];      // [channel][point]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float k1[DIM];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) k1[j] = kk[j][i];
+            CorePt<DIM> p;
+            core_pt<DIM, WT>(k1, p);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int hv = 0; hv < V / 4; ++hv) {
+              float4 cv[4];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) cv[v] = Tq[p.cb + off_compact<DIM, WT>(hv * 4 + v)];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float w = p.cw[hv * 4 + v];
+                // the reference's sum over corners in corner order (the first product initialises the sum)
+                if (hv == 0 && v == 0) { s0 = cv[0].x * w; s1 = cv[0].y * w; s2 = cv[0].z * w; s3 = cv[0].w * w; }
+                else { s0 += cv[v].x * w; s1 += cv[v].y * w; s2 += cv[v].z * w; s3 += cv[v].w * w; }
+              }
+            }
+            o[0][i] = HAS_PAD ? s0 * pv[i] : s0;
+            o[1][i] = HAS_PAD ? s1 * pv[i] : s1;
+            o[2][i] = HAS_PAD ? s2 * pv[i] : s2;
+            o[3][i] = HAS_PAD ? s3 * pv[i] : s3;
+            asm volatile("" : "+v"(o[0][i]), "+v"(o[1][i]), "+v"(o[2][i]), "+v"(o[3][i]));
+          }
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj)
+            st_stream4(dst + (size_t)(cq * 4 + cj) * N + n0, make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct CoreShape {
+  int dim, W, C;
+};
+constexpr CoreShape kCoreShapes[] = {{2, 32, 16}, {2, 16, 16}, {3, 8, 32}};
+
+int core_shape_index(int C, int dim, const int* W) {
+  if (!W) return -1;
+  for (int j = 1; j < dim; ++j)
+    if (W[j] != W[0]) return -1;
+  for (int i = 0; i < (int)(sizeof(kCoreShapes) / sizeof(kCoreShapes[0])); ++i)
+    if (kCoreShapes[i].dim == dim && kCoreShapes[i].W == W[0] && kCoreShapes[i].C == C) return i;
+  return -1;
+}
+
+int device_cus() {
+  static int cus = 0;          // immutable device property, cached
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+std::atomic<unsigned> g_core_flags{0};     // test hook (ct_debug_set_core): bit 0 = no clusters, bits 8.. = forced cluster size
+
+// workgroups per plane: enough to cover the chip once, S | N/4 ranges, C % S == 0, at most 8
+void core_split(int planes, int C, int N, int& S, int& SC, int& SN) {
+  S = 1;
+  const unsigned dbg = g_core_flags.load(std::memory_order_relaxed);
+  if ((dbg & 1u) == 0) {
+    const int cus = device_cus();
+    while (S < 8 && planes * S * 2 <= cus && C % (S * 2) == 0 && (N >> 2) >= S * 2 * 64) S *= 2;
+  }
+  const unsigned forced = dbg >> 8;
+  if (forced >= 1 && forced <= 8 && C % forced == 0 && (forced & (forced - 1)) == 0) S = (int)forced;
+  SC = (C / 16) < S ? (C / 16) : S;
+  SN = S / SC;
+}
+
+size_t core_ws_layout(int planes, int S, int C, int G, size_t& flags_off, size_t& status_off) {
+  size_t xch = S > 1 ? (size_t)planes * S * C * G * 4 : 0;
+  flags_off = (xch + 255) & ~(size_t)255;
+  status_off = flags_off + ((size_t)((planes + 1) & ~1) + 4) * 4;      // counters, pad, {occupancy sum (2 words), done, spare}
+  return status_off + 16;
+}
+
+template <int DIM, int WT, int C>
+int launch_core(CoreArgs a, hipStream_t st) {
+  using Gm = CoreGeom<DIM, WT, C>;
+  const dim3 grid(a.planes * a.S);
+  if (a.pad_dtype != CT_PAD_NONE) {
+    auto k = mhct_core_fwd_kernel<DIM, WT, C, true>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS_BYTES) != hipSuccess) return CT_ELAUNCH;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(k, grid, dim3(kCoreThreads), Gm::LDS_BYTES, st, a);
+  } else {
+    auto k = mhct_core_fwd_kernel<DIM, WT, C, false>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS_BYTES) != hipSuccess) return CT_ELAUNCH;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(k, grid, dim3(kCoreThreads), Gm::LDS_BYTES, st, a);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ct_debug_set_core(unsigned flags) { g_core_flags = flags; }
+
+int ct_mhct_core_supported(int B, int H, int C, int N, int dim, const int* W) {
+  if (B <= 0 || H <= 0 || N <= 0 || (N & 3) != 0 || (dim != 2 && dim != 3)) return 0;
+  return core_shape_index(C, dim, W) >= 0 ? 1 : 0;
+}
+
+size_t ct_mhct_core_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
+  if (!ct_mhct_core_supported(B, H, C, N, dim, W)) return 0;
+  int S, SC, SN;
+  core_split(B * H, C, N, S, SC, SN);
+  int G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  size_t fo, so;
+  return core_ws_layout(B * H, S, C, G, fo, so);
+}
+
+int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                     const float* conv_b, float* out, float* z_save, float* y_save, int64_t* occ_count, void* workspace,
+                     size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys || !feat || !conv_w || !out || !ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
+  if (pad_dtype != CT_PAD_NONE && !pad) return CT_EINVAL;
+  if (((((uintptr_t)keys) | ((uintptr_t)feat) | ((uintptr_t)out) | ((uintptr_t)z_save) | ((uintptr_t)y_save)) & 15) != 0) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  CoreArgs a;
+  a.keys = keys; a.feat = feat; a.pad = pad; a.pad_dtype = pad_dtype; a.w = conv_w; a.bias = conv_b;
+  a.out = out; a.z_save = z_save; a.y_save = y_save; a.occ = (long long*)occ_count;
+  a.B = B; a.H = H; a.N = N; a.planes = B * H;
+  core_split(a.planes, C, N, a.S, a.SC, a.SN);
+  a.xcd_map = (a.planes % 8 == 0) ? 1 : 0;
+  int G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  size_t fo, so;
+  const size_t need = core_ws_layout(a.planes, a.S, C, G, fo, so);
+  if (!workspace || workspace_bytes < need) return CT_EWORKSPACE;
+  a.xch = (float*)workspace;
+  a.flags = (unsigned*)((char*)workspace + fo);
+  a.status = (int*)((char*)workspace + so);
+  if (a.S > 1 || occ_count) {
+    if (hipMemsetAsync(a.flags, 0, so + 16 - fo, st) != hipSuccess) return CT_ELAUNCH;
+  }
+  const int idx = core_shape_index(C, dim, W);
+  if (idx == 0) return launch_core<2, 32, 16>(a, st);
+  if (idx == 1) return launch_core<2, 16, 16>(a, st);
+  return launch_core<3, 8, 32>(a, st);
+}
+
+size_t ct_mhct_core_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
+  if (!ct_mhct_core_supported(B, H, C, N, dim, W)) return 0;
+  size_t G = 1;
+  for (int j = 0; j < dim; ++j) G *= (size_t)W[j];
+  const size_t grid_bytes = ((size_t)B * H * C * G * 4 + 255) & ~(size_t)255;
+  size_t sub = ct_slice_bwd_workspace_bytes(B, H, C, N, dim, W);
+  const size_t wg = ct_gconv_bwd_weight_workspace_bytes(B, H, C, C, dim, W);
+  const size_t sp = ct_splat_bwd_ex_workspace_bytes(B, H, C, N, dim, W, CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS);
+  if (wg > sub) sub = wg;
+  if (sp > sub) sub = sp;                    // the three passes run one after the other: they share the scratch
+  return 2 * grid_bytes + sub;
+}
+
+int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                     const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
+                     float* g_b, void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim,
+                     const int* W, ct_stream_t s) {
+  if (!keys || !feat || !conv_w || !z || !y || !g_out || !g_feat || !g_keys || !g_w) return CT_EINVAL;
+  if (!ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
+  const size_t need = ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, W);
+  if (!workspace || workspace_bytes < need) return CT_EWORKSPACE;
+  size_t G = 1;
+  for (int j = 0; j < dim; ++j) G *= (size_t)W[j];
+  const size_t grid_bytes = ((size_t)B * H * C * G * 4 + 255) & ~(size_t)255;
+  float* g_y = (float*)workspace;
+  float* g_z = (float*)((char*)workspace + grid_bytes);
+  void* sub = (char*)workspace + 2 * grid_bytes;
+  const size_t sub_bytes = workspace_bytes - 2 * grid_bytes;
+  int rc = ct_slice_bwd_ws(keys, y, pad, pad_dtype, g_out, g_y, g_keys, sub, sub_bytes, B, H, C, N, dim, W, s);
+  if (rc != CT_OK) return rc;
+  rc = ct_gconv_bwd_data(g_y, conv_w, g_z, B, H, C, C, dim, W, s);
+  if (rc != CT_OK) return rc;
+  rc = ct_gconv_bwd_weight(z, g_y, g_w, g_b, sub, sub_bytes, B, H, C, C, dim, W, s);
+  if (rc != CT_OK) return rc;
+  return ct_splat_bwd_ex(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys, sub, sub_bytes, B, H, C, N, dim, W,
+                         CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS, s);
+}
+
+/* 0 = no cluster of the last launches on this workspace gave up waiting for its partners */
+int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
+                        int* host_status, ct_stream_t s) {
+  if (!workspace || !host_status || !ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
+  int S, SC, SN;
+  core_split(B * H, C, N, S, SC, SN);
+  int G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  size_t fo, so;
+  if (workspace_bytes < core_ws_layout(B * H, S, C, G, fo, so)) return CT_EWORKSPACE;
+  if (hipMemcpyAsync(host_status, (const char*)workspace + so, 4, hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess) return CT_ELAUNCH;
+  if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return CT_ELAUNCH;
+  return CT_OK;
+}
+
+}  // extern "C"

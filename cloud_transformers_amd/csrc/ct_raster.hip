@@ -15,6 +15,7 @@
 // and layers/utils.py:100-186 of the reference).
 #include "ct_common.h"
 #include <string.h>
+#include <atomic>
 
 #ifndef CT_QUAD_THREADS
 #define CT_QUAD_THREADS 512
@@ -1219,11 +1220,13 @@ __global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
 
 // ---------------------------------------------------------------------------
 // test hooks: which kernel family an entry point picked, and a switch that keeps the hot-shape kernels off
-// (process-wide host state — autograd runs backward on its own thread; never read by the kernels; the tag buffer
-//  is not synchronised: it is for single-stream tests)
+// (host state, never read by the kernels).  The flags are process-wide — a test sets them on the main thread and the
+// backward passes read them on autograd's thread — hence atomic; the tag buffer is PER THREAD: an entry point's tags
+// are read back by the thread that called it, and concurrent callers (forward on the main thread, backward on
+// autograd's, multi-stream users) never write the same buffer.
 // ---------------------------------------------------------------------------
-unsigned t_dbg_flags = 0;
-char t_last[256] = "";
+std::atomic<unsigned> t_dbg_flags{0};
+thread_local char t_last[256] = "";
 
 void note_reset() { t_last[0] = 0; }
 void note(const char* tag) {
@@ -1232,7 +1235,7 @@ void note(const char* tag) {
   if (n) t_last[n++] = '+';
   memcpy(t_last + n, tag, m + 1);
 }
-inline bool hot_enabled() { return (t_dbg_flags & CT_DEBUG_NO_HOT) == 0; }
+inline bool hot_enabled() { return (t_dbg_flags.load(std::memory_order_relaxed) & CT_DEBUG_NO_HOT) == 0; }
 
 // ---------------------------------------------------------------------------
 // host-side planning

@@ -22,6 +22,28 @@ def free_port():
     return port
 
 
+def visible_gpus(env=None, topology="/sys/class/kfd/kfd/topology/nodes"):
+    """Number of GPUs this process may use, counted WITHOUT the HIP runtime (torch.cuda.device_count() may fall back to
+    hipGetDeviceCount, which initialises HIP in the parent that is meant to stay GPU-free): KFD topology nodes that have
+    SIMDs, narrowed by the first of HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES that is set.
+    None when the topology cannot be read (the ranks then check LOCAL_RANK against their own device count)."""
+    env = os.environ if env is None else env
+    try:
+        n = 0
+        for node in os.listdir(topology):
+            with open(os.path.join(topology, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+    except (OSError, ValueError, IndexError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        if env.get(var, "") != "":
+            n = min(n, len([x for x in env[var].split(",") if x.strip() != ""]))
+            break
+    return n
+
+
 def under_launcher(env=None):
     """True when this process already is one rank of a job (torch.distributed.run or spawn_ranks started it)."""
     env = os.environ if env is None else env

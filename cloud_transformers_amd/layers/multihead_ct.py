@@ -117,7 +117,8 @@ class _MHCTCore(nn.Module):
         where they lie when both norms qualify, the modules on split views otherwise (eval mode, ...)."""
         Ck = self.heads * 3
         Cv = key_values.size(1) - Ck
-        if ops.bn_relu_eligible(self.key_bn, key_values, Ck) and ops.bn_relu_eligible(self.values_bn, key_values, Cv):
+        if (ops.bn_relu_eligible(self.key_bn, key_values, Ck) and ops.bn_relu_eligible(self.values_bn, key_values, Cv)
+                and ops.norms_share_group([self.key_bn, self.values_bn])):
             return ops.split_bn(key_values, self.key_bn, self.values_bn)
         k_part, v_part = torch.split(key_values, [Ck, Cv], dim=1)   # backward: one cat
         return self.key_bn(k_part), self.values_bn(v_part)
@@ -299,8 +300,8 @@ class MultiHeadUnion(_UnionBase):
             stats.append(s)
         # the heads' BatchNorm + ReLU write straight into their channel ranges of the concatenation when they qualify
         norms = [a.after for a in self.attentions]
-        if len(pres) > 1 and all(len(n) == 2 and type(n[1]) is nn.ReLU and ops.bn_relu_eligible(n[0], p)
-                                 for n, p in zip(norms, pres)):
+        if (len(pres) > 1 and all(len(n) == 2 and type(n[1]) is nn.ReLU and ops.bn_relu_eligible(n[0], p)
+                                  for n, p in zip(norms, pres)) and ops.norms_share_group([n[0] for n in norms])):
             joined = ops.join_bn_relu(pres, [n[0] for n in norms])
         else:
             joined = torch.cat([run_after(n, p) for n, p in zip(norms, pres)], dim=1)

@@ -580,6 +580,14 @@ def _sync_group(bn):
     return pg if dist.get_world_size(pg) > 1 else None
 
 
+def norms_share_group(bns):
+    """True when the norms of a fused group are of ONE type and exchange their statistics over ONE process group: the
+    group kernels take both from the first norm, so a mix (an unconverted BatchNorm1d beside SyncBatchNorms, or two
+    process groups) must go through the modules one by one."""
+    first, group = type(bns[0]), _sync_group(bns[0])
+    return all(type(bn) is first and _sync_group(bn) is group for bn in bns[1:])
+
+
 def _bn_group_fwd(items, B, N, device, group):
     """Run the norms of one group.  items: dicts with x (data_ptr), xbs, C, w, b, rm, rv, nbt, eps, mom, relu, res (ptr or
     None), rbs, y (ptr), ybs.  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
@@ -932,7 +940,7 @@ def union_keys_values_eligible(x, convs, key_bns, values_bns):
                 ok = _bn_supported[key] = bool(_lib.load().ct_bn_relu_supported(*key))
             if not ok:
                 return False
-    return True
+    return norms_share_group(list(key_bns) + list(values_bns))
 
 
 _bn_supported = {}
@@ -1048,3 +1056,74 @@ def grid_occupancy_count(grid):
     with _on(grid.device):
         _lib.check(lib.ct_grid_occupancy(_ptr(grid), grid.numel(), _ptr(count), _stream()), "ct_grid_occupancy")
     return count
+
+
+# ---------------------------------------------------------------------------
+# plane-resident MHCT core: Splat -> grouped conv -> Slice in one kernel
+# ---------------------------------------------------------------------------
+def mhct_core_supported(B, H, C, N, W):
+    return bool(_lib.load().ct_mhct_core_supported(B, H, C, N, len(W), _lib.int_array(W)))
+
+
+class MhctCoreFn(torch.autograd.Function):
+    """out = Slice(keys, conv(Splat(keys, feat))) and the occupancy count of the rasterised grid
+    (layers/multihead_ct.py:99-107).  Forward: ct_mhct_core_fwd — z and conv(z) stay in LDS; when a gradient is needed
+    the kernel also writes them out once for the backward (ct_mhct_core_bwd: Slice backward, the two conv gradients,
+    Splat backward with the key cotangents summed)."""
+
+    @staticmethod
+    def forward(ctx, keys, feat, pad, weight, bias, W, H):
+        _dev(keys, feat, pad, weight, bias)
+        keys, feat, weight = _f32c(keys), _f32c(feat), _f32c(weight)
+        bias = _f32c(bias) if bias is not None else None
+        dim = len(W)
+        B, HC, N = feat.shape
+        C = HC // H
+        assert keys.shape == (B, H * dim, N) and weight.shape[0] == HC and weight.shape[1] == C
+        padt, pad_code = _pad_args(pad, B, N)
+        dev = feat.device
+        need_grad = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+        out = torch.empty(B, HC, N, device=dev, dtype=torch.float32)
+        z = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad else None
+        y = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad else None
+        occ = torch.empty((), device=dev, dtype=torch.int64)
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
+        ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+        with _on(dev):
+            _lib.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(bias), _ptr(out),
+                                            _ptr(z), _ptr(y), _ptr(occ), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()),
+                       "ct_mhct_core_fwd")
+        ctx.save_for_backward(keys, feat, padt, weight, z, y)
+        ctx.meta = (W, H, C, pad_code, bias is not None)
+        ctx.mark_non_differentiable(occ)
+        return out, occ
+
+    @staticmethod
+    def backward(ctx, g_out, _g_occ):
+        keys, feat, padt, weight, z, y = ctx.saved_tensors
+        W, H, C, pad_code, has_bias = ctx.meta
+        dim = len(W)
+        B, HC, N = feat.shape
+        dev = feat.device
+        g_out = _f32c(g_out)
+        g_feat = torch.empty_like(feat)
+        g_keys = torch.empty_like(keys)
+        g_w = torch.empty_like(weight)
+        g_b = torch.empty(HC, device=dev, dtype=torch.float32) if has_bias else None
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        nws = lib.ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, Wa)
+        ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+        with _on(dev):
+            _lib.check(lib.ct_mhct_core_bwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(z), _ptr(y),
+                                            _ptr(g_out), _ptr(g_feat), _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(ws), nws,
+                                            B, H, C, N, dim, Wa, _stream()), "ct_mhct_core_bwd")
+        return g_keys, g_feat, None, g_w, g_b, None, None
+
+
+def mhct_core(keys, features, pts_padding, weight, bias, tensor_size, heads, dim):
+    """(sliced features, occupancy count) of one MHCT core; raises unless mhct_core_supported(...)."""
+    W = sizes_of(tensor_size, dim)
+    return MhctCoreFn.apply(keys, features, pts_padding, weight, bias, W, heads)

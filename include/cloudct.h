@@ -284,6 +284,43 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
                         int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Plane-resident MHCT core: the part of a MultiHead block between its norms,
+ *   out = Slice(lattice, conv(Splat(lattice, values)))                (layers/multihead_ct.py:99-107:
+ *   DifferentiablePositions -> Splat (max, zero floor) -> grouped 3^dim conv with bias -> Slice;
+ *   layers/multihead_ct_adain.py:118-125 and layers/cloud_transform.py:72-227 likewise)
+ * as ONE kernel per direction-independent plane: the rasterised grid z and the convolved grid y of a (batch, head)
+ * plane stay in LDS.  Shapes: the grids whose two tiles fit a CU beside the filter bank — 2D 32x32 C16, 2D 16x16 C16,
+ * 3D 8x8x8 C32 (ct_mhct_core_supported != 0), N % 4 == 0, 16-byte aligned tensors.
+ *   keys f32[B,H*dim,N] (the lattice), feat f32[B,H*C,N], pad as for Splat, conv_w f32[H*C,C,3^dim], conv_b f32[H*C] | NULL
+ *   out f32[B,H*C,N] (overwritten)
+ *   z_save, y_save f32[B,H*C,G] | NULL: the two grids as tensors, for ct_mhct_core_bwd (training); with NULL they never
+ *     leave the chip.  occ_count int64[1] | NULL: number of |z| > 1e-9 (layers/multihead_ct.py:104-105).
+ * With few planes (B*H < CUs/2) a plane is shared by a cluster of 2..8 workgroups that exchange their partial grids
+ * through `workspace` (ct_mhct_core_workspace_bytes; also holds the arrival counters: zero-filled by the call itself).
+ * A cluster spins on its partners: do not run two of these launches concurrently on different streams of one device.
+ * Backward (ct_mhct_core_bwd): from the saved grids, as Slice backward -> conv backward (data, weight) -> Splat backward
+ * on this library's kernels; overwrites g_feat f32[B,H*C,N], g_keys f32[B,H*dim,N] (Slice's and Splat's key cotangents
+ * summed), g_w f32[H*C,C,3^dim], g_b f32[H*C] | NULL; workspace of ct_mhct_core_bwd_workspace_bytes.
+ * ---------------------------------------------------------------------- */
+int ct_mhct_core_supported(int B, int H, int C, int N, int dim, const int* W);
+size_t ct_mhct_core_workspace_bytes(int B, int H, int C, int N, int dim, const int* W);
+int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                     const float* conv_b, float* out, float* z_save, float* y_save, int64_t* occ_count,
+                     void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
+                     ct_stream_t s);
+size_t ct_mhct_core_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W);
+int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                     const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
+                     float* g_b, void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim,
+                     const int* W, ct_stream_t s);
+/* Test hooks: bit 0 = one workgroup per plane (no clusters); bits 8.. = force that many workgroups per plane (1, 2, 4, 8).
+ * ct_mhct_core_status copies the workspace's status word to the host AFTER synchronising the stream (a test helper, the
+ * only call of this library that waits for the device): 0 = no cluster gave up waiting for its partners. */
+void ct_debug_set_core(unsigned flags);
+int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
+                        int* host_status, ct_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Chamfer distance (chamfer_extension/chamfer_cuda.cpp:30-33 `forward`,
  * `backward`; kernels chamfer.cu:12-195).  xyz1 f32[B,n,3], xyz2 f32[B,m,3];
  * dist1 f32[B,n], idx1 i32[B,n] (nearest point of cloud 2, lowest index on

@@ -16,7 +16,10 @@ def _clouds(B, n, seed):
 
 
 @pytest.mark.parametrize("B,n,eps,iters", [(2, 1024, 0.005, 50), (3, 2048, 0.005, 20), (1, 1024, 0.004, 300),
-                                           (2, 1024, 0.005, 1), (2, 4096, 0.005, 30)])
+                                           (2, 1024, 0.005, 1), (2, 4096, 0.005, 30),
+                                           # big eps, many rounds: prices in the hundreds, where the Bid kernel's candidate
+                                           # filter (absolute safety margin) must switch itself off to stay bit-identical
+                                           (2, 1024, 1.0, 200), (1, 2048, 5.0, 100)])
 def test_matches_oracle(B, n, eps, iters):
     from cloud_transformers_amd.emd import emdModule
     a, b = _clouds(B, n, 10 * B + iters)
@@ -68,6 +71,18 @@ def test_large_cloud_validity():
     assert torch.allclose(((a - sel) ** 2).sum(-1), dist, atol=1e-6)
     assert all(ass[i].unique().numel() > 0.9 * 16384 for i in range(2))
     assert float(dist.sqrt().mean()) < 0.05
+
+
+def test_large_cloud_matches_oracle_for_a_few_rounds():
+    """The completion config's size (B2, n=16384) against the oracle itself, not only by validity: the first rounds (all
+    16384 bidders, the longest unassigned lists) must give the oracle's assignment and distances bit for bit."""
+    from cloud_transformers_amd.emd import emdModule
+    a, b = _clouds(2, 16384, 77)
+    st, d_ref, ass_ref = emd_ref.forward(a, b, 0.005, 4)
+    assert st == 1
+    dist, ass = emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 0.005, 4)
+    assert np.array_equal(ass.cpu().numpy(), ass_ref)
+    assert np.array_equal(dist.cpu().numpy(), d_ref)
 
 
 @pytest.mark.parametrize("seed", range(6))

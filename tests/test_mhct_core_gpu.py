@@ -1,0 +1,218 @@
+"""Parity of the plane-resident MHCT core (ct_mhct_core_fwd / _bwd) — Splat -> grouped conv -> Slice
+of a (batch, head) plane in one kernel — against the oracle (oracle/ref_cpu.py pieces + torch's CPU convolution) and
+against this package's own unfused chain (ct_splat_fwd -> ct_gconv_fwd -> ct_slice_fwd) on identical inputs.
+
+Bars: the rasterised grid z bit-exact (and the occupancy count exact); conv output y, sliced features and every
+gradient within 1e-4 of the tensor's max (the north star's bar; observed ~1e-6).  Every cluster size (workgroups
+per plane exchanging partial grids through the workspace) is forced on the small shapes; the full-size shapes run the
+planner's own choice, several launches with fresh inputs (a stale exchange would show up as a wrong z), and the
+workspace's status word must stay 0."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 32, 16), (2, 16, 16), (3, 8, 32)]       # (dim, W, C): the three grids the kernel is built for
+
+
+def _libs():
+    from cloud_transformers_amd import _lib
+    return _lib, _lib.load()
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
+
+
+def make_inputs(B, H, C, N, dim, seed, pad_kind=None, dup=False):
+    g = torch.Generator().manual_seed(seed)
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    feat = torch.randn(B, H * C, N, generator=g)
+    if dup:                                   # duplicated points: exact ties in the max
+        keys[..., N // 2:] = keys[..., :N - N // 2]
+        feat[..., N // 2:] = feat[..., :N - N // 2]
+    taps = 3 ** dim
+    w = torch.randn(H * C, C, *([3] * dim), generator=g) / (C * taps) ** 0.5
+    bias = torch.randn(H * C, generator=g) * 0.1
+    cot = torch.randn(B, H * C, N, generator=g)
+    pad = None
+    if pad_kind == "f32":
+        pad = (torch.rand(B, N, generator=g) > 0.25).float()
+    elif pad_kind == "i32":
+        pad = (torch.rand(B, N, generator=g) > 0.25).to(torch.int32)
+    return keys, feat, w, bias, cot, pad
+
+
+def oracle_core(keys, feat, w, bias, cot, pad, W, H, dim):
+    k = keys.clone().requires_grad_(True)
+    f = feat.clone().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    bt = bias.clone().requires_grad_(True)
+    lc, idx = R.positions(k, W, H, dim)
+    z = R.splat(lc, idx, f, pad, W, H, dim, "max")
+    conv = F.conv2d if dim == 2 else F.conv3d
+    y = conv(z, wt, bt, padding=1, groups=H)
+    out = R.slice_(lc, idx, y, pad, W, H, dim)
+    out.backward(cot)
+    occ = int((z.detach().abs() > 1e-9).sum())
+    return dict(z=z.detach(), y=y.detach(), out=out.detach(), occ=occ, g_keys=k.grad, g_feat=f.grad, g_w=wt.grad, g_b=bt.grad)
+
+
+def fused_core(keys, feat, w, bias, cot, pad, W, H, dim, want_grids=True):
+    """straight through the C ABI"""
+    from cloud_transformers_amd.ops import _ptr, _stream, _pad_args
+    L, lib = _libs()
+    dev = "cuda"
+    keys, feat, w, bias, cot = (t.to(dev).contiguous() for t in (keys, feat, w, bias, cot))
+    B, HC, N = feat.shape
+    C = HC // H
+    Wl = [W] * dim
+    Wa = L.int_array(Wl)
+    padt, code = _pad_args(pad.to(dev) if pad is not None else None, B, N)
+    out = torch.empty(B, HC, N, device=dev)
+    z = torch.full((B, HC, *Wl), float("nan"), device=dev) if want_grids else None
+    y = torch.full((B, HC, *Wl), float("nan"), device=dev) if want_grids else None
+    occ = torch.full((), -1, device=dev, dtype=torch.int64)
+    nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
+    ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+    L.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), _ptr(padt), code, _ptr(w), _ptr(bias), _ptr(out), _ptr(z), _ptr(y),
+                                 _ptr(occ), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()), "ct_mhct_core_fwd")
+    st = ctypes.c_int(-1)
+    L.check(lib.ct_mhct_core_status(_ptr(ws), nws, B, H, C, N, dim, Wa, ctypes.byref(st), _stream()), "ct_mhct_core_status")
+    res = dict(z=z, y=y, out=out, occ=int(occ), status=st.value)
+    if want_grids:
+        g_feat, g_keys, g_w, g_b = torch.empty_like(feat), torch.empty_like(keys), torch.empty_like(w), torch.empty_like(bias)
+        nb = lib.ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, Wa)
+        wsb = torch.empty(nb, device=dev, dtype=torch.uint8)
+        L.check(lib.ct_mhct_core_bwd(_ptr(keys), _ptr(feat), _ptr(padt), code, _ptr(w), _ptr(z), _ptr(y), _ptr(cot), _ptr(g_feat),
+                                     _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(wsb), nb, B, H, C, N, dim, Wa, _stream()),
+                "ct_mhct_core_bwd")
+        res.update(g_feat=g_feat, g_keys=g_keys, g_w=g_w, g_b=g_b)
+    torch.cuda.synchronize()
+    return res
+
+
+def unfused_chain(keys, feat, w, bias, pad, W, H, dim):
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.gconv import GroupedConvFn
+    dev = "cuda"
+    keys, feat, w, bias = (t.to(dev) for t in (keys, feat, w, bias))
+    pad = pad.to(dev) if pad is not None else None
+    z = ops.splat_keys(keys, feat, pad, W, H, dim, "max")
+    y = GroupedConvFn.apply(z, w, bias, H)
+    out = ops.slice_keys(keys, y, pad, W, H, dim)
+    return dict(z=z, y=y, out=out, occ=int(ops.grid_occupancy_count(z)))
+
+
+@pytest.fixture
+def core_flags():
+    _, lib = _libs()
+    yield lib.ct_debug_set_core
+    lib.ct_debug_set_core(0)
+
+
+@pytest.mark.parametrize("dim,W,C", SHAPES)
+@pytest.mark.parametrize("S", [1, 2, 4, 8])
+@pytest.mark.parametrize("pad_kind", [None, "f32"])
+def test_core_matches_oracle_every_cluster_size(core_flags, dim, W, C, S, pad_kind):
+    core_flags(S << 8)
+    B, H, N = 2, 4, 2048
+    keys, feat, w, bias, cot, pad = make_inputs(B, H, C, N, dim, 100 + S, pad_kind)
+    ref = oracle_core(keys, feat, w, bias, cot, pad, W, H, dim)
+    got = fused_core(keys, feat, w, bias, cot, pad, W, H, dim)
+    assert got["status"] == 0
+    assert torch.equal(got["z"].cpu(), ref["z"]), "rasterised grid must be bit-exact"
+    assert got["occ"] == ref["occ"]
+    for name in ("y", "out", "g_keys", "g_feat", "g_w", "g_b"):
+        assert relerr(got[name], ref[name]) <= 1e-4, (name, relerr(got[name], ref[name]))
+
+
+@pytest.mark.parametrize("dim,W,C", SHAPES)
+def test_core_ragged_tail_ties_and_int_padding(core_flags, dim, W, C):
+    core_flags(0)
+    B, H, N = 3, 5, 1020                      # planes not a multiple of 8, N not a multiple of the workgroup's quads
+    keys, feat, w, bias, cot, pad = make_inputs(B, H, C, N, dim, 7, "i32", dup=True)
+    ref = oracle_core(keys, feat, w, bias, cot, pad, W, H, dim)
+    got = fused_core(keys, feat, w, bias, cot, pad, W, H, dim)
+    assert got["status"] == 0
+    assert torch.equal(got["z"].cpu(), ref["z"])
+    assert got["occ"] == ref["occ"]
+    for name in ("y", "out"):
+        assert relerr(got[name], ref[name]) <= 1e-4, (name, relerr(got[name], ref[name]))
+
+
+@pytest.mark.parametrize("dim,W,C", SHAPES)
+def test_core_without_side_outputs(core_flags, dim, W, C):
+    """inference form: z and y never leave the chip; `out` must not depend on the side outputs being requested"""
+    core_flags(0)
+    B, H, N = 2, 8, 4096
+    keys, feat, w, bias, cot, pad = make_inputs(B, H, C, N, dim, 11)
+    a = fused_core(keys, feat, w, bias, cot, pad, W, H, dim, want_grids=True)
+    b = fused_core(keys, feat, w, bias, cot, pad, W, H, dim, want_grids=False)
+    assert torch.equal(a["out"], b["out"]) and a["occ"] == b["occ"] and b["status"] == 0
+
+
+FULL = [  # (B, H, N, dim, W, C): the headline shape and the stage-3 zoo heads at training and decoder sizes
+    (8, 64, 4096, 2, 32, 16),
+    (8, 16, 4096, 2, 16, 16),
+    (8, 16, 4096, 3, 8, 32),
+    (2, 16, 16384, 2, 16, 16),
+    (2, 16, 16384, 3, 8, 32),
+]
+
+
+@pytest.mark.parametrize("B,H,N,dim,W,C", FULL)
+def test_core_full_size_vs_unfused_chain_and_oracle_planes(core_flags, B, H, N, dim, W, C):
+    core_flags(0)
+    for rep in range(3):                      # fresh inputs per launch: a stale exchange buffer would give a wrong z
+        keys, feat, w, bias, cot, pad = make_inputs(B, H, C, N, dim, 1000 + rep)
+        got = fused_core(keys, feat, w, bias, cot, pad, W, H, dim)
+        ref = unfused_chain(keys, feat, w, bias, pad, W, H, dim)
+        assert got["status"] == 0
+        assert torch.equal(got["z"], ref["z"]), "z differs from ct_splat_fwd (rep %d)" % rep
+        assert got["occ"] == ref["occ"]
+        assert relerr(got["y"], ref["y"]) <= 1e-5
+        assert relerr(got["out"], ref["out"]) <= 1e-5
+    # sampled planes against the oracle (planes are independent), gradients included
+    rng = np.random.RandomState(0)
+    for _ in range(3):
+        b, h = int(rng.randint(B)), int(rng.randint(H))
+        sl = lambda t, per: t[b:b + 1, h * per:(h + 1) * per]
+        kp, fp, cp = sl(keys, dim), sl(feat, C), sl(cot, C)
+        wp, bp = w[h * C:(h + 1) * C], bias[h * C:(h + 1) * C]
+        ref1 = oracle_core(kp, fp, wp, bp, cp, None, W, 1, dim)
+        assert torch.equal(sl(got["z"], C).cpu(), ref1["z"])
+        for name, per in (("out", C), ("g_feat", C), ("g_keys", dim)):
+            assert relerr(sl(got[name], per), ref1[name]) <= 1e-4, (name, relerr(sl(got[name], per), ref1[name]))
+
+
+def test_core_autograd_function_matches_module_chain(core_flags):
+    """ops.mhct_core (autograd.Function over the ABI pair) against the unfused autograd chain of this package"""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.gconv import GroupedConvFn
+    core_flags(0)
+    for dim, W, C in SHAPES:
+        B, H, N = 2, 16, 2048
+        keys, feat, w, bias, cot, _ = make_inputs(B, H, C, N, dim, 5)
+        outs = []
+        for fused in (True, False):
+            k, f, wt, bt = (t.cuda().requires_grad_(True) for t in (keys, feat, w, bias))
+            if fused:
+                out, occ = ops.mhct_core(k, f, None, wt, bt, W, H, dim)
+            else:
+                z = ops.splat_keys(k, f, None, W, H, dim, "max")
+                out = ops.slice_keys(k, GroupedConvFn.apply(z, wt, bt, H), None, W, H, dim)
+                occ = ops.grid_occupancy_count(z)
+            out.backward(cot.cuda())
+            outs.append((out.detach(), int(occ), k.grad, f.grad, wt.grad, bt.grad))
+        assert outs[0][1] == outs[1][1]
+        for a, b in zip(outs[0], outs[1]):
+            if torch.is_tensor(a):
+                assert relerr(a, b) <= 1e-5
