@@ -26,8 +26,11 @@ def visible_gpus(env=None, topology="/sys/class/kfd/kfd/topology/nodes"):
     """Number of GPUs this process may use, counted WITHOUT the HIP runtime (torch.cuda.device_count() may fall back to
     hipGetDeviceCount, which initialises HIP in the parent that is meant to stay GPU-free): KFD topology nodes that have
     SIMDs, narrowed by the first of HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES that is set.
-    None when the topology cannot be read (the ranks then check LOCAL_RANK against their own device count)."""
+    0 without the amdgpu compute driver (no KFD directory); None when the topology exists but cannot be read (the ranks
+    then check LOCAL_RANK against their own device count)."""
     env = os.environ if env is None else env
+    if not os.path.isdir(topology):
+        return 0
     try:
         n = 0
         for node in os.listdir(topology):
