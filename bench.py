@@ -268,6 +268,12 @@ def run_op(args):
         # the committed PMC passes were collected on the default workload only
         default_shape = (B, N, H, C, W, dim, args.reduce) == (8, 4096, 64, 16, 32, 2, "max")
         traffic = measured_traffic(step.KERNEL_OF.get(tags[dom], tags[dom])) if default_shape else None
+        roofline_passes = {}
+        for p in step.PASSES:
+            gbs = alg[p] / (passes[p] * 1e-3) / 1e9
+            kern = step.KERNEL_OF.get(tags[p], tags[p])
+            roofline_passes[p] = {"kernel": kern, "bytes": alg[p], "ms": passes[p], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                  "traffic": measured_traffic(kern) if default_shape and "+" not in tags[p] else None}
         out = {
             "metric": METRIC,
             "value": world * B * N / (dt / args.steps),
@@ -293,6 +299,10 @@ def run_op(args):
                          "traffic_source": "committed PMC pass (profiles/traffic_latest.json), not measured in this run"
                                            if traffic is not None else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": passes[dom]},
+            # every pass of the step against the same roofline, and the one furthest below it: the headline `roofline`
+            # object is the LONGEST kernel, which need not be the least efficient one
+            "roofline_passes": roofline_passes,
+            "worst_pass": min(roofline_passes, key=lambda k: roofline_passes[k]["frac"]),
             "passes_ms": passes,
             "kernels": {p: step.KERNEL_OF.get(t, t) for p, t in tags.items()},
             "step_roofline": {"algorithmic_bytes_per_step": alg["total"],

@@ -52,6 +52,41 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_and_link(force, verbose):
+    """One object per source (lib/obj/*.o, recompiled only when the source or a header is newer; up to 4 hipcc at a
+    time), then one link into a per-process temporary that is renamed into place."""
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "cloudct.h")]
+    h_time = max(os.path.getmtime(h) for h in headers)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for name in HIP_SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(obj_dir, os.path.splitext(name)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), h_time):
+            jobs.append([_hipcc()] + flags + ["-c", "-I", INCLUDE, src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(run, jobs))
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+    try:
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source into lib/libcloudct.so (cross-compiles without a GPU).
 
@@ -67,17 +102,7 @@ def build(force=False, verbose=False):
         try:
             if not force and not _stale():
                 return LIB_PATH
-            srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-            tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
-            cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE] + srcs + ["-o", tmp]
-            if verbose:
-                print(" ".join(cmd))
-            try:
-                subprocess.run(cmd, check=True)
-                os.replace(tmp, LIB_PATH)
-            finally:
-                if os.path.exists(tmp):
-                    os.remove(tmp)
+            _compile_and_link(force, verbose)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
@@ -134,6 +159,7 @@ SIGNATURES = {
     "ct_gconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_mhct_core_supported": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_mhct_core_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
+    "ct_mhct_core_workspace_init": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_mhct_core_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_mhct_core_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_mhct_core_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),

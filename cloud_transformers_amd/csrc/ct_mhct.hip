@@ -27,6 +27,9 @@ namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#ifndef CT_CORE_ABL
+#define CT_CORE_ABL 0        // ablation builds (tools/dev/build_core_abl.sh): 1 no scatter, 2 no MFMA loop, 4 no gather, 8 no exchange
+#endif
 constexpr int kCoreThreads = 1024;
 constexpr int kCoreSlack = 4;                  // floats in front of the z tile: the left neighbour of its first element
 constexpr int kSpinLimit = 1 << 22;            // polls of ~0.5 us before a workgroup gives up on its partners
@@ -43,7 +46,7 @@ struct CoreArgs {
   float* y_save;         // (B, H*C, G) | null
   long long* occ;        // [1] | null
   float* xch;            // [planes][S][C*G]   partial tiles of a cluster
-  unsigned* flags;       // [planes] arrival counters, then {occ sum (2 words), done counter}: zeroed before the launch
+  unsigned* flags;       // [planes] arrival counters, [planes] done counters, {occupancy sum (2 words), done}: zero between launches
   int* status;           // [1] set to 1 when a cluster gave up waiting (never in a correct run)
   int B, H, N;
   int S, SC, SN;         // workgroups per plane = SC (blocks of output channels) x SN (point ranges)
@@ -123,6 +126,13 @@ __device__ __forceinline__ constexpr int off_compact(int v) {
   return DIM == 2 ? (v & 1) * WT + (v >> 1) : (v & 1) * WT * WT + ((v >> 1) & 1) * WT + (v >> 2);
 }
 
+// write-through store (agent scope): the bytes leave the XCD's L2 when the store completes, so a partner on another XCD
+// needs no write-back of this L2 before it may read them (MI355X_MICROARCH.md, publish-large: 3.0 vs 8.2 us per 64 KB)
+__device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
+  const ct_f4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+
 __device__ __forceinline__ int wave_sum_int(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     const int per = (nq + S - 1) / S;
     const int q0 = s * per, q1 = min(nq, q0 + per);
     const float* src = a.feat + bh * C * (size_t)N;
-    for (int q = q0 + tid; q < q1; q += kCoreThreads) {
+    for (int q = q0 + tid; q < ((CT_CORE_ABL & 1) ? 0 : q1); q += kCoreThreads) {
       const int n0 = q << 2;
       float cw[4][V];
       int hb[4];
@@ -221,12 +231,26 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       float pv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+      // the next group's rows are requested before this group's atomics are issued (a thread owns one or two quads: without
+      // the prefetch every group would expose a full HBM round trip)
+      float nx[CG][4];
+#pragma unroll
+      for (int cj = 0; cj < CG; ++cj) {
+        const float4 t = *(const float4*)(src + (size_t)cj * N + n0);
+        nx[cj][0] = t.x; nx[cj][1] = t.y; nx[cj][2] = t.z; nx[cj][3] = t.w;
+      }
       for (int cg0 = 0; cg0 < C; cg0 += CG) {
         float fv[CG][4];
 #pragma unroll
-        for (int cj = 0; cj < CG; ++cj) {
-          const float4 t = *(const float4*)(src + (size_t)(cg0 + cj) * N + n0);
-          fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+        for (int cj = 0; cj < CG; ++cj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fv[cj][i] = nx[cj][i];
+        if (cg0 + CG < C) {
+#pragma unroll
+          for (int cj = 0; cj < CG; ++cj) {
+            const float4 t = *(const float4*)(src + (size_t)(cg0 + CG + cj) * N + n0);
+            nx[cj][0] = t.x; nx[cj][1] = t.y; nx[cj][2] = t.z; nx[cj][3] = t.w;
+          }
         }
 #pragma unroll
         for (int cj = 0; cj < CG; ++cj) {
@@ -247,28 +271,26 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
   __syncthreads();
 
   // ---- X: merge the partial tiles of the plane's workgroups
-  if (S > 1) {
+  if (S > 1 && !(CT_CORE_ABL & 8)) {
     float* mine = a.xch + ((size_t)plane * S + s) * (size_t)(C * G);
     for (int t = tid; t < (C * G) >> 2; t += kCoreThreads) {
       const int c = t / (G >> 2), cell = (t - c * (G >> 2)) << 2;
-      *(float4*)(mine + (size_t)c * G + cell) = *(const float4*)(Zf + (size_t)c * PLANE + halo_of<DIM, WT>(cell));
+      st_sc1_f4(mine + (size_t)c * G + cell, *(const float4*)(Zf + (size_t)c * PLANE + halo_of<DIM, WT>(cell)));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores are done
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(a.flags + plane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int it = 0;
       bool ok = true;
       while (__hip_atomic_load(a.flags + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(4);
         if (++it > kSpinLimit) {
           ok = false;
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this CU's L1 (and stale L2 lines) dropped before the reads
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!ok) {
         s_flag[0] = 1;
@@ -289,6 +311,15 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       }
     }
     __syncthreads();
+    // the counters clean up after themselves (no memset per launch): the last workgroup of the plane to have read its
+    // partners' tiles — nobody polls the plane's counter any more — zeroes both words for the next launch
+    if (tid == 0) {
+      unsigned* done = a.flags + a.planes + plane;
+      if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S - 1u) {
+        __hip_atomic_store(a.flags + plane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 
   // ---- side outputs of the merged tile: z (training) and the occupancy count; workgroup s takes C/S channels
@@ -307,14 +338,17 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       if (lane == 0 && cnt) atomicAdd(&s_flag[1], cnt);
       __syncthreads();
       if (tid == 0) {
-        // sum over all workgroups, written by the last one to arrive (device-scope atomics at the memory side)
-        unsigned long long* acc = (unsigned long long*)(a.flags + ((a.planes + 1) & ~1));
-        unsigned* done = a.flags + ((a.planes + 1) & ~1) + 2;
+        // sum over all workgroups, written (and the two words zeroed for the next launch) by the last one to arrive;
+        // device-scope atomics execute at the memory side, in this lane's program order
+        unsigned long long* acc = (unsigned long long*)(a.flags + 2 * a.planes);
+        unsigned* done = (unsigned*)(acc + 1);
         (void)__hip_atomic_fetch_add(acc, (unsigned long long)s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)(a.planes * S) - 1u)
-          *a.occ = (long long)__hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(a.planes * S) - 1u) {
+          *a.occ = (long long)__hip_atomic_exchange(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -359,7 +393,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     for (int st = 0; st < Gm::NST; ++st) {
       if (st + 1 < Gm::NST) load_wslice<DIM, WT, C>(wh, co0, st + 1, wr);
       const float* ws = WS + (size_t)(st & (Gm::NBUF - 1)) * Gm::SLICE;
-      if (has_item) {
+      if (has_item && !(CT_CORE_ABL & 2)) {
 #pragma unroll
         for (int rl = 0; rl < Gm::NRB; ++rl) {
           const int r = st * Gm::NRB + rl;
@@ -401,7 +435,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       const int per = (nq + a.SN - 1) / a.SN;
       const int q0 = sn * per, q1 = min(nq, q0 + per);
       float* dst = a.out + (bh * C + co0) * (size_t)N;
-      for (int qd = q0 + tid; qd < q1; qd += kCoreThreads) {
+      for (int qd = q0 + tid; qd < ((CT_CORE_ABL & 4) ? 0 : q1); qd += kCoreThreads) {
         const int n0 = qd << 2;
         float kk[DIM][4];
 #pragma unroll
@@ -457,8 +491,11 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
 // ---------------------------------------------------------------------------
 struct CoreShape {
   int dim, W, C;
+  int cu_div;     // clusters grow while planes * S <= CUs / cu_div (measured: the light 16^2 plane is fastest at one
+                  // workgroup per TWO CUs' worth of planes — its exchange costs what a halved scatter saves — the
+                  // MFMA- and atomics-heavy 8^3 C32 volume at one workgroup per CU)
 };
-constexpr CoreShape kCoreShapes[] = {{2, 32, 16}, {2, 16, 16}, {3, 8, 32}};
+constexpr CoreShape kCoreShapes[] = {{2, 32, 16, 1}, {2, 16, 16, 2}, {3, 8, 32, 1}};
 
 int core_shape_index(int C, int dim, const int* W) {
   if (!W) return -1;
@@ -484,11 +521,11 @@ int device_cus() {
 std::atomic<unsigned> g_core_flags{0};     // test hook (ct_debug_set_core): bit 0 = no clusters, bits 8.. = forced cluster size
 
 // workgroups per plane: enough to cover the chip once, S | N/4 ranges, C % S == 0, at most 8
-void core_split(int planes, int C, int N, int& S, int& SC, int& SN) {
+void core_split(int planes, int C, int N, int cu_div, int& S, int& SC, int& SN) {
   S = 1;
   const unsigned dbg = g_core_flags.load(std::memory_order_relaxed);
   if ((dbg & 1u) == 0) {
-    const int cus = device_cus();
+    const int cus = device_cus() / cu_div;
     while (S < 8 && planes * S * 2 <= cus && C % (S * 2) == 0 && (N >> 2) >= S * 2 * 64) S *= 2;
   }
   const unsigned forced = dbg >> 8;
@@ -500,7 +537,7 @@ void core_split(int planes, int C, int N, int& S, int& SC, int& SN) {
 size_t core_ws_layout(int planes, int S, int C, int G, size_t& flags_off, size_t& status_off) {
   size_t xch = S > 1 ? (size_t)planes * S * C * G * 4 : 0;
   flags_off = (xch + 255) & ~(size_t)255;
-  status_off = flags_off + ((size_t)((planes + 1) & ~1) + 4) * 4;      // counters, pad, {occupancy sum (2 words), done, spare}
+  status_off = flags_off + ((size_t)2 * planes + 4) * 4;      // arrival + done counters per plane, {occupancy sum (2 words), done, spare}
   return status_off + 16;
 }
 
@@ -537,7 +574,7 @@ int ct_mhct_core_supported(int B, int H, int C, int N, int dim, const int* W) {
 size_t ct_mhct_core_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
   if (!ct_mhct_core_supported(B, H, C, N, dim, W)) return 0;
   int S, SC, SN;
-  core_split(B * H, C, N, S, SC, SN);
+  core_split(B * H, C, N, kCoreShapes[core_shape_index(C, dim, W)].cu_div, S, SC, SN);
   int G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
   size_t fo, so;
@@ -555,7 +592,7 @@ int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int 
   a.keys = keys; a.feat = feat; a.pad = pad; a.pad_dtype = pad_dtype; a.w = conv_w; a.bias = conv_b;
   a.out = out; a.z_save = z_save; a.y_save = y_save; a.occ = (long long*)occ_count;
   a.B = B; a.H = H; a.N = N; a.planes = B * H;
-  core_split(a.planes, C, N, a.S, a.SC, a.SN);
+  core_split(a.planes, C, N, kCoreShapes[core_shape_index(C, dim, W)].cu_div, a.S, a.SC, a.SN);
   a.xcd_map = (a.planes % 8 == 0) ? 1 : 0;
   int G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
@@ -565,9 +602,6 @@ int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int 
   a.xch = (float*)workspace;
   a.flags = (unsigned*)((char*)workspace + fo);
   a.status = (int*)((char*)workspace + so);
-  if (a.S > 1 || occ_count) {
-    if (hipMemsetAsync(a.flags, 0, so + 16 - fo, st) != hipSuccess) return CT_ELAUNCH;
-  }
   const int idx = core_shape_index(C, dim, W);
   if (idx == 0) return launch_core<2, 32, 16>(a, st);
   if (idx == 1) return launch_core<2, 16, 16>(a, st);
@@ -612,12 +646,24 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
                          CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS, s);
 }
 
+int ct_mhct_core_workspace_init(void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!workspace || !ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
+  int S, SC, SN;
+  core_split(B * H, C, N, kCoreShapes[core_shape_index(C, dim, W)].cu_div, S, SC, SN);
+  int G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  size_t fo, so;
+  const size_t need = core_ws_layout(B * H, S, C, G, fo, so);
+  if (workspace_bytes < need) return CT_EWORKSPACE;
+  return hipMemsetAsync((char*)workspace + fo, 0, need - fo, (hipStream_t)s) == hipSuccess ? CT_OK : CT_ELAUNCH;
+}
+
 /* 0 = no cluster of the last launches on this workspace gave up waiting for its partners */
 int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
                         int* host_status, ct_stream_t s) {
   if (!workspace || !host_status || !ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
   int S, SC, SN;
-  core_split(B * H, C, N, S, SC, SN);
+  core_split(B * H, C, N, kCoreShapes[core_shape_index(C, dim, W)].cu_div, S, SC, SN);
   int G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
   size_t fo, so;

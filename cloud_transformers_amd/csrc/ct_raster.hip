@@ -16,6 +16,7 @@
 #include "ct_common.h"
 #include <string.h>
 #include <atomic>
+#include <mutex>
 
 #ifndef CT_QUAD_THREADS
 #define CT_QUAD_THREADS 512
@@ -1220,16 +1221,20 @@ __global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
 
 // ---------------------------------------------------------------------------
 // test hooks: which kernel family an entry point picked, and a switch that keeps the hot-shape kernels off
-// (host state, never read by the kernels).  The flags are process-wide — a test sets them on the main thread and the
-// backward passes read them on autograd's thread — hence atomic; the tag buffer is PER THREAD: an entry point's tags
-// are read back by the thread that called it, and concurrent callers (forward on the main thread, backward on
-// autograd's, multi-stream users) never write the same buffer.
+// (host state, never read by the kernels).  Both are process-wide — a test sets the flags on the main thread and reads the
+// tags there, while the backward passes run on autograd's thread — so the flags are atomic and the tag buffer is guarded by
+// a mutex (writers: every Splat / Slice entry point; the reader gets a copy in a buffer of its own thread).
 // ---------------------------------------------------------------------------
 std::atomic<unsigned> t_dbg_flags{0};
-thread_local char t_last[256] = "";
+std::mutex t_last_mu;
+char t_last[256] = "";
 
-void note_reset() { t_last[0] = 0; }
+void note_reset() {
+  std::lock_guard<std::mutex> lk(t_last_mu);
+  t_last[0] = 0;
+}
 void note(const char* tag) {
+  std::lock_guard<std::mutex> lk(t_last_mu);
   size_t n = strlen(t_last), m = strlen(tag);
   if (n + m + 2 >= sizeof(t_last)) return;
   if (n) t_last[n++] = '+';
@@ -2231,7 +2236,12 @@ int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int p
 
 void ct_debug_set_flags(unsigned flags) { t_dbg_flags = flags; }
 
-const char* ct_debug_last_launch(void) { return t_last; }
+const char* ct_debug_last_launch(void) {
+  static thread_local char copy[256];
+  std::lock_guard<std::mutex> lk(t_last_mu);
+  memcpy(copy, t_last, sizeof(copy));
+  return copy;
+}
 
 int ct_slice_fwd(const float* keys, const float* grid, const void* pad, int pad_dtype, float* out,
                  int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {

@@ -123,6 +123,28 @@ class _MHCTCore(nn.Module):
         k_part, v_part = torch.split(key_values, [Ck, Cv], dim=1)   # backward: one cat
         return self.key_bn(k_part), self.values_bn(v_part)
 
+    def _core(self, lattice, values, pts_padd=None):
+        """(sliced features, occupancy) = Slice(conv(Splat(values))) at the lattice (multihead_ct.py:99-107).  The grids whose
+        two tiles fit a CU run as ONE kernel that keeps them in LDS (ops.mhct_core: 32^2 / 16^2 with 16 features per head,
+        8^3 with 32 — measured 1.15-1.7x the three-kernel chain on the forward, tools/core_bench.py); every other grid goes
+        through Splat -> grouped conv -> Slice."""
+        B = lattice.size(0)
+        conv = self.conv[0] if len(self.conv) == 1 else None
+        if (ops.FUSED_CORE and conv is not None and isinstance(conv, (GroupedConv2d, GroupedConv3d)) and lattice.is_cuda
+                and values.dtype == torch.float32 and lattice.dtype == torch.float32 and lattice.size(2) % 4 == 0
+                and tuple(conv.kernel_size) == (3,) * self.tensor_dim and tuple(conv.stride) == (1,) * self.tensor_dim
+                and tuple(conv.padding) == (1,) * self.tensor_dim and tuple(conv.dilation) == (1,) * self.tensor_dim
+                and conv.padding_mode == "zeros" and conv.groups == self.heads and conv.in_channels == conv.out_channels
+                and conv.weight.dtype == torch.float32
+                and ops.mhct_core_supported(B, self.heads, self.in_feature_dim, lattice.size(2), ops.sizes_of(self.tensor_size, self.tensor_dim))):
+            pre, count = ops.mhct_core(lattice, values, pts_padd, conv.weight, conv.bias, self.tensor_size, self.heads, self.tensor_dim)
+            with torch.no_grad():
+                occ = count.float() / (B * self.in_feature_dim * self.heads)
+            return pre, occ
+        z = self.splat.forward_keys(lattice, values, pts_padd)
+        occ = self._occupancy(z, B)
+        return self.slice.forward_keys(lattice, self.conv(z), pts_padd), occ
+
     def _occupancy(self, z, batch):
         with torch.no_grad():
             return ops.grid_occupancy_count(z).float() / (batch * self.in_feature_dim * self.heads)
@@ -156,9 +178,7 @@ class MultiHead(_MHCTCore):
         else:
             keys_res, values = kv
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res)
-        z = self.splat.forward_keys(lattice, values, pts_padd)
-        occ = self._occupancy(z, keys.size(0))
-        pre = self.slice.forward_keys(lattice, self.conv(z), pts_padd)
+        pre, occ = self._core(lattice, values, pts_padd)
         with torch.no_grad():
             stats = (occ, kstats[0], kstats[1], None)       # mean / variance of the keys, reduced by the lattice kernel
         return pre, stats, lattice
@@ -230,9 +250,7 @@ class MultiHeadAdaIn(_MHCTCore):
         else:
             keys_res, values = kv
         keys, lattice, kstats = self._lattice(orig_pcd, keys_res, self.scale)
-        z = self.splat.forward_keys(lattice, values)
-        occ = self._occupancy(z, keys.size(0))
-        pre = self.slice.forward_keys(lattice, self.conv(z))
+        pre, occ = self._core(lattice, values)
         with torch.no_grad():
             # the reference moves these to the host and copies ALL keys to numpy on every
             # forward (multihead_ct_adain.py:127-131); here they stay on the device (no sync)

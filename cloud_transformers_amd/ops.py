@@ -1061,8 +1061,38 @@ def grid_occupancy_count(grid):
 # ---------------------------------------------------------------------------
 # plane-resident MHCT core: Splat -> grouped conv -> Slice in one kernel
 # ---------------------------------------------------------------------------
+# The blocks route their Splat -> conv -> Slice core through the plane-resident kernel where it is built (the shapes of
+# ct_mhct_core_supported); CLOUDCT_FUSED_CORE=0 (or ops.FUSED_CORE = False) keeps the three-kernel chain, for A/B runs.
+import os as _os
+FUSED_CORE = _os.environ.get("CLOUDCT_FUSED_CORE", "1") != "0"
+_core_supported = {}
+
+
 def mhct_core_supported(B, H, C, N, W):
-    return bool(_lib.load().ct_mhct_core_supported(B, H, C, N, len(W), _lib.int_array(W)))
+    key = (B, H, C, N, tuple(W))
+    ok = _core_supported.get(key)
+    if ok is None:
+        ok = _core_supported[key] = bool(_lib.load().ct_mhct_core_supported(B, H, C, N, len(W), _lib.int_array(W)))
+    return ok
+
+
+_core_ws = {}
+
+
+def mhct_core_workspace(device, B, H, C, N, W):
+    """The forward's exchange workspace for a shape, allocated and initialised (counters zeroed) ONCE per device and shape:
+    every launch leaves the counters zeroed, and launches on one stream are ordered, so the buffer is reused."""
+    key = (device.index, B, H, C, N, tuple(W))
+    ws = _core_ws.get(key)
+    if ws is None:
+        lib = _lib.load()
+        Wa = _lib.int_array(W)
+        n = lib.ct_mhct_core_workspace_bytes(B, H, C, N, len(W), Wa)
+        ws = torch.empty(n, device=device, dtype=torch.uint8)
+        with _on(device):
+            _lib.check(lib.ct_mhct_core_workspace_init(_ptr(ws), n, B, H, C, N, len(W), Wa, _stream()), "ct_mhct_core_workspace_init")
+        _core_ws[key] = ws
+    return ws
 
 
 class MhctCoreFn(torch.autograd.Function):
@@ -1089,8 +1119,8 @@ class MhctCoreFn(torch.autograd.Function):
         occ = torch.empty((), device=dev, dtype=torch.int64)
         lib = _lib.load()
         Wa = _lib.int_array(W)
-        nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
-        ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+        ws = mhct_core_workspace(dev, B, H, C, N, W)
+        nws = ws.numel()
         with _on(dev):
             _lib.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(bias), _ptr(out),
                                             _ptr(z), _ptr(y), _ptr(occ), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()),

@@ -101,8 +101,9 @@ int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int p
                     int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s);
 
 /* Test hooks (process-wide host state, never read by a kernel): flags select kernel families so that the
- * parity tests can compare them on identical inputs; the tag string names the kernels the last Splat / Slice
- * entry point launched (not synchronised: single-stream tests only). */
+ * parity tests can compare them on identical inputs (atomic: set on one thread, read by entry points on any); the tag string
+ * names the kernels the last Splat / Slice entry point launched — whichever thread called it, e.g. autograd's — and is
+ * returned as a copy owned by the calling thread (writers and readers serialise on a mutex). */
 #define CT_DEBUG_NO_HOT 1      /* keep the hot-shape kernels (csrc/ct_raster_hot.h) off */
 #define CT_DEBUG_FORCE_HOT 2   /* use them for every eligible layout, however few (b,h) planes there are */
 void ct_debug_set_flags(unsigned flags);
@@ -296,14 +297,19 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
  *   z_save, y_save f32[B,H*C,G] | NULL: the two grids as tensors, for ct_mhct_core_bwd (training); with NULL they never
  *     leave the chip.  occ_count int64[1] | NULL: number of |z| > 1e-9 (layers/multihead_ct.py:104-105).
  * With few planes (B*H < CUs/2) a plane is shared by a cluster of 2..8 workgroups that exchange their partial grids
- * through `workspace` (ct_mhct_core_workspace_bytes; also holds the arrival counters: zero-filled by the call itself).
- * A cluster spins on its partners: do not run two of these launches concurrently on different streams of one device.
+ * through `workspace` (ct_mhct_core_workspace_bytes).  The workspace also holds the clusters' arrival counters, which
+ * must be ZERO when a launch starts: call ct_mhct_core_workspace_init once after allocating it (one small memset); every
+ * launch leaves the counters zeroed again, so the workspace can be reused launch after launch (stream-ordered) without
+ * further resets.  A cluster spins on its partners (bounded): do not run two of these launches concurrently on different
+ * streams of one device, nor share one workspace between streams.
  * Backward (ct_mhct_core_bwd): from the saved grids, as Slice backward -> conv backward (data, weight) -> Splat backward
  * on this library's kernels; overwrites g_feat f32[B,H*C,N], g_keys f32[B,H*dim,N] (Slice's and Splat's key cotangents
  * summed), g_w f32[H*C,C,3^dim], g_b f32[H*C] | NULL; workspace of ct_mhct_core_bwd_workspace_bytes.
  * ---------------------------------------------------------------------- */
 int ct_mhct_core_supported(int B, int H, int C, int N, int dim, const int* W);
 size_t ct_mhct_core_workspace_bytes(int B, int H, int C, int N, int dim, const int* W);
+int ct_mhct_core_workspace_init(void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
+                                ct_stream_t s);
 int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
                      const float* conv_b, float* out, float* z_save, float* y_save, int64_t* occ_count,
                      void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,

@@ -306,3 +306,60 @@ def test_reconstructor_decoder_and_chamfer_loss_match_the_reference():
     out, _ = blk(x11, z.detach()[:1], noise.detach()[:1])
     out.backward(torch.from_numpy(gold["g_x12"]).cuda())
     _close(x11.grad, gold["g_x11"], "d/d(input of decoder block 12) on the reference's own input", 1e-4)
+
+
+# ---------------------------------------------------------------------------
+# Teacher-forced per-block parity (tests/golden/gen_zoo_blocks.py): every block of the segmenter (training mode) and of the
+# inpainter's AdaIN decoder on the input it receives inside the REFERENCE model, output and input-gradient held to 1e-4.
+# The loose whole-model bounds above are smoke tests; these are the gradient evidence for blocks 1-12.
+# ---------------------------------------------------------------------------
+def _from_bf16_bits(bits):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16).to(torch.float32)
+
+
+def _cot_for(i, shape):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(9000 + i))
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double().numpy(), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def segmenter_train():
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_segmenter_blocks.npz"))
+    return gold, _model(int(gold["seed"])).train()
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_segmenter_block_on_the_reference_input_training_mode(segmenter_train, i):
+    gold, net = segmenter_train
+    xyz = torch.from_numpy(gold["cloud"]).cuda().squeeze(2)[:, :3].contiguous()
+    x = _from_bf16_bits(gold["x_in_%d" % i]).cuda().requires_grad_(True)
+    out, _ = net.attentions_encoder[i](x, xyz)
+    assert _rel(out[:, :64], gold["out_%d" % i]) <= 1e-4, ("output of block %d" % (i + 1), _rel(out[:, :64], gold["out_%d" % i]))
+    (out * _cot_for(i, out.shape).cuda()).sum().backward()
+    assert _rel(x.grad[:, :64], gold["g_in_%d" % i]) <= 1e-4, ("input gradient of block %d" % (i + 1), _rel(x.grad[:, :64], gold["g_in_%d" % i]))
+
+
+@pytest.fixture(scope="module")
+def inpainter_decoder():
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_inpainter_decoder_blocks.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    net = Inpainter()
+    _perturb(net, int(gold["seed"]) + 2)
+    return gold, net.cuda().eval()
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_inpainter_decoder_block_on_the_reference_input(inpainter_decoder, i):
+    gold, net = inpainter_decoder
+    noise = torch.from_numpy(gold["noise"]).cuda()
+    z = torch.from_numpy(gold["z"]).cuda().requires_grad_(True)
+    x = _from_bf16_bits(gold["x_in_%d" % i]).cuda().requires_grad_(True)
+    out, _ = net.attentions_decoder[i](x, z, noise[:, :3].contiguous())
+    assert _rel(out[:, :64], gold["out_%d" % i]) <= 1e-4, ("output of decoder block %d" % (i + 1), _rel(out[:, :64], gold["out_%d" % i]))
+    (out * _cot_for(100 + i, out.shape).cuda()).sum().backward()
+    assert _rel(x.grad[:, :64], gold["g_in_%d" % i]) <= 1e-4, ("input gradient of decoder block %d" % (i + 1), _rel(x.grad[:, :64], gold["g_in_%d" % i]))
+    assert _rel(z.grad, gold["g_z_%d" % i]) <= 1e-4, ("style gradient of decoder block %d" % (i + 1), _rel(z.grad, gold["g_z_%d" % i]))

@@ -65,6 +65,7 @@ def main():
             lib.ct_debug_set_core(S << 8)
             nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
             ws = torch.empty(nws, device="cuda", dtype=torch.uint8)
+            _lib.check(lib.ct_mhct_core_workspace_init(_ptr(ws), nws, B, H, C, N, dim, Wa, _stream()), "init")
 
             def fused(train):
                 _lib.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), None, 0, _ptr(w), _ptr(bias), _ptr(out),
