@@ -368,6 +368,16 @@ def run_ddp_step(args):
     torch.cuda.synchronize()
     barrier(dist)
     dt = max_over_ranks(dist, time.perf_counter() - t0)
+    # every rank must hold the same parameters and running statistics after the steps (same initial weights, averaged
+    # gradients, job-wide batch statistics): one float64 checksum per rank, gathered
+    with torch.no_grad():
+        chk = torch.stack([t.double().sum() for t in list(net.parameters()) + [b for b in net.buffers() if b.is_floating_point()]]).sum().reshape(1)
+    chks = [torch.zeros_like(chk) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(chks, chk)
+    else:
+        chks = [chk]
+    spread = float((torch.stack(chks) - chks[0]).abs().max() / chks[0].abs().clamp_min(1e-30))
     if rank == 0:
         nbytes = sum(p.numel() for p in net.parameters()) * 4
         out = {
@@ -380,6 +390,7 @@ def run_ddp_step(args):
                        "per_gpu_batch": B, "parallelism": "dp%d" % world, "world_size_seen": world,
                        "gradient_allreduce_MB_per_step": nbytes / 1e6,
                        "norm_statistics_collectives_per_step": (ops.sync_stats_collectives() - coll0) / args.steps,
+                       "params_equal_across_ranks": spread <= 1e-9, "param_checksum_spread": spread,
                        "loss": float(loss.detach())},
         }
         dist.barrier()

@@ -108,6 +108,46 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_SOURCES = [os.path.join("host", "grid_subsampling.cpp")]
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libcloudct_host.so")
+_host = None
+
+
+def build_host(force=False):
+    """Compile the CPU-side data preparation (csrc/host/*.cpp, include/cloudct_host.h) with g++ into lib/libcloudct_host.so."""
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(INCLUDE, "cloudct_host.h")]
+    if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
+        return HOST_LIB_PATH
+    import fcntl
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build_host.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            tmp = "%s.%d.tmp" % (HOST_LIB_PATH, os.getpid())
+            subprocess.run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INCLUDE]
+                           + srcs + ["-o", tmp], check=True)
+            os.replace(tmp, HOST_LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return HOST_LIB_PATH
+
+
+def load_host():
+    """libcloudct_host.so (built on first use: g++ only, no GPU toolchain needed)."""
+    global _host
+    if _host is None:
+        with _lock:
+            if _host is None:
+                lib = ctypes.CDLL(build_host())
+                f32p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+                lib.ct_grid_subsample.restype = ctypes.c_int64
+                lib.ct_grid_subsample.argtypes = [f32p, f32p, i32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                  f32p, f32p, i32p]
+                _host = lib
+    return _host
+
+
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _ll = ctypes.c_longlong
 _ip = ctypes.POINTER(ctypes.c_int)

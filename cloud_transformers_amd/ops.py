@@ -617,13 +617,18 @@ def _bn_group_fwd(items, B, N, device, group):
                                        base + 4 * (stride - 1) if i == 0 else None, B, it["C"], N, _stream()), "ct_bn_stats_fwd")
         c0 += it["C"]
     gathered = torch.empty(world * stride, device=device, dtype=torch.float32)
-    dist.all_gather_into_tensor(gathered, local, group=group)
+    # non-blocking: the collective is enqueued on RCCL's own stream (behind the statistics kernels) and the compute stream
+    # waits for it only where the first normalising kernel is enqueued — the host prepares those launches meanwhile, and
+    # whatever else is already queued on other streams (DDP's gradient buckets in backward) is not held up behind it
+    work = dist.all_gather_into_tensor(gathered, local, group=group, async_op=True)
     _sync_stats_collectives += 1
     count = torch.empty(1, device=device, dtype=torch.float32)
+    outs = [(torch.empty(it["C"], device=device, dtype=torch.float32), torch.empty(it["C"], device=device, dtype=torch.float32))
+            for it in items]
+    work.wait()                       # stream-level wait (no host synchronisation with the RCCL backend)
     gb, c0 = gathered.data_ptr(), 0
     for i, it in enumerate(items):
-        mean = torch.empty(it["C"], device=device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
+        mean, rstd = outs[i]
         _lib.check(lib.ct_bn_apply_fwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), gb + 4 * c0, gb + 4 * (Ct + c0),
                                        gb + 4 * (stride - 1), world, stride, _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"]),
                                        it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
@@ -661,8 +666,9 @@ def _bn_group_bwd(items, B, N, device, group, count):
                                         _stream()), "ct_bn_reduce_bwd")
         c0 += it["C"]
     local = sums.clone()                                                  # this rank's g_bias / g_weight
-    dist.all_reduce(sums, group=group)
+    work = dist.all_reduce(sums, group=group, async_op=True)             # non-blocking, as in _bn_group_fwd
     _sync_stats_collectives += 1
+    work.wait()
     c0 = 0
     for it in items:
         _lib.check(lib.ct_bn_apply_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),

@@ -49,3 +49,25 @@ def test_ddp_syncbn_single_rank_matches_plain():
         P.barrier(dist)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node (the build's gpurun boxes have one)")
+def test_two_rank_ddp_step_on_rccl():
+    """So that the first 8-GPU run is not also the first RCCL run with more than one rank: `bench.py --gpus 2 --mode
+    ddp-step` through launch.spawn_ranks (one process per GPU, RCCL over xGMI) — both ranks must be seen, the fused
+    SyncBatchNorm groups must issue their 76 statistics collectives per step (6 per MultiHeadUnion block x 12 + 2 x 2 for
+    the stock norms of stem and head), and the ranks must end the steps with identical parameters and running statistics.
+    Reference recipe: train_segmentation.py:58-61,128-130."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "ddp-step", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["world_size_seen"] == 2
+    assert cfg["norm_statistics_collectives_per_step"] == 76
+    assert cfg["params_equal_across_ranks"], cfg["param_checksum_spread"]

@@ -7,7 +7,9 @@ import glob
 
 CLK_GHZ = 2.4
 SIMDS = 256 * 4
-SHAPES = {"2d": "2D 32^2 C16 H64 B8", "3d": "3D 16^3 C16 H16 B8"}
+SHAPES = {"2d": "2D 32^2 C16 H64 B8", "3d": "3D 16^3 C16 H16 B8", "8c64": "3D 8^3 64->64 per group, 16 groups, B8",
+          "4c64": "3D 4^3 64->64 per group, 16 groups, B8", "2c64": "3D 2^3 64->64 per group, 16 groups, B8",
+          "8c64_2d": "2D 8^2 64->64 per group, 16 groups, B8"}
 
 
 def main():
@@ -29,13 +31,14 @@ def main():
             busy = sum(acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / max(1, len(acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"]))
             n = sum(acc[k]["SQ_INSTS_MFMA"]) / max(1, len(acc[k]["SQ_INSTS_MFMA"]))
             d = dur.get(k)
-            if not d or not busy:
+            if not d:
                 continue
             util = busy / (d * CLK_GHZ * SIMDS)
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             lines.append(f"  {short:42s} {d / 1e3:7.1f} us/launch  {n:12.0f} MFMA wave-instr  busy {busy:.3e} cyc  -> {100 * util:4.1f} % of the matrix pipes")
         lines.append("")
-    open("profiles/r1_gconv_mfma_util.txt", "w").write("\n".join(lines))
+    import sys
+    open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gconv_mfma_util.txt", "w").write("\n".join(lines))
     print("\n".join(lines))
 
 
