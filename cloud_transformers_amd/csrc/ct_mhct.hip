@@ -27,6 +27,14 @@ namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#ifndef CT_CORE_STAMP
+#define CT_CORE_STAMP 0      // diagnostic builds: wave 0 of every workgroup records s_memrealtime (100 MHz) at the phase boundaries
+#endif
+#if CT_CORE_STAMP
+#define CT_STAMP(K) do { if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CT_STAMP(K) do { } while (0)
+#endif
 #ifndef CT_CORE_ABL
 #define CT_CORE_ABL 0        // ablation builds (tools/dev/build_core_abl.sh): 1 no scatter, 2 no MFMA loop, 4 no gather, 8 no exchange
 #endif
@@ -48,6 +56,7 @@ struct CoreArgs {
   float* xch;            // [planes][S][C*G]   partial tiles of a cluster
   unsigned* flags;       // [planes] arrival counters, [planes] done counters, {occupancy sum (2 words), done}: zero between launches
   int* status;           // [1] set to 1 when a cluster gave up waiting (never in a correct run)
+  unsigned long long* stamps;   // diagnostic builds only
   int B, H, N;
   int S, SC, SN;         // workgroups per plane = SC (blocks of output channels) x SN (point ranges)
   int planes, xcd_map;
@@ -194,11 +203,13 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
   const size_t bh = (size_t)plane;
   const int sc = s / a.SN, sn = s - sc * a.SN;
 
+  CT_STAMP(0);
   // ---- zero the z tile (halo included)
   for (int t = tid; t < (Gm::Z_FLOATS >> 2); t += kCoreThreads) ((float4*)lds)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
 
+  CT_STAMP(1);
   // ---- A: scatter-max of this workgroup's point range
   const int nq = N >> 2;
   {
@@ -270,6 +281,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
   }
   __syncthreads();
 
+  CT_STAMP(2);
   // ---- X: merge the partial tiles of the plane's workgroups
   if (S > 1 && !(CT_CORE_ABL & 8)) {
     float* mine = a.xch + ((size_t)plane * S + s) * (size_t)(C * G);
@@ -322,6 +334,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     }
   }
 
+  CT_STAMP(3);
   // ---- side outputs of the merged tile: z (training) and the occupancy count; workgroup s takes C/S channels
   if (a.z_save != nullptr || a.occ != nullptr) {
     const int cper = C / S, c_lo = s * cper;
@@ -335,24 +348,11 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     }
     if (a.occ != nullptr) {
       cnt = wave_sum_int(cnt);
-      if (lane == 0 && cnt) atomicAdd(&s_flag[1], cnt);
-      __syncthreads();
-      if (tid == 0) {
-        // sum over all workgroups, written (and the two words zeroed for the next launch) by the last one to arrive;
-        // device-scope atomics execute at the memory side, in this lane's program order
-        unsigned long long* acc = (unsigned long long*)(a.flags + 2 * a.planes);
-        unsigned* done = (unsigned*)(acc + 1);
-        (void)__hip_atomic_fetch_add(acc, (unsigned long long)s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)(a.planes * S) - 1u) {
-          *a.occ = (long long)__hip_atomic_exchange(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      if (lane == 0 && cnt) atomicAdd(&s_flag[1], cnt);         // published to the other workgroups at the END of the kernel
     }
   }
 
+  CT_STAMP(4);
   // ---- B + C per block of 16 output channels
   const int nmt = (C / 16) / a.SC;
   const int col = lane & 15, kq = lane >> 4;
@@ -366,9 +366,15 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     __syncthreads();                             // previous block: gathers done with Y4, bank consumed
     store_wslice<DIM, WT, C>(WS, wr);
     __syncthreads();
-    // span of this wave (waves beyond the spans only help staging)
-    const bool has_item = wave < nspans;
-    const int q = (has_item ? wave : 0) * 16 + col;
+    // span of this wave.  With fewer spans than waves (16^2: 4, 8^3: 8 of 16) the contraction is split: wave w takes the
+    // k-blocks [kpart * KB / NK, ...) of span w % nspans, the partial accumulators of the waves with kpart > 0 meet in LDS
+    // (the gather tile is free until the block's result is written there) — four waves per SIMD instead of two hide the
+    // operand reads behind the matrix instructions (8^3 C32: 34.6 -> see DESIGN)
+    constexpr int NK = (kCoreThreads / 64) / nspans >= 2 && 4 * G >= nspans * 256 ? 2 : 1;
+    static_assert(KB % NK == 0, "k-blocks per part");
+    const bool has_item = wave < nspans * NK;
+    const int kpart = has_item ? wave / nspans : 0;
+    const int q = (has_item ? wave % nspans : 0) * 16 + col;
     int off;
     bool bl, br;
     {
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     floatx4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float bv = a.bias != nullptr ? a.bias[(size_t)h * C + co0 + kq * 4 + r] : 0.0f;
+      const float bv = (a.bias != nullptr && kpart == 0) ? a.bias[(size_t)h * C + co0 + kq * 4 + r] : 0.0f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j][r] = bv;
     }
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
           const int r = st * Gm::NRB + rl;
           const int roff = DIM == 2 ? r * WT : ((r / 3) * HS + (r % 3)) * WT;
 #pragma unroll 2
-          for (int kb = 0; kb < KB; ++kb) {
+          for (int kb = kpart * (KB / NK); kb < (kpart + 1) * (KB / NK); ++kb) {
             const float4 a4 = *(const float4*)__builtin_assume_aligned(ws + ((size_t)(rl * KB + kb) * 4 + kq) * 64 + col * 4, 16);
             const float* rp = Zf + (size_t)(kb * 4 + kq) * PLANE + off + roff;
             const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
@@ -418,7 +424,27 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
         __syncthreads();
       }
     }
-    if (has_item) {
+    if constexpr (NK > 1) {
+      float4* scratch = Y4 + (size_t)((has_item ? wave : 0) - nspans) * 256 + lane * 4;      // [wave - nspans][lane][4]
+      if (has_item && kpart > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scratch[j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      }
+      __syncthreads();
+      if (has_item && kpart == 0) {
+#pragma unroll
+        for (int kp = 1; kp < NK; ++kp) {
+          const float4* part = Y4 + (size_t)((kp - 1) * nspans + wave) * 256 + lane * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 t = part[j];
+            acc[j][0] += t.x; acc[j][1] += t.y; acc[j][2] += t.z; acc[j][3] += t.w;
+          }
+        }
+      }
+      __syncthreads();                           // the partials are read: the tile may be overwritten
+    }
+    if (has_item && kpart == 0) {
       // D_j: row (output channel) = kq*4 + r, column = quad col, element j  ->  Y4[kq][cell] = 4 channels of a cell
 #pragma unroll
       for (int j = 0; j < 4; ++j) Y4[(size_t)kq * G + q * 4 + j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
@@ -430,6 +456,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     }
     __syncthreads();
 
+    CT_STAMP(5 + 2 * mi);
     // ---- C: gather this block's 16 channels for the workgroup's point range
     {
       const int per = (nq + a.SN - 1) / a.SN;
@@ -481,6 +508,25 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
           for (int cj = 0; cj < 4; ++cj)
             st_stream4(dst + (size_t)(cq * 4 + cj) * N + n0, make_float4(o[cj][0], o[cj][1], o[cj][2], o[cj][3]));
         }
+      }
+    }
+    CT_STAMP(6 + 2 * mi);
+  }
+  // ---- occupancy: sum over all workgroups, written (and the words zeroed for the next launch) by the last one to arrive.
+  //      Relaxed device-scope atomics — they execute at the memory side, in this lane's program order: the sum's add has
+  //      returned before the arrival is counted — placed here, off the critical path (an acquire / release pair in the
+  //      middle of the kernel wrote back this XCD's L2 behind the z stores: 6-10 us per launch).
+  if (a.occ != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long* acc = (unsigned long long*)(a.flags + 2 * a.planes);
+      unsigned* done = (unsigned*)(acc + 1);
+      (void)__hip_atomic_fetch_add(acc, (unsigned long long)s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)(a.planes * S) - 1u) {
+        *a.occ = (long long)__hip_atomic_exchange(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -538,7 +584,11 @@ size_t core_ws_layout(int planes, int S, int C, int G, size_t& flags_off, size_t
   size_t xch = S > 1 ? (size_t)planes * S * C * G * 4 : 0;
   flags_off = (xch + 255) & ~(size_t)255;
   status_off = flags_off + ((size_t)2 * planes + 4) * 4;      // arrival + done counters per plane, {occupancy sum (2 words), done, spare}
+#if CT_CORE_STAMP
+  return status_off + 16 + (size_t)planes * S * 16 * 8;
+#else
   return status_off + 16;
+#endif
 }
 
 template <int DIM, int WT, int C>
@@ -602,6 +652,7 @@ int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int 
   a.xch = (float*)workspace;
   a.flags = (unsigned*)((char*)workspace + fo);
   a.status = (int*)((char*)workspace + so);
+  a.stamps = (unsigned long long*)((char*)workspace + so + 16);
   const int idx = core_shape_index(C, dim, W);
   if (idx == 0) return launch_core<2, 32, 16>(a, st);
   if (idx == 1) return launch_core<2, 16, 16>(a, st);

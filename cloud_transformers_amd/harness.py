@@ -247,33 +247,93 @@ class Trainer:
             parallel.save_exp_parallel([self.model, self.optimizer], ["generator", "g_opt"], exp_path=self.exp_dir,
                                        epoch=self.iters, epoch_name="iter")
 
-    def fit(self, max_iters=None):
-        """Runs `train.num_epochs` epochs (or `max_iters` steps); returns the rank-0 loss history."""
+    # -- one training step -------------------------------------------------------------------------------------------
+    def _eager_step(self, batch):
+        loss = self._loss(batch)
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach()
+
+    def _capture(self, batch):
+        """forward + loss + backward of one batch shape as ONE HIP graph on static input buffers (every libcloudct launch
+        goes to torch's current stream, so the whole step captures); the optimizer step stays outside.  The blocks' eager
+        launch rate is host-bound (~250 launches per block through Python / ctypes: the segmenter step 30.8 ms eager vs
+        24.8 ms graphed, profiles/r3_tools_output.txt)."""
+        self._static = [t.to(self.device).clone() for t in batch]
+        buffers = [b.clone() for b in self.model.buffers()]          # the warm-up passes must not count as training steps
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.optimizer.zero_grad(set_to_none=True)
+                self._loss(self._static).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for b, saved in zip(self.model.buffers(), buffers):
+                b.copy_(saved)
+        self.optimizer.zero_grad(set_to_none=True)                   # the graph re-creates the gradients in place
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._loss(self._static)
+            self._static_loss.backward()
+        self._graph_shapes = [tuple(t.shape) for t in batch]
+
+    def _graph_step(self, batch):
+        if self._graph is None:
+            self._capture(batch)
+        if [tuple(t.shape) for t in batch] != self._graph_shapes:    # a ragged last batch: run it eagerly
+            return self._eager_step(batch)
+        for dst, src in zip(self._static, batch):
+            dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        self.optimizer.step()
+        return self._static_loss.detach().clone()
+
+    def fit(self, max_iters=None, hip_graph=None, log_each=None):
+        """Runs `train.num_epochs` epochs (or `max_iters` steps); returns the rank-0 loss history.
+
+        `hip_graph` (default: `train.hip_graph` of the config, else False): replay forward + loss + backward as one HIP graph
+        (single process only: under DDP the gradient all-reduce is not captured, the step stays eager).  Losses stay on the
+        device and are read back every `log_each` steps (default `train.log_each`, else 10) in ONE transfer — no host
+        synchronisation per step (the reference reads the loss every step: train_segmentation.py:180-186)."""
         tr = self.cfg["train"]
-        history = []
+        use_graph = bool(tr.get("hip_graph", False) if hip_graph is None else hip_graph) and not parallel._active(self.dist)
+        log_each = int(tr.get("log_each", 10) if log_each is None else log_each)
+        self._graph = None
+        history, pending = [], []
+
+        def flush():
+            if pending and self.rank == 0:
+                stamps, vals = zip(*pending)
+                for it, v in zip(stamps, torch.stack(vals).tolist()):      # one device-to-host copy for the interval
+                    history.append(v)
+                    self.writer.add_scalar("train/loss", v, global_step=it)
+            pending.clear()
+
         for epoch in range(tr["num_epochs"]):
             if self.sampler is not None:
                 self.sampler.set_epoch(epoch)
             self.model.train()
             end = time.time()
             for batch in self.loader:
-                loss = self._loss(batch)
-                loss.backward()
-                self.optimizer.step()
-                self.optimizer.zero_grad()
+                loss = self._graph_step(batch) if use_graph else self._eager_step(batch)
                 if self.scheduler is not None:
                     self.scheduler.step()
                 reduced = parallel.reduce_loss_dict(self.dist, {"loss": loss})
-                if self.rank == 0:
-                    history.append(float(reduced["loss"].detach()))
-                    self.writer.add_scalar("train/loss", history[-1], global_step=self.iters)
-                    self.writer.add_scalar("train/batch_time", time.time() - end, global_step=self.iters)
-                end = time.time()
+                pending.append((self.iters, reduced["loss"].detach().reshape(())))
                 self.iters += 1
+                if self.iters % log_each == 0:
+                    flush()
+                    if self.rank == 0:
+                        self.writer.add_scalar("train/batch_time", (time.time() - end) / log_each, global_step=self.iters)
+                    end = time.time()
                 if self.iters % tr.get("save_each", 1 << 62) == 0:
                     self.save()
                 if max_iters is not None and self.iters >= max_iters:
+                    flush()
                     return history
+        flush()
         return history
 
 

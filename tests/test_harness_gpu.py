@@ -87,3 +87,23 @@ def test_completion_task_steps_the_inpainter_with_emd_and_chamfer(tmp_path):
     assert len(tr.optimizer.param_groups) == 2 and len(tr.optimizer.param_groups[1]["params"]) > 0
     hist = tr.fit(max_iters=2)
     assert len(hist) == 2 and all(v == v and 0.0 < v < 10.0 for v in hist)
+
+
+def test_graph_captured_step_follows_the_eager_trajectory(tmp_path):
+    """`fit(hip_graph=True)`: forward + loss + backward replayed as one HIP graph on static input buffers, losses read back
+    once per logging interval — the loss history must follow the eager run's (same seed, same batches; the captured step's
+    warm-up passes must not leak into the running statistics or the weights)."""
+    from cloud_transformers_amd import harness as H
+    (tmp_path / "segmenter.py").write_text(MODEL)
+    cfg_path = tmp_path / "s3dis.yaml"
+    cfg_path.write_text(CONFIG.format(root=str(tmp_path)).replace("save_each: 3", "save_each: 100000"))
+    hists = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        tr = H.Trainer(H.load_config(cfg_path), "segmentation", n_classes=13, device=torch.device("cuda", 0), dataset_length=16,
+                       channels=6, make_dirs=False)
+        hists.append(tr.fit(max_iters=6, hip_graph=graph, log_each=4))
+        assert len(hists[-1]) == 6
+    eager, graphed = hists
+    assert abs(eager[0] - graphed[0]) <= 1e-4 * abs(eager[0])                  # first step: identical weights and inputs
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)      # then the same trajectory

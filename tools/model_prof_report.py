@@ -1,5 +1,7 @@
-"""Where a model's training step spends its GPU time: reduce a rocprofv3 --kernel-trace --stats table (kernel_stats.csv of one
-of the tools/*_step_bench.py runs) to kernel families — library GEMMs, this package's norm / grouped-conv / raster / lattice /
+"""Where a model's training step spends its GPU time: reduce a rocprofv3 --kernel-trace table (kernel_trace.csv of one of the
+tools/*_step_bench.py runs) to kernel families.  Only the LAST QUARTER of the run's dispatches is counted — the
+tools end with HIP-graph replays of the step, so that window is steady state: the libraries' auto-tuning runs of the first
+steps (MIOpen's find mode executes every candidate solver, its naive kernels included) and the eager warm-up are left out — — library GEMMs, this package's norm / grouped-conv / raster / lattice /
 loss kernels, torch's elementwise and reduction kernels, MIOpen, copies — with each family's share of the kernel time and
 its five largest kernels.      python3 tools/model_prof_report.py <kernel_stats.csv> [title]"""
 import collections
@@ -31,23 +33,23 @@ def main():
     path = sys.argv[1]
     title = sys.argv[2] if len(sys.argv) > 2 else path
     tot = collections.defaultdict(float)
-    top = collections.defaultdict(list)
-    min_calls = int(sys.argv[3]) if len(sys.argv) > 3 else 14      # the runs take >= 20 steps: rarer kernels are one-off
-    dropped = 0.0
-    for r in csv.DictReader(open(path)):
-        ns = float(r["TotalDurationNs"])
-        if int(r["Calls"]) < min_calls or "naive_conv" in r["Name"]:     # library auto-tuning (MIOpen find mode runs its naive kernels), set-up
-            dropped += ns
-            continue
-        fam = family(r["Name"])
-        tot[fam] += ns
-        top[fam].append((ns, int(r["Calls"]), r["Name"]))
+    top = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
+    rows.sort()
+    rows = rows[int(0.75 * len(rows)):]         # the last quarter of the DISPATCHES (the auto-tuning runs are few, long launches early on)
+    t0, t1 = rows[0][0], rows[-1][1]
+    for a, b, name in rows:
+        fam = family(name)
+        tot[fam] += b - a
+        rec = top[fam][name]
+        rec[0] += b - a
+        rec[1] += 1
     total = sum(tot.values())
-    print("== %s: %.1f ms of steady-state kernel time in the profiled run (%.1f ms of one-off kernels — library auto-tuning, set-up — left out)"
-          % (title, total / 1e6, dropped / 1e6))
+    print("== %s: %.1f ms of kernel time in the steady-state window (the last quarter of the dispatches, %.3f s of wall time)"
+          % (title, total / 1e6, (t1 - t0) / 1e9))
     for fam, ns in sorted(tot.items(), key=lambda kv: -kv[1]):
         print("  %5.1f %%  %s" % (100 * ns / total, fam))
-        for kns, calls, name in sorted(top[fam], reverse=True)[:5]:
+        for kns, calls, name in sorted(((v[0], v[1], k) for k, v in top[fam].items()), reverse=True)[:5]:
             short = name.replace("(anonymous namespace)::", "").replace("void ", "")[:110]
             print("            %5.1f %%  %6d calls  %s" % (100 * kns / total, calls, short))
 
