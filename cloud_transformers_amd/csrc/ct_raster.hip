@@ -59,6 +59,8 @@ struct RasterArgs {
   int cnt_mask;         // STATS: contributions are counted in cnt_mask+1 (a power of two) counters indexed by cell & cnt_mask
   size_t gpos_stride;   // > 0: channel-chunk group cg writes its partial g_pos to g_pos + cg*gpos_stride floats (summed afterwards)
   int accumulate;       // hot Splat(max) backward: g_pos += result instead of g_pos = result
+  int nseg;             // fused Slice backward: point segments per (b,h) plane (grid.z = B * nseg); a.N = points per segment,
+  int Nrow;             //   Nrow = length of a row of the point-sized tensors (= N when nseg == 1)
 };
 
 template <int DIM, bool FROM_KEYS>
@@ -1552,27 +1554,45 @@ int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   return CT_OK;
 }
 
+// Point segments of the fused Slice backward.  A workgroup keeps its points' g_keys sums in registers: at most 4096 points
+// (two quads per thread).  Longer clouds (the decoders: N = 16384 at B2) are cut into nseg equal segments, one workgroup
+// (per chunk group) each, scattering into its own partial g_grid tile in the workspace; the partial tiles are added in a
+// fixed order afterwards (sum_parts_kernel) — N-split + second-stage merge, still bitwise reproducible.  The partial tiles
+// are small where this matters (grids of 16^2 .. 16^3 cells), and the 32 planes of such a batch become 128 workgroups.
+// Returns 0 when N cannot be cut into equal float4-addressable segments.
+int slice_bwd_segments(int N) {
+  const int cap = 8 * kHotThreads;
+  if (N <= cap) return 1;
+  int nseg = (N + cap - 1) / cap;
+  while (nseg <= 64 && (N % nseg != 0 || ((N / nseg) & 3) != 0)) ++nseg;
+  return nseg <= 64 ? nseg : 0;
+}
+
 // Slice backward, fused.  CT_EINVAL: not eligible.  ws: scratch for the chunk groups' partial g_keys (may be null: then
 // only shapes that need a single group per plane qualify).
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   HotPlan hp;
   int ncg = 1;
-  if ((C & 3) || (N & 3) || (g.G & 3) || N > 8 * kHotThreads) return 0;
-  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
-  return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
+  const int nseg = slice_bwd_segments(N);
+  if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  return (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
 }
 
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
-  if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
-  // 32 planes (B2 H16 of the completion heads): one or two workgroups per plane walking 16k points lose to the
-  // split-N scatter + gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16)
-  if ((long long)a.B * a.H < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
+  const int nseg = slice_bwd_segments(a.N);
+  if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
+  // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
+  // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
+  if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
-  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
   const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+  const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
+  if (nseg > 1 && (!ws || ws_bytes < (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0) + (size_t)nseg * grid_n * 4)) return CT_EINVAL;
   if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
     // no scratch for the partial sums: one group per plane if there are planes enough to be worth it
     if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
@@ -1583,15 +1603,24 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
   a.g_pos = ncg > 1 ? (float*)ws : g_pos;
   a.gpos_stride = ncg > 1 ? gpos_n : 0;
-  dim3 wgrid(ncg, a.H, a.B);
+  float* const g_grid = a.tile_out;
+  float* const grid_parts = nseg > 1 ? (float*)((char*)ws + (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0)) : nullptr;
+  if (nseg > 1) a.tile_out = grid_parts;
+  a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+  dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
 #define CT_MK_SLICE_BWD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true>
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
-  note(ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
+  note(nseg > 1 ? "slice_bwd_fused_segments" : ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
+    CT_CHECK_LAUNCH();
+  }
+  if (nseg > 1) {
+    CT_CLEAR_ERROR();
+    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, 0, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1704,22 +1733,26 @@ int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   HotPlan hp;
   int ncg = 1;
-  if ((C & 3) || (N & 3) || (g.G & 3) || N > 8 * kHotThreads) return 0;
-  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
-  return ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0;
+  const int nseg = slice_bwd_segments(N);
+  if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  return (ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
 }
 
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
-  if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
-  // 32 planes (B2 H16 of the completion heads): one or two workgroups per plane walking 16k points lose to the
-  // split-N scatter + gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16)
-  if ((long long)a.B * a.H < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
+  const int nseg = slice_bwd_segments(a.N);
+  if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
+  // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
+  // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
+  if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
-  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
   const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
+  if (nseg > 1 && (!ws || ws_bytes < (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0) + (size_t)nseg * grid_n * 4)) return CT_EINVAL;
   if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
     if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
     if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
@@ -1729,16 +1762,25 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
   a.g_pos = ncg > 1 ? (float*)ws : g_pos;
   a.gpos_stride = ncg > 1 ? gpos_n : 0;
-  dim3 wgrid(ncg, a.H, a.B);
+  float* const g_grid = a.tile_out;
+  float* const grid_parts = nseg > 1 ? (float*)((char*)ws + (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0)) : nullptr;
+  if (nseg > 1) a.tile_out = grid_parts;
+  a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+  dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
   if (nq <= kHotThreads)
     CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 1>), (slice_bwd_fused3_kernel<false, 1>), wgrid, hot_threads(nq), hp.lds, st, a, g);
   else
     CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 2>), (slice_bwd_fused3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
-  note(ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
+  note(nseg > 1 ? "slice_bwd_fused3_segments" : ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
+    CT_CHECK_LAUNCH();
+  }
+  if (nseg > 1) {
+    CT_CLEAR_ERROR();
+    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, 0, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;

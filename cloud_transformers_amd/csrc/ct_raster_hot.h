@@ -110,20 +110,21 @@ constexpr int kHotThreads = CT_HOT_THREADS;
 // would overflow the fixed-point bound): re-reads the channel's src row; rare.
 template <bool HAS_PAD>
 __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int ch, float* row_acc,
-                                                      int es = 1 /* element stride of the channel's cells in row_acc */) {
-  const int N = a.N, W1 = g.W[1];
-  const float* src = a.src + (bh * a.C + ch) * (size_t)N;
+                                                      int es = 1 /* element stride of the channel's cells in row_acc */,
+                                                      size_t so = 0 /* start of the workgroup's point segment in its rows */) {
+  const int N = a.N, W1 = g.W[1], Nr = a.Nrow > 0 ? a.Nrow : a.N;
+  const float* src = a.src + (bh * a.C + ch) * (size_t)Nr + so;
   for (int q = threadIdx.x; q < (N >> 2); q += blockDim.x) {
     const int n0 = q << 2;
-    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
-    const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * Nr + so + n0);
+    const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * Nr + so + n0);
     const float4 tf = *(const float4*)(src + n0);
     const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w}, f[4] = {tf.x, tf.y, tf.z, tf.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       Pt2 p;
       pt2_from_keys(kx[i], ky[i], g, W1, p);
-      const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : f[i];
+      const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + so + n0 + i) : f[i];
       float* T = row_acc + p.base * es;
       atomicAdd(T, x * p.cw[0]);
       atomicAdd(T + W1 * es, x * p.cw[1]);
@@ -148,8 +149,13 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
   int* cnt = acc + (size_t)CC * G;
   unsigned* s_max = (unsigned*)(cnt + G);
   unsigned* s_k = s_max + a.C;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // blockIdx.z = (cloud, point segment): with more points per plane than a workgroup's registers hold (N > 4096) or too
+  // few planes, a plane's points are dealt to a.nseg workgroups, each scattering into its own partial tile (summed
+  // afterwards in a fixed order: still bitwise reproducible); rows are Nr floats long, this segment starts at `so`
+  const int h = blockIdx.y, nsg = a.nseg > 0 ? a.nseg : 1, b = blockIdx.z / nsg, seg = blockIdx.z - b * nsg;
   const size_t bh = (size_t)b * a.H + h;
+  const int Nr = a.Nrow > 0 ? a.Nrow : a.N;          // (0: a caller that knows no segments)
+  const size_t so = (size_t)seg * a.N;
   const int tid = threadIdx.x;
   const int off[4] = {0, W1, 1, W1 + 1};
   int n0[QPT], n0c[QPT];
@@ -161,14 +167,14 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
     n0c[u] = active[u] ? n0[u] : 0;      // threads past the end load the first quad and ignore it
   }
 
-  const float* keyx = a.pos.keys + (bh * 2 + 0) * N;      // wave-uniform row pointers
-  const float* keyy = a.pos.keys + (bh * 2 + 1) * N;
+  const float* keyx = a.pos.keys + (bh * 2 + 0) * Nr + so;      // wave-uniform row pointers
+  const float* keyy = a.pos.keys + (bh * 2 + 1) * Nr + so;
   float pv[QPT][4];
 #pragma unroll
   for (int u = 0; u < QPT; ++u)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0[u] + i) : 1.0f;
+      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + so + n0[u] + i) : 1.0f;
   for (int i = tid; i < G + a.C + 1; i += blockDim.x) cnt[i] = 0;     // cnt, s_max, s_k are contiguous
   __syncthreads();
 #pragma unroll
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);            // multiple of 4
     const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
-    float* gout = a.tile_out + (bh * a.C + c0) * (size_t)G;
+    float* gout = a.tile_out + (((size_t)seg * a.B * a.H + bh) * a.C + c0) * (size_t)G;
     // stage the conv chunk channel-interleaved (4 coalesced dword loads -> one conflict-free ds_write_b128)
     if (GATHER) {
       for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       float mx[4];
 #pragma unroll
       for (int cj = 0; cj < 4; ++cj) {
-        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;      // wave-uniform
+        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;      // wave-uniform
         const float4 t = ld_stream4(row + n0c[0]);                         // read once
         fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
       }
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       for (int u = 1; u < QPT; ++u) {
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) {
-          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
           const float4 t = *(const float4*)(row + n0c[u]);
           const float tv[4] = {t.x, t.y, t.z, t.w};
           float m = mx[cj];
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
           asm volatile("" : "+v"(n0r));      // a real second load: keeps the compiler from carrying the first one's 16 values
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
-            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
             const float4 t = ld_stream4(row + n0r);                        // second and last read
             fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
 #pragma unroll
@@ -384,9 +390,9 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
           fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iqd, fixed);
 #if CT_FUSED_PAIR
           if (iq[cj] == 0.0f)      // this channel's pair is on the float path: its half of the pair's words holds a float
-            scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + (size_t)(cj >> 1) * 2 * G) + (cj & 1), 2);
+            scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + (size_t)(cj >> 1) * 2 * G) + (cj & 1), 2, so);
 #else
-          if (!fixed) scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + cj * G));
+          if (!fixed) scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(accq + cj * G), 1, so);
 #endif
         }
       }
@@ -445,8 +451,8 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       oy.x = gs[u][0][1] * ct_key_mask(ty.x); oy.y = gs[u][1][1] * ct_key_mask(ty.y);
       oy.z = gs[u][2][1] * ct_key_mask(ty.z); oy.w = gs[u][3][1] * ct_key_mask(ty.w);
       float* gp = a.g_pos + (size_t)cgi * a.gpos_stride;
-      st_stream4(gp + (bh * 2 + 0) * N + n0[u], ox);
-      st_stream4(gp + (bh * 2 + 1) * N + n0[u], oy);
+      st_stream4(gp + (bh * 2 + 0) * Nr + so + n0[u], ox);
+      st_stream4(gp + (bh * 2 + 1) * Nr + so + n0[u], oy);
     }
   }
 }

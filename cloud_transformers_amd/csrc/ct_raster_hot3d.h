@@ -64,8 +64,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
   int* cnt = acc + (size_t)CC * G;
   unsigned* s_max = (unsigned*)(cnt + G);
   unsigned* s_k = s_max + a.C;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, nsg = a.nseg > 0 ? a.nseg : 1, b = blockIdx.z / nsg, seg = blockIdx.z - b * nsg;      // point segments: see slice_bwd_fused_kernel
   const size_t bh = (size_t)b * a.H + h;
+  const int Nr = a.Nrow > 0 ? a.Nrow : a.N;          // (0: a caller that knows no segments)
+  const int so = seg * a.N;
   const int tid = threadIdx.x;
   int off[8];
   corner_offsets3(g, off);
@@ -82,14 +84,14 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
   for (int u = 0; u < QPT; ++u)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0[u] + i) : 1.0f;
+      pv[u][i] = (HAS_PAD && active[u]) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + so + n0[u] + i) : 1.0f;
   for (int i = tid; i < G + a.C + 1; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < QPT; ++u) {
     if (active[u]) {
       float k[3][4];
-      load_keys3(a.pos.keys, bh, N, n0[u], k);
+      load_keys3(a.pos.keys, bh, Nr, so + n0[u], k);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         Pt3 p;
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);
     const float* gin = a.tile_in + (bh * a.C + c0) * (size_t)G;
-    float* gout = a.tile_out + (bh * a.C + c0) * (size_t)G;
+    float* gout = a.tile_out + (((size_t)seg * a.B * a.H + bh) * a.C + c0) * (size_t)G;
     for (int t = tid; t < (cc >> 2) * G; t += blockDim.x) {
       const int cq = t / G, cell = t - cq * G;
       const float* p = gin + (size_t)(cq * 4) * G + cell;
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
       float mx[4];
 #pragma unroll
       for (int cj = 0; cj < 4; ++cj) {
-        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+        const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
         const float4 t = ld_stream4(row + n0c[0]);
         fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
       }
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
       for (int u = 1; u < QPT; ++u) {
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) {
-          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+          const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
           const float4 t = *(const float4*)(row + n0c[u]);
           const float tv[4] = {t.x, t.y, t.z, t.w};
           float m = mx[cj];
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           asm volatile("" : "+v"(n0r));
 #pragma unroll
           for (int cj = 0; cj < 4; ++cj) {
-            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            const float* row = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
             const float4 t = ld_stream4(row + n0r);
             fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
 #pragma unroll
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           }
         }
         float k[3][4];
-        load_keys3(a.pos.keys, bh, N, n0c[u], k);
+        load_keys3(a.pos.keys, bh, Nr, so + n0c[u], k);
         if (!kKeepGs) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) gs[0][i][0] = gs[0][i][1] = gs[0][i][2] = 0.0f;
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (!kKeepGs && active[u]) store_gkeys3(gpos, bh, N, n0c[u], gs[0], k, chunk > cgi || cq > 0);
+        if (!kKeepGs && active[u]) store_gkeys3(gpos, bh, Nr, so + n0c[u], gs[0], k, chunk > cgi || cq > 0);
       }
       if (any_float) {
 #pragma unroll 1
@@ -289,18 +291,18 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
           if (!fixed) {
             float* row_acc = (float*)(accq + cj * G);
 #endif
-            const float* src = a.src + (bh * a.C + ch0 + cj) * (size_t)N;
+            const float* src = a.src + (bh * a.C + ch0 + cj) * (size_t)Nr + so;
             for (int qd = tid; qd < (N >> 2); qd += blockDim.x) {
               const int nn = qd << 2;
               float k[3][4];
-              load_keys3(a.pos.keys, bh, N, nn, k);
+              load_keys3(a.pos.keys, bh, Nr, so + nn, k);
               const float4 tf = *(const float4*)(src + nn);
               const float f[4] = {tf.x, tf.y, tf.z, tf.w};
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 Pt3 p;
                 pt3_from_keys(k[0][i], k[1][i], k[2][i], g, p);
-                const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + nn + i) : f[i];
+                const float x = HAS_PAD ? f[i] * ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + so + nn + i) : f[i];
 #pragma unroll
                 for (int v = 0; v < 8; ++v) atomicAdd(row_acc + (p.base + off[v]) * es, x * p.cw[v]);
               }
@@ -352,8 +354,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
   if (kKeepGs) {
     if (active[0]) {
       float k[3][4];
-      load_keys3(a.pos.keys, bh, N, n0[0], k);
-      store_gkeys3(gpos, bh, N, n0[0], gs[0], k, false);
+      load_keys3(a.pos.keys, bh, Nr, so + n0[0], k);
+      store_gkeys3(gpos, bh, Nr, so + n0[0], gs[0], k, false);
     }
   }
 }
