@@ -1560,12 +1560,19 @@ int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
 // fixed order afterwards (sum_parts_kernel) — N-split + second-stage merge, still bitwise reproducible.  The partial tiles
 // are small where this matters (grids of 16^2 .. 16^3 cells), and the 32 planes of such a batch become 128 workgroups.
 // Returns 0 when N cannot be cut into equal float4-addressable segments.
-int slice_bwd_segments(int N) {
+int slice_bwd_segments(int B, int H, int C, int N, int G, int dim) {
   const int cap = 8 * kHotThreads;
   if (N <= cap) return 1;
   int nseg = (N + cap - 1) / cap;
   while (nseg <= 64 && (N % nseg != 0 || ((N / nseg) & 3) != 0)) ++nseg;
-  return nseg <= 64 ? nseg : 0;
+  if (nseg > 64) return 0;
+  // Workgroups beyond one per (plane, segment) come from chunk groups, whose partial g_keys (dim * N floats per plane and
+  // group) go through memory; where a plane's grid is smaller than its keys (16^2, 8^3: the decoders' small heads) more
+  // segments are the cheaper way to fill the chip: their partial tiles are C * G floats.
+  while ((long long)B * H * nseg < 256 && (long long)C * G <= (long long)dim * N && N % (2 * nseg) == 0 &&
+         ((N / (2 * nseg)) & 3) == 0 && N / (2 * nseg) >= 1024)
+    nseg *= 2;
+  return nseg;
 }
 
 // Slice backward, fused.  CT_EINVAL: not eligible.  ws: scratch for the chunk groups' partial g_keys (may be null: then
@@ -1573,7 +1580,7 @@ int slice_bwd_segments(int N) {
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   HotPlan hp;
   int ncg = 1;
-  const int nseg = slice_bwd_segments(N);
+  const int nseg = slice_bwd_segments(B, H, C, N, g.G, 2);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
   if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
   return (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
@@ -1582,7 +1589,7 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
-  const int nseg = slice_bwd_segments(a.N);
+  const int nseg = slice_bwd_segments(a.B, a.H, a.C, a.N, g.G, 2);
   if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
   // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
   // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
@@ -1733,7 +1740,7 @@ int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   HotPlan hp;
   int ncg = 1;
-  const int nseg = slice_bwd_segments(N);
+  const int nseg = slice_bwd_segments(B, H, C, N, g.G, 3);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
   if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
   return (ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
@@ -1742,7 +1749,7 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
-  const int nseg = slice_bwd_segments(a.N);
+  const int nseg = slice_bwd_segments(a.B, a.H, a.C, a.N, g.G, 3);
   if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
   // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
   // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
