@@ -219,6 +219,49 @@ def test_core_workspace_is_reusable_launch_after_launch(core_flags, B, H, N, dim
         assert relerr(got["out"], refs[rep % 2]["out"]) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,N,dim,W,C", [(8, 16, 4096, 3, 8, 32), (2, 16, 16384, 2, 16, 16)])
+def test_core_clusters_under_uneven_load(core_flags, B, H, N, dim, W, C):
+    """The cluster hand-off (partial grids through the workspace, agent-scope arrive / acquire) with the chip busy and unevenly
+    loaded: a stream of large copies runs beside 40 back-to-back launches on alternating inputs; every launch's z must be the
+    three-kernel chain's bit for bit (idle chips and uniform load hide stale reads: MI355X_MICROARCH.md, hand-off testing)."""
+    from cloud_transformers_amd.ops import _ptr, _stream
+    L, lib = _libs()
+    core_flags(0)
+    Wl = [W] * dim
+    Wa = L.int_array(Wl)
+    sets = []
+    for i in range(2):
+        keys, feat, w, bias, _, _ = make_inputs(B, H, C, N, dim, 300 + i)
+        ref = unfused_chain(keys, feat, w, bias, None, W, H, dim)
+        sets.append(([t.cuda().contiguous() for t in (keys, feat, w, bias)], ref["z"].clone(), ref["occ"]))
+    nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
+    ws = torch.empty(nws, device="cuda", dtype=torch.uint8)
+    L.check(lib.ct_mhct_core_workspace_init(_ptr(ws), nws, B, H, C, N, dim, Wa, _stream()), "init")
+    out = torch.empty(B, H * C, N, device="cuda")
+    zs = [torch.empty(B, H * C, *Wl, device="cuda") for _ in range(40)]
+    y = torch.empty(B, H * C, *Wl, device="cuda")
+    occs = torch.zeros(40, device="cuda", dtype=torch.int64)
+    side = torch.cuda.Stream()
+    big_a = torch.empty(96 << 20, device="cuda", dtype=torch.uint8)         # a few CUs' worth of copy kernels at a time
+    big_b = torch.empty_like(big_a)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            big_b[: (17 << 20)].copy_(big_a[: (17 << 20)])
+            big_a.copy_(big_b)
+    for it in range(40):
+        (keys, feat, w, bias), _, _ = sets[it % 2]
+        L.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), None, 0, _ptr(w), _ptr(bias), _ptr(out), _ptr(zs[it]), _ptr(y),
+                                     occs[it:].data_ptr(), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()), "core")
+    torch.cuda.synchronize()
+    st = ctypes.c_int(-1)
+    L.check(lib.ct_mhct_core_status(_ptr(ws), nws, B, H, C, N, dim, Wa, ctypes.byref(st), _stream()), "status")
+    assert st.value == 0
+    for it in range(40):
+        assert torch.equal(zs[it], sets[it % 2][1]), "launch %d read a stale or partial grid" % it
+        assert int(occs[it]) == sets[it % 2][2]
+
+
 def test_core_autograd_function_matches_module_chain(core_flags):
     """ops.mhct_core (autograd.Function over the ABI pair) against the unfused autograd chain of this package"""
     from cloud_transformers_amd import ops
