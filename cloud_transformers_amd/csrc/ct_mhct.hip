@@ -150,26 +150,141 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 
 // slice `st` of the filter bank of output channels co0..co0+15 of head h:
 //   ws[((rl*KB + kb)*4 + k)*64 + m*4 + dx] = W[co0 + m][ci = kb*4 + k][tap = (st*NRB + rl)*3 + dx]     (dx == 3: 0)
-template <int DIM, int WT, int C>
-__device__ __forceinline__ void load_wslice(const float* wh, int co0, int st, float (&r)[CoreGeom<DIM, WT, C>::NLD]) {
+// TR (backward-data): the bank transposed and flipped, = W[kb*4 + k][co0 + m][taps - 1 - tap]
+template <int DIM, int WT, int C, bool TR, int THREADS>
+__device__ __forceinline__ void load_wslice(const float* wh, int co0, int st,
+                                            float (&r)[(CoreGeom<DIM, WT, C>::SLICE + THREADS - 1) / THREADS]) {
   using Gm = CoreGeom<DIM, WT, C>;
 #pragma unroll
-  for (int u = 0; u < Gm::NLD; ++u) {
-    const int i = (int)threadIdx.x + u * kCoreThreads;
+  for (int u = 0; u < (Gm::SLICE + THREADS - 1) / THREADS; ++u) {
+    const int i = (int)threadIdx.x + u * THREADS;
     const int dx = i & 3, m = (i >> 2) & 15, k = (i >> 6) & 3, rk = i >> 8;
     const int kb = rk % Gm::KB, rl = rk / Gm::KB;
     const int tap = (st * Gm::NRB + rl) * 3 + dx;
-    r[u] = (i < Gm::SLICE && dx < 3) ? wh[((size_t)(co0 + m) * C + kb * 4 + k) * Gm::TAPS + tap] : 0.0f;
+    if (!TR) r[u] = (i < Gm::SLICE && dx < 3) ? wh[((size_t)(co0 + m) * C + kb * 4 + k) * Gm::TAPS + tap] : 0.0f;
+    else r[u] = (i < Gm::SLICE && dx < 3) ? wh[((size_t)(kb * 4 + k) * C + co0 + m) * Gm::TAPS + (Gm::TAPS - 1 - tap)] : 0.0f;
   }
 }
-template <int DIM, int WT, int C>
-__device__ __forceinline__ void store_wslice(float* ws, const float (&r)[CoreGeom<DIM, WT, C>::NLD]) {
+template <int DIM, int WT, int C, int THREADS>
+__device__ __forceinline__ void store_wslice(float* ws, const float (&r)[(CoreGeom<DIM, WT, C>::SLICE + THREADS - 1) / THREADS]) {
   using Gm = CoreGeom<DIM, WT, C>;
 #pragma unroll
-  for (int u = 0; u < Gm::NLD; ++u) {
-    const int i = (int)threadIdx.x + u * kCoreThreads;
+  for (int u = 0; u < (Gm::SLICE + THREADS - 1) / THREADS; ++u) {
+    const int i = (int)threadIdx.x + u * THREADS;
     if (i < Gm::SLICE) ws[i] = r[u];
   }
+}
+
+// One block of 16 output channels (co0 .. co0 + 15) of a plane's grouped 3^DIM convolution on the matrix cores.  `Zin` is the
+// zero-padded input tile [C][PLANE] (kCoreSlack floats of slack in front), `wh` the head's filter bank (C x C x taps); TR reads it
+// transposed and flipped (backward-data: the input is then g_y and the result g_z of channels co0 ..).  The result lands in the
+// channel-interleaved tile Y4 ([4][G] x float4) and, optionally, in `y_save` (rows of G floats, already offset to co0).  Every
+// thread of the workgroup calls it (barriers inside; the first one also fences earlier readers of Y4 / WS, the last one
+// publishes Y4).
+template <int DIM, int WT, int C, bool TR, int THREADS = kCoreThreads>
+__device__ __forceinline__ void core_conv_block(const float* Zin, const float* wh, int co0, const float* bias, float* WS, float4* Y4,
+                                                float* y_save) {
+  using Gm = CoreGeom<DIM, WT, C>;
+  constexpr int G = Gm::G, PLANE = Gm::PLANE, HS = Gm::HS, KB = Gm::KB;
+  constexpr int wq = WT >> 2;
+  constexpr int nspans = G >> 6;                 // spans of 16 quads = 64 cells
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  float wr[(Gm::SLICE + THREADS - 1) / THREADS];
+  load_wslice<DIM, WT, C, TR, THREADS>(wh, co0, 0, wr);
+  __syncthreads();                             // previous block: gathers done with Y4, bank consumed
+  store_wslice<DIM, WT, C, THREADS>(WS, wr);
+  __syncthreads();
+  // span of this wave.  With fewer spans than waves (16^2: 4, 8^3: 8 of 16) the contraction is split: wave w takes the
+  // k-blocks [kpart * KB / NK, ...) of span w % nspans, the partial accumulators of the waves with kpart > 0 meet in LDS
+  // (the gather tile is free until the block's result is written there) — four waves per SIMD instead of two hide the
+  // operand reads behind the matrix instructions (8^3 C32: 34.6 -> see DESIGN)
+  constexpr int NK = (THREADS / 64) / nspans >= 2 && 4 * G >= nspans * 256 ? 2 : 1;
+  static_assert(KB % NK == 0, "k-blocks per part");
+  const bool has_item = wave < nspans * NK;
+  const int kpart = has_item ? wave / nspans : 0;
+  const int q = (has_item ? wave % nspans : 0) * 16 + col;
+  int off;
+  bool bl, br;
+  {
+    const int xq = q % wq;
+    const int x0 = xq * 4;
+    bl = x0 == 0;
+    br = x0 + 4 == WT;
+    if constexpr (DIM == 2) {
+      off = (q / wq) * WT + x0;
+    } else {
+      const int y = (q / wq) % WT, z = q / (wq * WT);
+      off = (z * HS + y) * WT + x0;
+    }
+  }
+  floatx4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float bv = (bias != nullptr && kpart == 0) ? bias[kq * 4 + r] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][r] = bv;
+  }
+  for (int st = 0; st < Gm::NST; ++st) {
+    if (st + 1 < Gm::NST) load_wslice<DIM, WT, C, TR, THREADS>(wh, co0, st + 1, wr);
+    const float* ws = WS + (size_t)(st & (Gm::NBUF - 1)) * Gm::SLICE;
+    if (has_item && !(CT_CORE_ABL & 2)) {
+#pragma unroll
+      for (int rl = 0; rl < Gm::NRB; ++rl) {
+        const int r = st * Gm::NRB + rl;
+        const int roff = DIM == 2 ? r * WT : ((r / 3) * HS + (r % 3)) * WT;
+#pragma unroll 2
+        for (int kb = kpart * (KB / NK); kb < (kpart + 1) * (KB / NK); ++kb) {
+          const float4 a4 = *(const float4*)__builtin_assume_aligned(ws + ((size_t)(rl * KB + kb) * 4 + kq) * 64 + col * 4, 16);
+          const float* rp = Zin + (size_t)(kb * 4 + kq) * PLANE + off + roff;
+          const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
+          const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
+          const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
+          const float av[3] = {a4.x, a4.y, a4.z};
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dx], v[j + dx], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < Gm::NST) {
+      store_wslice<DIM, WT, C, THREADS>(WS + (size_t)((st + 1) & (Gm::NBUF - 1)) * Gm::SLICE, wr);
+      __syncthreads();
+    }
+  }
+  if constexpr (NK > 1) {
+    float4* scratch = Y4 + (size_t)((has_item ? wave : 0) - nspans) * 256 + lane * 4;      // [wave - nspans][lane][4]
+    if (has_item && kpart > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) scratch[j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    }
+    __syncthreads();
+    if (has_item && kpart == 0) {
+#pragma unroll
+      for (int kp = 1; kp < NK; ++kp) {
+        const float4* part = Y4 + (size_t)((kp - 1) * nspans + wave) * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = part[j];
+          acc[j][0] += t.x; acc[j][1] += t.y; acc[j][2] += t.z; acc[j][3] += t.w;
+        }
+      }
+    }
+    __syncthreads();                           // the partials are read: the tile may be overwritten
+  }
+  if (has_item && kpart == 0) {
+    // D_j: row (output channel) = kq*4 + r, column = quad col, element j  ->  Y4[kq][cell] = 4 channels of a cell
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y4[(size_t)kq * G + q * 4 + j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    if (y_save != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *(float4*)(y_save + (size_t)(kq * 4 + r) * G + q * 4) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+  }
+  __syncthreads();
+
 }
 
 // grid = (planes * S)
@@ -355,106 +470,11 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
   CT_STAMP(4);
   // ---- B + C per block of 16 output channels
   const int nmt = (C / 16) / a.SC;
-  const int col = lane & 15, kq = lane >> 4;
-  constexpr int wq = WT >> 2;
-  constexpr int nspans = G >> 6;                 // spans of 16 quads = 64 cells
   const float* wh = a.w + (size_t)h * C * C * Gm::TAPS;
   for (int mi = 0; mi < nmt; ++mi) {
     const int co0 = (sc * nmt + mi) * 16;
-    float wr[Gm::NLD];
-    load_wslice<DIM, WT, C>(wh, co0, 0, wr);
-    __syncthreads();                             // previous block: gathers done with Y4, bank consumed
-    store_wslice<DIM, WT, C>(WS, wr);
-    __syncthreads();
-    // span of this wave.  With fewer spans than waves (16^2: 4, 8^3: 8 of 16) the contraction is split: wave w takes the
-    // k-blocks [kpart * KB / NK, ...) of span w % nspans, the partial accumulators of the waves with kpart > 0 meet in LDS
-    // (the gather tile is free until the block's result is written there) — four waves per SIMD instead of two hide the
-    // operand reads behind the matrix instructions (8^3 C32: 34.6 -> see DESIGN)
-    constexpr int NK = (kCoreThreads / 64) / nspans >= 2 && 4 * G >= nspans * 256 ? 2 : 1;
-    static_assert(KB % NK == 0, "k-blocks per part");
-    const bool has_item = wave < nspans * NK;
-    const int kpart = has_item ? wave / nspans : 0;
-    const int q = (has_item ? wave % nspans : 0) * 16 + col;
-    int off;
-    bool bl, br;
-    {
-      const int xq = q % wq;
-      const int x0 = xq * 4;
-      bl = x0 == 0;
-      br = x0 + 4 == WT;
-      if constexpr (DIM == 2) {
-        off = (q / wq) * WT + x0;
-      } else {
-        const int y = (q / wq) % WT, z = q / (wq * WT);
-        off = (z * HS + y) * WT + x0;
-      }
-    }
-    floatx4 acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float bv = (a.bias != nullptr && kpart == 0) ? a.bias[(size_t)h * C + co0 + kq * 4 + r] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j][r] = bv;
-    }
-    for (int st = 0; st < Gm::NST; ++st) {
-      if (st + 1 < Gm::NST) load_wslice<DIM, WT, C>(wh, co0, st + 1, wr);
-      const float* ws = WS + (size_t)(st & (Gm::NBUF - 1)) * Gm::SLICE;
-      if (has_item && !(CT_CORE_ABL & 2)) {
-#pragma unroll
-        for (int rl = 0; rl < Gm::NRB; ++rl) {
-          const int r = st * Gm::NRB + rl;
-          const int roff = DIM == 2 ? r * WT : ((r / 3) * HS + (r % 3)) * WT;
-#pragma unroll 2
-          for (int kb = kpart * (KB / NK); kb < (kpart + 1) * (KB / NK); ++kb) {
-            const float4 a4 = *(const float4*)__builtin_assume_aligned(ws + ((size_t)(rl * KB + kb) * 4 + kq) * 64 + col * 4, 16);
-            const float* rp = Zf + (size_t)(kb * 4 + kq) * PLANE + off + roff;
-            const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
-            const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
-            const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
-            const float av[3] = {a4.x, a4.y, a4.z};
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dx], v[j + dx], acc[j], 0, 0, 0);
-          }
-        }
-      }
-      if (st + 1 < Gm::NST) {
-        store_wslice<DIM, WT, C>(WS + (size_t)((st + 1) & (Gm::NBUF - 1)) * Gm::SLICE, wr);
-        __syncthreads();
-      }
-    }
-    if constexpr (NK > 1) {
-      float4* scratch = Y4 + (size_t)((has_item ? wave : 0) - nspans) * 256 + lane * 4;      // [wave - nspans][lane][4]
-      if (has_item && kpart > 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) scratch[j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-      }
-      __syncthreads();
-      if (has_item && kpart == 0) {
-#pragma unroll
-        for (int kp = 1; kp < NK; ++kp) {
-          const float4* part = Y4 + (size_t)((kp - 1) * nspans + wave) * 256 + lane * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 t = part[j];
-            acc[j][0] += t.x; acc[j][1] += t.y; acc[j][2] += t.z; acc[j][3] += t.w;
-          }
-        }
-      }
-      __syncthreads();                           // the partials are read: the tile may be overwritten
-    }
-    if (has_item && kpart == 0) {
-      // D_j: row (output channel) = kq*4 + r, column = quad col, element j  ->  Y4[kq][cell] = 4 channels of a cell
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Y4[(size_t)kq * G + q * 4 + j] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-      if (a.y_save != nullptr && sn == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *(float4*)(a.y_save + (bh * C + co0 + kq * 4 + r) * (size_t)G + q * 4) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-      }
-    }
-    __syncthreads();
+    core_conv_block<DIM, WT, C, false>(Zf, wh, co0, a.bias != nullptr ? a.bias + (size_t)h * C + co0 : nullptr, WS, Y4,
+                                       (a.y_save != nullptr && sn == 0) ? a.y_save + (bh * C + co0) * (size_t)G : nullptr);
 
     CT_STAMP(5 + 2 * mi);
     // ---- C: gather this block's 16 channels for the workgroup's point range
@@ -530,6 +550,449 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// LDS-resident BACKWARD of the core for the one grid whose five tiles fit a CU: 2D 16^2 with 16 features per head (z, y, the
+// integer accumulators of g_y, g_y as the transposed convolution's input, g_z: 85 KiB; 32^2 C16 and 8^3 C32 would need
+// > 190 KiB and run ct_mhct_core_bwd on saved grids).  One workgroup per (batch, head) plane RECOMPUTES z and y from the
+// points (nothing of the forward is kept in HBM), then walks the chain backwards:
+//   P1 scatter-max z (+ points per base cell)      P2 K = most contributions to a cell      P3 y = conv(z) + bias (matrix cores)
+//   P4 per-channel max |g_out|                     P5 Slice backward: g_keys (gather of y at the corners) and the fixed-point
+//   scatter-add of g_out into the accumulators (quantum per channel, as slice_bwd_fused_kernel)
+//   P6 g_y -> float, padded layout; bias cotangent P7 g_z = transposed conv of g_y (matrix cores)
+//   P8 filter cotangent of the plane: a tap per wave, K = the 256 positions (matrix cores), to the workspace
+//   P9 Splat(max) backward: a contribution bit-equal to its cell's z claims the cell (ds_cmpst: single winner on exact ties,
+//   as torch_scatter's backward) and receives g_z; g_feat, g_keys += .
+// The per-plane filter / bias cotangents are added over the batch in a fixed order by core_wgrad_reduce_kernel.
+// ---------------------------------------------------------------------------
+struct CoreBwdArgs {
+  const float* keys;     // (B, H*2, N)
+  const float* feat;     // (B, H*C, N)
+  const void* pad;
+  int pad_dtype;
+  const float* w;        // (H*C, C, 9)
+  const float* bias;     // (H*C) | null
+  const float* g_out;    // (B, H*C, N)
+  float* g_feat;         // (B, H*C, N)
+  float* g_keys;         // (B, H*2, N)
+  float* gw_part;        // [planes][C*C*9]
+  float* gb_part;        // [planes][C]
+  float* gk_scr;         // [planes][2][N]   Splat's share of g_keys (added to Slice's at the end of the kernel)
+  int B, H, N;
+  unsigned long long* stamps;   // diagnostic builds only
+};
+
+constexpr unsigned kCoreClaimed = 0x7FFFFFFFu;     // a NaN pattern no product of finite inputs has: a claimed cell
+
+__device__ __forceinline__ unsigned core_wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+// power-of-two quantum of a channel whose sums are bounded by MK = max |src| * max contributions per cell
+__device__ __forceinline__ void core_quantum(float MK, float& q, float& iq, bool& fixed) {
+  fixed = MK < 1e37f;                              // false for inf / NaN as well
+  int ex = 0;
+  if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
+  ex = max(ex, -90);
+  q = ldexpf(1.0f, ex - 30);
+  iq = ldexpf(1.0f, 30 - ex);
+}
+
+__device__ __forceinline__ int core_cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+struct CorePt2 {
+  float w0x, w1x, w0y, w1y, cw[4];
+  int cb;        // compact base cell
+};
+template <int WT>
+__device__ __forceinline__ void core_pt2(float kx, float ky, CorePt2& p) {
+  constexpr float hw = (float)(WT - 1) * 0.5f;
+  int fx, fy;
+  ct_axis(kx, hw, WT, p.w0x, p.w1x, fx);
+  ct_axis(ky, hw, WT, p.w0y, p.w1y, fy);
+  p.cb = fx * WT + fy;
+  p.cw[0] = p.w0x * p.w0y;
+  p.cw[1] = p.w1x * p.w0y;
+  p.cw[2] = p.w0x * p.w1y;
+  p.cw[3] = p.w1x * p.w1y;
+}
+
+constexpr int kBwdThreads = 512;     // 8 waves: the register budget of 256 per lane keeps a point's 36 LDS values live without spills
+
+template <int WT, int C, bool HAS_PAD>
+__global__ void __launch_bounds__(kBwdThreads) mhct_core_bwd_kernel(CoreBwdArgs a) {
+  using Gm = CoreGeom<2, WT, C>;
+  constexpr int G = Gm::G, PLANE = Gm::PLANE, TAPS = Gm::TAPS;
+  static_assert(C == 16 && Gm::NST == 1 && Gm::G == 256, "one 16-channel block, whole filter bank staged, one wave per 256-cell channel");
+  extern __shared__ __align__(16) float lds[];
+  float* const Zf = lds + kCoreSlack;
+  unsigned* const Zu = (unsigned*)Zf;
+  float4* const Y4 = (float4*)(lds + Gm::Z_FLOATS);
+  float* const WS = lds + Gm::Z_FLOATS + 16 * G;
+  int* const ACC = (int*)(WS + Gm::NBUF * Gm::SLICE);            // [C][G]
+  float* const GYf = (float*)(ACC + C * G) + kCoreSlack;          // padded layout, as Zf
+  int* const CNT = (int*)(GYf - kCoreSlack + Gm::Z_FLOATS);       // [G]
+  unsigned* const SMAX = (unsigned*)(CNT + G);                    // [C]
+  unsigned* const SK = SMAX + C;                                  // [1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x, N = a.N;
+  const int b = plane / a.H, h = plane - b * a.H;
+  const size_t bh = (size_t)plane;
+  const int nq = N >> 2;
+  const float* keyx = a.keys + (bh * 2 + 0) * N;
+  const float* keyy = a.keys + (bh * 2 + 1) * N;
+  const float* wh = a.w + (size_t)h * C * C * TAPS;
+  constexpr int offc[4] = {0, WT, 1, WT + 1};                     // corner v = dx + 2 dy: compact offsets (= padded-layout offsets)
+
+  CT_STAMP(0);
+  // ---- P0: zero everything that is accumulated into
+  {
+    constexpr int n4 = (Gm::Z_FLOATS + 16 * G + Gm::NBUF * Gm::SLICE + C * G + Gm::Z_FLOATS + G + C + 4) >> 2;
+    for (int t = tid; t < n4; t += kBwdThreads) ((float4*)lds)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  CT_STAMP(1);
+  // ---- P1: z = scatter-max of the plane's points; points per base cell
+  for (int q = tid; q < nq; q += kBwdThreads) {
+    const int n0 = q << 2;
+    const float4 tx = *(const float4*)(keyx + n0), ty = *(const float4*)(keyy + n0);
+    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+    int cb[4];
+    float cw[4][4], pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      CorePt2 p;
+      core_pt2<WT>(kx[i], ky[i], p);
+      cb[i] = p.cb;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) cw[i][v] = p.cw[v];
+      atomicAdd(&CNT[p.cb], 1);
+      pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+    }
+    float nx[4][4];                                   // next channel group's rows, requested before this group's atomics
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const float4 t = *(const float4*)(a.feat + (bh * C + cj) * (size_t)N + n0);
+      nx[cj][0] = t.x; nx[cj][1] = t.y; nx[cj][2] = t.z; nx[cj][3] = t.w;
+    }
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float fv[4][4];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fv[cj][i] = nx[cj][i];
+      if (c0 + 4 < C) {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const float4 t = *(const float4*)(a.feat + (bh * C + c0 + 4 + cj) * (size_t)N + n0);
+          nx[cj][0] = t.x; nx[cj][1] = t.y; nx[cj][2] = t.z; nx[cj][3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float prod = f * cw[i][v];
+            if (prod > 0.0f) atomicMax(Zu + (size_t)(c0 + cj) * PLANE + cb[i] + WT + offc[v], __float_as_uint(prod));
+          }
+        }
+    }
+  }
+  __syncthreads();
+
+  CT_STAMP(2);
+  // ---- P2: K = max over cells of the contributions a cell can receive (points based at it and at its three lower neighbours)
+  {
+    unsigned kloc = 0;
+    for (int X = tid; X < G; X += kBwdThreads) {
+      unsigned c = (unsigned)CNT[X];
+      if (X >= 1) c += (unsigned)CNT[X - 1];
+      if (X >= WT) c += (unsigned)CNT[X - WT];
+      if (X >= WT + 1) c += (unsigned)CNT[X - WT - 1];
+      kloc = max(kloc, c);
+    }
+    kloc = core_wave_max_u32(kloc);
+    if (lane == 0) atomicMax(SK, kloc);
+  }
+
+  CT_STAMP(3);
+  // ---- P3: y = conv(z) + bias -> Y4   (barriers inside)
+  core_conv_block<2, WT, C, false, kBwdThreads>(Zf, wh, 0, a.bias != nullptr ? a.bias + (size_t)h * C : nullptr, WS, Y4, nullptr);
+
+  CT_STAMP(4);
+  // ---- P4: per-channel max |g_out * pad| of the plane
+  {
+    float m[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) m[c] = 0.0f;
+    for (int q = tid; q < nq; q += kBwdThreads) {
+      float pv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + (q << 2) + i) : 1.0f;
+      float4 t[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) t[c] = *(const float4*)(a.g_out + (bh * C + c) * (size_t)N + (q << 2));       // all rows in flight
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float tv[4] = {t[c].x, t[c].y, t[c].z, t[c].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = fabsf(HAS_PAD ? tv[i] * pv[i] : tv[i]);
+          m[c] = fmaxf(m[c], (x < __builtin_inff()) ? x : __builtin_inff());      // inf / NaN -> inf
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const unsigned mb = core_wave_max_u32(__float_as_uint(m[c]));               // non-negative floats order like unsigned
+      if (lane == 0) atomicMax(&SMAX[c], mb);
+    }
+  }
+  __syncthreads();
+  const float Kf = (float)(*SK);
+
+  CT_STAMP(5);
+  // ---- P5: Slice backward
+  for (int q = tid; q < nq; q += kBwdThreads) {
+    const int n0 = q << 2;
+    const float4 tx = *(const float4*)(keyx + n0), ty = *(const float4*)(keyy + n0);
+    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+    float pv[4], gs[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+      gs[i][0] = gs[i][1] = 0.0f;
+    }
+    for (int cq = 0; cq < C / 4; ++cq) {
+      float fv[4][4], iq[4];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const float4 t = *(const float4*)(a.g_out + (bh * C + cq * 4 + cj) * (size_t)N + n0);
+        fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+        float qd;
+        bool fixed;
+        core_quantum(__uint_as_float(SMAX[cq * 4 + cj]) * Kf, qd, iq[cj], fixed);
+        if (!fixed) iq[cj] = 0.0f;                    // this channel accumulates IEEE floats (inf / NaN inside): rare
+      }
+      const float4* Tq = Y4 + (size_t)cq * G;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        CorePt2 p;
+        core_pt2<WT>(kx[i], ky[i], p);
+        float g4[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) g4[cj] = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+        float gw[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float4 cv = Tq[p.cb + offc[v]];
+          float sacc = cv.x * g4[0];
+          sacc = __builtin_fmaf(cv.y, g4[1], sacc);
+          sacc = __builtin_fmaf(cv.z, g4[2], sacc);
+          sacc = __builtin_fmaf(cv.w, g4[3], sacc);
+          gw[v] = sacc;
+        }
+        gs[i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[i][0]));
+        gs[i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[i][1]));
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          int* Tc = ACC + (size_t)(cq * 4 + cj) * G + p.cb;
+          if (iq[cj] != 0.0f) {                       // workgroup-uniform
+            const float fq = g4[cj] * iq[cj];         // power-of-two scale: exact
+#pragma unroll
+            for (int v = 0; v < 4; ++v) atomicAdd(Tc + offc[v], core_cvt_rpi(fq * p.cw[v]));
+          } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) atomicAdd((float*)(Tc + offc[v]), g4[cj] * p.cw[v]);
+          }
+        }
+      }
+    }
+    float4 ox, oy;
+    ox.x = gs[0][0] * ct_key_mask(kx[0]); ox.y = gs[1][0] * ct_key_mask(kx[1]); ox.z = gs[2][0] * ct_key_mask(kx[2]); ox.w = gs[3][0] * ct_key_mask(kx[3]);
+    oy.x = gs[0][1] * ct_key_mask(ky[0]); oy.y = gs[1][1] * ct_key_mask(ky[1]); oy.z = gs[2][1] * ct_key_mask(ky[2]); oy.w = gs[3][1] * ct_key_mask(ky[3]);
+    *(float4*)(a.g_keys + (bh * 2 + 0) * N + n0) = ox;          // Splat's share is added in P9 by the same thread
+    *(float4*)(a.g_keys + (bh * 2 + 1) * N + n0) = oy;
+  }
+  __syncthreads();
+
+  CT_STAMP(6);
+  // ---- P6: g_y as floats in the padded layout; the plane's bias cotangent
+  for (int t = tid; t < C * G; t += kBwdThreads) {
+    const int c = t / G, cell = t - c * G;
+    float qd, iqd;
+    bool fixed;
+    core_quantum(__uint_as_float(SMAX[c]) * Kf, qd, iqd, fixed);
+    const int r = ACC[t];
+    GYf[(size_t)c * PLANE + cell + WT] = fixed ? (float)r * qd : __int_as_float(r);
+  }
+  __syncthreads();
+  for (int c = wave; c < C; c += kBwdThreads / 64) {  // a wave per channel: 4 cells per lane, then a fixed-order butterfly
+    const float4 t = *(const float4*)(GYf + (size_t)c * PLANE + WT + lane * 4);
+    float sb = (t.x + t.y) + (t.z + t.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+    if (lane == 0) a.gb_part[bh * C + c] = sb;
+  }
+
+  CT_STAMP(7);
+  // ---- P7: g_z = conv^T(g_y) -> Y4 (y is dead)   (barriers inside)
+  core_conv_block<2, WT, C, true, kBwdThreads>(GYf, wh, 0, nullptr, WS, Y4, nullptr);
+
+  CT_STAMP(8);
+  // ---- P8: filter cotangent of this plane: wave w < 9 takes tap w; D[co][ci] += sum over positions g_y[co][p] * z[ci][p + tap]
+  for (int tap = wave; tap < TAPS; tap += kBwdThreads / 64) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int m = lane & 15, k = lane >> 4;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int step = 0; step < G / 4; ++step) {
+      const int row = step / (WT / 4), x = (step - row * (WT / 4)) * 4 + k;
+      const float av = GYf[(size_t)m * PLANE + (row + 1) * WT + x];                  // A[co = m][pos]
+      const int xi = x + dx - 1;
+      const float bv = (xi >= 0 && xi < WT) ? Zf[(size_t)m * PLANE + (row + dy) * WT + xi] : 0.0f;    // B[pos][ci = m]
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    float* gp = a.gw_part + bh * (size_t)(C * C * TAPS);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gp[((size_t)(k * 4 + r) * C + m) * TAPS + tap] = acc[r];    // D row = co, column = ci
+  }
+  if (tid < 2) CNT[tid] = 0;
+  __syncthreads();                                    // z is intact until here: P9 may claim cells in place
+
+  CT_STAMP(9);
+  // ---- P9: Splat(max) backward.  Pass 0: a contribution bit-equal to its cell's z receives g_z, no claims; matches are
+  //      counted against the non-zero cells — equal on a plane without exact ties (exactly one winner per cell).  Otherwise
+  //      (duplicated points) pass 1 redoes the plane with compare-and-swap claims: the first tied contribution to swap the
+  //      cell's word to the claimed pattern wins.  Splat's share of g_keys goes to a scratch row and is added afterwards.
+  {
+    int nz = 0;
+    for (int t = tid; t < C * G; t += kBwdThreads) {
+      const int c = t / G, cell = t - c * G;
+      nz += Zu[(size_t)c * PLANE + cell + WT] != 0u;
+    }
+    nz = wave_sum_int(nz);
+    if (lane == 0 && nz) atomicAdd(&CNT[0], nz);       // (CNT is free since P2; zeroed below)
+  }
+  float* const scr = a.gk_scr + bh * 2 * (size_t)N;
+  for (int pass = 0; pass < 2; ++pass) {
+    int nm = 0;
+    for (int q = tid; q < nq; q += kBwdThreads) {
+      const int n0 = q << 2;
+      const float4 tx = *(const float4*)(keyx + n0), ty = *(const float4*)(keyy + n0);
+      const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+      float pv[4], gs[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+        gs[i][0] = gs[i][1] = 0.0f;
+      }
+      for (int cq = 0; cq < C / 4; ++cq) {
+        float fv[4][4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const float4 t = *(const float4*)(a.feat + (bh * C + cq * 4 + cj) * (size_t)N + n0);
+          fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
+        }
+        const float4* Gq = Y4 + (size_t)cq * G;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          CorePt2 p;
+          core_pt2<WT>(kx[i], ky[i], p);
+          // every LDS read of the point first: 4 x g_z (4 channels each) and 16 z words
+          float4 gz[4];
+          unsigned zc[4][4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            gz[v] = Gq[p.cb + offc[v]];
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) zc[v][cj] = Zu[(size_t)(cq * 4 + cj) * PLANE + p.cb + WT + offc[v]];
+          }
+          float gw[4] = {0.f, 0.f, 0.f, 0.f}, gf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float gzv[4] = {gz[v].x, gz[v].y, gz[v].z, gz[v].w};
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) {
+              const float xa = HAS_PAD ? fv[cj][i] * pv[i] : fv[cj][i];
+              const float prod = xa * p.cw[v];                  // formed exactly as in P1 (one rounding)
+              bool mt = prod > 0.0f && __float_as_uint(prod) == zc[v][cj];
+              if (pass == 1 && mt)
+                mt = atomicCAS(Zu + (size_t)(cq * 4 + cj) * PLANE + p.cb + WT + offc[v], __float_as_uint(prod), kCoreClaimed) ==
+                     __float_as_uint(prod);
+              nm += (int)mt;
+              const float ga = mt ? gzv[cj] : 0.0f;
+              gf[cj] = __builtin_fmaf(ga, p.cw[v], gf[cj]);
+              gw[v] = __builtin_fmaf(ga, xa, gw[v]);
+            }
+          }
+          gs[i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[i][0]));
+          gs[i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[i][1]));
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj) fv[cj][i] = HAS_PAD ? gf[cj] * pv[i] : gf[cj];
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+          *(float4*)(a.g_feat + (bh * C + cq * 4 + cj) * (size_t)N + n0) = make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]);
+      }
+      *(float4*)(scr + n0) = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]), gs[2][0] * ct_key_mask(kx[2]),
+                                         gs[3][0] * ct_key_mask(kx[3]));
+      *(float4*)(scr + N + n0) = make_float4(gs[0][1] * ct_key_mask(ky[0]), gs[1][1] * ct_key_mask(ky[1]), gs[2][1] * ct_key_mask(ky[2]),
+                                             gs[3][1] * ct_key_mask(ky[3]));
+    }
+    if (pass == 1) break;
+    nm = wave_sum_int(nm);
+    if (lane == 0 && nm) atomicAdd(&CNT[1], nm);
+    __syncthreads();
+    if (CNT[0] == CNT[1]) break;                      // workgroup-uniform: no exact ties in this plane
+  }
+  // g_keys = Slice's share (stored in P5) + Splat's: every thread adds the quads it wrote itself
+  for (int q = tid; q < nq; q += kBwdThreads) {
+    const int n0 = q << 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* pk = a.g_keys + (bh * 2 + j) * N + n0;
+      const float4 u = *(const float4*)pk, v = *(const float4*)(scr + (size_t)j * N + n0);
+      *(float4*)pk = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+  }
+  CT_STAMP(10);
+}
+
+// g_w[h][e] = sum over the batch of the planes' partial filter cotangents, in batch order (bitwise reproducible); g_b likewise
+__global__ void __launch_bounds__(256) core_wgrad_reduce_kernel(const float* gw_part, const float* gb_part, float* g_w, float* g_b,
+                                                                int B, int H, int nw, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < H * nw) {
+    const int h = i / nw, e = i - h * nw;
+    float sacc = 0.0f;
+    for (int b = 0; b < B; ++b) sacc += gw_part[((size_t)b * H + h) * nw + e];
+    g_w[i] = sacc;
+  }
+  if (g_b != nullptr && i < H * C) {
+    const int h = i / C, c = i - h * C;
+    float sacc = 0.0f;
+    for (int b = 0; b < B; ++b) sacc += gb_part[((size_t)b * H + h) * C + c];
+    g_b[i] = sacc;
+  }
+}
+
+template <int WT, int C>
+constexpr size_t core_bwd_lds_bytes() {
+  using Gm = CoreGeom<2, WT, C>;
+  return (size_t)(Gm::Z_FLOATS + 16 * Gm::G + Gm::NBUF * Gm::SLICE + C * Gm::G + Gm::Z_FLOATS + Gm::G + C + 4) * 4;
 }
 
 // ---------------------------------------------------------------------------
@@ -695,6 +1158,57 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
   if (rc != CT_OK) return rc;
   return ct_splat_bwd_ex(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys, sub, sub_bytes, B, H, C, N, dim, W,
                          CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS, s);
+}
+
+int ct_mhct_core_bwd_fused_supported(int B, int H, int C, int N, int dim, const int* W) {
+  return (B > 0 && H > 0 && N > 0 && (N & 3) == 0 && dim == 2 && W && W[0] == 16 && W[1] == 16 && C == 16) ? 1 : 0;
+}
+
+size_t ct_mhct_core_bwd_fused_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
+  if (!ct_mhct_core_bwd_fused_supported(B, H, C, N, dim, W)) return 0;
+#if CT_CORE_STAMP
+  return (size_t)B * H * (C * C * 9 + C + 2 * (size_t)N) * 4 + (size_t)B * H * 16 * 8;
+#else
+  return (size_t)B * H * (C * C * 9 + C + 2 * (size_t)N) * 4;
+#endif
+}
+
+int ct_mhct_core_bwd_fused(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                           const float* conv_b, const float* g_out, float* g_feat, float* g_keys, float* g_w, float* g_b,
+                           void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys || !feat || !conv_w || !g_out || !g_feat || !g_keys || !g_w) return CT_EINVAL;
+  if (!ct_mhct_core_bwd_fused_supported(B, H, C, N, dim, W)) return CT_EINVAL;
+  if (pad_dtype != CT_PAD_NONE && !pad) return CT_EINVAL;
+  if (((((uintptr_t)keys) | ((uintptr_t)feat) | ((uintptr_t)g_out) | ((uintptr_t)g_feat) | ((uintptr_t)g_keys)) & 15) != 0) return CT_EINVAL;
+  const size_t need = ct_mhct_core_bwd_fused_workspace_bytes(B, H, C, N, dim, W);
+  if (!workspace || workspace_bytes < need) return CT_EWORKSPACE;
+  hipStream_t st = (hipStream_t)s;
+  CoreBwdArgs a;
+  a.keys = keys; a.feat = feat; a.pad = pad; a.pad_dtype = pad_dtype; a.w = conv_w; a.bias = conv_b; a.g_out = g_out;
+  a.g_feat = g_feat; a.g_keys = g_keys;
+  a.gw_part = (float*)workspace;
+  a.gb_part = a.gw_part + (size_t)B * H * C * C * 9;
+  a.gk_scr = a.gb_part + (size_t)B * H * C;
+  a.B = B; a.H = H; a.N = N;
+  a.stamps = (unsigned long long*)((char*)workspace + (size_t)B * H * (C * C * 9 + C + 2 * (size_t)N) * 4);
+  constexpr size_t lds = core_bwd_lds_bytes<16, 16>();
+  const dim3 grid(B * H);
+  if (pad_dtype != CT_PAD_NONE) {
+    auto k = mhct_core_bwd_kernel<16, 16, true>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CT_ELAUNCH;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(k, grid, dim3(kBwdThreads), lds, st, a);
+  } else {
+    auto k = mhct_core_bwd_kernel<16, 16, false>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CT_ELAUNCH;
+    CT_CLEAR_ERROR();
+    hipLaunchKernelGGL(k, grid, dim3(kBwdThreads), lds, st, a);
+  }
+  CT_CHECK_LAUNCH();
+  const int nw = C * C * 9;
+  hipLaunchKernelGGL(core_wgrad_reduce_kernel, dim3((H * nw + 255) / 256), dim3(256), 0, st, a.gw_part, a.gb_part, g_w, g_b, B, H, nw, C);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
 }
 
 int ct_mhct_core_workspace_init(void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s) {

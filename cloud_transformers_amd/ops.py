@@ -1071,6 +1071,10 @@ def grid_occupancy_count(grid):
 # ct_mhct_core_supported); CLOUDCT_FUSED_CORE=0 (or ops.FUSED_CORE = False) keeps the three-kernel chain, for A/B runs.
 import os as _os
 FUSED_CORE = _os.environ.get("CLOUDCT_FUSED_CORE", "1") != "0"
+# the LDS-resident backward (16^2 C16 planes: ct_mhct_core_bwd_fused).  Built, parity-tested and MEASURED SLOWER than the backward
+# from saved grids (114 vs 82 us at B8 H16 N4096, 74 vs 79 at N2048, tools/core_bwd_bench.py: one workgroup per plane moves
+# 5 x 256 KiB through one CU) — so it is off unless CLOUDCT_FUSED_CORE_BWD=1
+FUSED_CORE_BWD = _os.environ.get("CLOUDCT_FUSED_CORE_BWD", "0") == "1"
 _core_supported = {}
 
 
@@ -1119,26 +1123,28 @@ class MhctCoreFn(torch.autograd.Function):
         padt, pad_code = _pad_args(pad, B, N)
         dev = feat.device
         need_grad = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
-        out = torch.empty(B, HC, N, device=dev, dtype=torch.float32)
-        z = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad else None
-        y = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad else None
-        occ = torch.empty((), device=dev, dtype=torch.int64)
         lib = _lib.load()
         Wa = _lib.int_array(W)
+        # one workgroup per plane recomputes z and conv(z) in the backward where all five tiles fit a CU: nothing to save
+        recompute = bool(need_grad and FUSED_CORE_BWD and B * H >= 64 and lib.ct_mhct_core_bwd_fused_supported(B, H, C, N, dim, Wa))
+        out = torch.empty(B, HC, N, device=dev, dtype=torch.float32)
+        z = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad and not recompute else None
+        y = torch.empty(B, HC, *W, device=dev, dtype=torch.float32) if need_grad and not recompute else None
+        occ = torch.empty((), device=dev, dtype=torch.int64)
         ws = mhct_core_workspace(dev, B, H, C, N, W)
         nws = ws.numel()
         with _on(dev):
             _lib.check(lib.ct_mhct_core_fwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(bias), _ptr(out),
                                             _ptr(z), _ptr(y), _ptr(occ), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()),
                        "ct_mhct_core_fwd")
-        ctx.save_for_backward(keys, feat, padt, weight, z, y)
+        ctx.save_for_backward(keys, feat, padt, weight, z, y, bias if recompute else None)
         ctx.meta = (W, H, C, pad_code, bias is not None)
         ctx.mark_non_differentiable(occ)
         return out, occ
 
     @staticmethod
     def backward(ctx, g_out, _g_occ):
-        keys, feat, padt, weight, z, y = ctx.saved_tensors
+        keys, feat, padt, weight, z, y, bias = ctx.saved_tensors
         W, H, C, pad_code, has_bias = ctx.meta
         dim = len(W)
         B, HC, N = feat.shape
@@ -1150,6 +1156,14 @@ class MhctCoreFn(torch.autograd.Function):
         g_b = torch.empty(HC, device=dev, dtype=torch.float32) if has_bias else None
         lib = _lib.load()
         Wa = _lib.int_array(W)
+        if z is None:                 # LDS-resident backward: recomputes the grids from the points
+            nws = lib.ct_mhct_core_bwd_fused_workspace_bytes(B, H, C, N, dim, Wa)
+            ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+            with _on(dev):
+                _lib.check(lib.ct_mhct_core_bwd_fused(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(bias), _ptr(g_out),
+                                                      _ptr(g_feat), _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(ws), nws,
+                                                      B, H, C, N, dim, Wa, _stream()), "ct_mhct_core_bwd_fused")
+            return g_keys, g_feat, None, g_w, g_b, None, None
         nws = lib.ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, Wa)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         with _on(dev):

@@ -319,6 +319,17 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
                      const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
                      float* g_b, void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim,
                      const int* W, ct_stream_t s);
+/* The LDS-resident BACKWARD of the core, for the grid whose five tiles fit a CU (2D 16x16 with 16 features per head:
+ * ct_mhct_core_bwd_fused_supported): nothing of the forward is read back — one workgroup per plane recomputes z and conv(z)
+ * from the points and walks Slice backward -> conv^T / filter cotangent -> Splat backward in LDS (ct_mhct_core_fwd may then be
+ * called with z_save = y_save = NULL in training too).  Same outputs as ct_mhct_core_bwd; the per-plane filter / bias
+ * cotangents go through `workspace` (ct_mhct_core_bwd_fused_workspace_bytes) and are added over the batch in a fixed order. */
+int ct_mhct_core_bwd_fused_supported(int B, int H, int C, int N, int dim, const int* W);
+size_t ct_mhct_core_bwd_fused_workspace_bytes(int B, int H, int C, int N, int dim, const int* W);
+int ct_mhct_core_bwd_fused(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                           const float* conv_b, const float* g_out, float* g_feat, float* g_keys, float* g_w, float* g_b,
+                           void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
+                           ct_stream_t s);
 /* Test hooks: bit 0 = one workgroup per plane (no clusters); bits 8.. = force that many workgroups per plane (1, 2, 4, 8).
  * ct_mhct_core_status copies the workspace's status word to the host AFTER synchronising the stream (a test helper, the
  * only call of this library that waits for the device): 0 = no cluster gave up waiting for its partners. */

@@ -262,6 +262,59 @@ def test_core_clusters_under_uneven_load(core_flags, B, H, N, dim, W, C):
         assert int(occs[it]) == sets[it % 2][2]
 
 
+def fused_bwd(keys, feat, w, bias, cot, pad, W, H, dim):
+    from cloud_transformers_amd.ops import _ptr, _stream, _pad_args
+    L, lib = _libs()
+    keys, feat, w, bias, cot = (t.cuda().contiguous() for t in (keys, feat, w, bias, cot))
+    B, HC, N = feat.shape
+    C = HC // H
+    Wa = L.int_array([W] * dim)
+    padt, code = _pad_args(pad.cuda() if pad is not None else None, B, N)
+    g_feat, g_keys, g_w, g_b = (torch.full_like(t, float("nan")) for t in (feat, keys, w, bias))
+    nws = lib.ct_mhct_core_bwd_fused_workspace_bytes(B, H, C, N, dim, Wa)
+    ws = torch.empty(nws, device="cuda", dtype=torch.uint8)
+    L.check(lib.ct_mhct_core_bwd_fused(_ptr(keys), _ptr(feat), _ptr(padt), code, _ptr(w), _ptr(bias), _ptr(cot), _ptr(g_feat),
+                                       _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(ws), nws, B, H, C, N, dim, Wa, _stream()),
+            "ct_mhct_core_bwd_fused")
+    torch.cuda.synchronize()
+    return dict(g_feat=g_feat, g_keys=g_keys, g_w=g_w, g_b=g_b)
+
+
+@pytest.mark.parametrize("B,H,N,pad_kind", [(2, 4, 2048, None), (3, 5, 1020, "f32"), (2, 3, 5000, "i32"), (1, 2, 16384, None)])
+def test_lds_resident_backward_matches_oracle(B, H, N, pad_kind):
+    """ct_mhct_core_bwd_fused (2D 16^2 C16: z and conv(z) recomputed in LDS, nothing saved by the forward) against the oracle's
+    autograd through positions -> splat -> conv -> slice: every cotangent within 1e-4 of its maximum."""
+    dim, W, C = 2, 16, 16
+    keys, feat, w, bias, cot, pad = make_inputs(B, H, C, N, dim, 900 + N, pad_kind)
+    ref = oracle_core(keys, feat, w, bias, cot, pad, W, H, dim)
+    got = fused_bwd(keys, feat, w, bias, cot, pad, W, H, dim)
+    for name in ("g_keys", "g_feat", "g_w", "g_b"):
+        assert torch.isfinite(got[name]).all(), name
+        assert relerr(got[name], ref[name]) <= 1e-4, (name, relerr(got[name], ref[name]))
+
+
+def test_lds_resident_backward_full_size_and_reproducible():
+    """B8 H16 N4096 (the stage-3 zoo head): against ct_mhct_core_bwd on saved grids, twice (bitwise equal: fixed-point
+    accumulation, fixed-order sums over the batch), and exact ties route to a single winner."""
+    dim, W, C, B, H, N = 2, 16, 16, 8, 16, 4096
+    keys, feat, w, bias, cot, _ = make_inputs(B, H, C, N, dim, 31)
+    saved = fused_core(keys, feat, w, bias, cot, None, W, H, dim)
+    a = fused_bwd(keys, feat, w, bias, cot, None, W, H, dim)
+    b = fused_bwd(keys, feat, w, bias, cot, None, W, H, dim)
+    for name in ("g_keys", "g_feat", "g_w", "g_b"):
+        assert torch.equal(a[name], b[name]), name
+        assert relerr(a[name], saved[name]) <= 1e-5, (name, relerr(a[name], saved[name]))
+    # duplicated points: every tied pair sends the cell's cotangent to exactly one of the two
+    keys, feat, w, bias, cot, _ = make_inputs(2, 4, C, 2048, dim, 32, dup=True)
+    got = fused_bwd(keys, feat, w, bias, cot, None, W, 4, dim)
+    gf = got["g_feat"].cpu()
+    half = 1024
+    both = (gf[..., :half] != 0) & (gf[..., half:] != 0)
+    assert int(both.sum()) == 0
+    ref = oracle_core(keys, feat, w, bias, cot, None, W, 4, dim)
+    assert relerr(gf[..., :half] + gf[..., half:], ref["g_feat"][..., :half] + ref["g_feat"][..., half:]) <= 1e-4
+
+
 def test_core_autograd_function_matches_module_chain(core_flags):
     """ops.mhct_core (autograd.Function over the ABI pair) against the unfused autograd chain of this package"""
     from cloud_transformers_amd import ops
