@@ -22,6 +22,7 @@
 //                           gconv_wrw_reduce_kernel / gconv_c4_wrw_reduce_kernel in a fixed order
 //   gconv_bwd_weight_kernel backward-weight for rows that are not a multiple of 4 floats (tile form, float atomics)
 #include "ct_common.h"
+#include <atomic>
 
 namespace {
 
@@ -1156,6 +1157,196 @@ __global__ void __launch_bounds__(256 * kWsSplit) gconv_wrw_small_kernel(GconvAr
 }
 
 
+// ---------------------------------------------------------------------------
+// The same small volumes ON THE MATRIX CORES.  Per (group, 16 output channels, 16 input channels) the weight gradient is
+// 3^d small GEMMs  g_w[co, ci, tap] = sum_{b, p} g_y[b, co, p] * x[b, ci, p + tap]  with K = (batch, positions): one
+// v_mfma_f32_16x16x4_f32 contracts 4 consecutive x positions of a row,
+//     A (16x4)  = g_y[co 0..15][p .. p+3]            one ds_read_b32, shared by all 3^d taps
+//     B (4x16)  = x[ci 0..15][p + tap .. p + tap+3]  one ds_read_b32 from the zero-haloed tile (x halo too: no masks)
+//     D (16x16) = the tap's 16x16 block, 4 accumulator registers per lane, 3^d blocks per wave (108 registers in 3D).
+// One 512-thread workgroup per block; its 8 waves split K (k-step = wave, wave + 8, ...) and add their partial blocks in a
+// fixed tree through LDS at the end.  Operands are staged per (batch element, depth slab of TZ slices) through TWO LDS
+// buffers: the next stage's global loads are issued before this stage's MFMA run and written to the other buffer after it
+// (one barrier per stage).  Channel strides are == 2 (mod 4) floats with odd halves: the 16 channels x 2 positions a
+// half-wave reads fall on 32 different banks.  When the blocks do not cover the chip (32 -> 64 channels: 128 of them) the
+// batch is split over `ksplit` workgroups whose partials go to the workspace of the ring kernel's reduction
+// (gconv_wrw_reduce_kernel, fixed order).   grid = (ci_blocks * co_blocks * ksplit, groups)
+// ---------------------------------------------------------------------------
+std::atomic<unsigned> t_gconv_debug{0};      // ct_debug_set_gconv: bit 0 = small-volume weight gradient on the vector ALU
+constexpr int kWmThreads = 512;
+constexpr int kWmWaves = kWmThreads / 64;
+constexpr int kWmUnits = 4;                      // 16-byte staging units per thread and operand, at most
+
+template <int DIM, int WT>
+__global__ void __launch_bounds__(kWmThreads) gconv_wrw_mfma_kernel(GconvArgs a, const float* __restrict__ gy, float* __restrict__ gw,
+                                                                     float* __restrict__ gbias, float* __restrict__ ws,
+                                                                     int TZ, int XS, int GS, int ksplit) {
+  constexpr int NR = DIM == 3 ? 9 : 3, TAPS = NR * 3, WQ = WT / 4, Wp = WT + 2;
+  extern __shared__ __align__(16) float lds[];
+  const int D = a.D, H = a.H, Hp = H + 2;
+  const int ZS = DIM == 3 ? TZ + 2 : 1;
+  const int nslab = DIM == 3 ? D / TZ : 1;
+  const int cib = (a.Cin + 15) >> 4, cob = (a.Cout + 15) >> 4;
+  const int cb = blockIdx.x % cib, ob = (blockIdx.x / cib) % cob, ks = blockIdx.x / (cib * cob), grp = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const size_t vol = (size_t)D * H * WT;
+  const int STAGE = 16 * XS + 16 * GS;
+  const int bper = (a.B + ksplit - 1) / ksplit;
+  const int b_lo = min(a.B, ks * bper), b_hi = min(a.B, b_lo + bper);
+  const int NS = (b_hi - b_lo) * nslab;
+  const int rows = (DIM == 3 ? TZ : 1) * H;               // rows of a slab
+  const int n_xu = 16 * ZS * H * WQ, n_gu = 16 * rows * WQ;
+  const bool want_bias = gbias != nullptr && cb == 0;
+
+  // stage-invariant part of this thread's staging units
+  int x_src[kWmUnits], x_dst[kWmUnits], x_zr[kWmUnits], g_src[kWmUnits], g_dst[kWmUnits];
+#pragma unroll
+  for (int u = 0; u < kWmUnits; ++u) {
+    const int i = threadIdx.x + u * kWmThreads;
+    {
+      const int xq = i % WQ, y = (i / WQ) % H, zs = (i / (WQ * H)) % ZS, c = i / (WQ * H * ZS);
+      const bool ok = i < n_xu && cb * 16 + c < a.Cin;
+      x_zr[u] = ok ? (DIM == 3 ? zs - 1 : 0) : -(1 << 20);
+      x_src[u] = c * (int)vol + ((DIM == 3 ? zs - 1 : 0) * H + y) * WT + xq * 4;
+      x_dst[u] = i < n_xu ? c * XS + (zs * Hp + y + 1) * Wp + xq * 4 + 1 : -1;
+    }
+    {
+      const int p4 = i % (rows * WQ), c = i / (rows * WQ);
+      const bool ok = i < n_gu && ob * 16 + c < a.Cout;
+      g_src[u] = ok ? c * (int)vol + p4 * 4 : -1;
+      g_dst[u] = i < n_gu ? c * GS + p4 * 4 : -1;
+    }
+  }
+  float4 sx[kWmUnits], sg[kWmUnits];
+  auto load_stage = [&](int s) {
+    const int b = b_lo + s / nslab, z0 = (s % nslab) * TZ;
+    const float* xg = a.x + (((size_t)b * a.groups + grp) * a.Cin + cb * 16) * vol + (size_t)z0 * H * WT;
+    const float* gg = gy + (((size_t)b * a.groups + grp) * a.Cout + ob * 16) * vol + (size_t)z0 * H * WT;
+#pragma unroll
+    for (int u = 0; u < kWmUnits; ++u) {
+      const int z = z0 + x_zr[u];
+      sx[u] = (z >= 0 && z < D) ? *(const float4*)__builtin_assume_aligned(xg + x_src[u], 16) : make_float4(0, 0, 0, 0);
+      sg[u] = g_src[u] >= 0 ? *(const float4*)__builtin_assume_aligned(gg + g_src[u], 16) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* xs = lds + buf * STAGE;
+    float* gs = xs + 16 * XS;
+#pragma unroll
+    for (int u = 0; u < kWmUnits; ++u) {
+      if (x_dst[u] >= 0) {
+        float* p = xs + x_dst[u];
+        p[0] = sx[u].x; p[1] = sx[u].y; p[2] = sx[u].z; p[3] = sx[u].w;
+      }
+      if (g_dst[u] >= 0) {
+        float2* p = (float2*)__builtin_assume_aligned(gs + g_dst[u], 8);
+        p[0] = make_float2(sg[u].x, sg[u].y); p[1] = make_float2(sg[u].z, sg[u].w);
+      }
+    }
+  };
+
+  floatx4 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+  float bsum = 0.0f;
+  if (NS > 0) load_stage(0);
+  for (int i = threadIdx.x; i < 2 * STAGE; i += kWmThreads) lds[i] = 0.0f;          // halos (and unused channels) stay zero
+  __syncthreads();
+  if (NS > 0) store_stage(0);
+  __syncthreads();
+  const int nks = rows * WQ;
+  for (int s = 0; s < NS; ++s) {
+    if (s + 1 < NS) load_stage(s + 1);
+    const float* xs = lds + (s & 1) * STAGE + col * XS + kq;
+    const float* gs = lds + (s & 1) * STAGE + 16 * XS + col * GS + kq;
+    // software pipeline over this wave's units = (k-step, dz): the 9 operands of the next unit are requested before this
+    // unit's 9 MFMAs (the compiler, left alone, reads 7 values, waits, multiplies: every group's LDS latency is exposed; and
+    // whole k-steps of 27 would put more than the 15 LDS requests in flight that s_waitcnt can count).  The request past the
+    // wave's last unit re-reads a valid one: no branch, so no register merge that would wait.
+    constexpr int NZ = DIM == 3 ? 3 : 1;
+    auto load_u = [&](int it, int dz, float& av, float (&bv)[9]) {
+      const int k = wave + it * kWmWaves;
+      const int xq = k % WQ, zy = k / WQ;
+      const int z = DIM == 3 ? zy / H : 0, y = DIM == 3 ? zy - z * H : zy;
+      av = gs[k * 4];
+      const float* bp = xs + ((z + dz) * Hp + y) * Wp + xq * 4;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) bv[dy * 3 + dx] = bp[dy * Wp + dx];
+    };
+    float aA, aB, bA[9], bB[9];
+    const int nit = (nks - wave + kWmWaves - 1) / kWmWaves;          // k-steps of this wave
+    const int nU = nit * NZ;
+    if (nU > 0) load_u(0, 0, aA, bA);
+    for (int u0 = 0; u0 < nU; u0 += 2 * NZ) {
+#pragma unroll
+      for (int j = 0; j < 2 * NZ; ++j) {
+        if (u0 + j >= nU) break;
+        const int itn = min((u0 + j + 1) / NZ, nit - 1);
+        if ((j & 1) == 0) load_u(itn, (j + 1) % NZ, aB, bB); else load_u(itn, (j + 1) % NZ, aA, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        const float av = (j & 1) == 0 ? aA : aB;
+        if (j % NZ == 0) bsum += av;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[(j % NZ) * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, (j & 1) == 0 ? bA[t] : bB[t], acc[(j % NZ) * 9 + t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (s + 1 < NS) store_stage((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // partial blocks of the 8 waves: a fixed tree through LDS (upper half writes, lower half adds)
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  constexpr int NV = TAPS * 4 + 1;
+  for (int half = kWmWaves / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* red = lds + (size_t)(wave - half) * NV * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64] = acc[t][r];
+      red[TAPS * 4 * 64] = bsum;
+    }
+    __syncthreads();
+    if (wave < half) {
+      const float* red = lds + (size_t)wave * NV * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[(t * 4 + r) * 64];
+      bsum += red[TAPS * 4 * 64];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  if (ws != nullptr) {
+    // [chunk][grp][cob][cib][t][co16][ci16], bias partials behind: [chunk][grp][cob][16]
+    const size_t per_chunk = (size_t)a.groups * cob * cib * TAPS * 256;
+    float* o = ws + (size_t)ks * per_chunk + ((size_t)(grp * cob + ob) * cib + cb) * TAPS * 256 + (kq * 4) * 16 + col;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[t * 256 + r * 16] = acc[t][r];
+    if (cb == 0 && lane < 16) ws[(size_t)ksplit * per_chunk + ((size_t)ks * a.groups + grp) * cob * 16 + ob * 16 + lane] = bsum;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = ob * 16 + kq * 4 + r, ci = cb * 16 + col;
+      if (co < a.Cout && ci < a.Cin) {
+        float* o = gw + ((size_t)(grp * a.Cout + co) * a.Cin + ci) * TAPS;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) o[t] = acc[t][r];
+      }
+    }
+    if (want_bias && lane < 16 && ob * 16 + lane < a.Cout) gbias[grp * a.Cout + ob * 16 + lane] = bsum;
+  }
+}
+
 __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int Cin,
                                                                int Cout, int taps) {
   __shared__ float red[4][64];
@@ -1635,6 +1826,68 @@ int launch_wrw_small(GconvArgs a, int dim, const float* g_y, float* g_w, float* 
   return CT_OK;
 }
 
+// small volumes, many channels, on the matrix cores (see gconv_wrw_mfma_kernel)
+struct WrwMfmaPlan { int TZ, XS, GS, ksplit; size_t lds; };
+
+bool plan_wrw_mfma(const GconvArgs& a, int dim, WrwMfmaPlan& p) {
+  if (!(a.W == 4 || a.W == 8 || a.W == 16)) return false;
+  const int P = a.D * a.H * a.W;
+  if (P > 512 || P < 16 || (a.Cin < 32 && a.Cout < 32)) return false;
+  const int taps = dim == 3 ? 27 : 9;
+  const size_t red = (size_t)(kWmWaves / 2) * (taps * 4 + 1) * 64 * 4;
+  const int WQ = a.W / 4;
+  auto pad2 = [](int n) { return ((n + 3) & ~3) + 2; };          // == 2 (mod 4): see the kernel's header
+  p.TZ = 0;
+  for (int tz = dim == 3 ? a.D : 1; tz >= 1; --tz) {
+    if (dim == 3 && a.D % tz != 0) continue;
+    const int ZS = dim == 3 ? tz + 2 : 1;
+    const int XS = pad2(ZS * (a.H + 2) * (a.W + 2)), GS = pad2(tz * a.H * a.W);
+    const size_t lds = (size_t)2 * 16 * (XS + GS) * 4;
+    if (lds > (size_t)kLdsBudgetMax) continue;
+    if (16 * ZS * a.H * WQ > kWmUnits * kWmThreads || 16 * tz * a.H * WQ > kWmUnits * kWmThreads) continue;
+    p.TZ = tz; p.XS = XS; p.GS = GS; p.lds = lds > red ? lds : red;
+    break;
+  }
+  if (!p.TZ) return false;
+  const long long wgs = (long long)((a.Cin + 15) / 16) * ((a.Cout + 15) / 16) * a.groups;
+  int ksplit = 1;
+  while (wgs * ksplit < 256 && ksplit * 2 <= a.B) ksplit *= 2;
+  p.ksplit = ksplit;
+  return true;
+}
+
+size_t wrw_mfma_workspace(const GconvArgs& a, const WrwMfmaPlan& p) {
+  if (p.ksplit <= 1) return 0;
+  const size_t CiB = (a.Cin + 15) >> 4, CoB = (a.Cout + 15) >> 4;
+  return ((size_t)p.ksplit * a.groups * CoB * CiB * a.taps * 256 + (size_t)p.ksplit * a.groups * CoB * 16) * sizeof(float);
+}
+
+int launch_wrw_mfma(GconvArgs a, int dim, WrwMfmaPlan p, const float* g_y, float* g_w, float* g_bias, float* ws, size_t ws_bytes,
+                    hipStream_t st) {
+  if (p.ksplit > 1 && (!ws || ws_bytes < wrw_mfma_workspace(a, p))) p.ksplit = 1;      // no workspace: one workgroup per block
+  float* wsp = p.ksplit > 1 ? ws : nullptr;
+  const int CiB = (a.Cin + 15) / 16, CoB = (a.Cout + 15) / 16;
+  dim3 grid(CiB * CoB * p.ksplit, a.groups);
+  CT_CLEAR_ERROR();
+#define CT_WM_LAUNCH(DIMV, WTV)                                                                     \
+  do {                                                                                              \
+    if (set_lds_attr(gconv_wrw_mfma_kernel<DIMV, WTV>, p.lds) != CT_OK) return CT_ELAUNCH;          \
+    hipLaunchKernelGGL((gconv_wrw_mfma_kernel<DIMV, WTV>), grid, dim3(kWmThreads), p.lds, st, a, g_y, g_w, g_bias, wsp, \
+                       p.TZ, p.XS, p.GS, p.ksplit);                                                 \
+  } while (0)
+  if (dim == 2) { if (a.W == 4) CT_WM_LAUNCH(2, 4); else if (a.W == 8) CT_WM_LAUNCH(2, 8); else CT_WM_LAUNCH(2, 16); }
+  else { if (a.W == 4) CT_WM_LAUNCH(3, 4); else if (a.W == 8) CT_WM_LAUNCH(3, 8); else CT_WM_LAUNCH(3, 16); }
+#undef CT_WM_LAUNCH
+  CT_CHECK_LAUNCH();
+  if (wsp) {
+    const size_t n = (size_t)a.groups * CoB * CiB * a.taps * 256;
+    hipLaunchKernelGGL(gconv_wrw_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64, 4), 0, st, wsp, g_w, g_bias, p.ksplit,
+                       a.groups, a.Cin, a.Cout, a.taps);
+    CT_CHECK_LAUNCH();
+  }
+  return CT_OK;
+}
+
 bool fwd_plan_ok(GconvArgs a, int dim) {
   if (tiny_cob(a, dim)) return true;
   if (a.Cin == 4 && a.Cout == 4 && (a.W & 3) == 0 &&
@@ -1644,7 +1897,8 @@ bool fwd_plan_ok(GconvArgs a, int dim) {
 }
 
 bool wrw_plan_ok(GconvArgs a, int dim) {
-  if (wrw_small_eligible(a, dim)) return true;
+  WrwMfmaPlan pm;
+  if (plan_wrw_mfma(a, dim, pm) || wrw_small_eligible(a, dim)) return true;
   WrwRingPlan p;
   if ((a.W & 3) == 0 && plan_wrw_ring(a, dim, p, c4_wrw_eligible(a) ? 4 : 16)) return true;
   const size_t red_bytes = (size_t)(kThreads / 64) * 3 * 256 * 4;
@@ -1654,6 +1908,8 @@ bool wrw_plan_ok(GconvArgs a, int dim) {
 }  // namespace
 
 extern "C" {
+
+void ct_debug_set_gconv(unsigned flags) { t_gconv_debug.store(flags, std::memory_order_relaxed); }
 
 int ct_gconv_fwd(const float* x, const float* w, const float* bias, float* y,
                  int B, int groups, int Cin, int Cout, int dim, const int* W, ct_stream_t s) {
@@ -1692,7 +1948,10 @@ size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout,
     if (plan_wrw_ring(a, dim, p4, 4)) return c4_wrw_workspace(a, p4);
   }
   WrwRingPlan p;
-  return plan_wrw_ring(a, dim, p) ? wrw_ring_workspace(a, p) : 0;
+  size_t need = plan_wrw_ring(a, dim, p) ? wrw_ring_workspace(a, p) : 0;
+  WrwMfmaPlan pm;
+  if (plan_wrw_mfma(a, dim, pm) && wrw_mfma_workspace(a, pm) > need) need = wrw_mfma_workspace(a, pm);
+  return need;
 }
 
 int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_bias, void* workspace, size_t workspace_bytes,
@@ -1706,6 +1965,9 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
   CT_CLEAR_ERROR();
   const bool aligned = ((((uintptr_t)x) | ((uintptr_t)g_y)) & 15) == 0;
   bool ring_bias = (a.W & 3) == 0 && workspace != nullptr;        // the ring kernels' workspace path produces g_bias itself
+  WrwMfmaPlan pm;
+  if (aligned && !(t_gconv_debug.load(std::memory_order_relaxed) & 1) && plan_wrw_mfma(a, dim, pm))
+    return launch_wrw_mfma(a, dim, pm, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
   if (wrw_small_eligible(a, dim)) {
     r = launch_wrw_small(a, dim, g_y, g_w, g_bias, st);
     if (r != CT_OK) return r;

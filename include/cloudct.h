@@ -334,6 +334,9 @@ int ct_mhct_core_bwd_fused(const float* keys, const float* feat, const void* pad
  * ct_mhct_core_status copies the workspace's status word to the host AFTER synchronising the stream (a test helper, the
  * only call of this library that waits for the device): 0 = no cluster gave up waiting for its partners. */
 void ct_debug_set_core(unsigned flags);
+/* Test hook of the grouped convolution: bit 0 = small-volume weight gradients take the vector-ALU kernel instead of the
+ * matrix-core one (A/B measurements, tools/gconv64_bench.py). */
+void ct_debug_set_gconv(unsigned flags);
 int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
                         int* host_status, ct_stream_t s);
 
