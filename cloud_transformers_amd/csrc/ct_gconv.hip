@@ -28,6 +28,10 @@ namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// ct_debug_set_gconv: bit 0 = small-volume weight gradient on the vector ALU; bits 8..15 = input channels per group from which
+// the forward / backward-data pass takes the K-split kernel (0 = default)
+std::atomic<unsigned> t_gconv_debug{0};
+
 constexpr int kThreads = 256;                // small tiles: several workgroups per CU
 constexpr int kThreadsBig = 1024;            // tiles that leave room for one or two workgroups per CU
 constexpr int kP = 4;                      // position groups per wave sharing one A read
@@ -107,13 +111,15 @@ constexpr int kSlack = 4;
 
 template <int DIM>
 __device__ __forceinline__ void stage_halo_tile(float* xs, const float* xg, const GconvArgs& a, int planes,
-                                                int td0, int th0, int lane, int wave, int nwaves) {
+                                                int td0, int th0, int lane, int wave, int nwaves, bool clear = true) {
   const int Dz = DIM == 3 ? a.TD + 2 : 1;
   const size_t vol = (size_t)a.D * a.H * a.W;
   const int total = planes * a.plane;
-  for (int i = threadIdx.x; i < (total >> 2); i += blockDim.x) ((float4*)xs)[i] = make_float4(0, 0, 0, 0);
-  for (int i = ((total >> 2) << 2) + threadIdx.x; i < total; i += blockDim.x) xs[i] = 0.0f;
-  __syncthreads();
+  if (clear) {                                                   // workgroup-uniform
+    for (int i = threadIdx.x; i < (total >> 2); i += blockDim.x) ((float4*)xs)[i] = make_float4(0, 0, 0, 0);
+    for (int i = ((total >> 2) << 2) + threadIdx.x; i < total; i += blockDim.x) xs[i] = 0.0f;
+    __syncthreads();
+  }
   // interior rows of this tile: tensor rows [gy_lo, gy_hi) -> tile rows [gy_lo - th0 + 1, ...)
   const int gy_lo = max(th0 - 1, 0), gy_hi = min(th0 + a.TH + 1, a.H);
   const int cnt = (gy_hi - gy_lo) * a.W;                       // contiguous floats per (channel, depth slice)
@@ -329,16 +335,29 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4_kernel(GconvArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int kKBlk = 16;       // input channels per contraction block (4 MFMA k-groups)
 
-template <int DIM, int MAXI>
-__global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a) {
-  constexpr int NR = DIM == 3 ? 9 : 3;
+// The bank slice of a contraction block sits in LDS IN THE TENSOR'S OWN ORDER, so that staging is a handful of 1-KiB LDS-DMA
+// pieces per wave (round 2 gathered it element by element into an MFMA-shaped layout: 18 dependent global loads per thread and
+// block, ~40 % of the kernel at 8^3 64->64):
+//   forward         rows = output channel:  ws[mtl][co 16][CS],  row = w[co][ci k0..k0+15][taps]   (16 * taps contiguous floats)
+//   backward-data   rows = input channel of this pass (= output channel of the tensor):
+//                                           ws[mtl][ci 16][CS],  row = w[ci][co mt*16..+15][taps]  (read flipped: taps-1-tap)
+// The A operand of lane (co = l & 15, ci = l >> 4) is one ds_read_b32 per tap.  Row strides: forward 16*taps + 4 floats
+// (== 4 mod 8: the 16 rows fall on the 8 multiples of 4 twice, the four ci offsets 0, taps, 2 taps, 3 taps on the four
+// residues mod 4 — taps is odd), backward 16*taps (== 16 mod 32; co * taps covers 16 banks, + 16 the other 16): two lanes per
+// bank, the minimum for 64 lanes.
+template <int TAPS, bool TR> struct BankRow { static constexpr int RL = 16 * TAPS, CS = TR ? RL : RL + 4; };
+
+template <int DIM, int MAXI, bool TR>
+__global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a, int dma_bank) {
+  constexpr int NR = DIM == 3 ? 9 : 3, TAPS = NR * 3;
   constexpr int KBB = kKBlk / 4;
+  constexpr int RL = BankRow<TAPS, TR>::RL, CS = BankRow<TAPS, TR>::CS;
   extern __shared__ __align__(16) float lds[];
   const int tile = blockIdx.x / a.msplit, ms = blockIdx.x % a.msplit, grp = blockIdx.y, b = blockIdx.z;
   const int td0 = (tile / a.nH) * a.TD, th0 = (tile % a.nH) * a.TH;
   const int td = min(a.TD, a.D - td0), th = min(a.TH, a.H - th0);
   float* xs = lds + kSlack;                                              // [16][plane]
-  float* ws = lds + kSlack + (size_t)kKBlk * a.plane + kSlack;           // [nmt][NR][KBB][4 kq][16 co][4]
+  float* ws = lds + kSlack + (size_t)kKBlk * a.plane + kSlack;           // [nmt][16][CS]
   const size_t vol = (size_t)a.D * a.H * a.W;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
@@ -371,16 +390,33 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a) {
     __syncthreads();                                   // the previous block's operands are consumed
     GconvArgs ab = a;
     ab.Cin = min(kKBlk, a.Cin - k0);                   // channels of this block (the rest of the 16 planes stays zero)
-    stage_halo_tile<DIM>(xs, a.x + (((size_t)b * a.groups + grp) * a.Cin + k0) * vol, ab, kKBlk, td0, th0, lane, wave, nwaves);
-    for (int i = threadIdx.x; i < nmt * NR * KBB * 256; i += blockDim.x) {
-      const int dx = i & 3, m = (i >> 2) & 15, k = (i >> 6) & 3, rk = i >> 8;
-      const int kb = rk % KBB, r = (rk / KBB) % NR, mtl = rk / (KBB * NR);
-      const int co = (ms + mtl * a.msplit) * 16 + m, ci = k0 + kb * 4 + k, tap = r * 3 + dx;
-      float v = 0.0f;
-      if (dx < 3 && co < a.Cout && ci < a.Cin)
-        v = a.transposed ? a.w[((size_t)(grp * a.Cin + ci) * a.Cout + co) * a.taps + (a.taps - 1 - tap)]
-                         : a.w[((size_t)(grp * a.Cout + co) * a.Cin + ci) * a.taps + tap];
-      ws[i] = v;
+    // the halo and the planes past Cin are zero from the first block on: later blocks only overwrite the interior
+    stage_halo_tile<DIM>(xs, a.x + (((size_t)b * a.groups + grp) * a.Cin + k0) * vol, ab, kKBlk, td0, th0, lane, wave, nwaves,
+                         /*clear=*/k0 == 0 || ab.Cin < kKBlk);
+    if (dma_bank) {                                    // whole rows, 16-byte aligned: 2 LDS-DMA pieces per row
+      for (int rw = wave; rw < nmt * 16; rw += nwaves) {
+        const int mt = ms + (rw >> 4) * a.msplit, row = rw & 15;
+        const float* src = TR ? a.w + ((size_t)(grp * a.Cin + k0 + row) * a.Cout + mt * 16) * TAPS
+                              : a.w + ((size_t)(grp * a.Cout + mt * 16 + row) * a.Cin + k0) * TAPS;
+        float* dst = ws + (size_t)rw * CS;
+#pragma unroll
+        for (int p0 = 0; p0 < RL / 4; p0 += 64) {
+          if (p0 + lane < RL / 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(p0 + lane) * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + p0 * 4), 16, 0, 0);
+        }
+      }
+    } else {                                           // ragged channel counts: element by element, zeros past the ends
+      for (int i = threadIdx.x; i < nmt * 16 * RL; i += blockDim.x) {
+        const int j = i % RL, rw = i / RL;
+        const int mt = ms + (rw >> 4) * a.msplit, row = rw & 15;
+        const int c16 = j / TAPS, tp = j - c16 * TAPS;
+        const int co = TR ? mt * 16 + c16 : mt * 16 + row, ci = TR ? k0 + row : k0 + c16;
+        float v = 0.0f;
+        if (co < a.Cout && ci < a.Cin)
+          v = TR ? a.w[((size_t)(grp * a.Cin + ci) * a.Cout + co) * TAPS + tp] : a.w[((size_t)(grp * a.Cout + co) * a.Cin + ci) * TAPS + tp];
+        ws[(size_t)rw * CS + j] = v;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -391,18 +427,19 @@ __global__ void __launch_bounds__(kThreadsBig) gconv_fwd4k_kernel(GconvArgs a) {
       const int x0 = xq * 4;
       const bool bl = x0 == 0, br = x0 + 4 == a.W;
       const int off = (z * a.Hs + y) * a.W + x0;
-      const float* wm = ws + (size_t)it_mt[u] * NR * KBB * 256;
+      // forward: ws[co][ci][tap]; backward-data: ws[ci][co][taps - 1 - tap]
+      const float* wm = ws + (size_t)it_mt[u] * 16 * CS + (TR ? kq * CS + col * TAPS + (TAPS - 1) : col * CS + kq * TAPS);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int roff = ((r / 3) * a.Hs + (r % 3)) * a.W;
 #pragma unroll
         for (int kb = 0; kb < KBB; ++kb) {
-          const float4 a4 = *(const float4*)__builtin_assume_aligned(wm + ((size_t)(r * KBB + kb) * 4 + kq) * 64 + col * 4, 16);
+          const float* ap = wm + (TR ? kb * 4 * CS - r * 3 : kb * 4 * TAPS + r * 3);
+          const float av[3] = {ap[0], TR ? ap[-1] : ap[1], TR ? ap[-2] : ap[2]};
           const float* rp = xs + (size_t)(kb * 4 + kq) * a.plane + off + roff;
           const float4 q4 = *(const float4*)__builtin_assume_aligned(rp, 16);
           const float lf = bl ? 0.0f : rp[-1], rt = br ? 0.0f : rp[4];
           const float v[6] = {lf, q4.x, q4.y, q4.z, q4.w, rt};
-          const float av[3] = {a4.x, a4.y, a4.z};
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -1172,7 +1209,6 @@ __global__ void __launch_bounds__(256 * kWsSplit) gconv_wrw_small_kernel(GconvAr
 // batch is split over `ksplit` workgroups whose partials go to the workspace of the ring kernel's reduction
 // (gconv_wrw_reduce_kernel, fixed order).   grid = (ci_blocks * co_blocks * ksplit, groups)
 // ---------------------------------------------------------------------------
-std::atomic<unsigned> t_gconv_debug{0};      // ct_debug_set_gconv: bit 0 = small-volume weight gradient on the vector ALU
 constexpr int kWmThreads = 512;
 constexpr int kWmWaves = kWmThreads / 64;
 constexpr int kWmUnits = 4;                      // 16-byte staging units per thread and operand, at most
@@ -1564,7 +1600,9 @@ int launch_fwd4k(GconvArgs a, int dim, hipStream_t st) {
   for (int step = 0; step < MT; ++step) {
     const int msplit = pass == 0 ? step + 1 : MT - step;
     const int nmt = (MT + msplit - 1) / msplit;
-    const size_t wbytes = (size_t)nmt * NR * (kKBlk / 4) * 256 * 4;
+    const int CS = dim == 3 ? (a.transposed ? BankRow<27, true>::CS : BankRow<27, false>::CS)
+                            : (a.transposed ? BankRow<9, true>::CS : BankRow<9, false>::CS);
+    const size_t wbytes = (size_t)nmt * 16 * CS * 4;
     GconvArgs t = a;
     if (!plan_tiles_min_halo(t, dim, 0, wbytes, kKBlk, 16, kLdsBudgetMax)) continue;
     if (pass == 0 && t.nD * t.nH != 1) continue;
@@ -1577,14 +1615,19 @@ int launch_fwd4k(GconvArgs a, int dim, hipStream_t st) {
     const size_t lds = (size_t)kKBlk * t.plane * 4 + wbytes + 2 * kSlack * 4;
     dim3 grid(t.nD * t.nH * msplit, a.groups, a.B);
     const int maxi = items <= kWaves ? 1 : (items <= 2 * kWaves ? 2 : 4);
+    // whole 16-channel rows at 16-byte aligned addresses move by LDS-DMA
+    const int dma = (a.Cin % 16 == 0 && a.Cout % 16 == 0 && (((uintptr_t)a.w) & 15) == 0) ? 1 : 0;
     CT_CLEAR_ERROR();
-#define CT_F4K_LAUNCH(DIMV, MAXIV)                                                              \
-    do {                                                                                        \
-      if (set_lds_attr(gconv_fwd4k_kernel<DIMV, MAXIV>, lds) != CT_OK) return CT_ELAUNCH;       \
-      hipLaunchKernelGGL((gconv_fwd4k_kernel<DIMV, MAXIV>), grid, dim3(kThreadsBig), lds, st, t); \
+#define CT_F4K_LAUNCH(DIMV, MAXIV, TRV)                                                                \
+    do {                                                                                               \
+      if (set_lds_attr(gconv_fwd4k_kernel<DIMV, MAXIV, TRV>, lds) != CT_OK) return CT_ELAUNCH;         \
+      hipLaunchKernelGGL((gconv_fwd4k_kernel<DIMV, MAXIV, TRV>), grid, dim3(kThreadsBig), lds, st, t, dma); \
     } while (0)
-    if (dim == 2) { if (maxi == 1) CT_F4K_LAUNCH(2, 1); else if (maxi == 2) CT_F4K_LAUNCH(2, 2); else CT_F4K_LAUNCH(2, 4); }
-    else { if (maxi == 1) CT_F4K_LAUNCH(3, 1); else if (maxi == 2) CT_F4K_LAUNCH(3, 2); else CT_F4K_LAUNCH(3, 4); }
+#define CT_F4K_MAXI(DIMV, TRV) \
+    do { if (maxi == 1) CT_F4K_LAUNCH(DIMV, 1, TRV); else if (maxi == 2) CT_F4K_LAUNCH(DIMV, 2, TRV); else CT_F4K_LAUNCH(DIMV, 4, TRV); } while (0)
+    if (dim == 2) { if (a.transposed) CT_F4K_MAXI(2, true); else CT_F4K_MAXI(2, false); }
+    else { if (a.transposed) CT_F4K_MAXI(3, true); else CT_F4K_MAXI(3, false); }
+#undef CT_F4K_MAXI
 #undef CT_F4K_LAUNCH
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -1627,7 +1670,8 @@ int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   if (const int cob = tiny_cob(a, dim)) return launch_tiny(a, dim, cob, st);
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
-  if (rows16 && a.Cin > 32) {      // wide groups: contraction in blocks of 16 input channels
+  const unsigned dbg_cin = (t_gconv_debug.load(std::memory_order_relaxed) >> 8) & 0xffu;
+  if (rows16 && a.Cin >= (dbg_cin ? (int)dbg_cin : 32)) {      // wide groups (>= 32 input channels): contraction in blocks of 16
     const int r = launch_fwd4k(a, dim, st);
     if (r != CT_EINVAL) return r;
   }
