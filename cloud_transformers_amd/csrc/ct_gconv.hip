@@ -23,12 +23,15 @@
 //   gconv_bwd_weight_kernel backward-weight for rows that are not a multiple of 4 floats (tile form, float atomics)
 #include "ct_common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// ct_debug_set_gconv: bit 0 = small-volume weight gradient on the vector ALU; bits 8..15 = input channels per group from which
+// ct_debug_set_gconv: bit 0 = small-volume weight gradient on the vector ALU; bit 1 = four-channel 3D groups never / bit 2 = always
+// on the matrix cores;
+// bits 8..15 = input channels per group from which
 // the forward / backward-data pass takes the K-split kernel (0 = default)
 std::atomic<unsigned> t_gconv_debug{0};
 
@@ -146,6 +149,37 @@ __device__ __forceinline__ void stage_halo_tile(float* xs, const float* xg, cons
       }
     }
   }
+}
+
+// LDS-DMA issued through inline asm so that it stays OUT of the compiler's wait-count bookkeeping: with the
+// builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the next LDS read (it cannot tell the ring slots
+// apart), which drains the prefetch before the phase it was meant to overlap.  The issuing wave waits
+// itself (dma_wait_all) before the barrier that publishes the slot.
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// wait until at most n of this wave's vector-memory operations are outstanding (they retire in issue order): the immediate of
+// s_waitcnt must be a constant, hence the switch (n is wave-uniform)
+__device__ __forceinline__ void dma_wait_upto(int n) {
+#define CT_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 31 ? 31 : n)) {
+    CT_VMW(0) CT_VMW(1) CT_VMW(2) CT_VMW(3) CT_VMW(4) CT_VMW(5) CT_VMW(6) CT_VMW(7) CT_VMW(8) CT_VMW(9) CT_VMW(10) CT_VMW(11)
+    CT_VMW(12) CT_VMW(13) CT_VMW(14) CT_VMW(15) CT_VMW(16) CT_VMW(17) CT_VMW(18) CT_VMW(19) CT_VMW(20) CT_VMW(21) CT_VMW(22)
+    CT_VMW(23) CT_VMW(24) CT_VMW(25) CT_VMW(26) CT_VMW(27) CT_VMW(28) CT_VMW(29) CT_VMW(30) CT_VMW(31)
+  }
+#undef CT_VMW
 }
 
 // grid = (nD*nH, groups, B)
@@ -626,6 +660,224 @@ __global__ void __launch_bounds__(kThreads) gconv_c4_kernel(GconvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Four-channel groups in 3D (the zoo's 32^3 C4 head) ON THE MATRIX CORES, forward and backward-data.
+// With 4 output channels a 16x16x4 MFMA has 12 idle rows.  They are filled with the OTHER TWO DEPTH TAPS: for an input
+// slice s, one MFMA per in-plane tap (dy, dx) computes
+//     D[(g, co)][pos] += sum_ci W[co][ci][dz(g)][dy][dx] * X[ci][s][y + dy][pos + dx]        g = 0..2, 16 positions of a row
+// where lane group g (D rows 4g..4g+3 live in lanes 16g..16g+15) accumulates the output slice z in {s-1, s, s+1} with
+// z mod 3 == g, i.e. dz(g) = s - z: the B operand (the input slice) is shared by the three depth taps, 12 of 16 rows and all
+// of K (= the 4 input channels) are useful.  A wave walks z for its columns (a row y x 16 positions): 9 MFMAs per slice; after
+// slice s the output slice s-1 is complete — the lanes of group (s-1) mod 3 add the bias, store and clear their
+// accumulators.  The A operands (3 rotations x 9 taps, one register each) are loaded once.  Input slices stream through a
+// ring of three LDS buffers [ci][rows + 2][W + 2] (zero halo: no masks) by LDS-DMA two slices ahead, one barrier per slice.
+// grid = (row tiles * depth segments, groups, B); needs W % 16 == 0.
+// ---------------------------------------------------------------------------
+#ifndef CT_C4M_THREADS
+#define CT_C4M_THREADS 512
+#endif
+#ifndef CT_C4M_COLS
+#define CT_C4M_COLS 4
+#endif
+#ifndef CT_C4M_WGS
+#define CT_C4M_WGS 512
+#endif
+constexpr int kC4mThreads = CT_C4M_THREADS;
+constexpr int kC4mCols = CT_C4M_COLS;                 // columns per wave
+
+template <bool TR>
+__global__ void __launch_bounds__(kC4mThreads, 4) gconv_c4_mfma3_kernel(GconvArgs a, int TH, int LZ, int nZ, int CSX) {
+  extern __shared__ __align__(16) float lds[];
+  const int W = a.W, H = a.H, D = a.D, XB = W >> 4;
+  const int yt = blockIdx.x / nZ, zs = blockIdx.x % nZ, grp = blockIdx.y, b = blockIdx.z;
+  const int th0 = yt * TH, th = min(TH, H - th0);
+  const int l0 = zs * LZ, l1 = min(D, l0 + LZ);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NW = kC4mThreads / 64;
+  const int col = lane & 15, kq = lane >> 4;
+  const size_t vol = (size_t)D * H * W;
+  const float* xg = a.x + ((size_t)b * a.groups + grp) * 4 * vol;
+  float* yg = a.y + ((size_t)b * a.groups + grp) * 4 * vol;
+  const float* wg = a.w + (size_t)grp * 16 * 27;
+  float* ring = lds + kSlack;                                        // [3][4][CSX]: slices, rows th0 - 1 .. th0 + th, no x halo
+  float* outb = ring + (size_t)3 * 4 * CSX + kSlack;                 // [2][4][TH * W]: finished output slices
+
+  // A operands: lane (row i = col -> group gi = col >> 2, output channel co = col & 3; k = kq = input channel)
+  float A[3][9];
+  {
+    const int gi = col >> 2, co = col & 3, ci = kq;
+#pragma unroll
+    for (int rot = 0; rot < 3; ++rot) {
+      // slice s (s mod 3 == rot) meets group gi's output slice z (z mod 3 == gi) at depth tap s - z + 1
+      const int d = (rot - gi + 3) % 3;                              // (s - z) mod 3: 0 -> tap 1, 1 -> tap 2, 2 -> tap 0
+      const int dzt = d == 0 ? 1 : (d == 1 ? 2 : 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tap = dzt * 9 + t;
+        float v = 0.0f;
+        if (gi < 3) v = TR ? wg[(ci * 4 + co) * 27 + (26 - tap)] : wg[(co * 4 + ci) * 27 + tap];
+        A[rot][t] = v;
+      }
+    }
+  }
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = a.bias != nullptr ? a.bias[grp * 4 + r] : 0.0f;
+
+  // this wave's columns (a tile row x 16 positions)
+  const int ncols = th * XB;
+  int c_off[kC4mCols], c_out[kC4mCols];
+  bool c_ok[kC4mCols], c_ml[kC4mCols], c_mr[kC4mCols];
+  floatx4 acc[kC4mCols];
+#pragma unroll
+  for (int u = 0; u < kC4mCols; ++u) {
+    const int c = wave + u * NW;
+    c_ok[u] = c < ncols;
+    const int yrow = c_ok[u] ? c / XB : 0, xb = c_ok[u] ? c % XB : 0;         // (a column past the tile reads column 0's operands)
+    c_off[u] = kq * CSX + yrow * W + xb * 16 + col - 1;              // operand of (dy = 0, dx = 0): tile row yrow, x - 1
+    c_out[u] = yrow * W + xb * 16 + col;
+    c_ml[u] = xb == 0 && col == 0;                                   // the left / right neighbour is outside the row
+    c_mr[u] = xb == XB - 1 && col == 15;
+    acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  for (int i = threadIdx.x; i < 3 * 4 * CSX + 2 * kSlack; i += kC4mThreads) lds[i] = 0.0f;       // rows outside the image stay zero
+  __syncthreads();
+  // The rows of a (slice, channel) that exist in the image are contiguous in HBM and in LDS: 16-byte LDS-DMA pieces of 64
+  // lanes, dealt to the waves; issued outside the compiler's wait-count bookkeeping (glds16).
+  const int gy_lo = max(th0 - 1, 0), gy_hi = min(th0 + th + 1, H);
+  const int n16 = (gy_hi - gy_lo) * W / 4;                            // 16-byte units per (slice, channel)
+  const int ppc = (n16 + 63) / 64;                                    // pieces per channel
+  constexpr int kMaxPc = 2;                                           // pieces per wave and slice (host: 4 * ppc <= kMaxPc * waves)
+  int np = 0, pc_src[kMaxPc], pc_dst[kMaxPc];
+  bool pc_on[kMaxPc];
+#pragma unroll
+  for (int k = 0; k < kMaxPc; ++k) {
+    const int pc = wave + k * NW;
+    const bool on = pc < 4 * ppc;
+    const int ci = on ? pc / ppc : 0, p0 = on ? (pc - ci * ppc) * 64 : 0;
+    pc_on[k] = on && p0 + lane < n16;
+    np += on ? 1 : 0;
+    pc_src[k] = ci * (int)vol + gy_lo * W + (p0 + lane) * 4;          // + s * H * W
+    pc_dst[k] = (ci * CSX + (gy_lo - th0 + 1) * W + p0 * 4) * 4;       // bytes, + ring buffer
+  }
+  const unsigned ring_lds = lds_addr(ring);
+  auto load_slice = [&](int s, int rb) {
+    const float* src = xg + (size_t)s * H * W;
+#pragma unroll
+    for (int k = 0; k < kMaxPc; ++k) {
+      if (wave + k * NW < 4 * ppc) {                                   // wave-uniform
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(rb * 4 * CSX * 4 + pc_dst[k]));
+        if (pc_on[k]) glds16(src + pc_src[k], dst);
+      }
+    }
+  };
+  // a finished slice goes to LDS (lanes of its group) and leaves as whole 16-byte rows one step later
+  const int n4 = th * W;                                              // float4 units of a slice: [4][th * W / 4]
+  constexpr int kMaxSt = 2;                                           // 16-byte stores per thread and slice (host: n4 <= kMaxSt * threads)
+  int nst = 0, st_dst[kMaxSt];
+  bool st_on[kMaxSt];
+#pragma unroll
+  for (int k = 0; k < kMaxSt; ++k) {
+    const int t = threadIdx.x + k * kC4mThreads;
+    st_on[k] = t < n4;
+    nst += wave * 64 + k * kC4mThreads < n4 ? 1 : 0;                  // store instructions of this wave per slice
+    const int per = th * W / 4, co = st_on[k] ? t / per : 0, i = t - co * per;
+    st_dst[k] = co * (int)vol + th0 * W + i * 4;                      // + z * H * W
+  }
+  auto flush = [&](int z) {                                          // output slice z is complete (or out of range)
+    const int gd = ((z % 3) + 3) % 3;
+    if (kq == gd) {
+      if (z >= l0 && z < l1) {
+        float* ob = outb + (size_t)(z & 1) * 4 * TH * W;
+#pragma unroll
+        for (int u = 0; u < kC4mCols; ++u) {
+          if (c_ok[u]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r * th * W + c_out[u]] = acc[u][r] + bias[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kC4mCols; ++u) acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  auto store_slice = [&](int z) {                                    // -> number of store instructions issued
+    if (z < l0 || z >= l1) return 0;
+    const float4* ob = (const float4*)(outb + (size_t)(z & 1) * 4 * TH * W);
+    float* dst = yg + (size_t)z * H * W;
+#pragma unroll
+    for (int k = 0; k < kMaxSt; ++k)
+      if (st_on[k]) *(float4*)(dst + st_dst[k]) = ob[threadIdx.x + k * kC4mThreads];
+    return nst;
+  };
+  unsigned m_l[kC4mCols], m_r[kC4mCols];                              // all ones, or zero where the neighbour is outside the row
+#pragma unroll
+  for (int u = 0; u < kC4mCols; ++u) { m_l[u] = c_ml[u] ? 0u : ~0u; m_r[u] = c_mr[u] ? 0u : ~0u; }
+  auto step = [&](int rb, auto rotc) {                               // rb: ring buffer of the slice
+    constexpr int rot = decltype(rotc)::value;
+    const float* xs = ring + (size_t)rb * 4 * CSX;
+    // The columns' MFMAs alternate (independent accumulators); a column past the tile multiplies column 0's operands and is
+    // never stored.  Row dy + 1 is requested before row dy is multiplied; the out-of-row neighbours are masked by an AND (a
+    // select would become a predicated load: two EXEC updates per operand).
+    float v[2][kC4mCols][3];
+    auto load_row = [&](int dy, float (&w)[kC4mCols][3]) {
+#pragma unroll
+      for (int u = 0; u < kC4mCols; ++u) {
+        const float* bp = xs + c_off[u] + dy * W;
+        w[u][0] = __uint_as_float(__float_as_uint(bp[0]) & m_l[u]);
+        w[u][1] = bp[1];
+        w[u][2] = __uint_as_float(__float_as_uint(bp[2]) & m_r[u]);
+      }
+    };
+    load_row(0, v[0]);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      if (dy < 2) load_row(dy + 1, v[(dy + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int u = 0; u < kC4mCols; ++u)
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rot][dy * 3 + dx], v[dy & 1][u][dx], acc[u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Step s: wait for this wave's pieces of slice s only — the operations issued after them (the stores of the two previous
+  // steps and the pieces of slice s + 1) stay in flight —, barrier, request slice s + 2, send slice s - 2 out, multiply,
+  // park slice s - 1.
+  const int s_beg = max(l0 - 1, 0), s_end = min(l1, D - 1);
+  int rb = s_beg % 3, rot = rb;                       // ring buffer of slice s (= s mod 3, which is also the A rotation)
+  load_slice(s_beg, rb);
+  if (s_beg + 1 <= s_end) load_slice(s_beg + 1, (rb + 1) % 3);
+  int st1 = 0, st2 = 0;                               // stores issued one / two steps ago
+  for (int s = s_beg; s <= s_end; ++s) {
+    const int later = s == s_beg ? (s + 1 <= s_end ? np : 0)
+                                 : st2 + (s + 1 <= s_end ? np : 0) + st1;
+    dma_wait_upto(later);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes of the previous step (flush) are done
+    __builtin_amdgcn_s_barrier();                      // slice s has landed; slice s - 1 is consumed, slice s - 2 parked by every wave
+    const int rb2 = rb == 0 ? 2 : rb - 1;              // (s + 2) mod 3
+    if (s + 2 <= s_end) load_slice(s + 2, rb2);
+    st2 = st1;
+    st1 = store_slice(s - 2);
+    if (rot == 0) step(rb, std::integral_constant<int, 0>());
+    else if (rot == 1) step(rb, std::integral_constant<int, 1>());
+    else step(rb, std::integral_constant<int, 2>());
+    flush(s - 1);
+    rb = rb == 2 ? 0 : rb + 1;
+    rot = rb;
+  }
+  __syncthreads();
+  store_slice(s_end - 1);
+  if (l1 == D) {                                       // the last slice of the volume has no successor
+    flush(D - 1);
+    __syncthreads();
+    store_slice(D - 1);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // backward wrt the filter bank (and bias):
 //   g_w[co, ci, tap] = sum_{b, pos} g_y[b, co, pos] * x[b, ci, pos + tap]
 // implicit GEMM with K = (batch, positions): A (16x4) = g_y[co 0..15][4 positions], B (4x16) =
@@ -751,25 +1003,6 @@ __global__ void __launch_bounds__(kThreads) gconv_bwd_weight_kernel(GconvArgs a,
 // grid = (unit chunks, groups); the 3^d accumulators live in registers across all units of the
 // workgroup; one cross-wave reduction + float atomics on g_w at the end (g_w zeroed first).
 // ---------------------------------------------------------------------------
-// LDS-DMA issued through inline asm so that it stays OUT of the compiler's wait-count bookkeeping: with the
-// builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the next LDS read (it cannot tell the ring slots
-// apart), which drains the prefetch before the phase it was meant to overlap.  The issuing wave waits
-// itself (dma_wait_all) before the barrier that publishes the slot.
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // `count` contiguous floats -> LDS at dst (wave-uniform); 16-byte pieces when src / dst / count allow
 __device__ __forceinline__ void dma_run(float* dst, const float* src, int count, int lane, bool vec) {
   const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(dst));
@@ -1531,6 +1764,46 @@ int pick_msplit(const GconvArgs& a) {
   return m;
 }
 
+// four-channel groups in 3D with rows of 16-position blocks: the matrix-core kernel (see gconv_c4_mfma3_kernel)
+int c4_mfma3_rows(const GconvArgs& a) {
+  const int XB = a.W >> 4;
+  int TH = (kC4mCols * (kC4mThreads / 64)) / XB;              // columns of a workgroup: rows x 16-position blocks
+  return TH > a.H ? a.H : TH;
+}
+
+bool c4_mfma3_fits(const GconvArgs& a) {
+  if ((a.W & 15) != 0 || a.W > 16 * kC4mCols * (kC4mThreads / 64)) return false;
+  const int TH = c4_mfma3_rows(a);
+  if (TH < 1) return false;
+  // the kernel's static bounds: LDS-DMA pieces per wave (2) and 16-byte stores per thread (2) and slice
+  const int ppc = ((TH + 2) * a.W / 4 + 63) / 64;
+  return 4 * ppc <= 2 * (kC4mThreads / 64) && TH * a.W <= 2 * kC4mThreads;
+}
+
+int launch_c4_mfma3(GconvArgs a, hipStream_t st) {
+  const int TH = c4_mfma3_rows(a);
+  const int nH = (a.H + TH - 1) / TH;
+  // depth segments until the chip is covered (each walks two extra slices)
+  int nZ = 1;
+  while ((long long)a.B * a.groups * nH * nZ < CT_C4M_WGS && a.D / (nZ * 2) >= 4) nZ *= 2;
+  const int LZ = (a.D + nZ - 1) / nZ;
+  nZ = (a.D + LZ - 1) / LZ;
+  int CSX = (TH + 2) * a.W;
+  CSX += (16 - (CSX & 31) + 32) & 31;                         // == 16 (mod 32): the four channels' 16-float runs fall on all 32 banks twice
+  const size_t lds = ((size_t)3 * 4 * CSX + (size_t)2 * 4 * TH * a.W + 2 * kSlack) * 4;
+  dim3 grid(nH * nZ, a.groups, a.B);
+  CT_CLEAR_ERROR();
+  if (a.transposed) {
+    if (set_lds_attr(gconv_c4_mfma3_kernel<true>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_c4_mfma3_kernel<true>, grid, dim3(kC4mThreads), lds, st, a, TH, LZ, nZ, CSX);
+  } else {
+    if (set_lds_attr(gconv_c4_mfma3_kernel<false>, lds) != CT_OK) return CT_ELAUNCH;
+    hipLaunchKernelGGL(gconv_c4_mfma3_kernel<false>, grid, dim3(kC4mThreads), lds, st, a, TH, LZ, nZ, CSX);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 // four-channel groups with 16-byte rows: the vector-ALU kernel
 int launch_c4(GconvArgs a, int dim, hipStream_t st) {
   if (!plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudget) && !plan_tiles_min_halo(a, dim, 0, 0, 4, 4, kLdsBudgetMax)) return CT_EINVAL;
@@ -1669,6 +1942,14 @@ int launch_tiny(GconvArgs a, int dim, int cob, hipStream_t st) {
 int launch_fwd(GconvArgs a, int dim, hipStream_t st) {
   if (const int cob = tiny_cob(a, dim)) return launch_tiny(a, dim, cob, st);
   const bool rows16 = (a.W & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15) == 0;
+  // large four-channel volumes (the zoo's 32^3 C4 head at B8: 74 vs 93 us) take the matrix-core kernel; below ~2 M positions
+  // (B2: 31 vs 30 us, 16^3: 29 vs 16) its per-slice barriers cost more than the vector ALU's extra multiply-adds
+  // (debug bit 1 = never, bit 2 = always)
+  if (dim == 3 && rows16 && a.Cin == 4 && a.Cout == 4 && c4_mfma3_fits(a)) {
+    const unsigned dbg = t_gconv_debug.load(std::memory_order_relaxed);
+    const long long positions = (long long)a.B * a.groups * a.D * a.H * a.W;
+    if (!(dbg & 2) && ((dbg & 4) || positions >= (2ll << 20))) return launch_c4_mfma3(a, st);
+  }
   if (rows16 && a.Cin == 4 && a.Cout == 4) return launch_c4(a, dim, st);
   const unsigned dbg_cin = (t_gconv_debug.load(std::memory_order_relaxed) >> 8) & 0xffu;
   if (rows16 && a.Cin >= (dbg_cin ? (int)dbg_cin : 32)) {      // wide groups (>= 32 input channels): contraction in blocks of 16

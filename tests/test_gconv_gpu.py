@@ -212,3 +212,77 @@ def test_shapes_without_a_tile_plan_take_the_library_convolution():
     ref = torch.nn.functional.conv3d(x.detach().double(), m.weight.detach().double(), padding=1, groups=2)
     assert float((y.detach().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
     assert x.grad is not None and m.weight.grad is not None
+
+
+@pytest.mark.parametrize("B,G,W", [(2, 3, (32, 32, 32)), (1, 3, (5, 7, 16)), (2, 2, (9, 33, 48)), (3, 1, (1, 1, 16)), (2, 5, (2, 20, 64)),
+                                   (1, 2, (7, 5, 128)), (8, 16, (32, 32, 32))])
+def test_four_channel_3d_groups_on_the_matrix_cores(B, G, W):
+    """gconv_c4_mfma3_kernel (three depth taps per MFMA, slices streamed through an LDS ring) forced on — the dispatch takes it
+    from ~2 M positions — against float64 and against the vector-ALU kernel: forward and backward-data, ragged depth / height
+    (partial row tiles, depth segments), rows of 16 .. 128."""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    torch.manual_seed(sum(W) + B)
+    x = torch.randn(B, G * 4, *W, device="cuda")
+    w = torch.randn(G * 4, 4, 3, 3, 3, device="cuda") * 0.1
+    b = torch.randn(G * 4, device="cuda")
+    Wa = _lib.int_array(W)
+    outs = {}
+    try:
+        for flag in (4, 2):                                   # always / never
+            lib.ct_debug_set_gconv(flag)
+            y = torch.full_like(x, float("nan"))
+            gx = torch.full_like(x, float("nan"))
+            _lib.check(lib.ct_gconv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), B, G, 4, 4, 3, Wa, _stream()), "fwd")
+            _lib.check(lib.ct_gconv_bwd_data(_ptr(x), _ptr(w), _ptr(gx), B, G, 4, 4, 3, Wa, _stream()), "bwd_data")
+            outs[flag] = (y, gx)
+    finally:
+        lib.ct_debug_set_gconv(0)
+    if B * G * W[0] * W[1] * W[2] <= (1 << 20):               # float64 on the CPU for the small cases
+        xd = x.double().cpu().requires_grad_(True)
+        yr = torch.nn.functional.conv3d(xd, w.double().cpu(), b.double().cpu(), padding=1, groups=G)
+        gxr, = torch.autograd.grad(yr, xd, x.double().cpu())
+        for flag in (4, 2):
+            assert float((outs[flag][0].double().cpu() - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+            assert float((outs[flag][1].double().cpu() - gxr).abs().max()) <= 2e-5 * float(gxr.abs().max())
+    for k in range(2):
+        a, r = outs[4][k], outs[2][k]
+        assert torch.isfinite(a).all()
+        assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("B,G,Ci,Co,W", [(8, 16, 64, 64, (8, 8, 8)), (8, 16, 32, 64, (8, 8, 8)), (3, 5, 48, 40, (4, 8, 8)), (1, 2, 64, 64, (4, 4, 4)),
+                                         (8, 16, 64, 64, (16, 16)), (2, 3, 32, 64, (8, 8)), (5, 2, 64, 32, (4, 4)), (2, 16, 64, 64, (8, 8, 8))])
+def test_small_volume_weight_gradient_on_the_matrix_cores(B, G, Ci, Co, W):
+    """gconv_wrw_mfma_kernel (K = 4 x positions per MFMA, batch split over workgroups + fixed-order reduction when the channel
+    blocks do not cover the chip) against the vector-ALU form and float64; bitwise reproducible."""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    dim = len(W)
+    torch.manual_seed(Ci + Co + B)
+    x = torch.randn(B, G * Ci, *W, device="cuda")
+    gy = torch.randn(B, G * Co, *W, device="cuda")
+    Wa = _lib.int_array(W)
+    nws = lib.ct_gconv_bwd_weight_workspace_bytes(B, G, Ci, Co, dim, Wa)
+    ws = torch.empty(max(nws, 1), device="cuda", dtype=torch.uint8)
+    res = []
+    try:
+        for flag in (0, 0, 1):
+            lib.ct_debug_set_gconv(flag)
+            gw = torch.full((G * Co, Ci) + (3,) * dim, float("nan"), device="cuda")
+            gb = torch.full((G * Co,), float("nan"), device="cuda")
+            _lib.check(lib.ct_gconv_bwd_weight(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), nws, B, G, Ci, Co, dim, Wa, _stream()), "wrw")
+            res.append((gw, gb))
+    finally:
+        lib.ct_debug_set_gconv(0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    fn = torch.nn.functional.conv3d if dim == 3 else torch.nn.functional.conv2d
+    wd = torch.zeros((G * Co, Ci) + (3,) * dim, dtype=torch.float64, requires_grad=True)
+    bd = torch.zeros(G * Co, dtype=torch.float64, requires_grad=True)
+    yr = fn(x.double().cpu(), wd, bd, padding=1, groups=G)
+    gwr, gbr = torch.autograd.grad(yr, (wd, bd), gy.double().cpu())
+    for gw, gb in (res[0], res[2]):
+        assert float((gw.double().cpu() - gwr).abs().max()) <= 2e-5 * float(gwr.abs().max())
+        assert float((gb.double().cpu() - gbr).abs().max()) <= 2e-5 * float(gbr.abs().max())
