@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kBidThreads = 512;   // (256: 8 % slower over 50 iterations at n = 16384, 1024: 25 % slower)
 constexpr int kTile = 1024;   // targets per LDS tile (16 KiB as float4)
+constexpr int kEmdBigFrom = 5;   // first iteration (0-based) on the 4096-target tiles
 
 struct EmdWs {
   float* price;      // [B,n]
@@ -236,9 +237,19 @@ __device__ __forceinline__ void top2_push(Top2& t, float d, int idx) {
 // Late iterations have a handful of bidders and are pure latency: the next tile's global loads are in flight
 // while the current one is scanned (registers -> the other LDS buffer, one barrier per tile), a bidder gets up
 // to all 256 lanes, and the scan is unrolled by 4 so that four ds_read_b128 and four sqrt chains overlap.
+//
+// KTILE / KDEPTH: targets per LDS tile and tiles in flight to registers.  The first iterations (thousands of bidders: compute
+// bound) run 1024-target tiles four deep at two workgroups per CU; from the fourth iteration on (a few hundred to ~2000 bidders:
+// every tile step is a barrier + an LDS round trip + a filter refresh, 16 of them per launch at n = 16384) the launch takes
+// 4096-target tiles two deep on half as many workgroups: 4 steps instead of 16 (50 iterations at B2 n = 16384: 3.48 -> 3.34 ms
+// on uniform clouds, 2.69 -> 2.49 ms on a blob against a sphere shell).  Measured and dropped: the targets packed with their
+// prices as one float4 array (one 16-byte load per target instead of four dwords: +10 us per launch), rotated tile orders.
+template <int KTILE, int KDEPTH>
 __global__ void __launch_bounds__(kBidThreads)
 emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict__ xyz2, int n, float eps) {
-  __shared__ float4 tile[2][kTile];
+  constexpr int kTile = KTILE, kDepth = KDEPTH;
+  extern __shared__ __align__(16) float4 tile_lds[];            // [2][kTile]
+  float4 (*tile)[kTile] = (float4 (*)[kTile])tile_lds;
   __shared__ float s_best[kBidThreads / 64], s_better[kBidThreads / 64];
   __shared__ int s_idx[kBidThreads / 64];
   constexpr int kPer = kTile / kBidThreads;                     // tile elements staged per thread
@@ -254,7 +265,7 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   int T = kBidThreads / per_blk;                                // lanes per bidder
   T = T < 1 ? 1 : (T > 256 ? 256 : T);                         // (a tile holds 1024 targets: 4 per lane and step at most)
   T = 1 << (31 - __clz(T));                                     // power of two: a bidder is a lane group of a wave, or whole waves
-  // nblk = n/64 >= U/64  =>  per_blk <= 64  =>  T >= 8
+  // nblk >= n/128 >= U/128  =>  per_blk <= 128  =>  T >= 4
   const int slot = threadIdx.x / T, sub = threadIdx.x % T;
   const bool active = slot < mine;
   int j = -1;
@@ -266,7 +277,6 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
     z1 = xyz1[(off + j) * 3 + 2];
   }
   // software pipeline: tile t is scanned from LDS while tiles t+2 .. t+1+kDepth are in flight to registers
-  constexpr int kDepth = 4;
   float4 stage[kDepth][kPer];
   auto fetch = [&](int t, float4 (&st)[kPer]) {
 #pragma unroll
@@ -423,9 +433,17 @@ int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assig
   hipLaunchKernelGGL(emd_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (int*)assignment, total);
   hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n, 0, 0, 1, 0);
   const dim3 bid_grid(n / 64, B);
+  constexpr int kBigTile = 4096;
+  const bool big_ok = n % kBigTile == 0 && n >= 2 * kBigTile &&
+                      hipFuncSetAttribute((const void*)emd_bid_kernel<kBigTile, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          2 * kBigTile * (int)sizeof(float4)) == hipSuccess;
   for (int it = 0; it < iters; ++it) {
     const int last = it == iters - 1;
-    hipLaunchKernelGGL(emd_bid_kernel, bid_grid, dim3(kBidThreads), 0, st, w, xyz1, xyz2, n, eps);
+    // (the variant is chosen by the iteration number — the host never learns the number of bidders; either is correct for any)
+    if (big_ok && it >= kEmdBigFrom)
+      hipLaunchKernelGGL((emd_bid_kernel<kBigTile, 2>), dim3(n / 128, B), dim3(kBidThreads), 2 * kBigTile * sizeof(float4), st, w, xyz1, xyz2, n, eps);
+    else
+      hipLaunchKernelGGL((emd_bid_kernel<kTile, 4>), bid_grid, dim3(kBidThreads), 2 * kTile * sizeof(float4), st, w, xyz1, xyz2, n, eps);
     hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n,
                        1, last, last ? 0 : 1, last);
   }

@@ -11,7 +11,7 @@ for m in segmenter classifier inpainter; do
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_model -o m -- python3 $R/tools/${m}_step_bench.py > $OUT/prof_model_$m.log 2>&1)
   grep -h "training step" $OUT/prof_model_$m.log >> $OUT/model_breakdown.txt
   S=$(find $OUT/prof_model -name "*kernel_trace.csv" | head -1)
-  python3 tools/model_prof_report.py "$S" "$m training step (graph replays)" >> $OUT/model_breakdown.txt 2>&1
+  python3 tools/model_prof_report.py "$S" "$m training step (graph replays)" ${NTOP:-5} >> $OUT/model_breakdown.txt 2>&1
   echo >> $OUT/model_breakdown.txt
 done
 rm -rf $OUT/prof_model

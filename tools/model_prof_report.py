@@ -3,7 +3,7 @@ tools/*_step_bench.py runs) to kernel families.  Only the LAST QUARTER of the ru
 tools end with HIP-graph replays of the step, so that window is steady state: the libraries' auto-tuning runs of the first
 steps (MIOpen's find mode executes every candidate solver, its naive kernels included) and the eager warm-up are left out — — library GEMMs, this package's norm / grouped-conv / raster / lattice /
 loss kernels, torch's elementwise and reduction kernels, MIOpen, copies — with each family's share of the kernel time and
-its five largest kernels.      python3 tools/model_prof_report.py <kernel_stats.csv> [title]"""
+its largest kernels.      python3 tools/model_prof_report.py <kernel_trace.csv> [title] [kernels per family = 5]"""
 import collections
 import csv
 import sys
@@ -22,6 +22,9 @@ FAMILIES = [
 ]
 
 
+NTOP = 5
+
+
 def family(name):
     for fam, keys in FAMILIES:
         if any(k in name for k in keys):
@@ -32,6 +35,8 @@ def family(name):
 def main():
     path = sys.argv[1]
     title = sys.argv[2] if len(sys.argv) > 2 else path
+    global NTOP
+    NTOP = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     tot = collections.defaultdict(float)
     top = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
@@ -49,7 +54,7 @@ def main():
           % (title, total / 1e6, (t1 - t0) / 1e9))
     for fam, ns in sorted(tot.items(), key=lambda kv: -kv[1]):
         print("  %5.1f %%  %s" % (100 * ns / total, fam))
-        for kns, calls, name in sorted(((v[0], v[1], k) for k, v in top[fam].items()), reverse=True)[:5]:
+        for kns, calls, name in sorted(((v[0], v[1], k) for k, v in top[fam].items()), reverse=True)[:NTOP]:
             short = name.replace("(anonymous namespace)::", "").replace("void ", "")[:110]
             print("            %5.1f %%  %6d calls  %s" % (100 * kns / total, calls, short))
 
