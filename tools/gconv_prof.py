@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cloud_transformers_amd.layers.gconv import GroupedConv2d, GroupedConv3d
 cfg = sys.argv[1] if len(sys.argv) > 1 else "2d"
-WIDE = {"8c64": (3, 64, 8), "4c64": (3, 64, 4), "2c64": (3, 64, 2), "8c64_2d": (2, 64, 8)}      # (dim, channels per group, extent): the Res stacks
+WIDE = {"8c64": (3, 64, 8), "4c64": (3, 64, 4), "2c64": (3, 64, 2), "8c64_2d": (2, 64, 8), "8c32": (3, 32, 8), "32c4": (3, 4, 32)}      # (dim, channels per group, extent): the Res stacks
 if cfg in WIDE:
     d, c, w = WIDE[cfg]
     cls = GroupedConv3d if d == 3 else GroupedConv2d

@@ -9,7 +9,8 @@ CLK_GHZ = 2.4
 SIMDS = 256 * 4
 SHAPES = {"2d": "2D 32^2 C16 H64 B8", "3d": "3D 16^3 C16 H16 B8", "8c64": "3D 8^3 64->64 per group, 16 groups, B8",
           "4c64": "3D 4^3 64->64 per group, 16 groups, B8", "2c64": "3D 2^3 64->64 per group, 16 groups, B8",
-          "8c64_2d": "2D 8^2 64->64 per group, 16 groups, B8"}
+          "8c64_2d": "2D 8^2 64->64 per group, 16 groups, B8", "8c32": "3D 8^3 C32 (32->32 per group), 16 groups, B8",
+          "32c4": "3D 32^3 C4 (4->4 per group), 16 groups, B8"}
 
 
 def main():

@@ -7,7 +7,7 @@ R=/root/repo
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for cfg in 2d 3d 8c64 4c64 2c64 8c64_2d; do
+for cfg in 2d 3d 8c32 32c4 8c64 4c64 2c64 8c64_2d; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/mfma_pmc_$cfg -o m -- python3 $R/tools/gconv_prof.py $cfg > /dev/null 2> $OUT/mfma_pmc_$cfg.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$cfg -o m -- python3 $R/tools/gconv_prof.py $cfg > /dev/null 2> $OUT/mfma_stats_$cfg.err
 done
