@@ -286,3 +286,65 @@ def test_small_volume_weight_gradient_on_the_matrix_cores(B, G, Ci, Co, W):
     for gw, gb in (res[0], res[2]):
         assert float((gw.double().cpu() - gwr).abs().max()) <= 2e-5 * float(gwr.abs().max())
         assert float((gb.double().cpu() - gbr).abs().max()) <= 2e-5 * float(gbr.abs().max())
+
+
+def _rand_cfg_wide(rng):
+    """wide groups (24 .. 80 channels per side) on small volumes: the K-split forward / backward-data with its LDS-DMA and
+    element-wise bank staging, the matrix-core weight gradient with and without the batch split, ragged 16-channel blocks"""
+    dim = int(rng.integers(2, 4))
+    Wx = int(rng.choice([4, 8, 16]))
+    H = int(rng.integers(1, 9))
+    D = int(rng.integers(1, 9)) if dim == 3 else None
+    pick = lambda: int(rng.choice([32, 48, 64, 80])) if rng.random() < 0.5 else int(rng.integers(24, 81))      # noqa: E731
+    W = (D, H, Wx) if dim == 3 else (H, Wx)
+    return (int(rng.integers(1, 10)), int(rng.integers(1, 5)), pick(), pick(), dim, W, bool(rng.random() < 0.5))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gconv_fuzz_wide_groups(seed, cfg_of=_rand_cfg_wide, base=5000):
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.layers.gconv import GroupedConvFn
+    rng = np.random.default_rng(base + seed)
+    B, G, Cin, Cout, dim, W, bias = cfg_of(rng)
+    if not _lib.load().ct_gconv_supported(B, G, Cin, Cout, dim, _lib.int_array(W)):
+        pytest.skip("no tile plan: the module takes the library convolution")
+    torch.manual_seed(seed)
+    x = torch.randn(B, G * Cin, *W)
+    w = torch.randn(G * Cout, Cin, *([3] * dim)) / (Cin * 3 ** dim) ** 0.5
+    b = torch.randn(G * Cout) if bias else None
+    cot = torch.randn(B, G * Cout, *W)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    fn = torch.nn.functional.conv3d if dim == 3 else torch.nn.functional.conv2d
+    yr = fn(xr, wr, br, stride=1, padding=1, groups=G)
+    (yr * cot.double()).sum().backward()
+    xc, wc = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bc = b.cuda().requires_grad_(True) if bias else None
+    y = GroupedConvFn.apply(xc, wc, bc, G)
+    (y * cot.cuda()).sum().backward()
+
+    def close(a, r, name, tol):
+        err = float((a.detach().cpu().double() - r.detach()).abs().max())
+        assert err <= tol * max(1.0, float(r.abs().max())), (name, (B, G, Cin, Cout, dim, W, bias), err)
+
+    close(y, yr, "y", 2e-5)
+    close(xc.grad, xr.grad, "g_x", 2e-5)
+    close(wc.grad, wr.grad, "g_w", 5e-5)
+    if bias:
+        close(bc.grad, br.grad, "g_bias", 5e-5)
+
+
+def _rand_cfg_c4_3d(rng):
+    Wx = int(rng.choice([16, 32, 48, 64, 128]))
+    return (int(rng.integers(1, 4)), int(rng.integers(1, 4)), 4, 4, 3, (int(rng.integers(1, 12)), int(rng.integers(1, 40)), Wx), bool(rng.random() < 0.5))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gconv_fuzz_four_channel_3d_on_the_matrix_cores(seed):
+    from cloud_transformers_amd import _lib
+    lib = _lib.load()
+    lib.ct_debug_set_gconv(4)                                  # the matrix-core kernel whatever the size
+    try:
+        test_gconv_fuzz_wide_groups(seed, _rand_cfg_c4_3d, 6000)
+    finally:
+        lib.ct_debug_set_gconv(0)
