@@ -1642,6 +1642,178 @@ __global__ void __launch_bounds__(256) gconv_wrw_reduce_kernel(const float* ws, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of four-channel 3D groups ON THE MATRIX CORES.
+//   g_w[co][ci][dz][dy][dx] = sum_p g_y[co][p] x[ci][p + (dz-1)HW + (dy-1)W + (dx-1)]
+//                           = sum_q g_y[co][q - (dx-1)] x[ci][q + (dz-1)HW + (dy-1)W]           (q = p + dx - 1)
+// so with the column shift on g_y and the depth / row shifts on x a 16x16x4 MFMA over 4 consecutive positions q computes
+//     D[(dz, ci)][(dx, co)] += sum_k x[ci][slice z + dz-1][row + dy-1][q_k] * g_y[co][q_k - (dx-1)]
+// for one row tap dy: nine taps x 16 channel pairs per MFMA (12 of 16 rows and columns in use), three MFMAs (dy) per four
+// positions, the g_y operand shared by the three.  The lanes of an A operand differ in (dz, ci) — three ring slots with their
+// own offsets — and kq, never in the row, so no two of them meet on a bank beyond the 2-per-bank minimum of 64 lanes (the first
+// mapping had dy in the B operand's lanes: rows of exactly 32 floats put all of them on the same 8 banks, LDS 50 % busy at 63 %
+// conflicts).  g_y shifted out of its row is masked (one AND per k-step); x rows / slices outside the volume are zeros in LDS.
+// MFMA row 12 (dz group 3, ci 0) of the dy = 1 operand is the constant 1: D[12][(dx = 1, co)] = sum of g_y, the bias gradient.
+// A WAVE owns R rows of one (batch, group) volume and walks a depth segment on its own: its x slices (rows +- 1) and g_y slices
+// stream through wave-private LDS rings by LDS-DMA one step ahead — no workgroup barrier in the loop (a wave waits for its own
+// pieces with s_waitcnt vmcnt(0): nothing else of it is in flight).  The waves of a workgroup are the row blocks of one (batch,
+// group, depth segment); they add their partials through LDS in a fixed tree and write one slot of the ring kernel's
+// workspace ([chunk][group][ci][co * 27 + tap], bias partials behind), summed by gconv_c4_wrw_reduce_kernel in a fixed order.
+// grid = (depth segments, groups, B), block = ceil(H / R) waves
+// ---------------------------------------------------------------------------
+constexpr int kC4wRing = 4;                  // x slices in the ring (z-1, z, z+1 live + one in flight)
+
+__global__ void __launch_bounds__(1024) gconv_c4_wrw_mfma3_kernel(GconvArgs a, const float* __restrict__ gy, float* __restrict__ ws,
+                                                                  int R, int LZ, int SX, int SG, int chunks) {
+  extern __shared__ __align__(16) float lds[];
+  const int W = a.W, H = a.H, D = a.D, WQ = W >> 2;
+  const int zs = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int y0 = wave * R, rows = min(R, H - y0);                    // this wave's rows
+  const int l0 = zs * LZ, l1 = min(D, l0 + LZ);
+  const size_t vol = (size_t)D * H * W;
+  const float* xg = a.x + ((size_t)b * a.groups + grp) * 4 * vol;
+  const float* gg = gy + ((size_t)b * a.groups + grp) * 4 * vol;
+  // wave-private rings: x [kC4wRing][4 ci][SX] (rows y0 - 1 .. y0 + rows), g_y [2][4 co][SG] (rows y0 .. y0 + rows - 1)
+  const int per_wave = kC4wRing * 4 * SX + 2 * 4 * SG + 2 * kSlack + 16;     // (+ 16: what a unit past the end of a slice reads)
+  float* xr = lds + (size_t)wave * per_wave + kSlack;
+  float* gr = xr + kC4wRing * 4 * SX + kSlack;
+  for (int i = threadIdx.x; i < nwaves * per_wave; i += blockDim.x) lds[i] = 0.0f;      // x rows / slices outside the volume stay zero
+  __syncthreads();
+
+  floatx4 acc[3];                                                    // per row tap dy
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) acc[dy] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (rows > 0) {
+    // A operand: MFMA row i = col -> (dz = col >> 2, ci = col & 3), k = kq:  x[ci][slice z + dz - 1][row + dy - 1][x0 + kq]
+    // B operand: column j = col -> (dx = col >> 2, co = col & 3), k = kq:    g_y[co][slice z][row][x0 + kq - (dx - 1)]
+    const int grp4 = col >> 2, ch = col & 3;
+    const unsigned m_first = (kq == 0 && grp4 == 2) ? 0u : ~0u;      // first quad of a row: q - 1 is outside (dx = 2)
+    const unsigned m_last = (kq == 3 && grp4 == 0) ? 0u : ~0u;       // last quad: q + 1 is outside (dx = 0)
+    const unsigned m_keep = col == 12 ? 0u : ~0u;                     // MFMA row 12 of the dy = 1 operand ...
+    const unsigned m_one = col == 12 ? 0x3f800000u : 0u;             // ... is the constant 1
+    const int b_off = ch * SG + kq - grp4 + 1;
+    const int gy_lo = max(y0 - 1, 0), gy_hi = min(y0 + rows + 1, H);
+    const unsigned xr_lds = lds_addr(xr), gr_lds = lds_addr(gr);
+    const int nx16 = (gy_hi - gy_lo) * W / 4, ng16 = rows * W / 4;    // 16-byte units per channel
+    auto load_x = [&](int z) {                                       // slice z, rows y0 - 1 .. y0 + rows -> ring slot z mod 4
+      const int slot = z & (kC4wRing - 1);
+      if (z < 0 || z >= D) {                                         // outside the volume: the slot must read as zeros
+        for (int i = lane; i < 4 * SX; i += 64) xr[slot * 4 * SX + i] = 0.0f;
+        return;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* src = xg + (size_t)c * vol + ((size_t)z * H + gy_lo) * W;
+        for (int p0 = 0; p0 < nx16; p0 += 64) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(xr_lds + (unsigned)(((slot * 4 + c) * SX + (gy_lo - y0 + 1) * W + p0 * 4) * 4));
+          if (p0 + lane < nx16) glds16(src + (size_t)(p0 + lane) * 4, dst);
+        }
+      }
+    };
+    auto load_g = [&](int z) {
+      const int slot = z & 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* src = gg + (size_t)c * vol + ((size_t)z * H + y0) * W;
+        for (int p0 = 0; p0 < ng16; p0 += 64) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(gr_lds + (unsigned)(((slot * 4 + c) * SG + p0 * 4) * 4));
+          if (p0 + lane < ng16) glds16(src + (size_t)(p0 + lane) * 4, dst);
+        }
+      }
+    };
+    const int nunits = (rows * WQ) >> 1;                             // units of two k-steps = two neighbouring quads of a row
+    auto step = [&](int z) {
+      // this lane's slice: z + dz - 1 in slot (z + dz - 1) mod 4 (dz group 3 reads slot z + 2: any data, its rows are unused)
+      const float* xs = xr + (((z + grp4 - 1) & (kC4wRing - 1)) * 4 + ch) * SX + kq;
+      const float* gs = gr + (z & 1) * 4 * SG + b_off;
+      // Software pipeline by hand: the next unit's 8 operands are requested before this unit's 6 MFMAs (left to itself hipcc
+      // reads an operand pair, waits, multiplies), and stay raw until they are multiplied (an AND right behind a load would
+      // wait for it on the spot).  Rows are contiguous in both rings: a unit's operands sit at 8 * unit floats, only the g_y
+      // masks know about rows (W / 4 is even: a unit's first quad may start a row, its second may end one).  A unit past the
+      // end reads the slack behind the slice with its g_y operands zeroed: no branch in the stream.
+      int lu = 0, lxq = 0;
+      auto load_unit = [&](float (&av)[2][3], float (&bv)[2], unsigned (&mk)[2]) {
+        const int o = lu * 8;
+        mk[0] = lxq == 0 ? m_first : ~0u;
+        mk[1] = lxq + 2 == WQ ? m_last : ~0u;
+        bv[0] = gs[o];
+        bv[1] = gs[o + 4];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) { av[0][dy] = xs[o + dy * W]; av[1][dy] = xs[o + 4 + dy * W]; }
+        ++lu;
+        lxq = lxq + 2 == WQ ? 0 : lxq + 2;
+      };
+      auto mfma_unit = [&](const float (&av)[2][3], const float (&bv)[2], const unsigned (&mk)[2], unsigned live) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float bq = __uint_as_float(__float_as_uint(bv[u]) & (mk[u] & live));
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bq, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((__float_as_uint(av[u][1]) & m_keep) | m_one), bq, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bq, acc[2], 0, 0, 0);
+        }
+      };
+      float aA[2][3], aB[2][3], bA[2], bB[2];
+      unsigned mA[2], mB[2];
+      load_unit(aA, bA, mA);
+      for (int u0 = 0; u0 < nunits; u0 += 2) {
+        load_unit(aB, bB, mB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(aA, bA, mA, ~0u);
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(aA, bA, mA);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(aB, bB, mB, u0 + 1 < nunits ? ~0u : 0u);           // (a unit past the end multiplies zeros)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    load_x(l0 - 1); load_x(l0); load_x(l0 + 1); load_g(l0);
+    for (int z = l0; z < l1; ++z) {
+      dma_wait_all();                                                // everything this wave requested has landed (slices <= z + 1, g_y z)
+      if (z + 2 <= l1) load_x(z + 2);                                // slot (z + 2) mod 4 held slice z - 2: lands while this step multiplies
+      if (z + 1 < l1) load_g(z + 1);
+      step(z);
+    }
+  }
+  // partial filters of the waves: a fixed tree through LDS (upper half writes, lower half adds)
+  __syncthreads();
+  constexpr int NV = 12;
+  int half = 1;
+  while (half < nwaves) half <<= 1;
+  for (half >>= 1; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* red = lds + (size_t)(wave - half) * NV * 64 + lane;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(dy * 4 + r) * 64] = acc[dy][r];
+    }
+    __syncthreads();
+    if (wave < half && wave + half < nwaves) {
+      const float* red = lds + (size_t)wave * NV * 64 + lane;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[dy][r] += red[(dy * 4 + r) * 64];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  // lane (dz = kq, dx = col >> 2, co = col & 3), register r = ci: g_w[co][ci][dz][dy][dx]
+  const int chunk = blockIdx.z * gridDim.x + blockIdx.x;
+  float* o = ws + ((size_t)chunk * a.groups + grp) * 16 * 27;
+  const int dx = col >> 2, co = col & 3, dz = kq;
+  if (dz < 3 && dx < 3) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * (4 * 27) + co * 27 + dz * 9 + dy * 3 + dx] = acc[dy][r];
+  }
+  // bias gradient: D row 12 = lanes 48..63, register 0, of the dy = 1 accumulator; columns (dx = 1, co)
+  if (kq == 3 && dx == 1) ws[(size_t)chunks * a.groups * 16 * 27 + ((size_t)chunk * a.groups + grp) * 4 + co] = acc[1][0];
+}
+
 // second stage of the four-channel ring kernel's reduction.  Workspace: [chunk][group][ci][co*taps + t], then [chunk][group][co] (bias).
 __global__ void __launch_bounds__(256) gconv_c4_wrw_reduce_kernel(const float* ws, float* gw, float* gbias, int chunks, int groups, int taps) {
   __shared__ float red[4][64];
@@ -2083,6 +2255,43 @@ int launch_c4_wrw(GconvArgs a, int dim, const float* g_y, float* g_w, float* g_b
   return CT_OK;
 }
 
+// four-channel 3D groups: the matrix-core weight gradient (see gconv_c4_wrw_mfma3_kernel)
+struct C4WrwPlan { int R, nwaves, nZ, LZ, SX, SG, chunks; size_t lds; };
+
+bool plan_c4_wrw_mfma3(const GconvArgs& a, int dim, C4WrwPlan& p) {
+  if (dim != 3 || a.Cin != 4 || a.Cout != 4 || (a.W & 7) != 0) return false;      // (rows of an even number of quads)
+  p.R = 4;                                                    // rows per wave (2: same time at 32^3, twice the LDS-DMA pieces)
+  p.nwaves = (a.H + p.R - 1) / p.R;
+  if (p.nwaves > 16) return false;
+  p.nZ = 1;
+  while ((long long)a.B * a.groups * p.nZ < 256 && a.D / (p.nZ * 2) >= 4) p.nZ *= 2;
+  p.LZ = (a.D + p.nZ - 1) / p.nZ;
+  p.nZ = (a.D + p.LZ - 1) / p.LZ;
+  p.SX = (((p.R + 2) * a.W + 31) & ~31) + 4;                  // == 4 (mod 32): (ci, kq) on 16 banks, the ring slots (4 SX apart) on the other 16
+  p.SG = ((p.R * a.W + 31) & ~31) + 8;                        // == 8 (mod 32): the four channels' 7-float g_y windows on 28 banks
+  const size_t per_wave = (size_t)kC4wRing * 4 * p.SX + (size_t)2 * 4 * p.SG + 2 * kSlack + 16;
+  p.lds = (size_t)p.nwaves * per_wave * 4;
+  p.chunks = a.B * p.nZ;
+  return p.lds <= (size_t)kLdsBudgetMax;
+}
+
+size_t c4_wrw_mfma3_workspace(const GconvArgs& a, const C4WrwPlan& p) {
+  return ((size_t)p.chunks * a.groups * 16 * a.taps + (size_t)p.chunks * a.groups * 4) * sizeof(float);
+}
+
+int launch_c4_wrw_mfma3(GconvArgs a, const C4WrwPlan& p, const float* g_y, float* g_w, float* g_bias, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < c4_wrw_mfma3_workspace(a, p)) return CT_EWORKSPACE;
+  dim3 grid(p.nZ, a.groups, a.B);
+  CT_CLEAR_ERROR();
+  if (set_lds_attr(gconv_c4_wrw_mfma3_kernel, p.lds) != CT_OK) return CT_ELAUNCH;
+  hipLaunchKernelGGL(gconv_c4_wrw_mfma3_kernel, grid, dim3(p.nwaves * 64), p.lds, st, a, g_y, ws, p.R, p.LZ, p.SX, p.SG, p.chunks);
+  CT_CHECK_LAUNCH();
+  const int n = a.groups * 16 * a.taps;
+  hipLaunchKernelGGL(gconv_c4_wrw_reduce_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, ws, g_w, g_bias, p.chunks, a.groups, a.taps);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 // backward-weight, tile kernel (any row length): plan + launch
 int launch_wrw_tiles(GconvArgs a, int dim, const float* g_y, float* g_w, hipStream_t st) {
   const int B = a.B, groups = a.groups;
@@ -2270,12 +2479,17 @@ size_t ct_gconv_bwd_weight_workspace_bytes(int B, int groups, int Cin, int Cout,
   if (gconv_common(a, B, groups, Cin, Cout, dim, W) != CT_OK || (a.W & 3) != 0) return 0;
   if (c4_wrw_eligible(a)) {
     WrwRingPlan p4;
-    if (plan_wrw_ring(a, dim, p4, 4)) return c4_wrw_workspace(a, p4);
+    C4WrwPlan p4m;
+    size_t need4 = plan_wrw_ring(a, dim, p4, 4) ? c4_wrw_workspace(a, p4) : 0;
+    if (plan_c4_wrw_mfma3(a, dim, p4m) && c4_wrw_mfma3_workspace(a, p4m) > need4) need4 = c4_wrw_mfma3_workspace(a, p4m);
+    if (need4) return need4;
   }
   WrwRingPlan p;
   size_t need = plan_wrw_ring(a, dim, p) ? wrw_ring_workspace(a, p) : 0;
   WrwMfmaPlan pm;
   if (plan_wrw_mfma(a, dim, pm) && wrw_mfma_workspace(a, pm) > need) need = wrw_mfma_workspace(a, pm);
+  C4WrwPlan p4m;
+  if (plan_c4_wrw_mfma3(a, dim, p4m) && c4_wrw_mfma3_workspace(a, p4m) > need) need = c4_wrw_mfma3_workspace(a, p4m);
   return need;
 }
 
@@ -2299,6 +2513,12 @@ int ct_gconv_bwd_weight(const float* x, const float* g_y, float* g_w, float* g_b
     CT_CHECK_LAUNCH();
     return CT_OK;
   }
+  C4WrwPlan p4m;
+  // four-channel 3D groups: the matrix-core kernel wherever its plan fits (161 -> 90 us at 32^3 B8, 67 -> 30 at B2, 34 -> 18 on a
+  // 5 x 7 x 16 volume; debug bit 1 = never)
+  if (workspace && aligned && plan_c4_wrw_mfma3(a, dim, p4m) && !(t_gconv_debug.load(std::memory_order_relaxed) & 2) &&
+      workspace_bytes >= c4_wrw_mfma3_workspace(a, p4m))
+    return launch_c4_wrw_mfma3(a, p4m, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
   if (workspace && aligned && c4_wrw_eligible(a)) {
     r = launch_c4_wrw(a, dim, g_y, g_w, g_bias, (float*)workspace, workspace_bytes, st);
   } else {

@@ -250,6 +250,25 @@ def test_four_channel_3d_groups_on_the_matrix_cores(B, G, W):
         a, r = outs[4][k], outs[2][k]
         assert torch.isfinite(a).all()
         assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+    # weight gradient: gconv_c4_wrw_mfma3_kernel (rows (dz, ci) x columns (dx, co), one MFMA per row tap; taken whenever its plan
+    # fits) against the ring kernel's vector-ALU engine, twice (bitwise reproducible)
+    gy = torch.randn_like(x)
+    nws = lib.ct_gconv_bwd_weight_workspace_bytes(B, G, 4, 4, 3, Wa)
+    ws = torch.empty(max(nws, 1), device="cuda", dtype=torch.uint8)
+    res = []
+    try:
+        for flag in (0, 0, 2):
+            lib.ct_debug_set_gconv(flag)
+            gw = torch.full((G * 4, 4, 3, 3, 3), float("nan"), device="cuda")
+            gb = torch.full((G * 4,), float("nan"), device="cuda")
+            _lib.check(lib.ct_gconv_bwd_weight(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), nws, B, G, 4, 4, 3, Wa, _stream()), "wrw")
+            res.append((gw, gb))
+    finally:
+        lib.ct_debug_set_gconv(0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in range(2):
+        assert torch.isfinite(res[0][k]).all()
+        assert float((res[0][k] - res[2][k]).abs().max()) <= 2e-5 * float(res[2][k].abs().max())
 
 
 @pytest.mark.parametrize("B,G,Ci,Co,W", [(8, 16, 64, 64, (8, 8, 8)), (8, 16, 32, 64, (8, 8, 8)), (3, 5, 48, 40, (4, 8, 8)), (1, 2, 64, 64, (4, 4, 4)),
