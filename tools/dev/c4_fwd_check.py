@@ -1,5 +1,7 @@
+"""Forward / backward-data of four-channel 3D groups: gconv_c4_mfma3_kernel (ct_debug_set_gconv(4): always) against the vector-ALU
+kernel (2: never) and float64, times (HIP events) and errors on a set of shapes incl. ragged ones."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd import _lib
 from cloud_transformers_amd.ops import _ptr, _stream

@@ -1,5 +1,7 @@
+"""Weight gradient of four-channel 3D groups: gconv_c4_wrw_mfma3_kernel against the ring kernel's vector-ALU engine
+(ct_debug_set_gconv(2)) and float64: times and errors."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd import _lib
 from cloud_transformers_amd.ops import _ptr, _stream

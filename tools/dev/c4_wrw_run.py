@@ -1,5 +1,6 @@
+"""A few launches of both C4 32^3 weight-gradient kernels for tools/kprof.sh (bash tools/kprof.sh c4w tools/dev/c4_wrw_run.py)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd import _lib
 from cloud_transformers_amd.ops import _ptr, _stream

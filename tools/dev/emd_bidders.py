@@ -1,5 +1,7 @@
+"""EMD at B2 n=16384: number of unassigned bidders before every one of the 50 iterations (read from the workspace after runs of
+1 .. 50 iterations) and the time of the 50-iteration call; `uniform` clouds or a `blob` against a sphere shell."""
 import os, sys, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd import _lib
 from cloud_transformers_amd.ops import _ptr, _stream

@@ -1,6 +1,6 @@
 """forward / backward-data time of the grouped conv with the K-split kernel taking groups from 16 / 32 / 33 input channels"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd import _lib
 from cloud_transformers_amd.ops import _ptr, _stream

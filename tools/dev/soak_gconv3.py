@@ -1,5 +1,7 @@
+"""Round-3 soak of the grouped conv: wide-group, forced C4-3D and general fuzz generators of tests/test_gconv_gpu.py over many
+seeds.   python3 tools/dev/soak_gconv3.py [n]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pytest
 import tests.test_gconv_gpu as G
 from cloud_transformers_amd import _lib

@@ -10,7 +10,7 @@ Round-2 run (after the hot kernels, channel-pair accumulators, 3D backward kerne
 expected difference of the kind above: a zero feature against the zero floor, tools/dev/fuzz_case_probe.py prints the cells),
 40 EMD seeds, 800 forced-hot-kernel cases (2D/3D, max/sum, masks): clean.
 Round-3 run (after the matrix-core weight gradient, the LDS-DMA bank of the K-split kernel and the C4 3D matrix-core kernel;
-tools/dev/tmp/soak_gconv3.py): 300 wide-group seeds (tests/test_gconv_gpu.py::_rand_cfg_wide, 44 without a tile plan skipped),
+tools/dev/soak_gconv3.py): 300 wide-group seeds (tests/test_gconv_gpu.py::_rand_cfg_wide, 44 without a tile plan skipped),
 150 forced C4 3D seeds, 300 general seeds: clean."""
 import os
 import sys
