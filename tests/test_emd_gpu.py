@@ -85,6 +85,19 @@ def test_large_cloud_matches_oracle_for_a_few_rounds():
     assert np.array_equal(dist.cpu().numpy(), d_ref)
 
 
+@pytest.mark.parametrize("B,n,iters", [(1, 8192, 12), (2, 16384, 8)])
+def test_late_iterations_on_the_4096_target_tiles_match_the_oracle(B, n, iters):
+    """From the sixth iteration on the Bid launch takes 4096-target tiles on half as many workgroups (ct_emd.hip, kEmdBigFrom; n a
+    multiple of 4096 and >= 8192): enough iterations to run them, assignments and distances bit for bit."""
+    from cloud_transformers_amd.emd import emdModule
+    a, b = _clouds(B, n, 1000 + n)
+    st, d_ref, ass_ref = emd_ref.forward(a, b, 0.005, iters)
+    assert st == 1
+    dist, ass = emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 0.005, iters)
+    assert np.array_equal(ass.cpu().numpy(), ass_ref)
+    assert np.array_equal(dist.cpu().numpy(), d_ref)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_matches_oracle_exactly(seed):
     """Random (B, n, eps, iters) and clouds with structure (clusters, duplicated points, a shared point set): the
