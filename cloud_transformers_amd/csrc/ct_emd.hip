@@ -318,7 +318,8 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
           for (int k = sub; k < kTile; k += 4 * T) {           // kTile / T is a multiple of 4 (T <= 256)
             float4 q[4];
             float d2[4];
-            bool keep = false;
+            unsigned long long keep = 0ull;                    // lanes with a candidate, as compare masks (one v_cmp + s_or each:
+                                                               // per-lane booleans made hipcc build them with 16-bit shifts and ORs)
 #pragma unroll
             for (int u = 0; u < 4; ++u) q[u] = tl[k + u * T];
 #pragma unroll
@@ -326,9 +327,9 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
               const float x2 = q[u].x - x1, y2 = q[u].y - y1, z2 = q[u].z - z1;
               d2[u] = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
               const float tt = cthr - q[u].w;
-              keep |= !(d2[u] > tt * fabsf(tt));
+              keep |= __builtin_amdgcn_ballot_w64(!(d2[u] > tt * fabsf(tt)));
             }
-            if (__builtin_amdgcn_ballot_w64(keep) != 0ull) {   // wave-uniform
+            if (keep != 0ull) {                                // wave-uniform
               float d[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u)      // evaluated in double like the reference (its literal 3.0 is a double), rounded once
