@@ -24,7 +24,11 @@ namespace {
 
 constexpr int kBidThreads = 512;   // (256: 8 % slower over 50 iterations at n = 16384, 1024: 25 % slower)
 constexpr int kTile = 1024;   // targets per LDS tile (16 KiB as float4)
-constexpr int kEmdBigFrom = 5;   // first iteration (0-based) on the 4096-target tiles
+#ifndef CT_EMD_BIG_FROM
+#define CT_EMD_BIG_FROM 5
+#endif
+constexpr int kEmdBigFrom = CT_EMD_BIG_FROM;
+constexpr int kEmdBigMaxU = 2048;   // ... for batches with at most this many bidders   // first iteration (0-based) on the 4096-target tiles
 
 struct EmdWs {
   float* price;      // [B,n]
@@ -246,7 +250,7 @@ __device__ __forceinline__ void top2_push(Top2& t, float d, int idx) {
 // prices as one float4 array (one 16-byte load per target instead of four dwords: +10 us per launch), rotated tile orders.
 template <int KTILE, int KDEPTH>
 __global__ void __launch_bounds__(kBidThreads)
-emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict__ xyz2, int n, float eps) {
+emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict__ xyz2, int n, float eps, int u_min, int u_max) {
   constexpr int kTile = KTILE, kDepth = KDEPTH;
   extern __shared__ __align__(16) float4 tile_lds[];            // [2][kTile]
   float4 (*tile)[kTile] = (float4 (*)[kTile])tile_lds;
@@ -256,7 +260,7 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   const int b = blockIdx.y;
   const size_t off = (size_t)b * n;
   const int U = w.unass_cnt[b];
-  if (U == 0) return;
+  if (U == 0 || U < u_min || U > u_max) return;                 // (the other tile size takes this batch: see ct_emd_fwd)
   const int nblk = gridDim.x;
   const int per_blk = (U + nblk - 1) / nblk;                    // bidders of this workgroup
   const int first = blockIdx.x * per_blk;
@@ -440,11 +444,20 @@ int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assig
                                           2 * kBigTile * (int)sizeof(float4)) == hipSuccess;
   for (int it = 0; it < iters; ++it) {
     const int last = it == iters - 1;
-    // (the variant is chosen by the iteration number — the host never learns the number of bidders; either is correct for any)
-    if (big_ok && it >= kEmdBigFrom)
-      hipLaunchKernelGGL((emd_bid_kernel<kBigTile, 2>), dim3(n / 128, B), dim3(kBidThreads), 2 * kBigTile * sizeof(float4), st, w, xyz1, xyz2, n, eps);
-    else
-      hipLaunchKernelGGL((emd_bid_kernel<kTile, 4>), bid_grid, dim3(kBidThreads), 2 * kTile * sizeof(float4), st, w, xyz1, xyz2, n, eps);
+    // The host never learns the number of bidders, so from the sixth iteration on BOTH variants are launched and each batch
+    // picks its own on the device: few bidders -> the 4096-target tiles, many -> the 1024-target ones (the other launch returns
+    // at once, ~2 us).  Uniform clouds are down to ~2000 bidders by then (3.48 -> 3.3x ms per 50 iterations with the big
+    // tiles); a collapsed cloud — the completion network's output early in training — keeps 6000-8000 bidding to the end,
+    // where the big tiles on half the workgroups cost 9.87 vs 8.78 ms.
+    if (big_ok && it >= kEmdBigFrom) {
+      hipLaunchKernelGGL((emd_bid_kernel<kBigTile, 2>), dim3(n / 128, B), dim3(kBidThreads), 2 * kBigTile * sizeof(float4), st, w, xyz1, xyz2, n, eps,
+                         0, kEmdBigMaxU);
+      hipLaunchKernelGGL((emd_bid_kernel<kTile, 4>), bid_grid, dim3(kBidThreads), 2 * kTile * sizeof(float4), st, w, xyz1, xyz2, n, eps,
+                         kEmdBigMaxU + 1, 0x7fffffff);
+    } else {
+      hipLaunchKernelGGL((emd_bid_kernel<kTile, 4>), bid_grid, dim3(kBidThreads), 2 * kTile * sizeof(float4), st, w, xyz1, xyz2, n, eps,
+                         0, 0x7fffffff);
+    }
     hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n,
                        1, last, last ? 0 : 1, last);
   }
