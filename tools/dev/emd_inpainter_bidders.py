@@ -34,3 +34,20 @@ for _ in range(5):
     _lib.check(lib.ct_emd_fwd(_ptr(rec), _ptr(gt), _ptr(dist), _ptr(ass), _ptr(ws), nws, B, n, ctypes.c_float(0.005), 50, _stream()), "emd")
 e1.record(); torch.cuda.synchronize()
 print("50 iterations: %.2f ms" % (e0.elapsed_time(e1) / 5))
+# determinism and oracle check on this collapsed cloud
+outs = []
+for _ in range(3):
+    _lib.check(lib.ct_emd_fwd(_ptr(rec), _ptr(gt), _ptr(dist), _ptr(ass), _ptr(ws), nws, B, n, ctypes.c_float(0.005), 50, _stream()), "emd")
+    torch.cuda.synchronize()
+    outs.append((dist.clone(), ass.clone()))
+print("repeatable:", all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:]), " mean dist %.6f" % float(outs[0][0].mean()))
+try:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
+    import emd_ref
+    import numpy as np
+    st, d_ref, a_ref = emd_ref.forward(rec[:1].cpu().numpy(), gt[:1].cpu().numpy(), 0.005, 8)
+    _lib.check(lib.ct_emd_fwd(_ptr(rec), _ptr(gt), _ptr(dist), _ptr(ass), _ptr(ws), nws, B, n, ctypes.c_float(0.005), 8, _stream()), "emd")
+    torch.cuda.synchronize()
+    print("oracle (batch 0, 8 iterations): assignment equal", bool(np.array_equal(ass[0].cpu().numpy(), a_ref[0])), " dist equal", bool(np.array_equal(dist[0].cpu().numpy(), d_ref[0])))
+except Exception as e:
+    print("oracle check skipped:", str(e)[:200])
