@@ -23,6 +23,20 @@ struct LatticeArgs {
   int B, H, N, dim;
 };
 
+// wave64 sum over DPP (row_shr 1/2/4/8, row_bcast 15/31: no LDS traffic; ct_raster_hot.h has the integer forms), returned
+// wave-uniform.  The 16 parameter partials of the backward took 96 ds_bpermute per thread with __shfl_xor.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#define CT_FSTEP(CTRL, ROWMASK) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false))
+  CT_FSTEP(0x111, 0xf);
+  CT_FSTEP(0x112, 0xf);
+  CT_FSTEP(0x114, 0xf);
+  CT_FSTEP(0x118, 0xf);
+  CT_FSTEP(0x142, 0xa);
+  CT_FSTEP(0x143, 0xc);
+#undef CT_FSTEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // stat_parts (nullable): per-workgroup (sum, sum of squares) of the keys it wrote, [workgroup][2], for the lattice
 // statistics the blocks report (mean / variance of the keys, layers/multihead_ct.py:109-112) — reduced by
 // lattice_stats_kernel instead of two more passes over the keys.
@@ -88,9 +102,13 @@ __global__ void __launch_bounds__(256) lattice_stats_kernel(const float* stat_pa
 // lattice_bwd_finish_kernel then sums it over the heads into g_xyz and scales g_res by kscale in place (g_xyz used
 // to be accumulated with B*3*N*H device-scope float atomics, most of this pass's time).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
 // reduced per workgroup and added with one atomic each.
-// kBwdPts points per thread: the 16 parameter partials are accumulated in registers over them before the wave
-// reduction (96 shuffles per thread were most of this kernel with one point per thread)
-constexpr int kBwdPts = 4;
+// kBwdPts points per thread.  With __shfl_xor reductions (96 ds_bpermute per thread for the 16 parameter partials) four points
+// per thread amortised them: 19.3 us at B8 H16 N4096; with the DPP sum above the reduction is 96 vector instructions and one
+// point per thread — four times the workgroups — is fastest: 12.3 us at two, 10.6 us at one.
+#ifndef CT_LATTICE_BWD_PTS
+#define CT_LATTICE_BWD_PTS 1
+#endif
+constexpr int kBwdPts = CT_LATTICE_BWD_PTS;
 
 __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const float* lattice, const float* g_lattice,
                                                           const float* g_keys, float* g_xyz, float* g_res, float* g_R, float* g_shift,
@@ -142,8 +160,7 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    float v = part[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float v = wave_sum_f32(part[i]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
   }
   __syncthreads();
