@@ -56,7 +56,7 @@ def main():
         print("  %5.1f %%  %s" % (100 * ns / total, fam))
         for kns, calls, name in sorted(((v[0], v[1], k) for k, v in top[fam].items()), reverse=True)[:NTOP]:
             short = name.replace("(anonymous namespace)::", "").replace("void ", "")[:110]
-            print("            %5.1f %%  %6d calls  %s" % (100 * kns / total, calls, short))
+            print("            %5.1f %%  %6d calls  %7.1f us each  %s" % (100 * kns / total, calls, kns / calls / 1e3, short))
 
 
 if __name__ == "__main__":
