@@ -83,6 +83,82 @@ emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2
   // previous compaction — exactly the points with assignment == -1, since only the bid kernel ran in between —
   // instead of testing all n points.
   constexpr int kUpR = 8;
+  // Fast path (at most 8192 list entries, every iteration but the first few): a thread's entries stay in registers from GetMax
+  // to Assign (two dependent load levels less), and the next list is written by the same threads — an entry that did not
+  // win stays, an evicted owner joins — with wave-aggregated appends: no pass over all n assignments, no block scan.  The list
+  // is then no longer ascending; its order decides which workgroup scans which bidder in Bid and nothing else (every
+  // bid depends on the prices alone, the per-target maxima are atomic maxima, GetMax ties go to the highest index):
+  // the assignment stays bit for bit the oracle's (tests/test_emd_gpu.py).
+  if (do_assign && w.unass_cnt[b] <= 1024 * kUpR && (do_compact || last)) {
+    __shared__ int s_new;
+    const int U = w.unass_cnt[b];
+    int* list = w.unass_idx + off;
+    if (threadIdx.x == 0) s_new = 0;
+    int j[kUpR], t[kUpR], prev[kUpR];
+    float bi[kUpR], mi[kUpR];
+    bool win[kUpR];
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) {
+      const int i = u * 1024 + (int)threadIdx.x;
+      j[u] = i < U ? list[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) {
+      t[u] = j[u] >= 0 ? bid[j[u]] : 0;
+      bi[u] = j[u] >= 0 ? bid_inc[j[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) mi[u] = j[u] >= 0 ? max_inc[t[u]] : 0.0f;       // written by the bid kernel
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) {
+      if (j[u] >= 0 && (double)bi[u] - 1e-6 <= (double)mi[u] && (double)mi[u] <= (double)bi[u] + 1e-6)
+        atomicMax(&max_idx[t[u]], j[u]);
+    }
+    __threadfence_block();
+    __syncthreads();                                  // every entry is in registers: the list may be rewritten from here on
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) win[u] = j[u] >= 0 && (last || ld_coherent(&max_idx[t[u]]) == j[u]);
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) prev[u] = (win[u] && !last) ? ass_inv[t[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < kUpR; ++u) {
+      if (win[u]) {
+        if (!last) {
+          if (prev[u] != -1) __hip_atomic_store(&ass[prev[u]], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ass_inv[t[u]] = j[u];
+          price[t[u]] += bi[u];
+          max_inc[t[u]] = -1e9f;
+          max_idx[t[u]] = -1;
+        } else {
+          ass_inv[t[u]] = j[u];
+          atomicAdd(&price[t[u]], bi[u]);
+          max_inc[t[u]] = -1e9f;
+        }
+        __hip_atomic_store(&ass[j[u]], t[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (do_compact) {
+      const int lane = threadIdx.x & 63;
+      const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+      for (int u = 0; u < kUpR; ++u) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                  // k = 0: the entry stays unassigned; k = 1: its target's previous owner is evicted
+          const bool add = k == 0 ? (j[u] >= 0 && !win[u]) : (win[u] && prev[u] != -1);
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(add);
+          if (m == 0ull) continue;                     // wave-uniform
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_new, __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (add) list[base + __popcll(m & lt)] = k == 0 ? j[u] : prev[u];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) w.unass_cnt[b] = s_new;
+    }
+    __threadfence_block();
+    __syncthreads();
+  } else {
   if (do_assign) {
     const int U = w.unass_cnt[b];
     const int* list = w.unass_idx + off;
@@ -196,6 +272,7 @@ emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2
     }
     if (threadIdx.x == 0) w.unass_cnt[b] = base;
   }
+  }   // (slow path)
 
   if (do_dist) {
     const float* p1 = xyz1 + off * 3;
