@@ -305,6 +305,12 @@ __device__ __forceinline__ Top2 merge_top2(const Top2& a, const Top2& o) {
   return r;
 }
 
+// a lane's value seen through a DPP permutation of its 16-lane row (every lane has a source: no bound control needed)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 // one candidate target against a lane's running (best, second best); strict '>' so that an ascending scan keeps
 // the lowest index on ties (emd_cuda.cu:150-157) — branch-free
 __device__ __forceinline__ void top2_push(Top2& t, float d, int idx) {
@@ -418,12 +424,19 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
 #pragma unroll
               for (int u = 0; u < 4; ++u) top2_push(t2, d[u], k0 + k + u * T);
               // second-best value over the bidder's lanes in this wave (values only; the lanes keep their own pairs)
+              // (the first four steps — 16 lanes — over DPP: quad permutes, then the 8- and 16-lane mirrors; a step over LDS
+              //  (__shfl_xor = ds_bpermute) is a dependent ~100-cycle round trip, and this refresh runs in every slow-path step)
               float gb = t2.best, g2 = t2.better;
-              for (int m = 1; m < Tw; m <<= 1) {
-                const float ob = __shfl_xor(gb, m, 64), o2 = __shfl_xor(g2, m, 64);
+              auto fold = [&](float ob, float o2) {
                 g2 = fmaxf(fminf(gb, ob), fmaxf(g2, o2));
                 gb = fmaxf(gb, ob);
-              }
+              };
+              if (Tw >= 2) fold(dpp_f32<0xB1>(gb), dpp_f32<0xB1>(g2));          // quad_perm [1,0,3,2]
+              if (Tw >= 4) fold(dpp_f32<0x4E>(gb), dpp_f32<0x4E>(g2));          // quad_perm [2,3,0,1]
+              if (Tw >= 8) fold(dpp_f32<0x141>(gb), dpp_f32<0x141>(g2));        // row_half_mirror
+              if (Tw >= 16) fold(dpp_f32<0x140>(gb), dpp_f32<0x140>(g2));       // row_mirror
+              if (Tw >= 32) fold(__shfl_xor(gb, 16, 64), __shfl_xor(g2, 16, 64));
+              if (Tw >= 64) fold(__shfl_xor(gb, 32, 64), __shfl_xor(g2, 32, 64));
               // safety margin of the filter: a candidate whose exact value reaches g2 must survive the float test.  The
               // roundings of 3 - g2, of + margin, of - price and of tt^2 add up to < 1.6e-5 while |g2| <= 32 (values of
               // interest then have |price| <= 37: ulp(64) = 7.6e-6); beyond that (large eps, late iterations: prices in
