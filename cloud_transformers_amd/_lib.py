@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("CLOUDCT_LIB") or os.path.join(LIB_DIR, "libcloudct.so
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["ct_raster.hip", "ct_mhct.hip", "ct_lattice.hip", "ct_gconv.hip", "ct_chamfer.hip", "ct_emd.hip",
-               "ct_adain.hip", "ct_bnorm.hip"]
+               "ct_adain.hip", "ct_bnorm.hip", "ct_pwgemm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # index/weight math must round exactly like the reference's fp32 op sequence
                "-ffp-contract=off"]
@@ -214,6 +214,9 @@ SIGNATURES = {
     "ct_emd_workspace_bytes": (_sz, [_i, _i]),
     "ct_emd_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _f, _i, _vp]),
     "ct_emd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ct_amax_f32": (_i, [_vp, _ll, _vp, _vp]),
+    "ct_pw_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
 }
 
 

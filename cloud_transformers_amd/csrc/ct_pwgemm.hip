@@ -1,0 +1,404 @@
+// Pointwise (kernel-size-1) convolutions of the MHCT blocks: the `keys_values_pred` / `after` / union projections
+// (layers/multihead_ct.py:31-33,62-66,89-91; nn.Conv1d(k=1) = one [Co,Ci] x [Ci,N] product per cloud) and their two
+// gradients, at fp32 accuracy on the f16 matrix pipes of gfx950.
+//
+// Every fp32 operand element x is scaled by a per-tensor power of two s (from the tensor's max |x|, so that s*max < 2^14:
+// inside f16's range with headroom) and split into two f16 terms h = f16(s x), l = f16(s x - h): h + l carries 22 bits of
+// s x.  The product is the sum of three v_mfma_f32_32x32x16_f16 terms h_a h_b + h_a l_b + l_a h_b accumulated in fp32 (f16 x
+// f16 products are exact in fp32; the dropped l_a l_b term is 2^-22 of the product), rescaled by the exact 1/(s_a s_b) in
+// the epilogue: relative error per product <= ~2^-21, the order of an fp32 GEMM's own summation error at these K, at 3/16 of
+// the matrix-pipe time of the f32-input MFMA the library GEMMs use (cdna_hip_programming.md §3 "FP32-input MFMA").
+//
+// One kernel, three operand arrangements (CT_PW_FWD / DGRAD / WGRAD): a 128x128 output tile per 256-thread workgroup (four
+// waves, 64x64 each = 2x2 MFMA tiles, 64 accumulator registers), K in steps of 32 through two LDS stages of four
+// [128 rows][32 k] f16 images (A_h, A_l, B_h, B_l: 64 KiB, two workgroups per CU).  The fp32 tiles are loaded into registers
+// one K-step ahead, split and written to the other stage after the MFMAs of the current one: one barrier per K-step.  An
+// operand is staged from either orientation — k contiguous (W in forward, both operands of the weight gradient) or the
+// tile's row index contiguous (x / g_y [Ci,N] slices, W^T in the data gradient: eight k-rows per thread, packed pairwise
+// so that the transposition costs nothing) — into the same image; 16-byte k-groups are XOR-swizzled with the row so that
+// ds_read_b128 fragment reads are conflict-free without padding (MI355X_MICROARCH.md §LDS lane groups).
+// The weight gradient sums over clouds and points: K = B*N is cut into chunks, each chunk's partial [Co,Ci] tile goes to a
+// slab and a second kernel adds the slabs in a fixed order (deterministic).
+#include "ct_common.h"
+
+typedef _Float16 pw_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pw_h2 __attribute__((ext_vector_type(2)));
+typedef float pw_f2 __attribute__((ext_vector_type(2)));
+typedef float pw_acc __attribute__((ext_vector_type(16)));
+
+constexpr int kPwTile = 128, kPwBK = 32, kPwThreads = 256;
+constexpr int kPwImg = kPwTile * kPwBK;                 // halves per image
+constexpr int kPwStage = 4 * kPwImg;                    // A_h, A_l, B_h, B_l
+constexpr int kPwLdsBytes = 2 * kPwStage * 2;           // two stages
+
+struct PwArgs {
+  const float* A; const float* B; float* C;
+  long long a_bs, b_bs, c_zs;      // element strides: operand per cloud, output per z slice
+  int lda, ldb, ldc;
+  int M, N, K;                     // output rows / columns, summed extent per cloud
+  int tilesM, tilesN, ksplit, Kc;  // z = cloud * ksplit + chunk; the chunk sums k in [chunk*Kc, min(K, (chunk+1)*Kc))
+  const float* amax_a; const float* amax_b;
+};
+
+// power of two s with s * amax in [2^13, 2^14); 1 for an all-zero or non-finite tensor (inf / nan then flow through h)
+__device__ __forceinline__ int pw_scale_exp(const float* amax) {
+  if (!amax) return 0;
+  const float m = *amax;
+  if (!(m > 0.f) || !(m < __builtin_inff())) return 0;
+  int e;
+  (void)frexpf(m, &e);
+  return min(14 - e, 126);   // 2^126 is finite; the epilogue undoes the two scales one after the other
+}
+
+// image element (row, k8 group g) -> half offset: 16-byte groups XOR-swizzled with the row
+__device__ __forceinline__ int pw_slot(int row, int g) { return row * kPwBK + ((g ^ ((row >> 2) & 3)) << 3); }
+
+// Registers of one operand tile [128 rows][32 k] for thread t.  KMAJOR (k contiguous in memory): row t>>1, 16 consecutive k
+// from (t&1)*16, r[i] = k-th element.  Otherwise (row index contiguous): k rows 8*(t>>6) .. +7, rows 2*(t&63) and +1,
+// r[2j + c] = (k row j, row c).  Loads are unconditional from clamped addresses (a predicated load becomes a branch and a
+// wait per load); the returned bits say which of them lie inside the operand: bit q / bit j per load.
+template <bool KMAJOR>
+__device__ __forceinline__ unsigned pw_load(float (&r)[16], const float* __restrict__ src, int ld, int row0, int R, int k0, int kend,
+                                            int t) {
+  unsigned ok = 0;
+  if constexpr (KMAJOR) {
+    const int row = row0 + (t >> 1), k = k0 + (t & 1) * 16;
+    const float* p = src + (size_t)min(row, R - 1) * ld;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *(const float4*)(p + min(k + 4 * q, kend - 4));
+      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+      ok |= (unsigned)(row < R && k + 4 * q < kend) << q;
+    }
+  } else {
+    const int kb = k0 + 8 * (t >> 6), f = row0 + 2 * (t & 63);
+    const float* p = src + min(f, R - 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 v = *(const float2*)(p + (size_t)min(kb + j, kend - 1) * ld);
+      r[2 * j] = v.x; r[2 * j + 1] = v.y;
+      ok |= (unsigned)(f < R && kb + j < kend) << j;
+    }
+  }
+  return ok;
+}
+
+// eight scaled values -> the h and l fragments' 16 bytes
+__device__ __forceinline__ void pw_split8(const float (&v)[8], float s, uint4& h, uint4& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const pw_f2 a = {v[2 * i] * s, v[2 * i + 1] * s};
+    const pw_h2 hi = __builtin_convertvector(a, pw_h2);
+    const pw_f2 rem = a - __builtin_convertvector(hi, pw_f2);
+    const pw_h2 lo = __builtin_convertvector(rem, pw_h2);
+    hh[i] = __builtin_bit_cast(unsigned, hi);
+    ll[i] = __builtin_bit_cast(unsigned, lo);
+  }
+  h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* imgH, _Float16* imgL, float s, int t) {
+  if (ok != (KMAJOR ? 0xfu : 0xffu)) {       // edge tiles only
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (!((ok >> (KMAJOR ? i >> 2 : i >> 1)) & 1)) r[i] = 0.f;
+  }
+  if constexpr (KMAJOR) {
+    const int row = t >> 1, g0 = (t & 1) * 2;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = r[8 * g + i];
+      uint4 h, l;
+      pw_split8(v, s, h, l);
+      const int o = pw_slot(row, g0 + g);
+      *(uint4*)(imgH + o) = h;
+      *(uint4*)(imgL + o) = l;
+    }
+  } else {
+    const int kg = t >> 6;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = r[2 * j + c];
+      uint4 h, l;
+      pw_split8(v, s, h, l);
+      const int o = pw_slot(2 * (t & 63) + c, kg);
+      *(uint4*)(imgH + o) = h;
+      *(uint4*)(imgL + o) = l;
+    }
+  }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 pw_lds[];
+  // blocks that share an XCD (id % 8) take consecutive tiles: the M tiles of one [K, 128] operand panel run side by side on
+  // one L2 (bijective form of the remap, cdna_hip_programming.md §5)
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rr = nwg & 7;
+  const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blockIdx.x >> 3);
+  const int mt = id % a.tilesM, rest = id / a.tilesM, nt = rest % a.tilesN, z = rest / a.tilesN;
+  const int cloud = z / a.ksplit, chunk = z - cloud * a.ksplit;
+  const int kbeg = chunk * a.Kc, kend = min(a.K, kbeg + a.Kc);
+  const float* A = a.A + cloud * a.a_bs;
+  const float* B = a.B + cloud * a.b_bs;
+  float* C = a.C + z * a.c_zs;
+  const int m0 = mt * kPwTile, n0 = nt * kPwTile;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1, r = lane & 31, h = lane >> 5;
+  const int ea = pw_scale_exp(a.amax_a), eb = pw_scale_exp(a.amax_b);
+  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
+
+  pw_acc acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float ra[16], rb[16];
+  unsigned oka = pw_load<A_KMAJOR>(ra, A, a.lda, m0, a.M, kbeg, kend, t);
+  unsigned okb = pw_load<B_KMAJOR>(rb, B, a.ldb, n0, a.N, kbeg, kend, t);
+  pw_store<A_KMAJOR>(ra, oka, pw_lds, pw_lds + kPwImg, sa, t);
+  pw_store<B_KMAJOR>(rb, okb, pw_lds + 2 * kPwImg, pw_lds + 3 * kPwImg, sb, t);
+  __syncthreads();
+
+  // fragment offsets: row = 64*wm + 32*i + r (A), 64*wn + 32*j + r (B); k8 group 2*ks + h
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    offA[i] = (64 * wm + 32 * i + r) * kPwBK;
+    offB[i] = (64 * wn + 32 * i + r) * kPwBK;
+  }
+  const int sw = (r >> 2) & 3;
+  const int g0 = ((0 + h) ^ sw) << 3, g1 = ((2 + h) ^ sw) << 3;
+
+  const int T = (kend - kbeg + kPwBK - 1) / kPwBK;
+  for (int kt = 0; kt < T; ++kt) {
+    const _Float16* st = pw_lds + (kt & 1) * kPwStage;
+    _Float16* nx = pw_lds + ((kt + 1) & 1) * kPwStage;
+    const int kn = kbeg + (kt + 1) * kPwBK;          // past the end on the last step: clamped loads, all masked
+    oka = pw_load<A_KMAJOR>(ra, A, a.lda, m0, a.M, kn, kend, t);
+    okb = pw_load<B_KMAJOR>(rb, B, a.ldb, n0, a.N, kn, kend, t);
+    __builtin_amdgcn_sched_barrier(0);               // the loads go out before the MFMAs, not after them
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int g = ks ? g1 : g0;
+      pw_h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *(const pw_h8*)(st + offA[i] + g);
+        al[i] = *(const pw_h8*)(st + kPwImg + offA[i] + g);
+        bh[i] = *(const pw_h8*)(st + 2 * kPwImg + offB[i] + g);
+        bl[i] = *(const pw_h8*)(st + 3 * kPwImg + offB[i] + g);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pw_store<A_KMAJOR>(ra, oka, nx, nx + kPwImg, sa, t);
+    pw_store<B_KMAJOR>(rb, okb, nx + 2 * kPwImg, nx + 3 * kPwImg, sb, t);
+    __syncthreads();
+  }
+
+  // D of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  const float ia = ldexpf(1.f, -ea), ib = ldexpf(1.f, -eb);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 64 * wn + 32 * j + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][j][e] * ia * ib;
+      }
+    }
+}
+
+// out[i] = sum_z slabs[z][i] in a fixed order: 32 float4 outputs x 8 z-groups per block, each group summed z ascending
+// (four loads in flight), the groups added in order through LDS
+__global__ void __launch_bounds__(256) pw_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n4, int Z) {
+  __shared__ float4 part[8][32];
+  const int li = threadIdx.x & 31, zg = threadIdx.x >> 5, i = blockIdx.x * 32 + li;
+  const int per = (Z + 7) >> 3, z0 = zg * per, z1 = min(Z, z0 + per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = (const float4*)slabs + i;
+    int z = z0;
+    for (; z + 4 <= z1; z += 4) {
+      const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + 1) * n4], c = p[(size_t)(z + 2) * n4], d = p[(size_t)(z + 3) * n4];
+      s.x = (((s.x + a.x) + b.x) + c.x) + d.x; s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+      s.z = (((s.z + a.z) + b.z) + c.z) + d.z; s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; z < z1; ++z) {
+      const float4 a = p[(size_t)z * n4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  part[zg][li] = s;
+  __syncthreads();
+  if (zg == 0 && i < n4) {
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+      const float4 a = part[g][li];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    ((float4*)out)[i] = s;
+  }
+}
+
+// max |x| as the bit pattern's unsigned maximum (order-independent: deterministic); eight 16-byte loads in flight per thread
+__global__ void __launch_bounds__(256) pw_amax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const long long n4 = n >> 2;
+  typedef unsigned pw_u4 __attribute__((ext_vector_type(4)));
+  const pw_u4* p = (const pw_u4*)x;
+  long long i = ((long long)blockIdx.x * 8) * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 8 * 256;
+  for (; i + 7 * 256 < n4; i += stride) {
+    pw_u4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      m = max(max(m, v[u].x & 0x7fffffffu), max(v[u].y & 0x7fffffffu, max(v[u].z & 0x7fffffffu, v[u].w & 0x7fffffffu)));
+  }
+  for (int u = 0; u < 8; ++u)
+    if (i + u * 256 < n4) {
+      const pw_u4 v = p[i + u * 256];
+      m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = max(m, __float_as_uint(x[n4 * 4 + threadIdx.x]) & 0x7fffffffu);
+  __shared__ unsigned wave_max[4];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m) atomicMax(out, m);
+  }
+}
+
+#ifndef CT_PW_ZTARGET
+#define CT_PW_ZTARGET 512
+#endif
+constexpr int kPwZTarget = CT_PW_ZTARGET;
+
+struct PwPlan {
+  int M, N, K, Z, ksplit, Kc, tilesM, tilesN;
+  size_t ws;
+};
+
+static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
+  if (B < 1 || Co < 1 || Ci < 1 || N < 1 || (Co & 3) || (Ci & 3) || (N & 3)) return false;
+  if (mode == CT_PW_FWD) { p.M = Co; p.N = N; p.K = Ci; }
+  else if (mode == CT_PW_DGRAD) { p.M = Ci; p.N = N; p.K = Co; }
+  else if (mode == CT_PW_WGRAD) { p.M = Co; p.N = Ci; p.K = N; }
+  else return false;
+  p.tilesM = (p.M + kPwTile - 1) / kPwTile;
+  p.tilesN = (p.N + kPwTile - 1) / kPwTile;
+  p.ksplit = 1;
+  p.Kc = (p.K + kPwBK - 1) / kPwBK * kPwBK;
+  p.ws = 0;
+  if (mode == CT_PW_WGRAD) {
+    // about one round of the chip's 512 workgroup slots (every slice costs a slab round trip); chunks of whole K-steps, at
+    // least eight of them
+    const int tiles = p.tilesM * p.tilesN;
+    const int zwant = (kPwZTarget + tiles - 1) / tiles;
+    int ks = (zwant + B - 1) / B;
+    int kc = ((p.K + ks - 1) / ks + kPwBK - 1) / kPwBK * kPwBK;
+    if (kc < 8 * kPwBK) kc = 8 * kPwBK;
+    p.Kc = kc;
+    p.ksplit = (p.K + kc - 1) / kc;
+    if ((long long)B * p.ksplit > 1) p.ws = (size_t)B * p.ksplit * Co * Ci * sizeof(float);
+  }
+  p.Z = B * p.ksplit;
+  if ((long long)p.tilesM * p.tilesN * p.Z > 0x7fffffffLL) return false;
+  return true;
+}
+
+template <bool AK, bool BK>
+static int pw_launch(const PwArgs& a, int blocks, hipStream_t st) {
+  auto k = pw_gemm_kernel<AK, BK>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) != hipSuccess) return CT_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(kPwThreads), kPwLdsBytes, st, a);
+  return CT_OK;
+}
+
+extern "C" {
+
+int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s) {
+  if (!x || !amax || n < 1 || ((uintptr_t)x & 15)) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(amax, 0, sizeof(float), st) != hipSuccess) return CT_ELAUNCH;
+  long long blocks = ((n >> 2) + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;     // one same-address atomic per block: they serialise at the memory side
+  hipLaunchKernelGGL(pw_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)n, (unsigned*)amax);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
+  PwPlan p;
+  return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
+}
+
+int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, const float* amax_b, void* workspace,
+               size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s) {
+  PwPlan p;
+  if (!a || !b || !out || !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CT_EINVAL;
+  if (p.ws && (!workspace || workspace_bytes < p.ws || ((uintptr_t)workspace & 15))) return CT_EWORKSPACE;
+  CT_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)s;
+  PwArgs g{};
+  g.A = a; g.B = b; g.amax_a = amax_a; g.amax_b = amax_b;
+  g.M = p.M; g.N = p.N; g.K = p.K; g.tilesM = p.tilesM; g.tilesN = p.tilesN; g.ksplit = p.ksplit; g.Kc = p.Kc;
+  const int blocks = p.tilesM * p.tilesN * p.Z;
+  int rc;
+  if (mode == CT_PW_FWD) {            // A = W [Co][Ci] (k contiguous), B = x[b] [Ci][N] (columns contiguous)
+    g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Ci * N; g.C = out; g.ldc = N; g.c_zs = (long long)Co * N;
+    rc = pw_launch<true, false>(g, blocks, st);
+  } else if (mode == CT_PW_DGRAD) {   // A = W^T: element (m = ci, k = co) at W[k][m] (rows contiguous), B = g_y[b] [Co][N]
+    g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
+    rc = pw_launch<false, false>(g, blocks, st);
+  } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous
+    g.lda = N; g.a_bs = (long long)Co * N; g.ldb = N; g.b_bs = (long long)Ci * N; g.ldc = Ci;
+    g.C = p.ws ? (float*)workspace : out;
+    g.c_zs = (long long)Co * Ci;
+    rc = pw_launch<true, true>(g, blocks, st);
+  }
+  if (rc != CT_OK) return rc;
+  CT_CHECK_LAUNCH();
+  if (mode == CT_PW_WGRAD && p.ws) {
+    const int n4 = Co * Ci / 4;
+    hipLaunchKernelGGL(pw_reduce_kernel, dim3((n4 + 31) / 32), dim3(256), 0, st, (const float*)workspace, out, n4, p.Z);
+    CT_CHECK_LAUNCH();
+  }
+  return CT_OK;
+}
+
+}  // extern "C"

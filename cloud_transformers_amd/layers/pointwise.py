@@ -1,12 +1,12 @@
 """Point-wise (kernel_size 1) Conv1d of the MHCT blocks — `keys_values_pred`, the union's `after` and
 `shortcut` projections (reference layers/multihead_ct.py:31-33,149-160).
 
-A plain library GEMM, and it stays one — three rocBLAS batched GEMMs on the tensors as they lie:
-`y[b] = W @ x[b]`, `g_x[b] = W^T @ g_y[b]` (W and W^T as broadcast views), `g_w = sum_b g_y[b] @ x[b]^T`.
-torch's conv1d reaches the same GEMMs through MIOpen for forward / data gradient (5-10 % slower at these
-shapes), but for the WEIGHT gradient MIOpen picks an NHWC implicit-GEMM kernel bracketed by layout
-transposes of x and g_y: 18-24 % slower on the whole fwd+bwd of these layers at B8 N4096
-(tools/conv1d_bench.py).
+Three products on the tensors as they lie — `y[b] = W @ x[b]`, `g_x[b] = W^T @ g_y[b]`, `g_w = sum_b g_y[b] @ x[b]^T` —
+through `ops.pw_forward` / `ops.pw_backward`: this library's split-f16 MFMA kernels (csrc/ct_pwgemm.hip: fp32 in and out,
+22-bit operands, fp32 accumulation) where the sizes are multiples of 4, rocBLAS fp32 batched GEMMs (torch.bmm, W and W^T
+as broadcast views) otherwise or under CLOUDCT_PW_GEMM=lib.  torch's own conv1d reaches the library GEMMs through MIOpen for
+forward / data gradient and an NHWC implicit-GEMM kernel bracketed by layout transposes for the weight gradient
+(tools/conv1d_bench.py, tools/pw_gemm_bench.py).
 `PointwiseConv1d` subclasses nn.Conv1d: same parameters,
 same state-dict keys, same results.
 """
@@ -14,27 +14,27 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import ops
+
 
 class _PointwiseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        x = x.contiguous()
+        w2 = weight[:, :, 0].contiguous()
+        y, am_w, am_x = ops.pw_forward(w2, x)
+        ctx.save_for_backward(x, w2, am_w, am_x)
         ctx.has_bias = bias is not None
-        w2 = weight[:, :, 0]
-        # bmm with W broadcast over the batch keeps the [B, O, N] layout (torch.matmul(W, x) folds the batch into
-        # the GEMM's M and returns a transposed view, which costs transposing copies downstream)
-        y = torch.bmm(w2.unsqueeze(0).expand(x.size(0), -1, -1), x)
         return y if bias is None else y + bias[None, :, None]
 
     @staticmethod
     def backward(ctx, g_y):
-        x, weight = ctx.saved_tensors
+        x, w2, am_w, am_x = ctx.saved_tensors
         g_y = g_y.contiguous()
-        g_x = g_w = g_b = None
-        if ctx.needs_input_grad[0]:
-            g_x = torch.bmm(weight[:, :, 0].t().unsqueeze(0).expand(g_y.size(0), -1, -1), g_y)    # W^T as a view
-        if ctx.needs_input_grad[1]:
-            g_w = torch.bmm(g_y, x.transpose(1, 2)).sum(0).unsqueeze(-1)      # [O, I, 1]
+        g_b = None
+        g_x, g_w = ops.pw_backward(w2, x, g_y, am_w, am_x, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if g_w is not None:
+            g_w = g_w.unsqueeze(-1)                                           # [O, I, 1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g_b = g_y.sum(dim=(0, 2))
         return g_x, g_w, g_b

@@ -5,6 +5,7 @@ every computation happens inside libcloudct.so.  Tensors that are not on a HIP
 device raise — there is no CPU path in the product.
 """
 import math
+import os
 
 import torch
 
@@ -71,6 +72,86 @@ def _pad_args(pad, B, N):
     if pad.dtype == torch.int32:
         return pad.contiguous(), _lib.PAD_I32
     return pad.to(torch.float32).contiguous(), _lib.PAD_F32
+
+
+# ---------------------------------------------------------------------------
+# Pointwise-convolution GEMMs (ct_pw_gemm: fp32 in / out, split-f16 on the matrix pipes)
+# ---------------------------------------------------------------------------
+PW_FWD, PW_DGRAD, PW_WGRAD = 0, 1, 2
+# "split16": this library's kernels; "lib": rocBLAS fp32 through torch.bmm (the round-2 path, kept as the A/B switch and
+# for shapes the kernel does not take: a dimension that is not a multiple of 4)
+PW_GEMM = os.environ.get("CLOUDCT_PW_GEMM", "split16")
+
+
+def pw_eligible(Co, Ci, N, mode=None):
+    """Whether ct_pw_gemm takes the product; with `mode`, whether it also beats the library GEMM there: an output-row
+    extent under one 128-row tile leaves half the MFMA rows idle (tools/pw_gemm_bench.py: 0.7-0.95x at 64 rows)."""
+    if not (PW_GEMM == "split16" and Co % 4 == 0 and Ci % 4 == 0 and N % 4 == 0 and N >= 4):
+        return False
+    if mode == PW_FWD:
+        return Co >= 128
+    if mode == PW_DGRAD:
+        return Ci >= 128
+    if mode == PW_WGRAD:
+        return Co >= 128 and Ci >= 128
+    return True
+
+
+def amax(t):
+    """max |t| of a contiguous float32 tensor as a device scalar f32[1] (the per-tensor scale of ct_pw_gemm)."""
+    out = torch.empty(1, device=t.device, dtype=torch.float32)
+    with _on(t.device):
+        _lib.check(_lib.load().ct_amax_f32(_ptr(t), t.numel(), _ptr(out), _stream()), "ct_amax_f32")
+    return out
+
+
+def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
+    """ct_pw_gemm on contiguous float32 tensors: PW_FWD (a = W [Co,Ci], b = x [B,Ci,N]) -> y [B,Co,N]; PW_DGRAD (a = W,
+    b = g_y [B,Co,N]) -> g_x [B,Ci,N]; PW_WGRAD (a = g_y, b = x) -> g_W [Co,Ci].  amax_* from amax()."""
+    lib = _lib.load()
+    dev = b.device
+    if mode == PW_FWD:
+        out = torch.empty(B, Co, N, device=dev, dtype=torch.float32)
+    elif mode == PW_DGRAD:
+        out = torch.empty(B, Ci, N, device=dev, dtype=torch.float32)
+    else:
+        out = torch.empty(Co, Ci, device=dev, dtype=torch.float32)
+    nbytes = lib.ct_pw_gemm_workspace_bytes(mode, B, Co, Ci, N)
+    ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32) if nbytes else None
+    with _on(dev):
+        _lib.check(lib.ct_pw_gemm(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), _ptr(amax_b), _ptr(ws), nbytes, B, Co, Ci, N,
+                                  _stream()), "ct_pw_gemm")
+    return out
+
+
+def pw_forward(W, x):
+    """y[b] = W x[b] for W [Co,Ci], x [B,Ci,N] (both contiguous float32 on the device); returns (y, amax_W, amax_x) — the
+    scales are reused by the gradients — or (y, None, None) from the library GEMM."""
+    Co, Ci = W.shape
+    B, _, N = x.shape
+    if not pw_eligible(Co, Ci, N, PW_FWD):
+        return torch.bmm(W.unsqueeze(0).expand(B, -1, -1), x), None, None
+    am_w, am_x = amax(W), amax(x)
+    return pw_gemm(PW_FWD, W, x, am_w, am_x, B, Co, Ci, N), am_w, am_x
+
+
+def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True):
+    """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous)."""
+    Co, Ci = W.shape
+    B, _, N = x.shape
+    mine_x = need_x and pw_eligible(Co, Ci, N, PW_DGRAD)
+    mine_w = need_w and pw_eligible(Co, Ci, N, PW_WGRAD)
+    am_g = amax(g_y) if (mine_x or mine_w) else None
+    g_x = g_w = None
+    if mine_x:
+        g_x = pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
+    elif need_x:
+        g_x = torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y)
+    if mine_w:
+        g_w = pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax(x), B, Co, Ci, N)
+    elif need_w:
+        g_w = torch.bmm(g_y, x.transpose(1, 2)).sum(0)
+    return g_x, g_w
 
 
 # ---------------------------------------------------------------------------
@@ -453,7 +534,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)
         Ct = Wc.size(0)
-        y = torch.bmm(Wc.unsqueeze(0).expand(B, -1, -1), x)
+        y, am_w, am_x = pw_forward(Wc, x)
         lib = _lib.load()
         outs, saved, meta, c0 = [], [], [], 0
         with _on(x.device):
@@ -472,6 +553,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
                     c0 += C
         assert c0 == Ct, "keys_bn + values_bn must cover the projections"
         ctx.save_for_backward(x, y, Wc, *saved)
+        ctx.am = (am_w, am_x)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
         return tuple(outs)
@@ -498,8 +580,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
                 _lib.check(lib.ct_adain_bwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
                                             _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_gb), B, C, N, 0, _stream()), "ct_adain_bwd")
                 g_gbs.append(g_gb)
-        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[1] else None
-        g_Wc = torch.bmm(g_y, x.transpose(1, 2)).sum(0)
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True)
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
@@ -860,7 +941,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)               # [sum Co, Cin]
         Ct = Wc.size(0)
-        y = torch.bmm(Wc.unsqueeze(0).expand(B, -1, -1), x)                 # [B, sum Co, N]
+        y, am_w, am_x = pw_forward(Wc, x)                                   # [B, sum Co, N]
         outs, items, meta, c0 = [], [], [], 0
         for h in heads:
             for (w, b, rm, rv, nbt, eps, mom) in (h[1:8], h[8:15]):
@@ -879,6 +960,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         for it, (mean, rstd) in zip(items, stats):
             saved += [it["w"], it["b"], mean, rstd]
         ctx.save_for_backward(x, y, Wc, count, *saved)
+        ctx.am = (am_w, am_x)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
         ctx.group = group
@@ -904,8 +986,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
                               gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, relu=0, keep=gy))
         with _on(x.device):
             bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
-        g_x = torch.bmm(Wc.t().unsqueeze(0).expand(B, -1, -1), g_y) if ctx.needs_input_grad[2] else None
-        g_Wc = torch.bmm(g_y, x.transpose(1, 2)).sum(0)                     # [sum Co, Cin]
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True)   # g_Wc [sum Co, Cin]
         grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]

@@ -368,6 +368,27 @@ int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assig
 int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const int32_t* assignment,
                float* g_xyz1, int B, int n, ct_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * Pointwise (kernel size 1) convolutions of the MHCT blocks and their gradients
+ * (layers/multihead_ct.py:31-33,62-66,89-91: nn.Conv1d(Ci, Co, 1) on [B,Ci,N]), fp32 in /
+ * fp32 out on the f16 matrix pipes: operands are scaled by a per-tensor power of two
+ * and split into two f16 terms (22 bits), three MFMA terms per product, fp32 accumulation.
+ *   CT_PW_FWD:   a = W f32[Co,Ci], b = x f32[B,Ci,N]   -> out = y f32[B,Co,N]   (y[b] = W x[b])
+ *   CT_PW_DGRAD: a = W f32[Co,Ci], b = g_y f32[B,Co,N] -> out = g_x f32[B,Ci,N] (W^T g_y[b])
+ *   CT_PW_WGRAD: a = g_y f32[B,Co,N], b = x f32[B,Ci,N] -> out = g_W f32[Co,Ci] (sum_b g_y[b] x[b]^T,
+ *                partial sums added in a fixed order: deterministic)
+ * amax_a / amax_b: device f32[1] = max |.| of the whole operand tensor (ct_amax_f32), or
+ * NULL for scale 1 (the caller then guarantees |values| < 65504).  Co, Ci, N multiples of 4,
+ * 16-byte aligned pointers -> CT_EINVAL otherwise.  Workspace: ct_pw_gemm_workspace_bytes.
+ * ---------------------------------------------------------------------- */
+#define CT_PW_FWD 0
+#define CT_PW_DGRAD 1
+#define CT_PW_WGRAD 2
+int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s);
+size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N);
+int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, const float* amax_b,
+               void* workspace, size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""ct_pw_gemm (pointwise-convolution GEMMs, fp32 in / out through split-f16 MFMA terms) against float64 products of the same
+operands: the three operand arrangements, ragged sizes, operand magnitudes from 1e-7 to 1e6, exact integer data (layout),
+non-finite propagation, determinism of the chunked weight gradient, and the autograd layer on top
+(layers/multihead_ct.py:31-33: nn.Conv1d(k=1))."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# relative to sum_k |a_k b_k|: three f16 terms carry 2^-21 of each product; fp32 accumulation adds ~sqrt(K) 2^-24
+BOUND = 2.0e-6
+
+
+def _ref(mode, W, x, gy):
+    Wd, xd = W.double(), x.double()
+    if mode == 0:
+        return torch.matmul(Wd, xd), torch.matmul(Wd.abs(), xd.abs())
+    gd = gy.double()
+    if mode == 1:
+        return torch.matmul(Wd.t(), gd), torch.matmul(Wd.abs().t(), gd.abs())
+    return torch.matmul(gd, xd.transpose(1, 2)).sum(0), torch.matmul(gd.abs(), xd.abs().transpose(1, 2)).sum(0)
+
+
+def _run(mode, W, x, gy):
+    from cloud_transformers_amd import ops
+    Co, Ci = W.shape
+    B, _, N = x.shape
+    if mode == 0:
+        return ops.pw_gemm(0, W, x, ops.amax(W), ops.amax(x), B, Co, Ci, N)
+    if mode == 1:
+        return ops.pw_gemm(1, W, gy, ops.amax(W), ops.amax(gy), B, Co, Ci, N)
+    return ops.pw_gemm(2, gy, x, ops.amax(gy), ops.amax(x), B, Co, Ci, N)
+
+
+SHAPES = [(2, 208, 512, 1024), (1, 128, 64, 512), (3, 52, 36, 260), (2, 592, 256, 4096), (1, 4, 4, 4), (5, 132, 260, 36),
+          (8, 848, 512, 4096), (2, 512, 64, 16384)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_matches_the_float64_product(shape, mode):
+    B, Co, Ci, N = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + Co + mode)
+    W = torch.randn(Co, Ci, device="cuda", generator=g) / Ci ** 0.5
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    out = _run(mode, W, x, gy)
+    ref, mag = _ref(mode, W, x, gy)
+    err = (out.double() - ref).abs()
+    assert torch.isfinite(out).all()
+    assert bool((err <= BOUND * mag + 1e-30).all()), float((err / (mag + 1e-30)).max())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("scales", [(1e-7, 1.0), (1e6, 1e-5), (3e-4, 2e4), (1.0, 1e-30)])
+def test_operand_magnitudes(mode, scales):
+    B, Co, Ci, N = 2, 144, 96, 640
+    g = torch.Generator(device="cuda").manual_seed(11 + mode)
+    W = torch.randn(Co, Ci, device="cuda", generator=g)
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    # a wide spread inside one tensor as well: some rows 2^-12 of the largest
+    x[:, ::3] *= 2.0 ** -12
+    gy[:, 1::5] *= 2.0 ** -10
+    first, second = (W, x) if mode == 0 else (W, gy) if mode == 1 else (gy, x)
+    first *= scales[0]
+    second *= scales[1]
+    out = _run(mode, W, x, gy)
+    ref, mag = _ref(mode, W, x, gy)
+    err = (out.double() - ref).abs()
+    assert bool((err <= BOUND * mag + 1e-44).all()), float((err / (mag + 1e-44)).max())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_small_integers_are_exact(mode):
+    """Every term is exact on small integers, so any slip in a fragment, swizzle or output map shows as a wrong integer."""
+    B, Co, Ci, N = 2, 164, 100, 392
+    g = torch.Generator(device="cuda").manual_seed(5)
+    W = torch.randint(-8, 9, (Co, Ci), device="cuda", generator=g).float()
+    x = torch.randint(-8, 9, (B, Ci, N), device="cuda", generator=g).float()
+    gy = torch.randint(-8, 9, (B, Co, N), device="cuda", generator=g).float()
+    out = _run(mode, W, x, gy)
+    ref, _ = _ref(mode, W, x, gy)
+    assert torch.equal(out.double(), ref)
+
+
+def test_zero_and_non_finite_operands():
+    from cloud_transformers_amd import ops
+    B, Co, Ci, N = 1, 128, 32, 256
+    W = torch.zeros(Co, Ci, device="cuda")
+    x = torch.randn(B, Ci, N, device="cuda")
+    y = ops.pw_gemm(0, W, x, ops.amax(W), ops.amax(x), B, Co, Ci, N)
+    assert torch.equal(y, torch.zeros_like(y))
+    W = torch.randn(Co, Ci, device="cuda")
+    x[0, 3, 17] = float("nan")
+    x[0, 5, 100] = float("inf")
+    y = ops.pw_gemm(0, W, x, ops.amax(W), ops.amax(x), B, Co, Ci, N)
+    assert torch.isnan(y[0, :, 17]).all() and not torch.isfinite(y[0, :, 100]).any()
+    keep = torch.ones(N, dtype=torch.bool, device="cuda")
+    keep[17] = keep[100] = False
+    assert torch.isfinite(y[0][:, keep]).all()
+
+
+def test_weight_gradient_is_deterministic():
+    B, Co, Ci, N = 8, 208, 512, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    W = torch.empty(Co, Ci, device="cuda")
+    a = _run(2, W, x, gy)
+    for _ in range(3):
+        assert torch.equal(a, _run(2, W, x, gy))
+
+
+def test_rejects_what_it_does_not_take():
+    from cloud_transformers_amd import ops
+    x = torch.randn(1, 6, 10, device="cuda")
+    W = torch.randn(8, 6, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.pw_gemm(0, W, x, None, None, 1, 8, 6, 10)
+    assert not ops.pw_eligible(8, 6, 10)
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_pointwise_layer_against_float64_conv1d(bias):
+    from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
+    torch.manual_seed(0)
+    B, Ci, Co, N = 4, 192, 336, 2048
+    layer = PointwiseConv1d(Ci, Co, 1, bias=bias).cuda()
+    ref = torch.nn.Conv1d(Ci, Co, 1, bias=bias).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    x = torch.randn(B, Ci, N, device="cuda", requires_grad=True)
+    xd = x.detach().double().requires_grad_(True)
+    cot = torch.randn(B, Co, N, device="cuda")
+    layer(x).backward(cot)
+    yd = ref(xd)
+    yd.backward(cot.double())
+    y = layer(x)
+    assert float((y.double() - yd).abs().max()) <= 2e-6 * float(yd.abs().max()) * Ci ** 0.5
+    for got, want in [(x.grad, xd.grad), (layer.weight.grad, ref.weight.grad)] + ([(layer.bias.grad, ref.bias.grad)] if bias else []):
+        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) + 1e-30

@@ -3,4 +3,4 @@
 N=$1; shift
 cd /root/repo/cloud_transformers_amd/csrc
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -DCT_EXP=$N "$@" -I /root/repo/include \
-  ct_raster.hip ct_lattice.hip ct_gconv.hip ct_chamfer.hip ct_emd.hip ct_adain.hip ct_bnorm.hip ct_mhct.hip -o ../lib/libcloudct_exp$N.so
+  ct_raster.hip ct_lattice.hip ct_gconv.hip ct_chamfer.hip ct_emd.hip ct_adain.hip ct_bnorm.hip ct_mhct.hip ct_pwgemm.hip -o ../lib/libcloudct_exp$N.so
