@@ -20,6 +20,7 @@
 // The weight gradient sums over clouds and points: K = B*N is cut into chunks, each chunk's partial [Co,Ci] tile goes to a
 // slab and a second kernel adds the slabs in a fixed order (deterministic).
 #include "ct_common.h"
+#include <type_traits>
 
 typedef _Float16 pw_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pw_h2 __attribute__((ext_vector_type(2)));
@@ -54,54 +55,109 @@ __device__ __forceinline__ int pw_scale_exp(const float* amax) {
 __device__ __forceinline__ int pw_slot(int row, int g) { return row * kPwBK + ((g ^ ((row >> 2) & 3)) << 3); }
 
 // Registers of one operand tile [128 rows][32 k] for thread t.  KMAJOR (k contiguous in memory): row t>>1, 16 consecutive k
-// from (t&1)*16, r[i] = k-th element.  Otherwise (row index contiguous): k rows 8*(t>>6) .. +7, rows 2*(t&63) and +1,
-// r[2j + c] = (k row j, row c).  Loads are unconditional from clamped addresses (a predicated load becomes a branch and a
-// wait per load); the returned bits say which of them lie inside the operand: bit q / bit j per load.
+// from (t&1)*16, r[i] = k-th element.  Otherwise (row index contiguous): k rows 8*wave .. +7, rows 2*(t&63) and +1,
+// r[2j + c] = (k row j, row c).  Loads are unconditional (a predicated load becomes a branch and a wait per load): rows past
+// the operand's end read its last row(s) and are zeroed before the split (rowok).  FULL: the whole K-step lies inside
+// [.., kend) — addresses are the loop-invariant lane part plus a wave-uniform step offset, no clamps; otherwise k indices
+// are clamped too and the returned bits say which loads count: bit q / bit j per load.
 template <bool KMAJOR>
-__device__ __forceinline__ unsigned pw_load(float (&r)[16], const float* __restrict__ src, int ld, int row0, int R, int k0, int kend,
-                                            int t) {
-  unsigned ok = 0;
+struct PwLane {
+  const float* p;   // KMAJOR: src + min(row, R-1)*ld + (t&1)*16;  else: src + min(f, R-2)
+  unsigned off;     // the same as a byte offset from src (an operand slice is < 4 GiB: pw_plan)
+  bool rowok;
+};
+
+template <bool KMAJOR>
+__device__ __forceinline__ PwLane<KMAJOR> pw_lane(const float* __restrict__ src, int ld, int row0, int R, int t) {
+  PwLane<KMAJOR> L;
   if constexpr (KMAJOR) {
-    const int row = row0 + (t >> 1), k = k0 + (t & 1) * 16;
-    const float* p = src + (size_t)min(row, R - 1) * ld;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *(const float4*)(p + min(k + 4 * q, kend - 4));
-      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-      ok |= (unsigned)(row < R && k + 4 * q < kend) << q;
-    }
+    const int row = row0 + (t >> 1);
+    L.off = ((unsigned)min(row, R - 1) * (unsigned)ld + (t & 1) * 16) * 4u;
+    L.rowok = row < R;
   } else {
-    const int kb = k0 + 8 * (t >> 6), f = row0 + 2 * (t & 63);
-    const float* p = src + min(f, R - 2);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float2 v = *(const float2*)(p + (size_t)min(kb + j, kend - 1) * ld);
-      r[2 * j] = v.x; r[2 * j + 1] = v.y;
-      ok |= (unsigned)(f < R && kb + j < kend) << j;
-    }
+    const int f = row0 + 2 * (t & 63);
+    L.off = (unsigned)min(f, R - 2) * 4u;
+    L.rowok = f < R;
   }
-  return ok;
+  L.p = (const float*)((const char*)src + L.off);
+  return L;
 }
 
-// eight scaled values -> the h and l fragments' 16 bytes
+// A whole K-step: wave-uniform base (KMAJOR: src + k0 floats; else: src + (k0 + 8*wave) rows) + the lane's 32-bit offset — the
+// addressing stays on the scalar unit (global_load ... v_off, s[base]).
+template <bool KMAJOR>
+__device__ __forceinline__ void pw_load_full(float (&r)[16], const char* __restrict__ ubase, size_t ldbytes, unsigned off) {
+  if constexpr (KMAJOR) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *(const float4*)(ubase + off + 16 * q);
+      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 v = *(const float2*)(ubase + j * ldbytes + off);
+      r[2 * j] = v.x; r[2 * j + 1] = v.y;
+    }
+  }
+}
+
+// Any K-step (the first, and a partial last one): k indices clamped into [.., kend), the returned bits say which loads
+// count: bit q / bit j per load.
+template <bool KMAJOR>
+__device__ __forceinline__ unsigned pw_load(float (&r)[16], const PwLane<KMAJOR>& L, int ld, int k0, int kend, int wave, int t) {
+  unsigned ok = 0;
+  if constexpr (KMAJOR) {
+    const int k = k0 + (t & 1) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *(const float4*)(L.p + (min(k + 4 * q, kend - 4) - (t & 1) * 16));
+      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+      ok |= (unsigned)(k + 4 * q < kend) << q;
+    }
+  } else {
+    const int kb = k0 + 8 * wave;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 v = *(const float2*)(L.p + (size_t)min(kb + j, kend - 1) * ld);
+      r[2 * j] = v.x; r[2 * j + 1] = v.y;
+      ok |= (unsigned)(kb + j < kend) << j;
+    }
+  }
+  return L.rowok ? ok : 0u;
+}
+
+// two scaled values -> packed f16 pairs h = f16(s a), l = f16(s a - h): v_fma_mix{lo,hi}_f16 take the fp32 value, the scale
+// and the f16 h term in one instruction each (2 per element; the cvt / cvt-back / subtract chain is 3.5).  The s_nop covers
+// the wait state a half-register write needs before a VALU reads it (nothing is padded inside an asm statement).
+__device__ __forceinline__ void pw_split2(float a0, float a1, float s, unsigned& h, unsigned& l) {
+  asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+      "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+      "s_nop 0\n\t"
+      "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(h), "=&v"(l)
+      : "v"(a0), "v"(a1), "s"(s));
+}
+
+// eight values -> the h and l fragments' 16 bytes
 __device__ __forceinline__ void pw_split8(const float (&v)[8], float s, uint4& h, uint4& l) {
   unsigned hh[4], ll[4];
+#if defined(PW_ABL) && PW_ABL == 1
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const pw_f2 a = {v[2 * i] * s, v[2 * i + 1] * s};
-    const pw_h2 hi = __builtin_convertvector(a, pw_h2);
-    const pw_f2 rem = a - __builtin_convertvector(hi, pw_f2);
-    const pw_h2 lo = __builtin_convertvector(rem, pw_h2);
-    hh[i] = __builtin_bit_cast(unsigned, hi);
-    ll[i] = __builtin_bit_cast(unsigned, lo);
-  }
+  for (int i = 0; i < 4; ++i) { hh[i] = __float_as_uint(v[2 * i]); ll[i] = __float_as_uint(v[2 * i + 1]); }
+#else
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pw_split2(v[2 * i], v[2 * i + 1], s, hh[i], ll[i]);
+#endif
   h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
   l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
 }
 
 template <bool KMAJOR>
-__device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* imgH, _Float16* imgL, float s, int t) {
-  if (ok != (KMAJOR ? 0xfu : 0xffu)) {       // edge tiles only
+__device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* imgH, _Float16* imgL, float s, int wave, int t) {
+  if (ok != (KMAJOR ? 0xfu : 0xffu)) {       // edge tiles and the last partial K-step only
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       if (!((ok >> (KMAJOR ? i >> 2 : i >> 1)) & 1)) r[i] = 0.f;
@@ -120,7 +176,6 @@ __device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* 
       *(uint4*)(imgL + o) = l;
     }
   } else {
-    const int kg = t >> 6;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       float v[8];
@@ -128,7 +183,7 @@ __device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* 
       for (int j = 0; j < 8; ++j) v[j] = r[2 * j + c];
       uint4 h, l;
       pw_split8(v, s, h, l);
-      const int o = pw_slot(2 * (t & 63) + c, kg);
+      const int o = pw_slot(2 * (t & 63) + c, wave);
       *(uint4*)(imgH + o) = h;
       *(uint4*)(imgL + o) = l;
     }
@@ -149,7 +204,7 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
   const float* B = a.B + cloud * a.b_bs;
   float* C = a.C + z * a.c_zs;
   const int m0 = mt * kPwTile, n0 = nt * kPwTile;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1, r = lane & 31, h = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1, r = lane & 31, h = lane >> 5;
   const int ea = pw_scale_exp(a.amax_a), eb = pw_scale_exp(a.amax_b);
   const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
@@ -161,11 +216,42 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float ra[16], rb[16];
-  unsigned oka = pw_load<A_KMAJOR>(ra, A, a.lda, m0, a.M, kbeg, kend, t);
-  unsigned okb = pw_load<B_KMAJOR>(rb, B, a.ldb, n0, a.N, kbeg, kend, t);
-  pw_store<A_KMAJOR>(ra, oka, pw_lds, pw_lds + kPwImg, sa, t);
-  pw_store<B_KMAJOR>(rb, okb, pw_lds + 2 * kPwImg, pw_lds + 3 * kPwImg, sb, t);
+  // two register sets: the loads of K-step kt+2 go out at the top of step kt and are split into LDS at the end of step kt+1,
+  // so an HBM / L2 round trip has two steps of MFMAs (and the CU's other workgroup) to hide behind
+  float ra0[16], rb0[16], ra1[16], rb1[16];
+  unsigned oka0, okb0, oka1 = 0, okb1 = 0;
+  const PwLane<A_KMAJOR> la = pw_lane<A_KMAJOR>(A, a.lda, m0, a.M, t);
+  const PwLane<B_KMAJOR> lb = pw_lane<B_KMAJOR>(B, a.ldb, n0, a.N, t);
+  const int T = (kend - kbeg + kPwBK - 1) / kPwBK, F = (kend - kbeg) / kPwBK;   // K-steps, whole ones
+  // wave-uniform bases of the next whole K-step to load and their advance per step
+  const size_t lda4 = (size_t)a.lda * 4, ldb4 = (size_t)a.ldb * 4;
+  const char* ua = (const char*)A + (A_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 8 * w) * lda4);
+  const char* ub = (const char*)B + (B_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 8 * w) * ldb4);
+  const size_t stepa = A_KMAJOR ? (size_t)kPwBK * 4 : kPwBK * lda4, stepb = B_KMAJOR ? (size_t)kPwBK * 4 : kPwBK * ldb4;
+  const unsigned fulla = la.rowok ? (A_KMAJOR ? 0xfu : 0xffu) : 0u, fullb = lb.rowok ? (B_KMAJOR ? 0xfu : 0xffu) : 0u;
+
+  // loads of K-step `step` into one register set.  WHOLE: the caller knows step < F — no branch, so that the number of loads in
+  // flight is the same on every path into the split that follows (at a join the compiler waits for the shortest queue: a
+  // conditional fetch drains the ring).  Otherwise any step (nothing past the last: its stores refill a stage nobody reads).
+  auto fetch = [&](auto whole, int step, float (&xa)[16], float (&xb)[16], unsigned& xoka, unsigned& xokb) {
+    if (decltype(whole)::value || step < F) {
+#if !(defined(PW_ABL) && PW_ABL == 3)
+      pw_load_full<A_KMAJOR>(xa, ua, lda4, la.off);
+      pw_load_full<B_KMAJOR>(xb, ub, ldb4, lb.off);
+#endif
+      xoka = fulla; xokb = fullb;
+      ua += stepa; ub += stepb;
+    } else if (step < T) {                           // the partial last step
+      xoka = pw_load<A_KMAJOR>(xa, la, a.lda, kbeg + step * kPwBK, kend, w, t);
+      xokb = pw_load<B_KMAJOR>(xb, lb, a.ldb, kbeg + step * kPwBK, kend, w, t);
+    }
+  };
+
+  oka0 = pw_load<A_KMAJOR>(ra0, la, a.lda, kbeg, kend, w, t);
+  okb0 = pw_load<B_KMAJOR>(rb0, lb, a.ldb, kbeg, kend, w, t);
+  fetch(std::false_type{}, 1, ra1, rb1, oka1, okb1);
+  pw_store<A_KMAJOR>(ra0, oka0, pw_lds, pw_lds + kPwImg, sa, w, t);
+  pw_store<B_KMAJOR>(rb0, okb0, pw_lds + 2 * kPwImg, pw_lds + 3 * kPwImg, sb, w, t);
   __syncthreads();
 
   // fragment offsets: row = 64*wm + 32*i + r (A), 64*wn + 32*j + r (B); k8 group 2*ks + h
@@ -178,13 +264,12 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
   const int sw = (r >> 2) & 3;
   const int g0 = ((0 + h) ^ sw) << 3, g1 = ((2 + h) ^ sw) << 3;
 
-  const int T = (kend - kbeg + kPwBK - 1) / kPwBK;
-  for (int kt = 0; kt < T; ++kt) {
+  // K-step kt: fetch step kt+2 into (xa, xb), MFMAs on stage kt&1, split step kt+1 from (ya, yb) into the other stage
+  auto kstep = [&](auto whole, int kt, float (&xa)[16], float (&xb)[16], unsigned& xoka, unsigned& xokb, float (&ya)[16],
+                   float (&yb)[16], unsigned yoka, unsigned yokb) {
     const _Float16* st = pw_lds + (kt & 1) * kPwStage;
     _Float16* nx = pw_lds + ((kt + 1) & 1) * kPwStage;
-    const int kn = kbeg + (kt + 1) * kPwBK;          // past the end on the last step: clamped loads, all masked
-    oka = pw_load<A_KMAJOR>(ra, A, a.lda, m0, a.M, kn, kend, t);
-    okb = pw_load<B_KMAJOR>(rb, B, a.ldb, n0, a.N, kn, kend, t);
+    fetch(whole, kt + 2, xa, xb, xoka, xokb);
     __builtin_amdgcn_sched_barrier(0);               // the loads go out before the MFMAs, not after them
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -197,6 +282,14 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
         bh[i] = *(const pw_h8*)(st + 2 * kPwImg + offB[i] + g);
         bl[i] = *(const pw_h8*)(st + 3 * kPwImg + offB[i] + g);
       }
+#if defined(PW_ABL) && PW_ABL == 2
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)ah[i][e] + (float)bh[j][e] + (float)al[i][e] + (float)bl[j][e];
+#else
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -209,11 +302,27 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
-    pw_store<A_KMAJOR>(ra, oka, nx, nx + kPwImg, sa, t);
-    pw_store<B_KMAJOR>(rb, okb, nx + 2 * kPwImg, nx + 3 * kPwImg, sb, t);
+#if defined(PW_ABL) && PW_ABL == 4
+    if (ya[0] == 12345.f && yb[0] == 54321.f)
+#endif
+    {
+      pw_store<A_KMAJOR>(ya, yoka, nx, nx + kPwImg, sa, w, t);
+      pw_store<B_KMAJOR>(yb, yokb, nx + 2 * kPwImg, nx + 3 * kPwImg, sb, w, t);
+    }
     __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 3 < F; kt += 2) {                      // both fetches (steps kt+2, kt+3) are whole K-steps
+    kstep(std::true_type{}, kt, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1);
+    kstep(std::true_type{}, kt + 1, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0);
+  }
+  for (; kt < T; kt += 2) {                          // the last steps
+    kstep(std::false_type{}, kt, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1);
+    if (kt + 1 >= T) break;
+    kstep(std::false_type{}, kt + 1, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0);
   }
 
   // D of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -331,6 +440,7 @@ static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
   }
   p.Z = B * p.ksplit;
   if ((long long)p.tilesM * p.tilesN * p.Z > 0x7fffffffLL) return false;
+  if ((long long)Co * N >= (1LL << 30) || (long long)Ci * N >= (1LL << 30) || (long long)Co * Ci >= (1LL << 30)) return false;   // 32-bit lane offsets
   return true;
 }
 
