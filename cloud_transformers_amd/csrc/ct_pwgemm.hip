@@ -27,7 +27,7 @@ typedef _Float16 pw_h2 __attribute__((ext_vector_type(2)));
 typedef float pw_f2 __attribute__((ext_vector_type(2)));
 typedef float pw_acc __attribute__((ext_vector_type(16)));
 
-constexpr int kPwTile = 128, kPwBK = 32, kPwThreads = 256;
+constexpr int kPwTile = 128, kPwBK = 32, kPwThreads = 512, kPwR = 8;   // kPwR: operand elements per thread and K-step
 constexpr int kPwImg = kPwTile * kPwBK;                 // halves per image
 constexpr int kPwStage = 4 * kPwImg;                    // A_h, A_l, B_h, B_l
 constexpr int kPwLdsBytes = 2 * kPwStage * 2;           // two stages
@@ -39,6 +39,9 @@ struct PwArgs {
   int M, N, K;                     // output rows / columns, summed extent per cloud
   int tilesM, tilesN, ksplit, Kc;  // z = cloud * ksplit + chunk; the chunk sums k in [chunk*Kc, min(K, (chunk+1)*Kc))
   const float* amax_a; const float* amax_b;
+#ifdef PW_STAMP
+  unsigned long long* dbg;   // development builds: per-phase cycle sums of every wave (tools/dev/pw_stamp.py)
+#endif
 };
 
 // power of two s with s * amax in [2^13, 2^14); 1 for an all-zero or non-finite tensor (inf / nan then flow through h)
@@ -54,77 +57,65 @@ __device__ __forceinline__ int pw_scale_exp(const float* amax) {
 // image element (row, k8 group g) -> half offset: 16-byte groups XOR-swizzled with the row
 __device__ __forceinline__ int pw_slot(int row, int g) { return row * kPwBK + ((g ^ ((row >> 2) & 3)) << 3); }
 
-// Registers of one operand tile [128 rows][32 k] for thread t.  KMAJOR (k contiguous in memory): row t>>1, 16 consecutive k
-// from (t&1)*16, r[i] = k-th element.  Otherwise (row index contiguous): k rows 8*wave .. +7, rows 2*(t&63) and +1,
-// r[2j + c] = (k row j, row c).  Loads are unconditional (a predicated load becomes a branch and a wait per load): rows past
-// the operand's end read its last row(s) and are zeroed before the split (rowok).  FULL: the whole K-step lies inside
-// [.., kend) — addresses are the loop-invariant lane part plus a wave-uniform step offset, no clamps; otherwise k indices
-// are clamped too and the returned bits say which loads count: bit q / bit j per load.
+// Registers of one operand tile [128 rows][32 k] for thread t of 512: eight elements, two 16-byte loads.
+// KMAJOR (k contiguous in memory): row t>>2, k8 group t&3, r[i] = k-th element; image [row][k] halves, 16-byte k8 groups
+// XOR-swizzled with the row (pw_slot), fragments by one ds_read_b128.
+// Otherwise (row index contiguous): k pair t>>5 (k rows 2p, 2p+1), rows 4*(t&31) .. +3, r[4j + c] = (k row j, row c); a
+// dword-wide load here costs 64 issue cycles against 90 for 16 bytes (phase stamps, tools/dev/pw_stamp.py), so the
+// thread takes four rows of two k rows and the image is [k pair][row] dwords (the (k, k+1) halves of a row in one dword):
+// the four rows' dwords are one contiguous ds_write_b128, and a fragment is four conflict-free dword reads 128 dwords apart.
+// Loads are unconditional (a predicated load becomes a branch and a wait per load): rows past the operand's end read its
+// last rows instead — they only reach output rows / columns that are never stored, so nothing has to be zeroed for them.
 template <bool KMAJOR>
 struct PwLane {
-  const float* p;   // KMAJOR: src + min(row, R-1)*ld + (t&1)*16;  else: src + min(f, R-2)
+  const float* p;   // KMAJOR: src + min(row, R-1)*ld + 8*(t&3);  else: src + 2*(lane>>5)*ld + min(row, R-4)
   unsigned off;     // the same as a byte offset from src (an operand slice is < 4 GiB: pw_plan)
-  bool rowok;
 };
 
 template <bool KMAJOR>
-__device__ __forceinline__ PwLane<KMAJOR> pw_lane(const float* __restrict__ src, int ld, int row0, int R, int t) {
+__device__ __forceinline__ PwLane<KMAJOR> pw_lane(const float* __restrict__ src, int ld, int row0, int R, int wave, int t) {
   PwLane<KMAJOR> L;
   if constexpr (KMAJOR) {
-    const int row = row0 + (t >> 1);
-    L.off = ((unsigned)min(row, R - 1) * (unsigned)ld + (t & 1) * 16) * 4u;
-    L.rowok = row < R;
+    const int row = row0 + (t >> 2);
+    L.off = ((unsigned)min(row, R - 1) * (unsigned)ld + (t & 3) * 8) * 4u;
   } else {
-    const int f = row0 + 2 * (t & 63);
-    L.off = (unsigned)min(f, R - 2) * 4u;
-    L.rowok = f < R;
+    const int row = row0 + 4 * (t & 31);
+    L.off = ((unsigned)(2 * ((t >> 5) & 1)) * (unsigned)ld + (unsigned)min(row, R - 4)) * 4u;
   }
   L.p = (const float*)((const char*)src + L.off);
   return L;
 }
 
-// A whole K-step: wave-uniform base (KMAJOR: src + k0 floats; else: src + (k0 + 8*wave) rows) + the lane's 32-bit offset — the
-// addressing stays on the scalar unit (global_load ... v_off, s[base]).
+// A whole K-step: wave-uniform base (KMAJOR: src + k0 floats; else: src + (k0 + 4*wave) rows) + the lane's 32-bit offset.
 template <bool KMAJOR>
-__device__ __forceinline__ void pw_load_full(float (&r)[16], const char* __restrict__ ubase, size_t ldbytes, unsigned off) {
-  if constexpr (KMAJOR) {
+__device__ __forceinline__ void pw_load_full(float (&r)[kPwR], const char* __restrict__ ubase, size_t ldbytes, unsigned off) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *(const float4*)(ubase + off + 16 * q);
-      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float2 v = *(const float2*)(ubase + j * ldbytes + off);
-      r[2 * j] = v.x; r[2 * j + 1] = v.y;
-    }
+  for (int q = 0; q < 2; ++q) {
+    const float4 v = *(const float4*)(ubase + (KMAJOR ? (size_t)16 * q : q * ldbytes) + off);
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
   }
 }
 
 // Any K-step (the first, and a partial last one): k indices clamped into [.., kend), the returned bits say which loads
-// count: bit q / bit j per load.
+// count: bit q per load.
 template <bool KMAJOR>
-__device__ __forceinline__ unsigned pw_load(float (&r)[16], const PwLane<KMAJOR>& L, int ld, int k0, int kend, int wave, int t) {
+__device__ __forceinline__ unsigned pw_load(float (&r)[kPwR], const PwLane<KMAJOR>& L, int ld, int k0, int kend, int wave, int t) {
   unsigned ok = 0;
-  if constexpr (KMAJOR) {
-    const int k = k0 + (t & 1) * 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *(const float4*)(L.p + (min(k + 4 * q, kend - 4) - (t & 1) * 16));
-      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-      ok |= (unsigned)(k + 4 * q < kend) << q;
+  for (int q = 0; q < 2; ++q) {
+    float4 v;
+    if constexpr (KMAJOR) {
+      const int k = k0 + (t & 3) * 8 + 4 * q;
+      v = *(const float4*)(L.p + (min(k, kend - 4) - (t & 3) * 8));
+      ok |= (unsigned)(k < kend) << q;
+    } else {
+      const int lk = 2 * ((t >> 5) & 1), k = k0 + 4 * wave + lk + q;       // L.p already holds the lane's lk rows
+      v = *(const float4*)(L.p + ((long long)min(k, kend - 1) - lk) * ld);
+      ok |= (unsigned)(k < kend) << q;
     }
-  } else {
-    const int kb = k0 + 8 * wave;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float2 v = *(const float2*)(L.p + (size_t)min(kb + j, kend - 1) * ld);
-      r[2 * j] = v.x; r[2 * j + 1] = v.y;
-      ok |= (unsigned)(kb + j < kend) << j;
-    }
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
   }
-  return L.rowok ? ok : 0u;
+  return ok;
 }
 
 // two scaled values -> packed f16 pairs h = f16(s a), l = f16(s a - h): v_fma_mix{lo,hi}_f16 take the fp32 value, the scale
@@ -156,42 +147,64 @@ __device__ __forceinline__ void pw_split8(const float (&v)[8], float s, uint4& h
 }
 
 template <bool KMAJOR>
-__device__ __forceinline__ void pw_store(float (&r)[16], unsigned ok, _Float16* imgH, _Float16* imgL, float s, int wave, int t) {
-  if (ok != (KMAJOR ? 0xfu : 0xffu)) {       // edge tiles and the last partial K-step only
+__device__ __forceinline__ void pw_store(float (&r)[kPwR], unsigned ok, _Float16* imgH, _Float16* imgL, float s, int wave, int t) {
+  if (ok != 0x3u) {                          // edge tiles and the last partial K-step only
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (!((ok >> (KMAJOR ? i >> 2 : i >> 1)) & 1)) r[i] = 0.f;
+    for (int i = 0; i < 8; ++i)
+      if (!((ok >> (i >> 2)) & 1)) r[i] = 0.f;
   }
+  uint4 h, l;
   if constexpr (KMAJOR) {
-    const int row = t >> 1, g0 = (t & 1) * 2;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = r[8 * g + i];
-      uint4 h, l;
-      pw_split8(v, s, h, l);
-      const int o = pw_slot(row, g0 + g);
-      *(uint4*)(imgH + o) = h;
-      *(uint4*)(imgL + o) = l;
-    }
+    pw_split8(r, s, h, l);
+    const int o = pw_slot(t >> 2, t & 3);
+    *(uint4*)(imgH + o) = h;
+    *(uint4*)(imgL + o) = l;
   } else {
+    pw_split2(r[0], r[4], s, h.x, l.x);
+    pw_split2(r[1], r[5], s, h.y, l.y);
+    pw_split2(r[2], r[6], s, h.z, l.z);
+    pw_split2(r[3], r[7], s, h.w, l.w);
+    const int o = ((2 * wave + ((t >> 5) & 1)) * kPwTile + 4 * (t & 31)) * 2;      // dword [k pair][row], in halves
+    *(uint4*)(imgH + o) = h;
+    *(uint4*)(imgL + o) = l;
+  }
+}
+
+// The same in pieces, for interleaving with the MFMAs of the current K-step: the mask (edge tiles only), four units of one
+// (k, k+1) pair each, the two stores.
+__device__ __forceinline__ void pw_mask(float (&r)[kPwR], unsigned ok) {
+  if (ok != 0x3u) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = r[2 * j + c];
-      uint4 h, l;
-      pw_split8(v, s, h, l);
-      const int o = pw_slot(2 * (t & 63) + c, wave);
-      *(uint4*)(imgH + o) = h;
-      *(uint4*)(imgL + o) = l;
-    }
+    for (int i = 0; i < 8; ++i)
+      if (!((ok >> (i >> 2)) & 1)) r[i] = 0.f;
+  }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void pw_unit(const float (&r)[kPwR], int i, float s, unsigned (&h)[4], unsigned (&l)[4]) {
+  if constexpr (KMAJOR) pw_split2(r[2 * i], r[2 * i + 1], s, h[i], l[i]);
+  else pw_split2(r[i], r[4 + i], s, h[i], l[i]);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void pw_write(const unsigned (&h)[4], const unsigned (&l)[4], _Float16* imgH, _Float16* imgL, int wave, int t) {
+  const int o = KMAJOR ? pw_slot(t >> 2, t & 3) : ((2 * wave + ((t >> 5) & 1)) * kPwTile + 4 * (t & 31)) * 2;
+  *(uint4*)(imgH + o) = make_uint4(h[0], h[1], h[2], h[3]);
+  *(uint4*)(imgL + o) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// fragment of the 32x32x16 MFMA for lane (row, k8 group g) of an image
+template <bool KMAJOR>
+__device__ __forceinline__ pw_h8 pw_frag(const _Float16* img, int row, int sw, int g) {
+  if constexpr (KMAJOR) {
+    return *(const pw_h8*)(img + row * kPwBK + ((g ^ sw) << 3));
+  } else {
+    const unsigned* d = (const unsigned*)img + (4 * g) * kPwTile + row;
+    const uint4 v = make_uint4(d[0], d[kPwTile], d[2 * kPwTile], d[3 * kPwTile]);
+    return __builtin_bit_cast(pw_h8, v);
   }
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
+__global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 pw_lds[];
   // blocks that share an XCD (id % 8) take consecutive tiles: the M tiles of one [K, 128] operand panel run side by side on
   // one L2 (bijective form of the remap, cdna_hip_programming.md §5)
@@ -204,42 +217,39 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
   const float* B = a.B + cloud * a.b_bs;
   float* C = a.C + z * a.c_zs;
   const int m0 = mt * kPwTile, n0 = nt * kPwTile;
-  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1, r = lane & 31, h = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 2, wn = w & 3, r = lane & 31, h = lane >> 5;
   const int ea = pw_scale_exp(a.amax_a), eb = pw_scale_exp(a.amax_b);
   const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
-  pw_acc acc[2][2];
+  pw_acc acc[2];                                     // wave tile 64 x 32: rows 64*wm + 32*i, columns 32*wn
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   // two register sets: the loads of K-step kt+2 go out at the top of step kt and are split into LDS at the end of step kt+1,
   // so an HBM / L2 round trip has two steps of MFMAs (and the CU's other workgroup) to hide behind
-  float ra0[16], rb0[16], ra1[16], rb1[16];
+  float ra0[kPwR], rb0[kPwR], ra1[kPwR], rb1[kPwR];
   unsigned oka0, okb0, oka1 = 0, okb1 = 0;
-  const PwLane<A_KMAJOR> la = pw_lane<A_KMAJOR>(A, a.lda, m0, a.M, t);
-  const PwLane<B_KMAJOR> lb = pw_lane<B_KMAJOR>(B, a.ldb, n0, a.N, t);
+  const PwLane<A_KMAJOR> la = pw_lane<A_KMAJOR>(A, a.lda, m0, a.M, w, t);
+  const PwLane<B_KMAJOR> lb = pw_lane<B_KMAJOR>(B, a.ldb, n0, a.N, w, t);
   const int T = (kend - kbeg + kPwBK - 1) / kPwBK, F = (kend - kbeg) / kPwBK;   // K-steps, whole ones
   // wave-uniform bases of the next whole K-step to load and their advance per step
   const size_t lda4 = (size_t)a.lda * 4, ldb4 = (size_t)a.ldb * 4;
-  const char* ua = (const char*)A + (A_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 8 * w) * lda4);
-  const char* ub = (const char*)B + (B_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 8 * w) * ldb4);
+  const char* ua = (const char*)A + (A_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 4 * w) * lda4);
+  const char* ub = (const char*)B + (B_KMAJOR ? (size_t)(kbeg + kPwBK) * 4 : (size_t)(kbeg + kPwBK + 4 * w) * ldb4);
   const size_t stepa = A_KMAJOR ? (size_t)kPwBK * 4 : kPwBK * lda4, stepb = B_KMAJOR ? (size_t)kPwBK * 4 : kPwBK * ldb4;
-  const unsigned fulla = la.rowok ? (A_KMAJOR ? 0xfu : 0xffu) : 0u, fullb = lb.rowok ? (B_KMAJOR ? 0xfu : 0xffu) : 0u;
 
   // loads of K-step `step` into one register set.  WHOLE: the caller knows step < F — no branch, so that the number of loads in
   // flight is the same on every path into the split that follows (at a join the compiler waits for the shortest queue: a
   // conditional fetch drains the ring).  Otherwise any step (nothing past the last: its stores refill a stage nobody reads).
-  auto fetch = [&](auto whole, int step, float (&xa)[16], float (&xb)[16], unsigned& xoka, unsigned& xokb) {
+  auto fetch = [&](auto whole, int step, float (&xa)[kPwR], float (&xb)[kPwR], unsigned& xoka, unsigned& xokb) {
     if (decltype(whole)::value || step < F) {
 #if !(defined(PW_ABL) && PW_ABL == 3)
       pw_load_full<A_KMAJOR>(xa, ua, lda4, la.off);
       pw_load_full<B_KMAJOR>(xb, ub, ldb4, lb.off);
 #endif
-      xoka = fulla; xokb = fullb;
+      xoka = 0x3u; xokb = 0x3u;
       ua += stepa; ub += stepb;
     } else if (step < T) {                           // the partial last step
       xoka = pw_load<A_KMAJOR>(xa, la, a.lda, kbeg + step * kPwBK, kend, w, t);
@@ -254,65 +264,77 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
   pw_store<B_KMAJOR>(rb0, okb0, pw_lds + 2 * kPwImg, pw_lds + 3 * kPwImg, sb, w, t);
   __syncthreads();
 
-  // fragment offsets: row = 64*wm + 32*i + r (A), 64*wn + 32*j + r (B); k8 group 2*ks + h
-  int offA[2], offB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    offA[i] = (64 * wm + 32 * i + r) * kPwBK;
-    offB[i] = (64 * wn + 32 * i + r) * kPwBK;
-  }
-  const int sw = (r >> 2) & 3;
-  const int g0 = ((0 + h) ^ sw) << 3, g1 = ((2 + h) ^ sw) << 3;
+  // fragment rows: 64*wm + 32*i + r (A), 32*wn + r (B); k8 group 2*ks + h
+  const int rowA = 64 * wm + r, rowB = 32 * wn + r, sw = (r >> 2) & 3;
 
+#ifdef PW_STAMP
+  unsigned long long tprev = __builtin_amdgcn_s_memtime(), tsum[6] = {0, 0, 0, 0, 0, 0};
+#define PW_T(i)                                             \
+  do {                                                      \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+    tsum[i] += now__ - tprev;                               \
+    tprev = now__;                                          \
+  } while (0)
+#else
+#define PW_T(i) ((void)0)
+#endif
   // K-step kt: fetch step kt+2 into (xa, xb), MFMAs on stage kt&1, split step kt+1 from (ya, yb) into the other stage
-  auto kstep = [&](auto whole, int kt, float (&xa)[16], float (&xb)[16], unsigned& xoka, unsigned& xokb, float (&ya)[16],
-                   float (&yb)[16], unsigned yoka, unsigned yokb) {
+  auto kstep = [&](auto whole, int kt, float (&xa)[kPwR], float (&xb)[kPwR], unsigned& xoka, unsigned& xokb, float (&ya)[kPwR],
+                   float (&yb)[kPwR], unsigned yoka, unsigned yokb) {
     const _Float16* st = pw_lds + (kt & 1) * kPwStage;
     _Float16* nx = pw_lds + ((kt + 1) & 1) * kPwStage;
+    PW_T(0);
     fetch(whole, kt + 2, xa, xb, xoka, xokb);
     __builtin_amdgcn_sched_barrier(0);               // the loads go out before the MFMAs, not after them
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int g = ks ? g1 : g0;
-      pw_h8 ah[2], al[2], bh[2], bl[2];
+    PW_T(1);
+    // The split of step kt+1 (its loads landed a step ago) is issued in the shadow of this step's MFMAs: the wave's MFMAs queue
+    // behind those of the SIMD's other three waves, and between two of them it has vector-ALU work that needs neither the
+    // matrix pipe nor this step's LDS stage.  sched_barrier pins the order (the compiler keeps asm and MFMA blocks apart).
+    if constexpr (!decltype(whole)::value) {          // only the last steps can hold a partial K-step
+      pw_mask(ya, yoka);
+      pw_mask(yb, yokb);
+    }
+    unsigned hA[4], lA[4], hB[4], lB[4];
+    pw_h8 ah[2], al[2], bh, bl;
+    auto frags = [&](int ks) {
+      const int g = 2 * ks + h;
+      bh = pw_frag<B_KMAJOR>(st + 2 * kPwImg, rowB, sw, g);
+      bl = pw_frag<B_KMAJOR>(st + 3 * kPwImg, rowB, sw, g);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = *(const pw_h8*)(st + offA[i] + g);
-        al[i] = *(const pw_h8*)(st + kPwImg + offA[i] + g);
-        bh[i] = *(const pw_h8*)(st + 2 * kPwImg + offB[i] + g);
-        bl[i] = *(const pw_h8*)(st + 3 * kPwImg + offB[i] + g);
+        ah[i] = pw_frag<A_KMAJOR>(st, rowA + 32 * i, sw, g);
+        al[i] = pw_frag<A_KMAJOR>(st + kPwImg, rowA + 32 * i, sw, g);
       }
-#if defined(PW_ABL) && PW_ABL == 2
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)ah[i][e] + (float)bh[j][e] + (float)al[i][e] + (float)bl[j][e];
-#else
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#if defined(PW_ABL) && PW_ABL == 4
-    if (ya[0] == 12345.f && yb[0] == 54321.f)
-#endif
-    {
-      pw_store<A_KMAJOR>(ya, yoka, nx, nx + kPwImg, sa, w, t);
-      pw_store<B_KMAJOR>(yb, yokb, nx + 2 * kPwImg, nx + 3 * kPwImg, sb, w, t);
-    }
+    };
+#define PW_MF(x, y)                                                                   \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], y, acc[0], 0, 0, 0);        \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], y, acc[1], 0, 0, 0);        \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  } while (0)
+    frags(0);
+    PW_MF(ah, bh);
+    pw_unit<A_KMAJOR>(ya, 0, sa, hA, lA);
+    pw_unit<A_KMAJOR>(ya, 1, sa, hA, lA);
+    PW_MF(ah, bl);
+    pw_unit<A_KMAJOR>(ya, 2, sa, hA, lA);
+    PW_MF(al, bh);
+    pw_unit<A_KMAJOR>(ya, 3, sa, hA, lA);
+    pw_write<A_KMAJOR>(hA, lA, nx, nx + kPwImg, w, t);
+    frags(1);
+    PW_MF(ah, bh);
+    pw_unit<B_KMAJOR>(yb, 0, sb, hB, lB);
+    pw_unit<B_KMAJOR>(yb, 1, sb, hB, lB);
+    PW_MF(ah, bl);
+    pw_unit<B_KMAJOR>(yb, 2, sb, hB, lB);
+    PW_MF(al, bh);
+    pw_unit<B_KMAJOR>(yb, 3, sb, hB, lB);
+    pw_write<B_KMAJOR>(hB, lB, nx + 2 * kPwImg, nx + 3 * kPwImg, w, t);
+#undef PW_MF
+    PW_T(4);
     __syncthreads();
+    PW_T(5);
   };
   int kt = 0;
   for (; kt + 3 < F; kt += 2) {                      // both fetches (steps kt+2, kt+3) are whole K-steps
@@ -325,18 +347,19 @@ __global__ void __launch_bounds__(kPwThreads, 2) pw_gemm_kernel(PwArgs a) {
     kstep(std::false_type{}, kt + 1, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0);
   }
 
+#ifdef PW_STAMP
+  if (a.dbg && lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 6; ++i) a.dbg[((size_t)blockIdx.x * 8 + w) * 6 + i] = tsum[i];
+#endif
   // D of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const float ia = ldexpf(1.f, -ea), ib = ldexpf(1.f, -eb);
+  const int col = n0 + 32 * wn + r;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + 64 * wn + 32 * j + r;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][j][e] * ia * ib;
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][e] * ia * ib;
     }
 }
 
@@ -410,6 +433,23 @@ __global__ void __launch_bounds__(256) pw_amax_kernel(const float* __restrict__ 
 #endif
 constexpr int kPwZTarget = CT_PW_ZTARGET;
 
+// W [R][C] -> W^T [C][R] (the data gradient then runs the forward arrangement: its A operand k-contiguous)
+__global__ void __launch_bounds__(256) pw_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < R && c < C) tile[ty + 8 * i][tx] = w[(size_t)r * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) wt[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 struct PwPlan {
   int M, N, K, Z, ksplit, Kc, tilesM, tilesN;
   size_t ws;
@@ -438,6 +478,7 @@ static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
     p.ksplit = (p.K + kc - 1) / kc;
     if ((long long)B * p.ksplit > 1) p.ws = (size_t)B * p.ksplit * Co * Ci * sizeof(float);
   }
+  if (mode == CT_PW_DGRAD) p.ws = (size_t)Co * Ci * sizeof(float);   // W^T
   p.Z = B * p.ksplit;
   if ((long long)p.tilesM * p.tilesN * p.Z > 0x7fffffffLL) return false;
   if ((long long)Co * N >= (1LL << 30) || (long long)Ci * N >= (1LL << 30) || (long long)Co * Ci >= (1LL << 30)) return false;   // 32-bit lane offsets
@@ -455,6 +496,11 @@ static int pw_launch(const PwArgs& a, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(blocks), dim3(kPwThreads), kPwLdsBytes, st, a);
   return CT_OK;
 }
+
+#ifdef PW_STAMP
+static unsigned long long* g_pw_dbg = nullptr;
+extern "C" void ct_debug_pw_stamp(unsigned long long* buf) { g_pw_dbg = buf; }
+#endif
 
 extern "C" {
 
@@ -486,15 +532,21 @@ int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float
   hipStream_t st = (hipStream_t)s;
   PwArgs g{};
   g.A = a; g.B = b; g.amax_a = amax_a; g.amax_b = amax_b;
+#ifdef PW_STAMP
+  g.dbg = g_pw_dbg;
+#endif
   g.M = p.M; g.N = p.N; g.K = p.K; g.tilesM = p.tilesM; g.tilesN = p.tilesN; g.ksplit = p.ksplit; g.Kc = p.Kc;
   const int blocks = p.tilesM * p.tilesN * p.Z;
   int rc;
   if (mode == CT_PW_FWD) {            // A = W [Co][Ci] (k contiguous), B = x[b] [Ci][N] (columns contiguous)
     g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Ci * N; g.C = out; g.ldc = N; g.c_zs = (long long)Co * N;
     rc = pw_launch<true, false>(g, blocks, st);
-  } else if (mode == CT_PW_DGRAD) {   // A = W^T: element (m = ci, k = co) at W[k][m] (rows contiguous), B = g_y[b] [Co][N]
-    g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = pw_launch<false, false>(g, blocks, st);
+  } else if (mode == CT_PW_DGRAD) {   // A = W^T [Ci][Co] written to the workspace (k = co contiguous), B = g_y[b] [Co][N]
+    hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, st, a, (float*)workspace, Co, Ci);
+    CT_CHECK_LAUNCH();
+    g.A = (const float*)workspace;
+    g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
+    rc = pw_launch<true, false>(g, blocks, st);
   } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous
     g.lda = N; g.a_bs = (long long)Co * N; g.ldb = N; g.b_bs = (long long)Ci * N; g.ldc = Ci;
     g.C = p.ws ? (float*)workspace : out;

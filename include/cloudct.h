@@ -374,7 +374,8 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
  * fp32 out on the f16 matrix pipes: operands are scaled by a per-tensor power of two
  * and split into two f16 terms (22 bits), three MFMA terms per product, fp32 accumulation.
  *   CT_PW_FWD:   a = W f32[Co,Ci], b = x f32[B,Ci,N]   -> out = y f32[B,Co,N]   (y[b] = W x[b])
- *   CT_PW_DGRAD: a = W f32[Co,Ci], b = g_y f32[B,Co,N] -> out = g_x f32[B,Ci,N] (W^T g_y[b])
+ *   CT_PW_DGRAD: a = W f32[Co,Ci], b = g_y f32[B,Co,N] -> out = g_x f32[B,Ci,N] (W^T g_y[b]; W^T goes
+ *                through the workspace)
  *   CT_PW_WGRAD: a = g_y f32[B,Co,N], b = x f32[B,Ci,N] -> out = g_W f32[Co,Ci] (sum_b g_y[b] x[b]^T,
  *                partial sums added in a fixed order: deterministic)
  * amax_a / amax_b: device f32[1] = max |.| of the whole operand tensor (ct_amax_f32), or
