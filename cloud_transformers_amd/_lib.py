@@ -215,6 +215,7 @@ SIGNATURES = {
     "ct_emd_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _f, _i, _vp]),
     "ct_emd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ct_amax_f32": (_i, [_vp, _ll, _vp, _vp]),
+    "ct_amax_len": (_i, []),
     "ct_pw_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
 }

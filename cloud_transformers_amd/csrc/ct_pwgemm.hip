@@ -45,9 +45,8 @@ struct PwArgs {
 };
 
 // power of two s with s * amax in [2^13, 2^14); 1 for an all-zero or non-finite tensor (inf / nan then flow through h)
-__device__ __forceinline__ int pw_scale_exp(const float* amax) {
-  if (!amax) return 0;
-  const float m = *amax;
+__device__ __forceinline__ int pw_scale_exp(unsigned amax_bits) {
+  const float m = __uint_as_float(amax_bits);
   if (!(m > 0.f) || !(m < __builtin_inff())) return 0;
   int e;
   (void)frexpf(m, &e);
@@ -218,7 +217,20 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   float* C = a.C + z * a.c_zs;
   const int m0 = mt * kPwTile, n0 = nt * kPwTile;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 2, wn = w & 3, r = lane & 31, h = lane >> 5;
-  const int ea = pw_scale_exp(a.amax_a), eb = pw_scale_exp(a.amax_b);
+  // the operands' max |.|: one of ct_amax_f32's kPwAmaxLen partial maxima per thread, folded through the (still unused) LDS
+  unsigned ma = a.amax_a ? __float_as_uint(a.amax_a[t]) : 0u, mb = a.amax_b ? __float_as_uint(a.amax_b[t]) : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ma = max(ma, (unsigned)__shfl_xor((int)ma, o, 64));
+    mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+  }
+  unsigned* fold = (unsigned*)pw_lds;
+  if (lane == 0) { fold[w] = ma; fold[8 + w] = mb; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { ma = max(ma, fold[i]); mb = max(mb, fold[8 + i]); }
+  __syncthreads();
+  const int ea = pw_scale_exp(ma), eb = pw_scale_exp(mb);
   const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
   pw_acc acc[2];                                     // wave tile 64 x 32: rows 64*wm + 32*i, columns 32*wn
@@ -395,11 +407,14 @@ __global__ void __launch_bounds__(256) pw_reduce_kernel(const float* __restrict_
   }
 }
 
-// max |x| as the bit pattern's unsigned maximum (order-independent: deterministic); eight 16-byte loads in flight per thread
+// max |x| as the bit pattern's unsigned maximum, one partial maximum per block (kPwAmaxLen of them, zero where a block has no
+// data): no same-address atomics (they serialise at ~40 ns each: 512 tickets cost as much as streaming 67 MB), no memset
+// node, no second launch — the GEMM's 512 threads fold the 512 partials when it starts.  Eight 16-byte loads in flight per
+// thread.
 __global__ void __launch_bounds__(256) pw_amax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  typedef unsigned pw_u4 __attribute__((ext_vector_type(4)));
   unsigned m = 0;
   const long long n4 = n >> 2;
-  typedef unsigned pw_u4 __attribute__((ext_vector_type(4)));
   const pw_u4* p = (const pw_u4*)x;
   long long i = ((long long)blockIdx.x * 8) * 256 + threadIdx.x;
   const long long stride = (long long)gridDim.x * 8 * 256;
@@ -422,16 +437,8 @@ __global__ void __launch_bounds__(256) pw_amax_kernel(const float* __restrict__ 
   for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
-    if (m) atomicMax(out, m);
-  }
+  if (threadIdx.x == 0) out[blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 }
-
-#ifndef CT_PW_ZTARGET
-#define CT_PW_ZTARGET 512
-#endif
-constexpr int kPwZTarget = CT_PW_ZTARGET;
 
 // W [R][C] -> W^T [C][R] (the data gradient then runs the forward arrangement: its A operand k-contiguous)
 __global__ void __launch_bounds__(256) pw_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int C) {
@@ -449,6 +456,12 @@ __global__ void __launch_bounds__(256) pw_transpose_kernel(const float* __restri
     if (r < R && c < C) wt[(size_t)c * R + r] = tile[tx][ty + 8 * i];
   }
 }
+
+#ifndef CT_PW_ZTARGET
+#define CT_PW_ZTARGET 512
+#endif
+constexpr int kPwZTarget = CT_PW_ZTARGET;
+constexpr int kPwAmaxLen = 512;       // = kPwThreads: one partial maximum per GEMM thread
 
 struct PwPlan {
   int M, N, K, Z, ksplit, Kc, tilesM, tilesN;
@@ -507,15 +520,12 @@ extern "C" {
 int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s) {
   if (!x || !amax || n < 1 || ((uintptr_t)x & 15)) return CT_EINVAL;
   CT_CLEAR_ERROR();
-  hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(amax, 0, sizeof(float), st) != hipSuccess) return CT_ELAUNCH;
-  long long blocks = ((n >> 2) + 256 * 8 - 1) / (256 * 8);
-  if (blocks < 1) blocks = 1;
-  if (blocks > 512) blocks = 512;     // one same-address atomic per block: they serialise at the memory side
-  hipLaunchKernelGGL(pw_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)n, (unsigned*)amax);
+  hipLaunchKernelGGL(pw_amax_kernel, dim3(kPwAmaxLen), dim3(256), 0, (hipStream_t)s, x, (long long)n, (unsigned*)amax);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
+
+int ct_amax_len(void) { return kPwAmaxLen; }
 
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   PwPlan p;

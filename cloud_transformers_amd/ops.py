@@ -97,11 +97,19 @@ def pw_eligible(Co, Ci, N, mode=None):
     return True
 
 
+_amax_len = None
+
+
 def amax(t):
-    """max |t| of a contiguous float32 tensor as a device scalar f32[1] (the per-tensor scale of ct_pw_gemm)."""
-    out = torch.empty(1, device=t.device, dtype=torch.float32)
+    """Partial maxima of |t| for a contiguous float32 tensor: f32[ct_amax_len()], one per block of the kernel (max |t| is
+    their maximum; ct_pw_gemm folds them when it starts) — the per-tensor scale of ct_pw_gemm."""
+    global _amax_len
+    lib = _lib.load()
+    if _amax_len is None:
+        _amax_len = lib.ct_amax_len()
+    out = torch.empty(_amax_len, device=t.device, dtype=torch.float32)
     with _on(t.device):
-        _lib.check(_lib.load().ct_amax_f32(_ptr(t), t.numel(), _ptr(out), _stream()), "ct_amax_f32")
+        _lib.check(lib.ct_amax_f32(_ptr(t), t.numel(), _ptr(out), _stream()), "ct_amax_f32")
     return out
 
 

@@ -378,7 +378,8 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
  *                through the workspace)
  *   CT_PW_WGRAD: a = g_y f32[B,Co,N], b = x f32[B,Ci,N] -> out = g_W f32[Co,Ci] (sum_b g_y[b] x[b]^T,
  *                partial sums added in a fixed order: deterministic)
- * amax_a / amax_b: device f32[1] = max |.| of the whole operand tensor (ct_amax_f32), or
+ * amax_a / amax_b: device f32[ct_amax_len()] written by ct_amax_f32 on the whole operand
+ * tensor — partial maxima of |.|, one per block of that kernel; the GEMM folds them — or
  * NULL for scale 1 (the caller then guarantees |values| < 65504).  Co, Ci, N multiples of 4,
  * 16-byte aligned pointers -> CT_EINVAL otherwise.  Workspace: ct_pw_gemm_workspace_bytes.
  * ---------------------------------------------------------------------- */
@@ -386,6 +387,7 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
 #define CT_PW_DGRAD 1
 #define CT_PW_WGRAD 2
 int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s);
+int ct_amax_len(void);
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N);
 int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, const float* amax_b,
                void* workspace, size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s);

@@ -1,7 +1,8 @@
 """Phase stamps of ct_pw_gemm's K-step (development build: bash tools/dev/build_exp.sh 50 -DPW_STAMP;
 CLOUDCT_LIB=.../libcloudct_exp50.so python tools/dev/pw_stamp.py [B Co Ci N]): mean cycles per K-step and wave spent in
-0 loop top -> 1 fetch issued -> 2 fragment reads + MFMAs issued -> 3 the loads of the step to split have landed ->
-4 split + LDS stores issued -> 5 barrier passed (s_memtime; each stamp drains the LDS queue first)."""
+loop top -> fetch of step kt+2 issued -> (the loads of step kt+1 have landed: explicit vmcnt wait) -> fragment reads, MFMAs
+of step kt with the split + LDS stores of step kt+1 between them -> barrier passed (s_memtime; each stamp drains the LDS
+queue first)."""
 import ctypes
 import os
 import sys
@@ -37,5 +38,5 @@ for mode, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad")):
     tot = t.sum(dim=2).mean()
     frac = t.mean(dim=(0, 1)) / tot
     print(name, "blocks", int(used.sum()), "cycles per wave in the loop %.0f" % float(tot),
-          "| share fetch %.2f  mfma %.2f  vmcnt %.2f  split+store %.2f  barrier %.2f  (loop top %.2f)" %
-          (float(frac[1]), float(frac[2]), float(frac[3]), float(frac[4]), float(frac[5]), float(frac[0])))
+          "| share: fetch issue %.2f  waiting for loads %.2f  MFMAs + split + LDS stores %.2f  barrier %.2f  loop top %.2f" %
+          (float(frac[1]), float(frac[2] + frac[3]), float(frac[4]), float(frac[5]), float(frac[0])))
