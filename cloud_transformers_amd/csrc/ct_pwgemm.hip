@@ -331,18 +331,18 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
     pw_unit<A_KMAJOR>(ya, 1, sa, hA, lA);
     PW_MF(ah, bl);
     pw_unit<A_KMAJOR>(ya, 2, sa, hA, lA);
-    PW_MF(al, bh);
     pw_unit<A_KMAJOR>(ya, 3, sa, hA, lA);
     pw_write<A_KMAJOR>(hA, lA, nx, nx + kPwImg, w, t);
+    PW_MF(al, bh);
     frags(1);
-    PW_MF(ah, bh);
     pw_unit<B_KMAJOR>(yb, 0, sb, hB, lB);
     pw_unit<B_KMAJOR>(yb, 1, sb, hB, lB);
-    PW_MF(ah, bl);
+    PW_MF(ah, bh);
     pw_unit<B_KMAJOR>(yb, 2, sb, hB, lB);
-    PW_MF(al, bh);
     pw_unit<B_KMAJOR>(yb, 3, sb, hB, lB);
-    pw_write<B_KMAJOR>(hB, lB, nx + 2 * kPwImg, nx + 3 * kPwImg, w, t);
+    pw_write<B_KMAJOR>(hB, lB, nx + 2 * kPwImg, nx + 3 * kPwImg, w, t);     // two MFMA groups ahead of the barrier
+    PW_MF(ah, bl);
+    PW_MF(al, bh);
 #undef PW_MF
     PW_T(4);
     __syncthreads();
