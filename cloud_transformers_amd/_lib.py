@@ -187,6 +187,8 @@ SIGNATURES = {
     "ct_bn_relu_supported": (_i, [_i, _i, _i]),
     "ct_bn_relu_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ct_bn_relu_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "ct_bn_relu_bwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_bn_stats_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ct_bn_apply_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp,
                              _i, _i, _i, _f, _f, _i, _vp]),
@@ -217,7 +219,7 @@ SIGNATURES = {
     "ct_amax_f32": (_i, [_vp, _ll, _vp, _vp]),
     "ct_amax_len": (_i, []),
     "ct_pw_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
 }
 
 

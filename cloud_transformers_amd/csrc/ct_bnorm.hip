@@ -43,6 +43,18 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float (*red)[kWaves]) {
   __syncthreads();
 }
 
+// max over the workgroup of a non-negative value (thread 0 gets the result)
+__device__ __forceinline__ float block_max(float v, float (*red)[kWaves]) {
+#pragma unroll
+  for (int o = CT_WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, CT_WAVE));
+  if ((threadIdx.x & (CT_WAVE - 1)) == 0) red[0][threadIdx.x / CT_WAVE] = v;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) m = fmaxf(m, red[0][w]);
+  return m;
+}
+
 struct BnArgs {
   const float* x;
   const float* weight;
@@ -73,6 +85,9 @@ struct BnArgs {
   const float* g_count;
   int world;
   long long g_stride;
+  // nullable: amax_out[c] = max |y| of channel c as written (after ReLU and skip) — the per-tensor scale of the pointwise GEMM
+  // that reads y next (ct_pw_gemm folds per-channel maxima like ct_amax_f32's partials), at no extra pass over y
+  float* amax_out;
 };
 
 // mode 2: merge the ranks' statistics of channel c (Chan et al.: M2 = sum M2_r + sum n_r (mean_r - mean)^2)
@@ -154,6 +169,7 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* _
   const float g = a.weight[c] * rs;
   const float be = a.bias[c];
   const float lo = a.relu ? 0.0f : -INFINITY;
+  float am = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
@@ -168,7 +184,12 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* _
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       *reinterpret_cast<float4*>(y + quad_offset(q, nq, c, a.ybs, a.N)) = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[c] = am;
   }
 }
 
@@ -193,6 +214,7 @@ struct BnBwdArgs {
   const float* sum0;
   const float* sum1;
   const float* count;
+  float* amax_out;   // nullable: amax_out[c] = max |gx| of channel c (see BnArgs::amax_out)
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * (weight * rstd) + bias, same operation
@@ -243,13 +265,20 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdArgs a) {
     M = a.count[0];
   }
   const float m0 = s[0] / M, m1 = s[1] / M;
+  float am = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
-    if (q < total)
-      *reinterpret_cast<float4*>(a.gx + quad_offset(q, nq, c, a.gxbs, a.N)) =
-          make_float4(gfw * (g[k].x - m0 - xh[k].x * m1), gfw * (g[k].y - m0 - xh[k].y * m1),
-                      gfw * (g[k].z - m0 - xh[k].z * m1), gfw * (g[k].w - m0 - xh[k].w * m1));
+    if (q < total) {
+      const float4 o = make_float4(gfw * (g[k].x - m0 - xh[k].x * m1), gfw * (g[k].y - m0 - xh[k].y * m1),
+                                   gfw * (g[k].z - m0 - xh[k].z * m1), gfw * (g[k].w - m0 - xh[k].w * m1));
+      *reinterpret_cast<float4*>(a.gx + quad_offset(q, nq, c, a.gxbs, a.N)) = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[c] = am;
   }
 }
 
@@ -321,6 +350,7 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* 
   const float g = a.weight[c] * rs;
   const float be = a.bias[c];
   const float lo = a.relu ? 0.0f : -INFINITY;
+  float am = 0.f;
   for (int i = threadIdx.x; i < total; i += kThreads) {
     const float* p = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
     float* o = y + item_offset<VEC>(i, a.N, c, a.ybs);
@@ -334,9 +364,15 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* 
       q.w = fmaxf((v.w - mu) * g + be, lo);
       if (r) { const float4 rv = *reinterpret_cast<const float4*>(r); q.x += rv.x; q.y += rv.y; q.z += rv.z; q.w += rv.w; }
       *reinterpret_cast<float4*>(o) = q;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
     } else {
       o[0] = fmaxf((p[0] - mu) * g + be, lo) + (r ? r[0] : 0.0f);
+      am = fmaxf(am, fabsf(o[0]));
     }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[c] = am;
   }
 }
 
@@ -378,6 +414,7 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
     M = a.count[0];
   }
   const float m0 = s[0] / M, m1 = s[1] / M;
+  float am = 0.f;
   for (int i = threadIdx.x; i < total; i += kThreads) {
     const float* px = a.x + item_offset<VEC>(i, a.N, c, a.xbs);
     const float* pg = a.gy + item_offset<VEC>(i, a.N, c, a.gybs);
@@ -390,9 +427,15 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
       o.z = gfw * (masked(gv.z, xv.z - mu, gfw, be, a.relu) - m0 - ((xv.z - mu) * rs) * m1);
       o.w = gfw * (masked(gv.w, xv.w - mu, gfw, be, a.relu) - m0 - ((xv.w - mu) * rs) * m1);
       *reinterpret_cast<float4*>(po) = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     } else {
       po[0] = gfw * (masked(pg[0], px[0] - mu, gfw, be, a.relu) - m0 - ((px[0] - mu) * rs) * m1);
+      am = fmaxf(am, fabsf(po[0]));
     }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[c] = am;
   }
 }
 
@@ -496,6 +539,29 @@ extern "C" int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const fl
                               int relu, ct_stream_t s) {
   if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
   BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+  return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, gx_batch_stride, (hipStream_t)s);
+}
+
+// The same two with amax_out f32[C] (nullable): max |y| / max |gx| per channel, for ct_pw_gemm's operand scale.
+extern "C" int ct_bn_relu_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                                   const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                                   float* save_mean, float* save_rstd, float* amax_out, int B, int C, int N, float eps,
+                                   float momentum, int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !y || !save_mean || !save_rstd || !(eps >= 0.0f)) return CT_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
+  BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
+           residual, 0, num_batches_tracked, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, amax_out};
+  return bn_fwd_launch(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_relu_bwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                                   const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
+                                   float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, float* amax_out,
+                                   int B, int C, int N, int relu, ct_stream_t s) {
+  if (!x || !weight || !bias || !save_mean || !save_rstd || !gy || !gx || !g_weight || !g_bias) return CT_EINVAL;
+  BnBwdArgs a{x, weight, bias, save_mean, save_rstd, gy, gx, g_weight, g_bias, B, C, N, relu, 0, 0, 0, 0, nullptr, nullptr, nullptr,
+              amax_out};
   return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, gx_batch_stride, (hipStream_t)s);
 }
 

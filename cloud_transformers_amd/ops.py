@@ -113,6 +113,33 @@ def amax(t):
     return out
 
 
+PW_AMAX_MAX = 1024      # partial maxima ct_pw_gemm folds per operand
+
+
+def _amax_slots(C, device):
+    """Per-channel maxima buffer for a producer kernel (ct_bn_relu_fwd_amax / _bwd_amax), or None when the consumer could not
+    use it (library GEMMs selected, or more channels than ct_pw_gemm folds)."""
+    if PW_GEMM != "split16" or C > PW_AMAX_MAX:
+        return None
+    return torch.empty(C, device=device, dtype=torch.float32)
+
+
+def tag_amax(t, slots):
+    """Remember on tensor `t` the maxima its producer left in `slots` (valid until `t` is modified in place)."""
+    if slots is not None:
+        t._ct_amax = (slots, t._version)
+    return t
+
+
+def amax_of(t):
+    """The operand maxima of `t` for ct_pw_gemm: what its producer left behind if `t` is unchanged since (an in-place op
+    bumps `_version`), else a ct_amax_f32 pass over it."""
+    tag = getattr(t, "_ct_amax", None)
+    if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+        return tag[0]
+    return amax(t)
+
+
 def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
     """ct_pw_gemm on contiguous float32 tensors: PW_FWD (a = W [Co,Ci], b = x [B,Ci,N]) -> y [B,Co,N]; PW_DGRAD (a = W,
     b = g_y [B,Co,N]) -> g_x [B,Ci,N]; PW_WGRAD (a = g_y, b = x) -> g_W [Co,Ci].  amax_* from amax()."""
@@ -127,7 +154,8 @@ def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
     nbytes = lib.ct_pw_gemm_workspace_bytes(mode, B, Co, Ci, N)
     ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32) if nbytes else None
     with _on(dev):
-        _lib.check(lib.ct_pw_gemm(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), _ptr(amax_b), _ptr(ws), nbytes, B, Co, Ci, N,
+        _lib.check(lib.ct_pw_gemm(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), 0 if amax_a is None else amax_a.numel(),
+                                  _ptr(amax_b), 0 if amax_b is None else amax_b.numel(), _ptr(ws), nbytes, B, Co, Ci, N,
                                   _stream()), "ct_pw_gemm")
     return out
 
@@ -139,24 +167,25 @@ def pw_forward(W, x):
     B, _, N = x.shape
     if not pw_eligible(Co, Ci, N, PW_FWD):
         return torch.bmm(W.unsqueeze(0).expand(B, -1, -1), x), None, None
-    am_w, am_x = amax(W), amax(x)
+    am_w, am_x = amax(W), amax_of(x)
     return pw_gemm(PW_FWD, W, x, am_w, am_x, B, Co, Ci, N), am_w, am_x
 
 
-def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True):
-    """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous)."""
+def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None):
+    """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous); am_g: g_y's maxima where the caller has them."""
     Co, Ci = W.shape
     B, _, N = x.shape
     mine_x = need_x and pw_eligible(Co, Ci, N, PW_DGRAD)
     mine_w = need_w and pw_eligible(Co, Ci, N, PW_WGRAD)
-    am_g = amax(g_y) if (mine_x or mine_w) else None
+    if am_g is None and (mine_x or mine_w):
+        am_g = amax_of(g_y)
     g_x = g_w = None
     if mine_x:
         g_x = pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
     elif need_x:
         g_x = torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y)
     if mine_w:
-        g_w = pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax(x), B, Co, Ci, N)
+        g_w = pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax_of(x), B, Co, Ci, N)
     elif need_w:
         g_w = torch.bmm(g_y, x.transpose(1, 2)).sum(0)
     return g_x, g_w
@@ -679,7 +708,8 @@ def norms_share_group(bns):
 
 def _bn_group_fwd(items, B, N, device, group):
     """Run the norms of one group.  items: dicts with x (data_ptr), xbs, C, w, b, rm, rv, nbt, eps, mom, relu, res (ptr or
-    None), rbs, y (ptr), ybs.  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
+    None), rbs, y (ptr), ybs and, optionally, amax (ptr to C floats: the per-channel max |y|, written without a group only —
+    callers check `group is None` before they tag a tensor with it).  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
     device tensor with the job's values per channel.  With a group: local statistics of ALL items into one buffer, ONE
     all_gather, then the normalising kernels merge the ranks' statistics themselves (csrc/ct_bnorm.hip mode 1 / 2)."""
     global _sync_stats_collectives
@@ -689,10 +719,10 @@ def _bn_group_fwd(items, B, N, device, group):
         for it in items:
             mean = torch.empty(it["C"], device=device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
-            _lib.check(lib.ct_bn_relu_fwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["rm"]), _ptr(it["rv"]),
-                                          _ptr(it["nbt"]), it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
-                                          B, it["C"], N, float(it["eps"]), float(it["mom"]), int(it["relu"]), _stream()),
-                       "ct_bn_relu_fwd")
+            _lib.check(lib.ct_bn_relu_fwd_amax(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["rm"]), _ptr(it["rv"]),
+                                               _ptr(it["nbt"]), it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
+                                               it.get("amax"), B, it["C"], N, float(it["eps"]), float(it["mom"]),
+                                               int(it["relu"]), _stream()), "ct_bn_relu_fwd")
             stats.append((mean, rstd))
         return stats, None
     import torch.distributed as dist
@@ -740,9 +770,9 @@ def _bn_group_bwd(items, B, N, device, group, count):
         for it in items:
             g_w = torch.empty(it["C"], device=device, dtype=torch.float32)
             g_b = torch.empty_like(g_w)
-            _lib.check(lib.ct_bn_relu_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
-                                          it["gy"], it["gybs"], it["gx"], it["gxbs"], _ptr(g_w), _ptr(g_b), B, it["C"], N,
-                                          int(it["relu"]), _stream()), "ct_bn_relu_bwd")
+            _lib.check(lib.ct_bn_relu_bwd_amax(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
+                                               it["gy"], it["gybs"], it["gx"], it["gxbs"], _ptr(g_w), _ptr(g_b), it.get("amax"),
+                                               B, it["C"], N, int(it["relu"]), _stream()), "ct_bn_relu_bwd")
             out.append((g_w, g_b))
         return out
     import torch.distributed as dist
@@ -785,10 +815,13 @@ class BnReluFn(torch.autograd.Function):
             if rbs is None:
                 residual = _f32c(residual)
                 rbs = 0
+        slots = _amax_slots(C, x.device) if group is None else None
         with _on(x.device):
             stats, count = _bn_group_fwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, rm=running_mean, rv=running_var, nbt=nbt,
-                                               eps=eps, mom=momentum, relu=relu, res=_ptr(residual), rbs=rbs, y=_ptr(y), ybs=0)],
+                                               eps=eps, mom=momentum, relu=relu, res=_ptr(residual), rbs=rbs, y=_ptr(y), ybs=0,
+                                               amax=_ptr(slots))],
                                          B, N, x.device, group)
+        tag_amax(y, slots)
         mean, rstd = stats[0]
         ctx.save_for_backward(x, weight, bias, mean, rstd, count)
         ctx.relu = int(bool(relu))
@@ -805,9 +838,12 @@ class BnReluFn(torch.autograd.Function):
             gy = _f32c(gy)
             gybs = 0
         gx = torch.empty_like(x)
+        slots = _amax_slots(C, x.device) if ctx.group is None else None
         with _on(x.device):
             ((g_w, g_b),) = _bn_group_bwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, mean=mean, rstd=rstd, gy=_ptr(gy),
-                                                gybs=gybs, gx=_ptr(gx), gxbs=0, relu=ctx.relu)], B, N, x.device, ctx.group, count)
+                                                gybs=gybs, gx=_ptr(gx), gxbs=0, relu=ctx.relu, amax=_ptr(slots))],
+                                          B, N, x.device, ctx.group, count)
+        tag_amax(gx, slots)
         return gx, g_w, g_b, None, None, None, None, None, None, (gy if ctx.has_residual else None), None
 
 
@@ -876,14 +912,17 @@ class JoinBnReluFn(torch.autograd.Function):
         B, _, N = xs[0].shape
         Ct = sum(x.size(1) for x in xs)
         y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
+        slots = _amax_slots(Ct, y.device) if group is None else None
         items, c0 = [], 0
         for x, (_, w, b, rm, rv, nbt, eps, mom) in zip(xs, heads):
             C = x.size(1)
             items.append(dict(x=_ptr(x), xbs=0, C=C, w=_f32c(w), b=_f32c(b), rm=rm, rv=rv, nbt=nbt, eps=eps, mom=mom, relu=1,
-                              res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N))
+                              res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N,
+                              amax=None if slots is None else _ptr(slots) + 4 * c0))
             c0 += C
         with _on(y.device):
             stats, count = _bn_group_fwd(items, B, N, y.device, group)
+        tag_amax(y, slots)
         saved = []
         for x, it, (mean, rstd) in zip(xs, items, stats):
             saved += [x, it["w"], it["b"], mean, rstd]
@@ -907,11 +946,14 @@ class JoinBnReluFn(torch.autograd.Function):
             C = x.size(1)
             gx = torch.empty_like(x)
             gxs.append(gx)
+            slots = _amax_slots(C, gx.device) if ctx.group is None else None
             items.append(dict(x=_ptr(x), xbs=0, C=C, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs,
-                              gx=_ptr(gx), gxbs=0, relu=1))
+                              gx=_ptr(gx), gxbs=0, relu=1, amax=_ptr(slots), slots=slots))
             c0 += C
         with _on(gy.device):
             wb = _bn_group_bwd(items, B, N, gy.device, ctx.group, count)
+        for gx, it in zip(gxs, items):
+            tag_amax(gx, it["slots"])
         grads = [None, None]
         for gx, (g_w, g_b) in zip(gxs, wb):
             grads += [gx, g_w, g_b, None, None, None, None, None]
@@ -981,6 +1023,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Ct = Wc.size(0)
         g_y = torch.empty_like(y)
+        slots = _amax_slots(Ct, x.device) if ctx.group is None else None
         items = []
         for i, (c0, C) in enumerate(ctx.meta):
             w, b, mean, rstd = saved[i * 4:(i + 1) * 4]
@@ -991,10 +1034,11 @@ class UnionKeysValuesFn(torch.autograd.Function):
             if gybs is None:
                 gy, gybs = _f32c(gy), 0
             items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, C=C, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
-                              gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, relu=0, keep=gy))
+                              gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, relu=0, keep=gy,
+                              amax=None if slots is None else _ptr(slots) + 4 * c0))
         with _on(x.device):
             bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True)   # g_Wc [sum Co, Cin]
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True, am_g=slots)   # g_Wc [sum Co, Cin]
         grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]

@@ -217,6 +217,17 @@ int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight
                    const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
                    float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N, int relu,
                    ct_stream_t s);
+/* The same two with amax_out f32[C] (nullable): max |y| (after ReLU and skip) / max |g_x| per channel, a by-product of the
+ * pass — the operand maxima ct_pw_gemm needs for the pointwise convolution that reads y / g_x next (n_amax = C). */
+int ct_bn_relu_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                        float* save_mean, float* save_rstd, float* amax_out, int B, int C, int N, float eps,
+                        float momentum, int relu, ct_stream_t s);
+int ct_bn_relu_bwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                        const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
+                        float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, float* amax_out,
+                        int B, int C, int N, int relu, ct_stream_t s);
 
 /* The same norm split around an exchange of statistics between ranks — nn.SyncBatchNorm under data parallelism
  * (train_segmentation.py:128-130 converts every BatchNorm of the model).  Forward: ct_bn_stats_fwd on every norm of a
@@ -378,9 +389,11 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
  *                through the workspace)
  *   CT_PW_WGRAD: a = g_y f32[B,Co,N], b = x f32[B,Ci,N] -> out = g_W f32[Co,Ci] (sum_b g_y[b] x[b]^T,
  *                partial sums added in a fixed order: deterministic)
- * amax_a / amax_b: device f32[ct_amax_len()] written by ct_amax_f32 on the whole operand
- * tensor — partial maxima of |.|, one per block of that kernel; the GEMM folds them — or
- * NULL for scale 1 (the caller then guarantees |values| < 65504).  Co, Ci, N multiples of 4,
+ * amax_a / amax_b: device f32[n_amax_*] whose maximum is (an upper bound within ~2^10 of) max |.| of the
+ * whole operand tensor; the GEMM folds them when it starts.  Either ct_amax_f32's ct_amax_len()
+ * partial maxima, or what the kernel that produced the operand left behind (ct_bn_relu_fwd_amax /
+ * _bwd_amax: one per channel); n_amax_* <= 1024.  NULL = scale 1 (the caller then guarantees
+ * |values| < 65504).  Co, Ci, N multiples of 4,
  * 16-byte aligned pointers -> CT_EINVAL otherwise.  Workspace: ct_pw_gemm_workspace_bytes.
  * ---------------------------------------------------------------------- */
 #define CT_PW_FWD 0
@@ -389,8 +402,9 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
 int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s);
 int ct_amax_len(void);
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N);
-int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, const float* amax_b,
-               void* workspace, size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s);
+int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a,
+               const float* amax_b, int n_amax_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,
+               int N, ct_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,59 @@ def test_pointwise_layer_against_float64_conv1d(bias):
     assert float((y.double() - yd).abs().max()) <= 2e-6 * float(yd.abs().max()) * Ci ** 0.5
     for got, want in [(x.grad, xd.grad), (layer.weight.grad, ref.weight.grad)] + ([(layer.bias.grad, ref.bias.grad)] if bias else []):
         assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) + 1e-30
+
+
+def test_batchnorm_kernels_leave_the_channel_maxima_of_what_they_write():
+    """ct_bn_relu_fwd_amax / _bwd_amax: max |y| (after ReLU and skip) and max |g_x| per channel, bit for bit the maxima of the
+    tensors they wrote — the operand scale of the pointwise GEMM that reads them next, without a pass over them."""
+    from cloud_transformers_amd import ops
+    torch.manual_seed(1)
+    for (B, C, N, relu, res) in [(4, 96, 1024, True, True), (2, 40, 260, False, False), (8, 16, 8192, True, False)]:
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 2.0)
+            bn.bias.uniform_(-1.0, 1.0)
+        x = (torch.randn(B, C, N, device="cuda") * 3).requires_grad_(True)
+        skip = torch.randn(B, C, N, device="cuda") if res else None
+        y = ops.bn_relu(x, bn, relu=relu, residual=skip)
+        slots, version = y._ct_amax
+        assert version == y._version and torch.equal(slots, y.detach().abs().amax(dim=(0, 2)))
+        assert ops.amax_of(y) is slots
+        cot = torch.randn_like(y) * 1e-3
+        seen = []
+        x.register_hook(lambda g: seen.append(g))
+        y.backward(cot)
+        gslots, _ = seen[0]._ct_amax
+        assert torch.equal(gslots, seen[0].abs().amax(dim=(0, 2)))
+        y.detach().mul_(2.0)                       # an in-place change: the remembered maxima no longer describe y
+        assert ops.amax_of(y) is not slots and float(ops.amax_of(y).max()) == float(y.abs().max())
+
+
+def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
+    """BatchNorm+ReLU -> PointwiseConv1d -> BatchNorm+ReLU, forward and backward: the only ct_amax_f32 passes left are the
+    weight's and the first input's; results equal the ones computed with a pass over every operand."""
+    from cloud_transformers_amd import ops
+    from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
+    torch.manual_seed(2)
+    B, C, N = 4, 128, 2048
+    bn0, bn1 = torch.nn.BatchNorm1d(C).cuda(), torch.nn.BatchNorm1d(256).cuda()
+    conv = PointwiseConv1d(C, 256, 1, bias=False).cuda()
+    x = torch.randn(B, C, N, device="cuda", requires_grad=True)
+    cot = torch.randn(B, 256, N, device="cuda")
+
+    def run():
+        for p in list(conv.parameters()) + [x]:
+            p.grad = None
+        out = ops.bn_relu(conv(ops.bn_relu(x, bn0, relu=True)), bn1, relu=True)
+        out.backward(cot)
+        return out.detach().clone(), x.grad.clone(), conv.weight.grad.clone()
+
+    calls = []
+    real = ops.amax
+    monkeypatch.setattr(ops, "amax", lambda t: (calls.append(tuple(t.shape)), real(t))[1])
+    got = run()
+    assert sorted(calls) == [(256, C)], calls          # the weight only: x and g_y came with their maxima
+    monkeypatch.setattr(ops, "amax_of", lambda t: real(t))
+    want = run()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)                        # the same power-of-two scales either way
