@@ -184,6 +184,8 @@ SIGNATURES = {
     "ct_so3_exp_bwd": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "ct_adain_fwd": (_i, [_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "ct_adain_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _vp]),
+    "ct_adain_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _f, _i, _vp]),
+    "ct_adain_bwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
     "ct_bn_relu_supported": (_i, [_i, _i, _i]),
     "ct_bn_relu_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),

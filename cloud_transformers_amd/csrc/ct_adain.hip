@@ -46,6 +46,18 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float (*red)[kWaves]) {
   __syncthreads();
 }
 
+// max over the workgroup of a non-negative value (thread 0 gets the result)
+__device__ __forceinline__ float block_max(float v, float (*red)[kWaves]) {
+#pragma unroll
+  for (int o = CT_WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, CT_WAVE));
+  if ((threadIdx.x & (CT_WAVE - 1)) == 0) red[0][threadIdx.x / CT_WAVE] = v;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) m = fmaxf(m, red[0][w]);
+  return m;
+}
+
 struct AdainArgs {
   const float* x;
   const float* gamma_beta;
@@ -57,6 +69,10 @@ struct AdainArgs {
   long long xbs, ybs;        // batch strides in floats (C*N when contiguous; larger for a channel slice of a wider tensor)
   const float* residual;     // nullable: added after the ReLU (the union block's skip connection)
   long long rbs;
+  // nullable: amax_out[b * amax_bs + c] = max |y| of row (b, c) as written — the operand maxima of the pointwise GEMM that reads
+  // y next (ct_pw_gemm folds them like ct_amax_f32's partials), at no extra pass over y
+  float* amax_out;
+  long long amax_bs;
 };
 
 template <int NV>
@@ -97,6 +113,7 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
   const float lo = a.relu ? 0.0f : -INFINITY;
   float4* yr = reinterpret_cast<float4*>(y + (size_t)b * a.ybs + (size_t)c * a.N);
   const float4* rr = a.residual ? reinterpret_cast<const float4*>(a.residual + (size_t)b * a.rbs + (size_t)c * a.N) : nullptr;
+  float am = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
@@ -111,7 +128,12 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       yr[q] = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[(size_t)b * a.amax_bs + c] = am;
   }
 }
 
@@ -140,7 +162,16 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainArgs a
   const float lo = a.relu ? 0.0f : -INFINITY;
   float* yr = y + (size_t)b * a.ybs + (size_t)c * a.N;
   const float* rr = a.residual ? a.residual + (size_t)b * a.rbs + (size_t)c * a.N : nullptr;
-  for (int n = threadIdx.x; n < a.N; n += kThreads) yr[n] = fmaxf((xr[n] - mu) * g + be, lo) + (rr ? rr[n] : 0.0f);
+  float am = 0.f;
+  for (int n = threadIdx.x; n < a.N; n += kThreads) {
+    const float o = fmaxf((xr[n] - mu) * g + be, lo) + (rr ? rr[n] : 0.0f);
+    yr[n] = o;
+    am = fmaxf(am, fabsf(o));
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[(size_t)b * a.amax_bs + c] = am;
+  }
 }
 
 // Backward of y = relu?(xhat * (gamma + 1) + beta) wrt x, gamma, beta.  With g' = gy masked by the ReLU:
@@ -157,6 +188,8 @@ struct AdainBwdArgs {
   int B, C, N;
   int relu;
   long long xbs, gybs, gxbs; // batch strides in floats
+  float* amax_out;           // nullable: amax_out[b * amax_bs + c] = max |gx| of row (b, c) (see AdainArgs::amax_out)
+  long long amax_bs;
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * ((gamma + 1) * rstd) + beta, same
@@ -201,12 +234,20 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
   const float inv_n = 1.0f / (float)a.N;
   const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
   float4* or_ = reinterpret_cast<float4*>(a.gx + (size_t)b * a.gxbs + (size_t)c * a.N);
+  float am = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int q = threadIdx.x + k * kThreads;
-    if (q < nq)
-      or_[q] = make_float4(sc * (g[k].x - m0 - xh[k].x * m1), sc * (g[k].y - m0 - xh[k].y * m1),
-                           sc * (g[k].z - m0 - xh[k].z * m1), sc * (g[k].w - m0 - xh[k].w * m1));
+    if (q < nq) {
+      const float4 o = make_float4(sc * (g[k].x - m0 - xh[k].x * m1), sc * (g[k].y - m0 - xh[k].y * m1),
+                                   sc * (g[k].z - m0 - xh[k].z * m1), sc * (g[k].w - m0 - xh[k].w * m1));
+      or_[q] = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[(size_t)b * a.amax_bs + c] = am;
   }
 }
 
@@ -234,10 +275,17 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   const float inv_n = 1.0f / (float)a.N;
   const float m0 = s[0] * inv_n, m1 = s[1] * inv_n, sc = rs * g1;
   float* or_ = a.gx + (size_t)b * a.gxbs + (size_t)c * a.N;
+  float am = 0.f;
   for (int n = threadIdx.x; n < a.N; n += kThreads) {
     const float xh = (xr[n] - mu) * rs;
     const float g = masked(gr[n], xr[n] - mu, gfw, be, a.relu);
-    or_[n] = sc * (g - m0 - xh * m1);
+    const float o = sc * (g - m0 - xh * m1);
+    or_[n] = o;
+    am = fmaxf(am, fabsf(o));
+  }
+  if (a.amax_out) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) a.amax_out[(size_t)b * a.amax_bs + c] = am;
   }
 }
 
@@ -273,16 +321,16 @@ static bool adain_stride(long long bs, int C, int N, long long& out) {
   return true;
 }
 
-extern "C" int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
-                            long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
-                            int B, int C, int N, float eps, int relu, ct_stream_t s) {
+static int adain_fwd_impl(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                          long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                          float* amax_out, long long amax_batch_stride, int B, int C, int N, float eps, int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
   if ((size_t)B * C == 0 || N == 0) return CT_OK;
   if (!x || !gamma_beta || !y || !mean || !rstd) return CT_EINVAL;
   if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
   const int rows = B * C;
-  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0};
+  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
   if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(y_batch_stride, C, N, a.ybs) ||
       !adain_stride(residual_batch_stride, C, N, a.rbs))
     return CT_EINVAL;
@@ -296,9 +344,27 @@ extern "C" int ct_adain_fwd(const float* x, long long x_batch_stride, const floa
   return CT_OK;
 }
 
-extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
-                            const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
-                            long long gx_batch_stride, float* g_gamma_beta, int B, int C, int N, int relu, ct_stream_t s) {
+extern "C" int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                            long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                            int B, int C, int N, float eps, int relu, ct_stream_t s) {
+  return adain_fwd_impl(x, x_batch_stride, gamma_beta, residual, residual_batch_stride, y, y_batch_stride, mean, rstd, nullptr, 0,
+                        B, C, N, eps, relu, s);
+}
+
+// with amax_out f32 (nullable): amax_out[b * amax_batch_stride + c] = max |y| of row (b, c); stride 0 = C
+extern "C" int ct_adain_fwd_amax(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                                 long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                                 float* amax_out, long long amax_batch_stride, int B, int C, int N, float eps, int relu,
+                                 ct_stream_t s) {
+  if (amax_batch_stride != 0 && amax_batch_stride < C) return CT_EINVAL;
+  return adain_fwd_impl(x, x_batch_stride, gamma_beta, residual, residual_batch_stride, y, y_batch_stride, mean, rstd, amax_out,
+                        amax_batch_stride, B, C, N, eps, relu, s);
+}
+
+static int adain_bwd_impl(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
+                          const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
+                          long long gx_batch_stride, float* g_gamma_beta, float* amax_out, long long amax_batch_stride, int B, int C,
+                          int N, int relu, ct_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
   if (B < 0 || C < 0 || N < 0) return CT_EINVAL;
   if ((size_t)B * C == 0) return CT_OK;
@@ -307,7 +373,7 @@ extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const floa
   if (N == 0) return hipMemsetAsync(g_gamma_beta, 0, (size_t)B * 2 * C * sizeof(float), stream) == hipSuccess ? CT_OK : CT_ELAUNCH;
   if (!x || !gy || !gx) return CT_EINVAL;
   const int rows = B * C;
-  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0};
+  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
   if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(gy_batch_stride, C, N, a.gybs) ||
       !adain_stride(gx_batch_stride, C, N, a.gxbs))
     return CT_EINVAL;
@@ -319,4 +385,21 @@ extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const floa
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
+}
+
+extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
+                            const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
+                            long long gx_batch_stride, float* g_gamma_beta, int B, int C, int N, int relu, ct_stream_t s) {
+  return adain_bwd_impl(x, x_batch_stride, gamma_beta, mean, rstd, gy, gy_batch_stride, gx, gx_batch_stride, g_gamma_beta, nullptr, 0,
+                        B, C, N, relu, s);
+}
+
+// with amax_out f32 (nullable): amax_out[b * amax_batch_stride + c] = max |gx| of row (b, c); stride 0 = C
+extern "C" int ct_adain_bwd_amax(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
+                                 const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
+                                 long long gx_batch_stride, float* g_gamma_beta, float* amax_out, long long amax_batch_stride,
+                                 int B, int C, int N, int relu, ct_stream_t s) {
+  if (amax_batch_stride != 0 && amax_batch_stride < C) return CT_EINVAL;
+  return adain_bwd_impl(x, x_batch_stride, gamma_beta, mean, rstd, gy, gy_batch_stride, gx, gx_batch_stride, g_gamma_beta, amax_out,
+                        amax_batch_stride, B, C, N, relu, s);
 }

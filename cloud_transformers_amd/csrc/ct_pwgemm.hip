@@ -39,7 +39,7 @@ struct PwArgs {
   int M, N, K;                     // output rows / columns, summed extent per cloud
   int tilesM, tilesN, ksplit, Kc;  // z = cloud * ksplit + chunk; the chunk sums k in [chunk*Kc, min(K, (chunk+1)*Kc))
   const float* amax_a; const float* amax_b;
-  int n_amax_a, n_amax_b;          // partial maxima per operand (<= 2 * kPwThreads)
+  int n_amax_a, n_amax_b;          // partial maxima per operand (<= kPwAmaxMax)
 #ifdef PW_STAMP
   unsigned long long* dbg;   // development builds: per-phase cycle sums of every wave (tools/dev/pw_stamp.py)
 #endif
@@ -218,17 +218,14 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   float* C = a.C + z * a.c_zs;
   const int m0 = mt * kPwTile, n0 = nt * kPwTile;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 2, wn = w & 3, r = lane & 31, h = lane >> 5;
-  // the operands' max |.|: up to two partial maxima per thread (ct_amax_f32's kPwAmaxLen, or a producer's per-channel maxima),
+  // the operands' max |.|: the partial maxima (ct_amax_f32's kPwAmaxLen, or a producer's per-channel / per-row maxima) strided
+  // over the threads,
   // folded through the (still unused) LDS
   unsigned ma = 0u, mb = 0u;
-  if (a.amax_a) {
-    if (t < a.n_amax_a) ma = __float_as_uint(a.amax_a[t]) & 0x7fffffffu;
-    if (t + kPwThreads < a.n_amax_a) ma = max(ma, __float_as_uint(a.amax_a[t + kPwThreads]) & 0x7fffffffu);
-  }
-  if (a.amax_b) {
-    if (t < a.n_amax_b) mb = __float_as_uint(a.amax_b[t]) & 0x7fffffffu;
-    if (t + kPwThreads < a.n_amax_b) mb = max(mb, __float_as_uint(a.amax_b[t + kPwThreads]) & 0x7fffffffu);
-  }
+  if (a.amax_a)
+    for (int i = t; i < a.n_amax_a; i += kPwThreads) ma = max(ma, __float_as_uint(a.amax_a[i]) & 0x7fffffffu);
+  if (a.amax_b)
+    for (int i = t; i < a.n_amax_b; i += kPwThreads) mb = max(mb, __float_as_uint(a.amax_b[i]) & 0x7fffffffu);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     ma = max(ma, (unsigned)__shfl_xor((int)ma, o, 64));
@@ -472,6 +469,7 @@ __global__ void __launch_bounds__(256) pw_transpose_kernel(const float* __restri
 #endif
 constexpr int kPwZTarget = CT_PW_ZTARGET;
 constexpr int kPwAmaxLen = 512;       // = kPwThreads: one partial maximum per GEMM thread
+constexpr int kPwAmaxMax = 4096;      // what a producer may leave instead (per channel, per (cloud, channel))
 
 struct PwPlan {
   int M, N, K, Z, ksplit, Kc, tilesM, tilesN;
@@ -546,7 +544,7 @@ int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float
                int n_amax_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s) {
   PwPlan p;
   if (!a || !b || !out || !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
-  if ((amax_a && (n_amax_a < 1 || n_amax_a > 2 * kPwThreads)) || (amax_b && (n_amax_b < 1 || n_amax_b > 2 * kPwThreads))) return CT_EINVAL;
+  if ((amax_a && (n_amax_a < 1 || n_amax_a > kPwAmaxMax)) || (amax_b && (n_amax_b < 1 || n_amax_b > kPwAmaxMax))) return CT_EINVAL;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CT_EINVAL;
   if (p.ws && (!workspace || workspace_bytes < p.ws || ((uintptr_t)workspace & 15))) return CT_EWORKSPACE;
   CT_CLEAR_ERROR();

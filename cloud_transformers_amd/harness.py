@@ -193,6 +193,9 @@ class Trainer:
                 params["config_path"] = cfg["config_path"]
             self.writer, self.exp_dir, _ = create_experiment(exp_name, params_dict=params)
         model = get_model(model_file, model_cfg, exp_dir=self.exp_dir).to(self.device)
+        if self.device.type == "cuda":
+            from .layers.pointwise import convert_pointwise
+            convert_pointwise(model)      # the model file's plain nn.Conv1d(k=1) stems / heads onto the blocks' GEMM kernels
         if "restore" in cfg and "generator" in cfg["restore"]:
             restore_exp_fix([model], [cfg["restore"]["generator"]], device=self.device, verbose=self.rank == 0)
         if parallel._active(dist):

@@ -50,3 +50,16 @@ class PointwiseConv1d(nn.Conv1d):
         if self._eligible(x):
             return _PointwiseConvFn.apply(x, self.weight, self.bias)
         return super().forward(x)
+
+
+def convert_pointwise(module):
+    """Turn every plain `nn.Conv1d` of `module` that is a pointwise convolution (kernel size 1, stride 1, no padding /
+    dilation / groups) into a `PointwiseConv1d`, in place — the stems and heads the reference's model files build with
+    `nn.Conv1d(C, C', 1)` (model_zoo/s3dis/segmenter.py, model_zoo/completion/inpainter.py) then take the same kernels as the
+    blocks' own projections.  The class has no state of its own: parameters, buffers, hooks and state-dict keys stay as they
+    are (the counterpart of `SyncBatchNorm.convert_sync_batchnorm` for this layer).  Returns `module`."""
+    for m in module.modules():
+        if type(m) is nn.Conv1d and m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.dilation == (1,) \
+                and m.groups == 1 and m.padding_mode == "zeros":
+            m.__class__ = PointwiseConv1d
+    return module

@@ -113,12 +113,12 @@ def amax(t):
     return out
 
 
-PW_AMAX_MAX = 1024      # partial maxima ct_pw_gemm folds per operand
+PW_AMAX_MAX = 4096      # partial maxima ct_pw_gemm folds per operand
 
 
 def _amax_slots(C, device):
-    """Per-channel maxima buffer for a producer kernel (ct_bn_relu_fwd_amax / _bwd_amax), or None when the consumer could not
-    use it (library GEMMs selected, or more channels than ct_pw_gemm folds)."""
+    """Maxima buffer for a producer kernel (ct_bn_relu_*_amax: one slot per channel; ct_adain_*_amax: one per (cloud, channel)),
+    or None when the consumer could not use it (library GEMMs selected, or more slots than ct_pw_gemm folds)."""
     if PW_GEMM != "split16" or C > PW_AMAX_MAX:
         return None
     return torch.empty(C, device=device, dtype=torch.float32)
@@ -526,9 +526,11 @@ class AdaInFn(torch.autograd.Function):
         mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib = _lib.load()
+        slots = _amax_slots(B * C, x.device)
         with _on(x.device):
-            _lib.check(lib.ct_adain_fwd(_ptr(x), xbs, _ptr(gamma_beta), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd),
-                                        B, C, N, float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
+            _lib.check(lib.ct_adain_fwd_amax(_ptr(x), xbs, _ptr(gamma_beta), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd),
+                                             _ptr(slots), 0, B, C, N, float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
+        tag_amax(y, slots)
         ctx.save_for_backward(x, gamma_beta, mean, rstd)
         ctx.relu = int(bool(relu))
         ctx.xbs = xbs
@@ -545,9 +547,11 @@ class AdaInFn(torch.autograd.Function):
         gx = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
         g_gb = torch.empty_like(gamma_beta)
         lib = _lib.load()
+        slots = _amax_slots(B * C, x.device)
         with _on(x.device):
-            _lib.check(lib.ct_adain_bwd(_ptr(x), ctx.xbs, _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), gybs, _ptr(gx), 0,
-                                        _ptr(g_gb), B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
+            _lib.check(lib.ct_adain_bwd_amax(_ptr(x), ctx.xbs, _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), gybs, _ptr(gx), 0,
+                                             _ptr(g_gb), _ptr(slots), 0, B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
+        tag_amax(gx, slots)
         return gx, g_gb, None, None, (gy if ctx.has_residual else None)
 
 
@@ -604,6 +608,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         g_y = torch.empty_like(y)
         lib = _lib.load()
         g_gbs = []
+        slots = _amax_slots(B * Ct, x.device)           # [B][Ct]: every norm writes its channel range of every cloud
         with _on(x.device):
             for i, (c0, C) in enumerate(ctx.meta):
                 gb, mean, rstd = saved[i * 3:(i + 1) * 3]
@@ -614,10 +619,12 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
                 if gybs is None:
                     gy, gybs = _f32c(gy), 0
                 g_gb = torch.empty_like(gb)
-                _lib.check(lib.ct_adain_bwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
-                                            _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_gb), B, C, N, 0, _stream()), "ct_adain_bwd")
+                _lib.check(lib.ct_adain_bwd_amax(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
+                                                 _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_gb),
+                                                 None if slots is None else _ptr(slots) + 4 * c0, Ct, B, C, N, 0, _stream()),
+                           "ct_adain_bwd")
                 g_gbs.append(g_gb)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True)
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True, am_g=slots)
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
@@ -638,16 +645,19 @@ class JoinAdaInReluFn(torch.autograd.Function):
         Ct = sum(x.size(1) for x in xs)
         y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
         lib = _lib.load()
+        slots = _amax_slots(B * Ct, y.device)
         saved, c0 = [], 0
         with _on(y.device):
             for x, gb in zip(xs, gbs):
                 C = x.size(1)
                 mean = torch.empty(B * C, device=y.device, dtype=torch.float32)
                 rstd = torch.empty_like(mean)
-                _lib.check(lib.ct_adain_fwd(_ptr(x), 0, _ptr(gb), None, 0, _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd),
-                                            B, C, N, float(eps), 1, _stream()), "ct_adain_fwd")
+                _lib.check(lib.ct_adain_fwd_amax(_ptr(x), 0, _ptr(gb), None, 0, _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd),
+                                                 None if slots is None else _ptr(slots) + 4 * c0, Ct, B, C, N, float(eps), 1,
+                                                 _stream()), "ct_adain_fwd")
                 saved += [x, gb, mean, rstd]
                 c0 += C
+        tag_amax(y, slots)
         ctx.save_for_backward(*saved)
         ctx.n = n
         return y
@@ -666,9 +676,10 @@ class JoinAdaInReluFn(torch.autograd.Function):
                 x, gb, mean, rstd = saved[i * 4:(i + 1) * 4]
                 C = x.size(1)
                 gx, g_gb = torch.empty_like(x), torch.empty_like(gb)
-                _lib.check(lib.ct_adain_bwd(_ptr(x), 0, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs, _ptr(gx), 0,
-                                            _ptr(g_gb), B, C, N, 1, _stream()), "ct_adain_bwd")
-                grads += [gx, g_gb]
+                slots = _amax_slots(B * C, gx.device)
+                _lib.check(lib.ct_adain_bwd_amax(_ptr(x), 0, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs, _ptr(gx), 0,
+                                                 _ptr(g_gb), _ptr(slots), 0, B, C, N, 1, _stream()), "ct_adain_bwd")
+                grads += [tag_amax(gx, slots), g_gb]
                 c0 += C
         return tuple(grads)
 

@@ -270,6 +270,15 @@ int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_be
 int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean, const float* rstd,
                  const float* gy, long long gy_batch_stride, float* gx, long long gx_batch_stride, float* g_gamma_beta,
                  int B, int C, int N, int relu, ct_stream_t s);
+/* The same two with amax_out (nullable): amax_out[b * amax_batch_stride + c] = max |y| / max |g_x| of row (b, c), a by-product of
+ * the pass (amax_batch_stride 0 = C) — operand maxima for ct_pw_gemm, as ct_bn_relu_fwd_amax. */
+int ct_adain_fwd_amax(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                      long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                      float* amax_out, long long amax_batch_stride, int B, int C, int N, float eps, int relu, ct_stream_t s);
+int ct_adain_bwd_amax(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
+                      const float* rstd, const float* gy, long long gy_batch_stride, float* gx, long long gx_batch_stride,
+                      float* g_gamma_beta, float* amax_out, long long amax_batch_stride, int B, int C, int N, int relu,
+                      ct_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Grouped 3^dim convolution over the rasterised planes / volumes, stride 1, padding 1
@@ -392,7 +401,7 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
  * amax_a / amax_b: device f32[n_amax_*] whose maximum is (an upper bound within ~2^10 of) max |.| of the
  * whole operand tensor; the GEMM folds them when it starts.  Either ct_amax_f32's ct_amax_len()
  * partial maxima, or what the kernel that produced the operand left behind (ct_bn_relu_fwd_amax /
- * _bwd_amax: one per channel); n_amax_* <= 1024.  NULL = scale 1 (the caller then guarantees
+ * _bwd_amax: one per channel; ct_adain_*_amax: one per (cloud, channel)); n_amax_* <= 4096.  NULL = scale 1 (the caller then guarantees
  * |values| < 65504).  Co, Ci, N multiples of 4,
  * 16-byte aligned pointers -> CT_EINVAL otherwise.  Workspace: ct_pw_gemm_workspace_bytes.
  * ---------------------------------------------------------------------- */

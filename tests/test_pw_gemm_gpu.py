@@ -195,3 +195,20 @@ def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
     want = run()
     for a, b in zip(got, want):
         assert torch.equal(a, b)                        # the same power-of-two scales either way
+
+
+def test_adain_kernels_leave_the_row_maxima_of_what_they_write():
+    from cloud_transformers_amd import ops
+    torch.manual_seed(3)
+    for (B, C, N, relu, res) in [(2, 96, 4096, True, True), (3, 40, 260, False, False)]:
+        x = (torch.randn(B, C, N, device="cuda") * 2).requires_grad_(True)
+        gb = torch.randn(B, 2, C, device="cuda") * 0.5
+        skip = torch.randn(B, C, N, device="cuda") if res else None
+        y = ops.adain(x, gb, relu=relu, residual=skip)
+        slots, _ = y._ct_amax
+        assert torch.equal(slots.view(B, C), y.detach().abs().amax(dim=2))
+        seen = []
+        x.register_hook(lambda g: seen.append(g))
+        y.backward(torch.randn_like(y) * 1e-2)
+        gslots, _ = seen[0]._ct_amax
+        assert torch.equal(gslots.view(B, C), seen[0].abs().amax(dim=2))

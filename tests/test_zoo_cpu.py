@@ -150,3 +150,20 @@ def test_reference_written_checkpoint_loads_strictly(rel, tmp_path):
                        text=True, timeout=300, env=env, cwd="/tmp")
     assert b.returncode == 0, b.stderr[-3000:]
     assert "DIFFERING 0 " in b.stdout and "LOADED" in b.stdout, b.stdout[-500:]
+
+
+def test_convert_pointwise_keeps_parameters_and_keys():
+    """layers.pointwise.convert_pointwise: plain nn.Conv1d(k=1) layers of a model file become PointwiseConv1d in place — same
+    parameter objects, same state-dict keys, other convolutions untouched; on CPU tensors the layer still runs torch's conv."""
+    import torch
+    from torch import nn
+    from cloud_transformers_amd.layers.pointwise import PointwiseConv1d, convert_pointwise
+    m = nn.Sequential(nn.Conv1d(6, 8, 1), nn.Conv1d(8, 8, 3, padding=1), nn.Conv1d(8, 4, 1, bias=False), nn.Conv1d(4, 4, 1, groups=2))
+    params = [p for p in m.parameters()]
+    keys = list(m.state_dict().keys())
+    x = torch.randn(2, 6, 10)
+    want = m(x)
+    assert convert_pointwise(m) is m
+    assert [type(l) for l in m] == [PointwiseConv1d, nn.Conv1d, PointwiseConv1d, nn.Conv1d]
+    assert all(a is b for a, b in zip(params, m.parameters())) and list(m.state_dict().keys()) == keys
+    assert torch.equal(m(x), want)

@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cloud_transformers_amd.layers.pointwise import convert_pointwise          # noqa: E402
 from tests.test_zoo_gpu import Classifier          # noqa: E402
 
 
@@ -28,7 +29,7 @@ def timeit(fn, iters):
 def main():
     B, N = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 2048
     torch.manual_seed(0)
-    net = Classifier().cuda().train()
+    net = convert_pointwise(Classifier().cuda()).train()
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
     cloud = torch.rand(B, 3, 1, N, device="cuda") * 2 - 1
     labels = torch.randint(15, (B,), device="cuda")

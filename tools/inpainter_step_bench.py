@@ -11,6 +11,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cloud_transformers_amd.layers.pointwise import convert_pointwise          # noqa: E402
 from cloud_transformers_amd.chamfer import loss_chamfer                    # noqa: E402
 from cloud_transformers_amd.emd import emdModule                           # noqa: E402
 from cloud_transformers_amd.metrics import sphere_noise                    # noqa: E402
@@ -31,7 +32,7 @@ def timeit(fn, iters):
 def main():
     B, n_part, n_out = 2, 2048, 16384
     torch.manual_seed(0)
-    net = Inpainter().cuda().train()
+    net = convert_pointwise(Inpainter().cuda()).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     emd = emdModule()
     gen = torch.Generator(device="cuda").manual_seed(1)

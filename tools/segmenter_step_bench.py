@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cloud_transformers_amd.layers.pointwise import convert_pointwise
 from cloud_transformers_amd.layers.multihead_ct import MultiHeadUnion
 
 ZOO = [([4, 4], [128, 32]), ([16, 16], [64, 16]), ([16, 32], [16, 8])]
@@ -56,7 +57,7 @@ def main_ddp(world, rank, local_rank, N):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.manual_seed(0)                               # same initial weights on every rank
-    net = Segmenter().cuda()
+    net = convert_pointwise(Segmenter().cuda())
     ddp = data_parallel(net, local_rank, broadcast_buffers=os.environ.get("CT_DDP_BCAST", "0") == "1")
     opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
     torch.manual_seed(1234 + rank)                     # its own shard of the batch
@@ -97,7 +98,7 @@ def main():
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         return main_ddp(int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), N)
     torch.manual_seed(0)
-    net = Segmenter().cuda()
+    net = convert_pointwise(Segmenter().cuda())
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
     cloud = torch.cat([torch.rand(B, 3, N, device="cuda") * 2 - 1, torch.rand(B, 3, N, device="cuda")], dim=1)
     labels = torch.randint(13, (B, N), device="cuda")
