@@ -9,16 +9,19 @@
 // the epilogue: relative error per product <= ~2^-21, the order of an fp32 GEMM's own summation error at these K, at 3/16 of
 // the matrix-pipe time of the f32-input MFMA the library GEMMs use (cdna_hip_programming.md §3 "FP32-input MFMA").
 //
-// One kernel, three operand arrangements (CT_PW_FWD / DGRAD / WGRAD): a 128x128 output tile per 256-thread workgroup (four
-// waves, 64x64 each = 2x2 MFMA tiles, 64 accumulator registers), K in steps of 32 through two LDS stages of four
-// [128 rows][32 k] f16 images (A_h, A_l, B_h, B_l: 64 KiB, two workgroups per CU).  The fp32 tiles are loaded into registers
-// one K-step ahead, split and written to the other stage after the MFMAs of the current one: one barrier per K-step.  An
-// operand is staged from either orientation — k contiguous (W in forward, both operands of the weight gradient) or the
-// tile's row index contiguous (x / g_y [Ci,N] slices, W^T in the data gradient: eight k-rows per thread, packed pairwise
-// so that the transposition costs nothing) — into the same image; 16-byte k-groups are XOR-swizzled with the row so that
-// ds_read_b128 fragment reads are conflict-free without padding (MI355X_MICROARCH.md §LDS lane groups).
-// The weight gradient sums over clouds and points: K = B*N is cut into chunks, each chunk's partial [Co,Ci] tile goes to a
-// slab and a second kernel adds the slabs in a fixed order (deterministic).
+// One kernel, two operand arrangements (forward and data gradient: A k-contiguous, B row-contiguous; weight gradient: both
+// k-contiguous): a 128x128 output tile per 512-thread workgroup (eight waves as 2 x 4, 64x32 each = two 32x32 MFMA tiles, 32
+// accumulator registers; <= 128 VGPRs: two workgroups = four waves per SIMD on a CU), K in steps of 32 through two LDS stages
+// of four [128 rows][32 k] f16 images (A_h, A_l, B_h, B_l: 64 KiB per workgroup), one barrier per K-step.  The fp32 tiles are
+// fetched into registers two K-steps ahead (two register sets) and split into the other stage BETWEEN the MFMAs of the
+// current step.  An operand is staged from either orientation with 16-byte loads (see pw_load): k-contiguous rows into an
+// image [row][k] whose 16-byte k-groups are XOR-swizzled with the row (one conflict-free ds_read_b128 per fragment,
+// MI355X_MICROARCH.md §LDS lane groups); row-contiguous k rows into an image [k pair][row] of dwords (the transposition is
+// the split's own pairing of two k rows; one ds_write_b128 per thread, four conflict-free dword reads per fragment).
+// The data gradient runs the forward arrangement on a W^T copy.  The weight gradient sums over clouds and points: K = B*N is
+// cut into chunks, each chunk's partial [Co,Ci] tile goes to a slab and a second kernel adds the slabs in a fixed order
+// (deterministic).  The per-tensor maxima arrive as partial maxima (ct_amax_f32's per-block ones, or what the kernel that
+// wrote the operand left per channel) and are folded when the kernel starts.  DESIGN.md §4.9 has the measurements.
 #include "ct_common.h"
 #include <type_traits>
 
