@@ -17,6 +17,8 @@ HBM, there are no host synchronisations (the reference's four `.all()` asserts
 per block, cloud_transform.py:101-111), and the occupancy statistic is one small
 device reduction.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -265,6 +267,49 @@ class MultiHeadAdaIn(_MHCTCore):
         return result, stats
 
 
+HEAD_STREAMS = os.environ.get("CLOUDCT_HEAD_STREAMS", "0") == "1"
+_side_streams = {}
+
+
+def _run_heads(calls, ref):
+    """[f() for f in calls] — the per-head chains of a union block (lattice, Splat, grouped conv, Slice of each head: independent
+    until the concatenation).  With CLOUDCT_HEAD_STREAMS=1 and a HIP tensor `ref`, head i > 0 runs on its own side stream, forked
+    from the current stream and joined before the results are used: the heads' kernels are many and small (a 3D head's raster
+    kernels launch 128 workgroups on 256 CUs), so two chains side by side fill the chip and hide each other's launch gaps.
+    Autograd replays every op's backward on the stream of its forward, so the backward chains overlap the same way; a HIP-graph
+    capture records the fork and join as graph dependencies."""
+    if not (HEAD_STREAMS and len(calls) > 1 and ref.is_cuda):
+        return [f() for f in calls]
+    cur = torch.cuda.current_stream(ref.device)
+    key = (ref.device.index, len(calls))
+    sides = _side_streams.get(key)
+    if sides is None:
+        sides = _side_streams[key] = [torch.cuda.Stream(device=ref.device) for _ in range(len(calls) - 1)]
+    outs = [None] * len(calls)
+    for i, side in enumerate(sides, start=1):
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            outs[i] = calls[i]()
+    outs[0] = calls[0]()
+    for i, side in enumerate(sides, start=1):
+        cur.wait_stream(side)
+        _record(outs[i], cur)
+    return outs
+
+
+def _record(obj, stream):
+    """Tell the caching allocator that tensors made on a side stream are used on `stream` from here on."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            _record(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record(o, stream)
+
+
 class _UnionBase(nn.Module):
     """K MHCT blocks on the same input, concatenated on channels, projected back to
     the model width and added to a (possibly projected) residual."""
@@ -312,8 +357,8 @@ class MultiHeadUnion(_UnionBase):
         convs = [a.keys_values_pred[0] for a in self.attentions]
         kbs, vbs = [a.key_bn for a in self.attentions], [a.values_bn for a in self.attentions]
         kvs = ops.union_keys_values(x, convs, kbs, vbs) if ops.union_keys_values_eligible(x, convs, kbs, vbs) else None
-        for i, attention in enumerate(self.attentions):
-            r, s, _ = attention._forward_pre(x, orig_pcd, None if kvs is None else kvs[i])
+        for r, s, _ in _run_heads([(lambda a=a, i=i: a._forward_pre(x, orig_pcd, None if kvs is None else kvs[i]))
+                                   for i, a in enumerate(self.attentions)], x):
             pres.append(r)
             stats.append(s)
         # the heads' BatchNorm + ReLU write straight into their channel ranges of the concatenation when they qualify
@@ -350,8 +395,8 @@ class MultiHeadUnionAdaIn(_UnionBase):
         residual = forward_style(self.shortcut, x, style)
         pres, stats = [], []
         kvs = self._fused_keys_values(x, style)
-        for i, attention in enumerate(self.attentions):
-            r, s, _ = attention._forward_pre(x, style, orig_pcd, None if kvs is None else kvs[i])
+        for r, s, _ in _run_heads([(lambda a=a, i=i: a._forward_pre(x, style, orig_pcd, None if kvs is None else kvs[i]))
+                                   for i, a in enumerate(self.attentions)], x):
             pres.append(r)
             stats.append(s)
         afters = [a.after for a in self.attentions]

@@ -221,3 +221,66 @@ def test_union_fusions_equal_the_per_head_path(kind):
     for n in plain[2]:
         a, b = fused[2][n], plain[2][n]
         assert float((a - b).abs().max()) <= 2e-3 * max(1.0, float(b.abs().max())), (n, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["bn", "adain"])
+def test_heads_on_side_streams_equal_the_serial_block(kind, monkeypatch):
+    """CLOUDCT_HEAD_STREAMS=1 (layers.multihead_ct._run_heads): the heads' chains on forked streams — eager, and replayed from a
+    HIP graph that captured the fork / join — give the serial block's output and gradients (same kernels, same order per head)."""
+    from cloud_transformers_amd.layers import multihead_ct as M
+    torch.manual_seed(21)
+    B, D, N = 2, 32, 1024
+    if kind == "bn":
+        blk = M.MultiHeadUnion(D, [4, 4], [16, 8], [2, 3], [4, 2]).cuda().train()
+    else:
+        blk = M.MultiHeadUnionAdaIn(D, [4, 4], [16, 8], [2, 3], [4, 2], n_latent=24).cuda().train()
+    x0 = torch.randn(B, D, N, device="cuda")
+    pcd = torch.rand(B, 3, N, device="cuda") * 2 - 1
+    style = torch.randn(B, 24, device="cuda")
+    cot = torch.randn(B, D, N, device="cuda")
+    state = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def run(x):
+        out, _ = blk(x, pcd) if kind == "bn" else blk(x, style, pcd)
+        (out * cot).sum().backward()
+        return out
+
+    def fresh():
+        blk.load_state_dict(state)                     # running statistics back to the start
+        blk.zero_grad(set_to_none=True)
+        return x0.clone().requires_grad_(True)
+
+    x = fresh()
+    want = (run(x).detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None})
+    monkeypatch.setattr(M, "HEAD_STREAMS", True)
+    x = fresh()
+    got = (run(x).detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None})
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0])
+    # float-atomic sums in the raster backward differ in the last bits between runs, with or without streams
+    np.testing.assert_allclose(got[1].cpu().numpy(), want[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for n in want[2]:
+        np.testing.assert_allclose(got[2][n].cpu().numpy(), want[2][n].cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=n)
+
+    # the same through a captured graph
+    xs = x0.clone().requires_grad_(True)
+    blk.load_state_dict(state)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            blk.zero_grad(set_to_none=True)
+            xs.grad = None
+            run(xs)
+    torch.cuda.current_stream().wait_stream(side)
+    blk.load_state_dict(state)
+    blk.zero_grad(set_to_none=True)
+    xs.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_s = run(xs)
+    blk.load_state_dict(state)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_s.detach(), want[0])
+    np.testing.assert_allclose(xs.grad.cpu().numpy(), want[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
