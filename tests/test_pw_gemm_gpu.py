@@ -212,3 +212,24 @@ def test_adain_kernels_leave_the_row_maxima_of_what_they_write():
         y.backward(torch.randn_like(y) * 1e-2)
         gslots, _ = seen[0]._ct_amax
         assert torch.equal(gslots.view(B, C), seen[0].abs().amax(dim=2))
+
+
+def test_random_shapes_all_arrangements():
+    """Forty random (B, Co, Ci, N), every dimension a multiple of 4 up to a few tiles / K-steps / chunks, all three arrangements,
+    operands with their own magnitudes: the elementwise bound against the float64 product."""
+    import random
+    rnd = random.Random(1234)
+    for case in range(40):
+        B = rnd.choice([1, 1, 2, 3, 5, 8])
+        Co = 4 * rnd.randint(1, 90)
+        Ci = 4 * rnd.randint(1, 90)
+        N = 4 * rnd.randint(1, 700)
+        g = torch.Generator(device="cuda").manual_seed(case)
+        W = torch.randn(Co, Ci, device="cuda", generator=g) * 10.0 ** rnd.uniform(-3, 2)
+        x = torch.randn(B, Ci, N, device="cuda", generator=g) * 10.0 ** rnd.uniform(-3, 3)
+        gy = torch.randn(B, Co, N, device="cuda", generator=g) * 10.0 ** rnd.uniform(-6, 1)
+        for mode in (0, 1, 2):
+            out = _run(mode, W, x, gy)
+            ref, mag = _ref(mode, W, x, gy)
+            err = (out.double() - ref).abs()
+            assert bool((err <= BOUND * mag + 1e-30).all()), (case, mode, (B, Co, Ci, N), float((err / (mag + 1e-30)).max()))
