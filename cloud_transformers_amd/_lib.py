@@ -196,6 +196,9 @@ SIGNATURES = {
                              _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_reduce_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_bn_apply_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "ct_bn_apply_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp,
+                                  _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "ct_bn_apply_bwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp]),
     "ct_gconv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_gconv_supported": (_i, [_i, _i, _i, _i, _i, _ip]),

@@ -575,7 +575,7 @@ extern "C" int ct_bn_stats_fwd(const float* x, long long x_batch_stride, float* 
   return bn_fwd_launch(a, const_cast<float*>(x), x_batch_stride, x_batch_stride, 0, (hipStream_t)s);
 }
 
-extern "C" int ct_bn_apply_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+static int bn_apply_fwd_impl(float* amax_out, const float* x, long long x_batch_stride, const float* weight, const float* bias,
                                const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
                                float* running_mean, float* running_var, long long* num_batches_tracked,
                                const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
@@ -586,8 +586,31 @@ extern "C" int ct_bn_apply_fwd(const float* x, long long x_batch_stride, const f
     return CT_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CT_EINVAL;
   BnArgs a{x, weight, bias, running_mean, running_var, save_mean, save_rstd, B, C, N, eps, momentum, relu, 0, 0,
-           residual, 0, num_batches_tracked, 2, count_total, g_mean, g_m2, g_count, world, g_stride};
+           residual, 0, num_batches_tracked, 2, count_total, g_mean, g_m2, g_count, world, g_stride, amax_out};
   return bn_fwd_launch(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_apply_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                               const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
+                               float* running_mean, float* running_var, long long* num_batches_tracked,
+                               const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                               float* save_mean, float* save_rstd, float* count_total, int B, int C, int N, float eps,
+                               float momentum, int relu, ct_stream_t s) {
+  return bn_apply_fwd_impl(nullptr, x, x_batch_stride, weight, bias, g_mean, g_m2, g_count, world, g_stride, running_mean, running_var,
+                           num_batches_tracked, residual, residual_batch_stride, y, y_batch_stride, save_mean, save_rstd, count_total,
+                           B, C, N, eps, momentum, relu, s);
+}
+
+// with amax_out f32[C] (nullable), as ct_bn_relu_fwd_amax
+extern "C" int ct_bn_apply_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                                    const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,
+                                    float* save_mean, float* save_rstd, float* count_total, float* amax_out, int B, int C, int N,
+                                    float eps, float momentum, int relu, ct_stream_t s) {
+  return bn_apply_fwd_impl(amax_out, x, x_batch_stride, weight, bias, g_mean, g_m2, g_count, world, g_stride, running_mean,
+                           running_var, num_batches_tracked, residual, residual_batch_stride, y, y_batch_stride, save_mean,
+                           save_rstd, count_total, B, C, N, eps, momentum, relu, s);
 }
 
 extern "C" int ct_bn_reduce_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
@@ -599,11 +622,28 @@ extern "C" int ct_bn_reduce_bwd(const float* x, long long x_batch_stride, const 
   return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, x_batch_stride, (hipStream_t)s);
 }
 
-extern "C" int ct_bn_apply_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+static int bn_apply_bwd_impl(float* amax_out, const float* x, long long x_batch_stride, const float* weight, const float* bias,
                                const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
                                const float* sum_g, const float* sum_gxhat, const float* count, float* gx,
                                long long gx_batch_stride, int B, int C, int N, int relu, ct_stream_t s) {
   if (!x || !weight || !bias || !mean || !rstd || !gy || !gx || !sum_g || !sum_gxhat || !count) return CT_EINVAL;
-  BnBwdArgs a{x, weight, bias, mean, rstd, gy, gx, nullptr, nullptr, B, C, N, relu, 0, 0, 0, 2, sum_g, sum_gxhat, count};
+  BnBwdArgs a{x, weight, bias, mean, rstd, gy, gx, nullptr, nullptr, B, C, N, relu, 0, 0, 0, 2, sum_g, sum_gxhat, count, amax_out};
   return bn_bwd_launch(a, x_batch_stride, gy_batch_stride, gx_batch_stride, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_apply_bwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                               const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                               const float* sum_g, const float* sum_gxhat, const float* count, float* gx,
+                               long long gx_batch_stride, int B, int C, int N, int relu, ct_stream_t s) {
+  return bn_apply_bwd_impl(nullptr, x, x_batch_stride, weight, bias, mean, rstd, gy, gy_batch_stride, sum_g, sum_gxhat, count, gx,
+                           gx_batch_stride, B, C, N, relu, s);
+}
+
+// with amax_out f32[C] (nullable), as ct_bn_relu_bwd_amax
+extern "C" int ct_bn_apply_bwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                                    const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                                    const float* sum_g, const float* sum_gxhat, const float* count, float* gx,
+                                    long long gx_batch_stride, float* amax_out, int B, int C, int N, int relu, ct_stream_t s) {
+  return bn_apply_bwd_impl(amax_out, x, x_batch_stride, weight, bias, mean, rstd, gy, gy_batch_stride, sum_g, sum_gxhat, count, gx,
+                           gx_batch_stride, B, C, N, relu, s);
 }

@@ -719,8 +719,7 @@ def norms_share_group(bns):
 
 def _bn_group_fwd(items, B, N, device, group):
     """Run the norms of one group.  items: dicts with x (data_ptr), xbs, C, w, b, rm, rv, nbt, eps, mom, relu, res (ptr or
-    None), rbs, y (ptr), ybs and, optionally, amax (ptr to C floats: the per-channel max |y|, written without a group only —
-    callers check `group is None` before they tag a tensor with it).  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
+    None), rbs, y (ptr), ybs and, optionally, amax (ptr to C floats: the per-channel max |y| as written).  Returns ([(mean, rstd)] per item, count) — count is None without a group, else a 1-float
     device tensor with the job's values per channel.  With a group: local statistics of ALL items into one buffer, ONE
     all_gather, then the normalising kernels merge the ranks' statistics themselves (csrc/ct_bnorm.hip mode 1 / 2)."""
     global _sync_stats_collectives
@@ -759,11 +758,11 @@ def _bn_group_fwd(items, B, N, device, group):
     gb, c0 = gathered.data_ptr(), 0
     for i, it in enumerate(items):
         mean, rstd = outs[i]
-        _lib.check(lib.ct_bn_apply_fwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), gb + 4 * c0, gb + 4 * (Ct + c0),
-                                       gb + 4 * (stride - 1), world, stride, _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"]),
-                                       it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
-                                       _ptr(count) if i == 0 else None, B, it["C"], N, float(it["eps"]), float(it["mom"]),
-                                       int(it["relu"]), _stream()), "ct_bn_apply_fwd")
+        _lib.check(lib.ct_bn_apply_fwd_amax(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), gb + 4 * c0, gb + 4 * (Ct + c0),
+                                            gb + 4 * (stride - 1), world, stride, _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"]),
+                                            it["res"], it["rbs"], it["y"], it["ybs"], _ptr(mean), _ptr(rstd),
+                                            _ptr(count) if i == 0 else None, it.get("amax"), B, it["C"], N, float(it["eps"]),
+                                            float(it["mom"]), int(it["relu"]), _stream()), "ct_bn_apply_fwd")
         stats.append((mean, rstd))
         c0 += it["C"]
     # (`gathered` is read by the kernels just enqueued: torch's caching allocator keeps it alive on this stream)
@@ -801,9 +800,9 @@ def _bn_group_bwd(items, B, N, device, group, count):
     work.wait()
     c0 = 0
     for it in items:
-        _lib.check(lib.ct_bn_apply_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
-                                       it["gy"], it["gybs"], sb + 4 * c0, sb + 4 * (Ct + c0), _ptr(count), it["gx"], it["gxbs"],
-                                       B, it["C"], N, int(it["relu"]), _stream()), "ct_bn_apply_bwd")
+        _lib.check(lib.ct_bn_apply_bwd_amax(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),
+                                            it["gy"], it["gybs"], sb + 4 * c0, sb + 4 * (Ct + c0), _ptr(count), it["gx"], it["gxbs"],
+                                            it.get("amax"), B, it["C"], N, int(it["relu"]), _stream()), "ct_bn_apply_bwd")
         out.append((local[Ct + c0:Ct + c0 + it["C"]], local[c0:c0 + it["C"]]))
         c0 += it["C"]
     return out
@@ -826,7 +825,7 @@ class BnReluFn(torch.autograd.Function):
             if rbs is None:
                 residual = _f32c(residual)
                 rbs = 0
-        slots = _amax_slots(C, x.device) if group is None else None
+        slots = _amax_slots(C, x.device)
         with _on(x.device):
             stats, count = _bn_group_fwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, rm=running_mean, rv=running_var, nbt=nbt,
                                                eps=eps, mom=momentum, relu=relu, res=_ptr(residual), rbs=rbs, y=_ptr(y), ybs=0,
@@ -849,7 +848,7 @@ class BnReluFn(torch.autograd.Function):
             gy = _f32c(gy)
             gybs = 0
         gx = torch.empty_like(x)
-        slots = _amax_slots(C, x.device) if ctx.group is None else None
+        slots = _amax_slots(C, x.device)
         with _on(x.device):
             ((g_w, g_b),) = _bn_group_bwd([dict(x=_ptr(x), xbs=0, C=C, w=weight, b=bias, mean=mean, rstd=rstd, gy=_ptr(gy),
                                                 gybs=gybs, gx=_ptr(gx), gxbs=0, relu=ctx.relu, amax=_ptr(slots))],
@@ -923,7 +922,7 @@ class JoinBnReluFn(torch.autograd.Function):
         B, _, N = xs[0].shape
         Ct = sum(x.size(1) for x in xs)
         y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
-        slots = _amax_slots(Ct, y.device) if group is None else None
+        slots = _amax_slots(Ct, y.device)
         items, c0 = [], 0
         for x, (_, w, b, rm, rv, nbt, eps, mom) in zip(xs, heads):
             C = x.size(1)
@@ -957,7 +956,7 @@ class JoinBnReluFn(torch.autograd.Function):
             C = x.size(1)
             gx = torch.empty_like(x)
             gxs.append(gx)
-            slots = _amax_slots(C, gx.device) if ctx.group is None else None
+            slots = _amax_slots(C, gx.device)
             items.append(dict(x=_ptr(x), xbs=0, C=C, w=w, b=b, mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs,
                               gx=_ptr(gx), gxbs=0, relu=1, amax=_ptr(slots), slots=slots))
             c0 += C
@@ -1034,7 +1033,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Ct = Wc.size(0)
         g_y = torch.empty_like(y)
-        slots = _amax_slots(Ct, x.device) if ctx.group is None else None
+        slots = _amax_slots(Ct, x.device)
         items = []
         for i, (c0, C) in enumerate(ctx.meta):
             w, b, mean, rstd = saved[i * 4:(i + 1) * 4]

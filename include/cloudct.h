@@ -251,6 +251,17 @@ int ct_bn_apply_bwd(const float* x, long long x_batch_stride, const float* weigh
                     const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
                     const float* sum_g, const float* sum_gxhat, const float* count, float* gx, long long gx_batch_stride,
                     int B, int C, int N, int relu, ct_stream_t s);
+/* ct_bn_apply_fwd / _bwd with amax_out f32[C] (nullable), as ct_bn_relu_fwd_amax / _bwd_amax. */
+int ct_bn_apply_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                         const float* g_mean, const float* g_m2, const float* g_count, int world, long long g_stride,
+                         float* running_mean, float* running_var, long long* num_batches_tracked, const float* residual,
+                         long long residual_batch_stride, float* y, long long y_batch_stride, float* save_mean,
+                         float* save_rstd, float* count_total, float* amax_out, int B, int C, int N, float eps,
+                         float momentum, int relu, ct_stream_t s);
+int ct_bn_apply_bwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
+                         const float* mean, const float* rstd, const float* gy, long long gy_batch_stride,
+                         const float* sum_g, const float* sum_gxhat, const float* count, float* gx,
+                         long long gx_batch_stride, float* amax_out, int B, int C, int N, int relu, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Adaptive instance normalisation of the AdaIN blocks (AdaIn1dUpd: layers/utils.py:82-97 =

@@ -233,3 +233,34 @@ def test_random_shapes_all_arrangements():
             ref, mag = _ref(mode, W, x, gy)
             err = (out.double() - ref).abs()
             assert bool((err <= BOUND * mag + 1e-30).all()), (case, mode, (B, Co, Ci, N), float((err / (mag + 1e-30)).max()))
+
+
+def test_syncbn_apply_kernels_leave_the_channel_maxima():
+    """The split passes of SyncBatchNorm (statistics -> exchange -> apply; here a 'world' of one rank's buffer fed back in) with
+    amax_out: the maxima of what the apply kernels wrote, forward and backward."""
+    from cloud_transformers_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(5)
+    B, C, N = 4, 48, 1024
+    x = torch.randn(B, C, N, device="cuda") * 2
+    w, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    local = torch.empty(2 * C + 1, device="cuda")
+    _lib.check(lib.ct_bn_stats_fwd(x.data_ptr(), 0, local.data_ptr(), local.data_ptr() + 4 * C, local.data_ptr() + 8 * C, B, C, N, st), "stats")
+    y, mean, rstd, count, am = torch.empty_like(x), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(1, device="cuda"), \
+        torch.empty(C, device="cuda")
+    _lib.check(lib.ct_bn_apply_fwd_amax(x.data_ptr(), 0, w.data_ptr(), b.data_ptr(), local.data_ptr(), local.data_ptr() + 4 * C,
+                                        local.data_ptr() + 8 * C, 1, 2 * C + 1, None, None, None, None, 0, y.data_ptr(), 0, mean.data_ptr(),
+                                        rstd.data_ptr(), count.data_ptr(), am.data_ptr(), B, C, N, 1e-5, 0.1, 1, st), "apply_fwd")
+    assert torch.equal(am, y.abs().amax(dim=(0, 2)))
+    want = torch.relu(torch.nn.functional.batch_norm(x, None, None, w, b, True, 0.1, 1e-5))
+    assert float((y - want).abs().max()) < 1e-5
+    gy = torch.randn_like(x)
+    sums = torch.empty(2 * C, device="cuda")
+    _lib.check(lib.ct_bn_reduce_bwd(x.data_ptr(), 0, w.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(), 0,
+                                    sums.data_ptr(), sums.data_ptr() + 4 * C, B, C, N, 1, st), "reduce")
+    gx, gam = torch.empty_like(x), torch.empty(C, device="cuda")
+    _lib.check(lib.ct_bn_apply_bwd_amax(x.data_ptr(), 0, w.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(), 0,
+                                        sums.data_ptr(), sums.data_ptr() + 4 * C, count.data_ptr(), gx.data_ptr(), 0, gam.data_ptr(),
+                                        B, C, N, 1, st), "apply_bwd")
+    assert torch.equal(gam, gx.abs().amax(dim=(0, 2)))
