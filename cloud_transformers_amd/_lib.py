@@ -26,6 +26,26 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # index/weight math must round exactly like the reference's fp32 op sequence
                "-ffp-contract=off"]
 
+class BnFwdItem(ctypes.Structure):
+    """ct_bn_fwd_item (include/cloudct.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_longlong), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("num_batches_tracked", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("residual_batch_stride", ctypes.c_longlong), ("y", ctypes.c_void_p),
+                ("y_batch_stride", ctypes.c_longlong), ("save_mean", ctypes.c_void_p), ("save_rstd", ctypes.c_void_p),
+                ("amax_out", ctypes.c_void_p), ("C", ctypes.c_int), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("relu", ctypes.c_int)]
+
+
+class BnBwdItem(ctypes.Structure):
+    """ct_bn_bwd_item (include/cloudct.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_longlong), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("save_mean", ctypes.c_void_p), ("save_rstd", ctypes.c_void_p), ("gy", ctypes.c_void_p),
+                ("gy_batch_stride", ctypes.c_longlong), ("gx", ctypes.c_void_p), ("gx_batch_stride", ctypes.c_longlong),
+                ("g_weight", ctypes.c_void_p), ("g_bias", ctypes.c_void_p), ("amax_out", ctypes.c_void_p), ("C", ctypes.c_int),
+                ("relu", ctypes.c_int)]
+
+
+BN_GROUP_MAX = 8
 CT_OK = 0
 REDUCE = {"max": 0, "sum": 1}
 PAD_NONE, PAD_F32, PAD_I32 = 0, 1, 2
@@ -189,6 +209,8 @@ SIGNATURES = {
     "ct_bn_relu_supported": (_i, [_i, _i, _i]),
     "ct_bn_relu_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ct_bn_group_fwd": (_i, [_vp, _i, _i, _i, _vp]),
+    "ct_bn_group_bwd": (_i, [_vp, _i, _i, _i, _vp]),
     "ct_bn_relu_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ct_bn_stats_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _i, _i, _i, _vp]),

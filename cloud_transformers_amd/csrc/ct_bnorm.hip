@@ -115,9 +115,8 @@ __device__ __forceinline__ size_t quad_offset(int q, int nq, int c, long long bs
 }
 
 template <int NV>
-__global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnArgs a, float* __restrict__ y) {
+__device__ __forceinline__ void bn_fwd_reg_body(const BnArgs& a, float* __restrict__ y, const int c) {
   __shared__ float red[1][kWaves];
-  const int c = blockIdx.x;
   const int nq = a.N >> 2, total = a.B * nq;
   float4 v[NV];
 #pragma unroll
@@ -226,9 +225,8 @@ __device__ __forceinline__ float masked(float gy, float xc, float gfw, float be,
 // With g' = gy masked by the ReLU:  g_bias = sum g',  g_weight = sum g' * xhat,
 //   gx = weight * rstd * (g' - mean(g') - xhat * mean(g' * xhat))
 template <int NV>
-__global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdArgs a) {
+__device__ __forceinline__ void bn_bwd_reg_body(const BnBwdArgs& a, const int c) {
   __shared__ float red[2][kWaves];
-  const int c = blockIdx.x;
   const int nq = a.N >> 2, total = a.B * nq;
   const float mu = a.save_mean[c], rs = a.save_rstd[c];
   const float w = a.weight[c];
@@ -296,9 +294,8 @@ __device__ __forceinline__ size_t item_offset(int i, int N, int c, long long bs)
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* __restrict__ y) {
+__device__ __forceinline__ void bn_fwd_loop_body(const BnArgs& a, float* __restrict__ y, const int c) {
   __shared__ float red[1][kWaves];
-  const int c = blockIdx.x;
   const int total = chan_items<VEC>(a.B, a.N);
   float M = (float)a.B * (float)a.N;
   float mu, var;
@@ -377,9 +374,8 @@ __global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnArgs a, float* 
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
+__device__ __forceinline__ void bn_bwd_loop_body(const BnBwdArgs& a, const int c) {
   __shared__ float red[2][kWaves];
-  const int c = blockIdx.x;
   const int total = chan_items<VEC>(a.B, a.N);
   const float mu = a.save_mean[c], rs = a.save_rstd[c];
   const float gfw = a.weight[c] * rs;
@@ -439,6 +435,56 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdArgs a) {
   }
 }
 
+// Several norms in ONE launch (the key / values norms of the heads on channel ranges of the stacked projection, the heads' `after`
+// norms on ranges of the concatenation): a workgroup per channel of every norm, its norm found by the channel prefix sums.
+// The norms of a block's group are 32-512 channels each: one by one they are 13-28 us launches of 32-512 workgroups on 256
+// CUs; together they are one launch that fills the chip.
+constexpr int kBnMaxItems = 8;
+struct BnTable {
+  int n;
+  int cstart[kBnMaxItems + 1];
+  BnArgs item[kBnMaxItems];
+  float* y[kBnMaxItems];
+};
+struct BnBwdTable {
+  int n;
+  int cstart[kBnMaxItems + 1];
+  BnBwdArgs item[kBnMaxItems];
+};
+
+template <typename T>
+__device__ __forceinline__ int bn_item_of(const T& t, int& c) {
+  int i = 0;
+  while (i + 1 < t.n && c >= t.cstart[i + 1]) ++i;
+  c -= t.cstart[i];
+  return i;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(kThreads) bn_fwd_reg_kernel(BnTable t) {
+  int c = blockIdx.x;
+  const int i = bn_item_of(t, c);
+  bn_fwd_reg_body<NV>(t.item[i], t.y[i], c);
+}
+template <int NV>
+__global__ void __launch_bounds__(kThreads) bn_bwd_reg_kernel(BnBwdTable t) {
+  int c = blockIdx.x;
+  const int i = bn_item_of(t, c);
+  bn_bwd_reg_body<NV>(t.item[i], c);
+}
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads) bn_fwd_loop_kernel(BnTable t) {
+  int c = blockIdx.x;
+  const int i = bn_item_of(t, c);
+  bn_fwd_loop_body<VEC>(t.item[i], t.y[i], c);
+}
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads) bn_bwd_loop_kernel(BnBwdTable t) {
+  int c = blockIdx.x;
+  const int i = bn_item_of(t, c);
+  bn_bwd_loop_body<VEC>(t.item[i], c);
+}
+
 int nv_for(long long quads) {
   const long long per = (quads + kThreads - 1) / kThreads;
   int nv = 1;
@@ -479,22 +525,61 @@ static bool stride_ok(long long bs, int C, int N, long long& out) {
   return true;
 }
 
-static int bn_fwd_launch(BnArgs a, float* y, long long x_batch_stride, long long y_batch_stride, long long residual_batch_stride,
-                         hipStream_t stream) {
-  const int B = a.B, C = a.C, N = a.N;
-  if (!shape_ok(B, C, N)) return CT_EINVAL;
-  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(y_batch_stride, C, N, a.ybs) ||
-      !stride_ok(residual_batch_stride, C, N, a.rbs))
+// strides and the float4 condition of one norm of a launch
+static int bn_fwd_prepare(BnArgs& a, float* y, long long x_batch_stride, long long y_batch_stride, long long residual_batch_stride,
+                          bool& vec) {
+  if (!shape_ok(a.B, a.C, a.N)) return CT_EINVAL;
+  if (!stride_ok(x_batch_stride, a.C, a.N, a.xbs) || !stride_ok(y_batch_stride, a.C, a.N, a.ybs) ||
+      !stride_ok(residual_batch_stride, a.C, a.N, a.rbs))
     return CT_EINVAL;
-  const bool vec = (N & 3) == 0 && ((a.xbs | a.ybs | a.rbs) & 3) == 0 &&
-                   ((((uintptr_t)a.x) | ((uintptr_t)y) | ((uintptr_t)a.residual)) & 15) == 0;
+  vec = (a.N & 3) == 0 && ((a.xbs | a.ybs | a.rbs) & 3) == 0 &&
+        ((((uintptr_t)a.x) | ((uintptr_t)y) | ((uintptr_t)a.residual)) & 15) == 0;
+  return CT_OK;
+}
+
+static int bn_fwd_launch_table(BnTable& t, bool vec, hipStream_t stream) {
+  const int B = t.item[0].B, N = t.item[0].N, C = t.cstart[t.n];
   CT_CLEAR_ERROR();
   if (vec && reg_ok(B, N)) {
-    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, a, y)
+    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_fwd_reg_kernel, t)
   } else if (vec) {
-    hipLaunchKernelGGL(bn_fwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, a, y);
+    hipLaunchKernelGGL(bn_fwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, t);
   } else {
-    hipLaunchKernelGGL(bn_fwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, a, y);
+    hipLaunchKernelGGL(bn_fwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, t);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+static int bn_fwd_launch(BnArgs a, float* y, long long x_batch_stride, long long y_batch_stride, long long residual_batch_stride,
+                         hipStream_t stream) {
+  bool vec;
+  const int rc = bn_fwd_prepare(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, vec);
+  if (rc != CT_OK) return rc;
+  BnTable t{};
+  t.n = 1; t.cstart[0] = 0; t.cstart[1] = a.C; t.item[0] = a; t.y[0] = y;
+  return bn_fwd_launch_table(t, vec, stream);
+}
+
+static int bn_bwd_prepare(BnBwdArgs& a, long long x_batch_stride, long long gy_batch_stride, long long gx_batch_stride, bool& vec) {
+  if (!shape_ok(a.B, a.C, a.N)) return CT_EINVAL;
+  if (!stride_ok(x_batch_stride, a.C, a.N, a.xbs) || !stride_ok(gy_batch_stride, a.C, a.N, a.gybs) ||
+      !stride_ok(gx_batch_stride, a.C, a.N, a.gxbs))
+    return CT_EINVAL;
+  vec = (a.N & 3) == 0 && ((a.xbs | a.gybs | a.gxbs) & 3) == 0 &&
+        ((((uintptr_t)a.x) | ((uintptr_t)a.gy) | ((uintptr_t)a.gx)) & 15) == 0;
+  return CT_OK;
+}
+
+static int bn_bwd_launch_table(BnBwdTable& t, bool vec, hipStream_t stream) {
+  const int B = t.item[0].B, N = t.item[0].N, C = t.cstart[t.n];
+  CT_CLEAR_ERROR();
+  if (vec && reg_ok(B, N)) {
+    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, t)
+  } else if (vec) {
+    hipLaunchKernelGGL(bn_bwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, t);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, t);
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
@@ -502,23 +587,62 @@ static int bn_fwd_launch(BnArgs a, float* y, long long x_batch_stride, long long
 
 static int bn_bwd_launch(BnBwdArgs a, long long x_batch_stride, long long gy_batch_stride, long long gx_batch_stride,
                          hipStream_t stream) {
-  const int B = a.B, C = a.C, N = a.N;
-  if (!shape_ok(B, C, N)) return CT_EINVAL;
-  if (!stride_ok(x_batch_stride, C, N, a.xbs) || !stride_ok(gy_batch_stride, C, N, a.gybs) ||
-      !stride_ok(gx_batch_stride, C, N, a.gxbs))
-    return CT_EINVAL;
-  const bool vec = (N & 3) == 0 && ((a.xbs | a.gybs | a.gxbs) & 3) == 0 &&
-                   ((((uintptr_t)a.x) | ((uintptr_t)a.gy) | ((uintptr_t)a.gx)) & 15) == 0;
-  CT_CLEAR_ERROR();
-  if (vec && reg_ok(B, N)) {
-    CT_BN_DISPATCH(nv_for((long long)B * (N >> 2)), bn_bwd_reg_kernel, a)
-  } else if (vec) {
-    hipLaunchKernelGGL(bn_bwd_loop_kernel<true>, dim3(C), dim3(kThreads), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL(bn_bwd_loop_kernel<false>, dim3(C), dim3(kThreads), 0, stream, a);
+  bool vec;
+  const int rc = bn_bwd_prepare(a, x_batch_stride, gy_batch_stride, gx_batch_stride, vec);
+  if (rc != CT_OK) return rc;
+  BnBwdTable t{};
+  t.n = 1; t.cstart[0] = 0; t.cstart[1] = a.C; t.item[0] = a;
+  return bn_bwd_launch_table(t, vec, stream);
+}
+
+// Up to kBnMaxItems norms over the same (B, N) in one launch: ct_bn_relu_fwd_amax / _bwd_amax of every item.
+extern "C" int ct_bn_group_fwd(const ct_bn_fwd_item* items, int n, int B, int N, ct_stream_t s) {
+  if (!items || n < 1 || n > kBnMaxItems) return CT_EINVAL;
+  BnTable t{};
+  t.n = n;
+  bool vec_all = true;
+  int c0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_bn_fwd_item& it = items[i];
+    if (!it.x || !it.weight || !it.bias || !it.y || !it.save_mean || !it.save_rstd || !(it.eps >= 0.0f)) return CT_EINVAL;
+    if ((it.running_mean == nullptr) != (it.running_var == nullptr)) return CT_EINVAL;
+    BnArgs a{it.x, it.weight, it.bias, it.running_mean, it.running_var, it.save_mean, it.save_rstd, B, it.C, N, it.eps, it.momentum,
+             it.relu, 0, 0, it.residual, 0, it.num_batches_tracked, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, it.amax_out};
+    bool vec;
+    const int rc = bn_fwd_prepare(a, it.y, it.x_batch_stride, it.y_batch_stride, it.residual_batch_stride, vec);
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.cstart[i] = c0;
+    t.item[i] = a;
+    t.y[i] = it.y;
+    c0 += it.C;
   }
-  CT_CHECK_LAUNCH();
-  return CT_OK;
+  t.cstart[n] = c0;
+  return bn_fwd_launch_table(t, vec_all, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_group_bwd(const ct_bn_bwd_item* items, int n, int B, int N, ct_stream_t s) {
+  if (!items || n < 1 || n > kBnMaxItems) return CT_EINVAL;
+  BnBwdTable t{};
+  t.n = n;
+  bool vec_all = true;
+  int c0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_bn_bwd_item& it = items[i];
+    if (!it.x || !it.weight || !it.bias || !it.save_mean || !it.save_rstd || !it.gy || !it.gx || !it.g_weight || !it.g_bias)
+      return CT_EINVAL;
+    BnBwdArgs a{it.x, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, it.gx, it.g_weight, it.g_bias, B, it.C, N, it.relu,
+                0, 0, 0, 0, nullptr, nullptr, nullptr, it.amax_out};
+    bool vec;
+    const int rc = bn_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.gx_batch_stride, vec);
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.cstart[i] = c0;
+    t.item[i] = a;
+    c0 += it.C;
+  }
+  t.cstart[n] = c0;
+  return bn_bwd_launch_table(t, vec_all, (hipStream_t)s);
 }
 
 extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream;
 every computation happens inside libcloudct.so.  Tensors that are not on a HIP
 device raise — there is no CPU path in the product.
 """
+import ctypes
 import math
 import os
 
@@ -688,6 +689,7 @@ class JoinAdaInReluFn(torch.autograd.Function):
 # training-mode BatchNorm1d (+ ReLU, + skip) groups, with or without an exchange of statistics between ranks
 # ---------------------------------------------------------------------------
 _sync_stats_collectives = 0
+BN_GROUP_LAUNCH = os.environ.get("CLOUDCT_BN_GROUP", "1") != "0"     # A/B switch: the norms of a group one by one
 
 
 def sync_stats_collectives():
@@ -725,6 +727,20 @@ def _bn_group_fwd(items, B, N, device, group):
     global _sync_stats_collectives
     lib = _lib.load()
     stats = []
+    if group is None and 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH:
+        # the norms of a block's group in ONE launch (a workgroup per channel of every norm)
+        arr = (_lib.BnFwdItem * len(items))()
+        for e, it in zip(arr, items):
+            mean = torch.empty(it["C"], device=device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            e.x, e.x_batch_stride, e.weight, e.bias = it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"])
+            e.running_mean, e.running_var, e.num_batches_tracked = _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"])
+            e.residual, e.residual_batch_stride, e.y, e.y_batch_stride = it["res"], it["rbs"], it["y"], it["ybs"]
+            e.save_mean, e.save_rstd, e.amax_out = _ptr(mean), _ptr(rstd), it.get("amax")
+            e.C, e.eps, e.momentum, e.relu = it["C"], float(it["eps"]), float(it["mom"]), int(it["relu"])
+            stats.append((mean, rstd))
+        _lib.check(lib.ct_bn_group_fwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_bn_group_fwd")
+        return stats, None
     if group is None:
         for it in items:
             mean = torch.empty(it["C"], device=device, dtype=torch.float32)
@@ -776,6 +792,18 @@ def _bn_group_bwd(items, B, N, device, group, count):
     global _sync_stats_collectives
     lib = _lib.load()
     out = []
+    if group is None and 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH:
+        arr = (_lib.BnBwdItem * len(items))()
+        for e, it in zip(arr, items):
+            g_w = torch.empty(it["C"], device=device, dtype=torch.float32)
+            g_b = torch.empty_like(g_w)
+            e.x, e.x_batch_stride, e.weight, e.bias = it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"])
+            e.save_mean, e.save_rstd, e.gy, e.gy_batch_stride = _ptr(it["mean"]), _ptr(it["rstd"]), it["gy"], it["gybs"]
+            e.gx, e.gx_batch_stride, e.g_weight, e.g_bias, e.amax_out = it["gx"], it["gxbs"], _ptr(g_w), _ptr(g_b), it.get("amax")
+            e.C, e.relu = it["C"], int(it["relu"])
+            out.append((g_w, g_b))
+        _lib.check(lib.ct_bn_group_bwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_bn_group_bwd")
+        return out
     if group is None:
         for it in items:
             g_w = torch.empty(it["C"], device=device, dtype=torch.float32)

@@ -217,6 +217,21 @@ int ct_bn_relu_bwd(const float* x, long long x_batch_stride, const float* weight
                    const float* save_mean, const float* save_rstd, const float* gy, long long gy_batch_stride,
                    float* gx, long long gx_batch_stride, float* g_weight, float* g_bias, int B, int C, int N, int relu,
                    ct_stream_t s);
+/* Several norms over the same (B, N) in ONE launch (n <= 8): the key / values norms of a block's heads on channel ranges of the
+ * stacked projection, the heads' `after` norms on ranges of the concatenation (layers/multihead_ct.py:89-91,67-68) — one
+ * workgroup per channel of every norm.  Fields as the arguments of ct_bn_relu_fwd_amax / ct_bn_relu_bwd_amax. */
+typedef struct {
+  const float* x; long long x_batch_stride; const float* weight; const float* bias; float* running_mean; float* running_var;
+  long long* num_batches_tracked; const float* residual; long long residual_batch_stride; float* y; long long y_batch_stride;
+  float* save_mean; float* save_rstd; float* amax_out; int C; float eps; float momentum; int relu;
+} ct_bn_fwd_item;
+typedef struct {
+  const float* x; long long x_batch_stride; const float* weight; const float* bias; const float* save_mean; const float* save_rstd;
+  const float* gy; long long gy_batch_stride; float* gx; long long gx_batch_stride; float* g_weight; float* g_bias; float* amax_out;
+  int C; int relu;
+} ct_bn_bwd_item;
+int ct_bn_group_fwd(const ct_bn_fwd_item* items, int n, int B, int N, ct_stream_t s);
+int ct_bn_group_bwd(const ct_bn_bwd_item* items, int n, int B, int N, ct_stream_t s);
 /* The same two with amax_out f32[C] (nullable): max |y| (after ReLU and skip) / max |g_x| per channel, a by-product of the
  * pass — the operand maxima ct_pw_gemm needs for the pointwise convolution that reads y / g_x next (n_amax = C). */
 int ct_bn_relu_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
