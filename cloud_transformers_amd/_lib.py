@@ -45,6 +45,23 @@ class BnBwdItem(ctypes.Structure):
                 ("relu", ctypes.c_int)]
 
 
+class AdainFwdItem(ctypes.Structure):
+    """ct_adain_fwd_item (include/cloudct.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_longlong), ("gamma_beta", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("residual_batch_stride", ctypes.c_longlong), ("y", ctypes.c_void_p),
+                ("y_batch_stride", ctypes.c_longlong), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("amax_out", ctypes.c_void_p), ("amax_batch_stride", ctypes.c_longlong), ("C", ctypes.c_int), ("eps", ctypes.c_float),
+                ("relu", ctypes.c_int)]
+
+
+class AdainBwdItem(ctypes.Structure):
+    """ct_adain_bwd_item (include/cloudct.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_longlong), ("gamma_beta", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("gy", ctypes.c_void_p), ("gy_batch_stride", ctypes.c_longlong),
+                ("gx", ctypes.c_void_p), ("gx_batch_stride", ctypes.c_longlong), ("g_gamma_beta", ctypes.c_void_p),
+                ("amax_out", ctypes.c_void_p), ("amax_batch_stride", ctypes.c_longlong), ("C", ctypes.c_int), ("relu", ctypes.c_int)]
+
+
 BN_GROUP_MAX = 8
 CT_OK = 0
 REDUCE = {"max": 0, "sum": 1}
@@ -209,6 +226,8 @@ SIGNATURES = {
     "ct_bn_relu_supported": (_i, [_i, _i, _i]),
     "ct_bn_relu_fwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ct_adain_group_fwd": (_i, [_vp, _i, _i, _i, _vp]),
+    "ct_adain_group_bwd": (_i, [_vp, _i, _i, _i, _vp]),
     "ct_bn_group_fwd": (_i, [_vp, _i, _i, _i, _vp]),
     "ct_bn_group_bwd": (_i, [_vp, _i, _i, _i, _vp]),
     "ct_bn_relu_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),

@@ -76,9 +76,9 @@ struct AdainArgs {
 };
 
 template <int NV>
-__global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, float* __restrict__ y) {
+__device__ __forceinline__ void adain_fwd_reg_body(const AdainArgs& a, float* __restrict__ y, const int row) {
   __shared__ float red[2][kWaves];
-  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int b = row / a.C, c = row - b * a.C;
   const int nq = a.N >> 2;
   const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.xbs + (size_t)c * a.N);
   float4 v[NV];
@@ -137,9 +137,9 @@ __global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainArgs a, fl
   }
 }
 
-__global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainArgs a, float* __restrict__ y) {
+__device__ __forceinline__ void adain_fwd_strided_body(const AdainArgs& a, float* __restrict__ y, const int row) {
   __shared__ float red[2][kWaves];
-  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int b = row / a.C, c = row - b * a.C;
   const float* xr = a.x + (size_t)b * a.xbs + (size_t)c * a.N;
   float s[1] = {0.f};
   for (int n = threadIdx.x; n < a.N; n += kThreads) s[0] += xr[n];
@@ -199,9 +199,9 @@ __device__ __forceinline__ float masked(float gy, float xc, float gfw, float be,
 }
 
 template <int NV>
-__global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a) {
+__device__ __forceinline__ void adain_bwd_reg_body(const AdainBwdArgs& a, const int row) {
   __shared__ float red[2][kWaves];
-  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int b = row / a.C, c = row - b * a.C;
   const int nq = a.N >> 2;
   const float mu = a.mean[row], rs = a.rstd[row];
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
@@ -251,9 +251,9 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdArgs a)
   }
 }
 
-__global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArgs a) {
+__device__ __forceinline__ void adain_bwd_strided_body(const AdainBwdArgs& a, const int row) {
   __shared__ float red[2][kWaves];
-  const int row = blockIdx.x, b = row / a.C, c = row - b * a.C;
+  const int b = row / a.C, c = row - b * a.C;
   const float mu = a.mean[row], rs = a.rstd[row];
   const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
   const float gfw = g1 * rs;                            // the forward's scale
@@ -289,6 +289,53 @@ __global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdArg
   }
 }
 
+// Several norms in ONE launch (the keys / values norms of the heads on channel ranges of the stacked projection, the heads' `after`
+// norms on ranges of the concatenation): a workgroup per (cloud, channel) row of every norm, its norm found by the row prefix
+// sums — as ct_bnorm.hip's BnTable.
+constexpr int kAdainMaxItems = 8;
+struct AdainTable {
+  int n;
+  int rstart[kAdainMaxItems + 1];
+  AdainArgs item[kAdainMaxItems];
+  float* y[kAdainMaxItems];
+};
+struct AdainBwdTable {
+  int n;
+  int rstart[kAdainMaxItems + 1];
+  AdainBwdArgs item[kAdainMaxItems];
+};
+
+template <typename T>
+__device__ __forceinline__ int adain_item_of(const T& t, int& row) {
+  int i = 0;
+  while (i + 1 < t.n && row >= t.rstart[i + 1]) ++i;
+  row -= t.rstart[i];
+  return i;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(kThreads) adain_fwd_reg_kernel(AdainTable t) {
+  int row = blockIdx.x;
+  const int i = adain_item_of(t, row);
+  adain_fwd_reg_body<NV>(t.item[i], t.y[i], row);
+}
+__global__ void __launch_bounds__(kThreads) adain_fwd_strided_kernel(AdainTable t) {
+  int row = blockIdx.x;
+  const int i = adain_item_of(t, row);
+  adain_fwd_strided_body(t.item[i], t.y[i], row);
+}
+template <int NV>
+__global__ void __launch_bounds__(kThreads) adain_bwd_reg_kernel(AdainBwdTable t) {
+  int row = blockIdx.x;
+  const int i = adain_item_of(t, row);
+  adain_bwd_reg_body<NV>(t.item[i], row);
+}
+__global__ void __launch_bounds__(kThreads) adain_bwd_strided_kernel(AdainBwdTable t) {
+  int row = blockIdx.x;
+  const int i = adain_item_of(t, row);
+  adain_bwd_strided_body(t.item[i], row);
+}
+
 bool vec_ok(int N, const void* p0, const void* p1, const void* p2) {
   const uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
   return (N & 3) == 0 && N <= 4 * kThreads * 16 && (bits & 15) == 0;
@@ -321,27 +368,67 @@ static bool adain_stride(long long bs, int C, int N, long long& out) {
   return true;
 }
 
-static int adain_fwd_impl(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
-                          long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
-                          float* amax_out, long long amax_batch_stride, int B, int C, int N, float eps, int relu, ct_stream_t s) {
-  hipStream_t stream = (hipStream_t)s;
-  if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
-  if ((size_t)B * C == 0 || N == 0) return CT_OK;
-  if (!x || !gamma_beta || !y || !mean || !rstd) return CT_EINVAL;
-  if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
-  const int rows = B * C;
-  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
-  if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(y_batch_stride, C, N, a.ybs) ||
-      !adain_stride(residual_batch_stride, C, N, a.rbs))
+static int adain_fwd_prepare(AdainArgs& a, float* y, long long x_batch_stride, long long y_batch_stride,
+                             long long residual_batch_stride, bool& vec) {
+  if (!a.x || !a.gamma_beta || !y || !a.mean || !a.rstd) return CT_EINVAL;
+  if (!adain_stride(x_batch_stride, a.C, a.N, a.xbs) || !adain_stride(y_batch_stride, a.C, a.N, a.ybs) ||
+      !adain_stride(residual_batch_stride, a.C, a.N, a.rbs))
     return CT_EINVAL;
+  vec = vec_ok(a.N, a.x, y, a.residual) && ((a.xbs | a.ybs | a.rbs) & 3) == 0;
+  return CT_OK;
+}
+
+static int adain_fwd_launch_table(AdainTable& t, bool vec, hipStream_t stream) {
+  const int rows = t.rstart[t.n];
   CT_CLEAR_ERROR();
-  if (vec_ok(N, x, y, residual) && ((a.xbs | a.ybs | a.rbs) & 3) == 0) {
-    CT_ADAIN_DISPATCH(nv_for(N), adain_fwd_reg_kernel, a, y)
+  if (vec) {
+    CT_ADAIN_DISPATCH(nv_for(t.item[0].N), adain_fwd_reg_kernel, t)
   } else {
-    hipLaunchKernelGGL(adain_fwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a, y);
+    hipLaunchKernelGGL(adain_fwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, t);
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
+}
+
+static int adain_fwd_impl(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
+                          long long residual_batch_stride, float* y, long long y_batch_stride, float* mean, float* rstd,
+                          float* amax_out, long long amax_batch_stride, int B, int C, int N, float eps, int relu, ct_stream_t s) {
+  if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
+  if ((size_t)B * C == 0 || N == 0) return CT_OK;
+  if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
+  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
+  bool vec;
+  const int rc = adain_fwd_prepare(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, vec);
+  if (rc != CT_OK) return rc;
+  AdainTable t{};
+  t.n = 1; t.rstart[0] = 0; t.rstart[1] = B * C; t.item[0] = a; t.y[0] = y;
+  return adain_fwd_launch_table(t, vec, (hipStream_t)s);
+}
+
+// Up to kAdainMaxItems norms over the same (B, N) in one launch: ct_adain_fwd_amax of every item (non-empty shapes only).
+extern "C" int ct_adain_group_fwd(const ct_adain_fwd_item* items, int n, int B, int N, ct_stream_t s) {
+  if (!items || n < 1 || n > kAdainMaxItems || B < 1 || N < 1) return CT_EINVAL;
+  AdainTable t{};
+  t.n = n;
+  bool vec_all = true;
+  long long r0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_adain_fwd_item& it = items[i];
+    if (it.C < 1 || !(it.eps >= 0.0f) || (it.amax_batch_stride != 0 && it.amax_batch_stride < it.C)) return CT_EINVAL;
+    AdainArgs a{it.x, it.gamma_beta, it.mean, it.rstd, B, it.C, N, it.eps, it.relu, 0, 0, it.residual, 0, it.amax_out,
+                it.amax_batch_stride ? it.amax_batch_stride : it.C};
+    bool vec;
+    const int rc = adain_fwd_prepare(a, it.y, it.x_batch_stride, it.y_batch_stride, it.residual_batch_stride, vec);
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.rstart[i] = (int)r0;
+    t.item[i] = a;
+    t.y[i] = it.y;
+    r0 += (long long)B * it.C;
+    if (r0 > 0x7fffffffLL) return CT_EINVAL;
+  }
+  t.rstart[n] = (int)r0;
+  return adain_fwd_launch_table(t, vec_all, (hipStream_t)s);
 }
 
 extern "C" int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
@@ -361,6 +448,28 @@ extern "C" int ct_adain_fwd_amax(const float* x, long long x_batch_stride, const
                         amax_batch_stride, B, C, N, eps, relu, s);
 }
 
+static int adain_bwd_prepare(AdainBwdArgs& a, long long x_batch_stride, long long gy_batch_stride, long long gx_batch_stride,
+                             bool& vec) {
+  if (!a.x || !a.gy || !a.gx || !a.gamma_beta || !a.mean || !a.rstd || !a.g_gamma_beta) return CT_EINVAL;
+  if (!adain_stride(x_batch_stride, a.C, a.N, a.xbs) || !adain_stride(gy_batch_stride, a.C, a.N, a.gybs) ||
+      !adain_stride(gx_batch_stride, a.C, a.N, a.gxbs))
+    return CT_EINVAL;
+  vec = vec_ok(a.N, a.x, a.gy, a.gx) && ((a.xbs | a.gybs | a.gxbs) & 3) == 0;
+  return CT_OK;
+}
+
+static int adain_bwd_launch_table(AdainBwdTable& t, bool vec, hipStream_t stream) {
+  const int rows = t.rstart[t.n];
+  CT_CLEAR_ERROR();
+  if (vec) {
+    CT_ADAIN_DISPATCH(nv_for(t.item[0].N), adain_bwd_reg_kernel, t)
+  } else {
+    hipLaunchKernelGGL(adain_bwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, t);
+  }
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 static int adain_bwd_impl(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,
                           const float* rstd, const float* gy, long long gy_batch_stride, float* gx,
                           long long gx_batch_stride, float* g_gamma_beta, float* amax_out, long long amax_batch_stride, int B, int C,
@@ -371,20 +480,38 @@ static int adain_bwd_impl(const float* x, long long x_batch_stride, const float*
   if (!gamma_beta || !mean || !rstd || !g_gamma_beta) return CT_EINVAL;
   if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
   if (N == 0) return hipMemsetAsync(g_gamma_beta, 0, (size_t)B * 2 * C * sizeof(float), stream) == hipSuccess ? CT_OK : CT_ELAUNCH;
-  if (!x || !gy || !gx) return CT_EINVAL;
-  const int rows = B * C;
-  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
-  if (!adain_stride(x_batch_stride, C, N, a.xbs) || !adain_stride(gy_batch_stride, C, N, a.gybs) ||
-      !adain_stride(gx_batch_stride, C, N, a.gxbs))
-    return CT_EINVAL;
-  CT_CLEAR_ERROR();
-  if (vec_ok(N, x, gy, gx) && ((a.xbs | a.gybs | a.gxbs) & 3) == 0) {
-    CT_ADAIN_DISPATCH(nv_for(N), adain_bwd_reg_kernel, a)
-  } else {
-    hipLaunchKernelGGL(adain_bwd_strided_kernel, dim3(rows), dim3(kThreads), 0, stream, a);
+  AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0, amax_out,
+                 amax_batch_stride ? amax_batch_stride : C};
+  bool vec;
+  const int rc = adain_bwd_prepare(a, x_batch_stride, gy_batch_stride, gx_batch_stride, vec);
+  if (rc != CT_OK) return rc;
+  AdainBwdTable t{};
+  t.n = 1; t.rstart[0] = 0; t.rstart[1] = B * C; t.item[0] = a;
+  return adain_bwd_launch_table(t, vec, stream);
+}
+
+extern "C" int ct_adain_group_bwd(const ct_adain_bwd_item* items, int n, int B, int N, ct_stream_t s) {
+  if (!items || n < 1 || n > kAdainMaxItems || B < 1 || N < 1) return CT_EINVAL;
+  AdainBwdTable t{};
+  t.n = n;
+  bool vec_all = true;
+  long long r0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_adain_bwd_item& it = items[i];
+    if (it.C < 1 || (it.amax_batch_stride != 0 && it.amax_batch_stride < it.C)) return CT_EINVAL;
+    AdainBwdArgs a{it.x, it.gamma_beta, it.mean, it.rstd, it.gy, it.gx, it.g_gamma_beta, B, it.C, N, it.relu, 0, 0, 0, it.amax_out,
+                   it.amax_batch_stride ? it.amax_batch_stride : it.C};
+    bool vec;
+    const int rc = adain_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.gx_batch_stride, vec);
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.rstart[i] = (int)r0;
+    t.item[i] = a;
+    r0 += (long long)B * it.C;
+    if (r0 > 0x7fffffffLL) return CT_EINVAL;
   }
-  CT_CHECK_LAUNCH();
-  return CT_OK;
+  t.rstart[n] = (int)r0;
+  return adain_bwd_launch_table(t, vec_all, (hipStream_t)s);
 }
 
 extern "C" int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean,

@@ -562,6 +562,42 @@ def adain(x, gamma_beta, eps=1e-5, relu=False, residual=None):
     return AdaInFn.apply(x, gamma_beta, eps, relu, residual)
 
 
+def _adain_group_fwd(items, B, N):
+    """ct_adain_fwd_amax of every item — in ONE launch when there are several (ct_adain_group_fwd).  items: dicts with x (ptr),
+    xbs, gb, res, rbs, y (ptr), ybs, mean, rstd, amax (ptr or None), abs (amax batch stride), C, eps, relu."""
+    lib = _lib.load()
+    if 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH and B > 0 and N > 0 and all(it["C"] > 0 for it in items):
+        arr = (_lib.AdainFwdItem * len(items))()
+        for e, it in zip(arr, items):
+            e.x, e.x_batch_stride, e.gamma_beta, e.residual, e.residual_batch_stride = it["x"], it["xbs"], _ptr(it["gb"]), it["res"], it["rbs"]
+            e.y, e.y_batch_stride, e.mean, e.rstd = it["y"], it["ybs"], _ptr(it["mean"]), _ptr(it["rstd"])
+            e.amax_out, e.amax_batch_stride, e.C, e.eps, e.relu = it["amax"], it["abs"], it["C"], float(it["eps"]), int(it["relu"])
+        _lib.check(lib.ct_adain_group_fwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_adain_group_fwd")
+        return
+    for it in items:
+        _lib.check(lib.ct_adain_fwd_amax(it["x"], it["xbs"], _ptr(it["gb"]), it["res"], it["rbs"], it["y"], it["ybs"], _ptr(it["mean"]),
+                                         _ptr(it["rstd"]), it["amax"], it["abs"], B, it["C"], N, float(it["eps"]), int(it["relu"]),
+                                         _stream()), "ct_adain_fwd")
+
+
+def _adain_group_bwd(items, B, N):
+    """ct_adain_bwd_amax of every item, in ONE launch when there are several.  items: dicts with x (ptr), xbs, gb, mean, rstd,
+    gy (ptr), gybs, gx (ptr), gxbs, g_gb, amax, abs, C, relu."""
+    lib = _lib.load()
+    if 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH and B > 0 and N > 0 and all(it["C"] > 0 for it in items):
+        arr = (_lib.AdainBwdItem * len(items))()
+        for e, it in zip(arr, items):
+            e.x, e.x_batch_stride, e.gamma_beta, e.mean, e.rstd = it["x"], it["xbs"], _ptr(it["gb"]), _ptr(it["mean"]), _ptr(it["rstd"])
+            e.gy, e.gy_batch_stride, e.gx, e.gx_batch_stride, e.g_gamma_beta = it["gy"], it["gybs"], it["gx"], it["gxbs"], _ptr(it["g_gb"])
+            e.amax_out, e.amax_batch_stride, e.C, e.relu = it["amax"], it["abs"], it["C"], int(it["relu"])
+        _lib.check(lib.ct_adain_group_bwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_adain_group_bwd")
+        return
+    for it in items:
+        _lib.check(lib.ct_adain_bwd_amax(it["x"], it["xbs"], _ptr(it["gb"]), _ptr(it["mean"]), _ptr(it["rstd"]), it["gy"], it["gybs"],
+                                         it["gx"], it["gxbs"], _ptr(it["g_gb"]), it["amax"], it["abs"], B, it["C"], N, int(it["relu"]),
+                                         _stream()), "ct_adain_bwd")
+
+
 class UnionKeysValuesAdaInFn(torch.autograd.Function):
     """UnionKeysValuesFn for the AdaIN blocks (layers/multihead_ct_adain.py:104-111): one stacked GEMM for the heads'
     keys_values_pred projections, keys_bn / values_bn = adaptive instance norms on channel ranges of its output.
@@ -577,22 +613,22 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)
         Ct = Wc.size(0)
         y, am_w, am_x = pw_forward(Wc, x)
-        lib = _lib.load()
-        outs, saved, meta, c0 = [], [], [], 0
+        outs, saved, meta, items, c0 = [], [], [], [], 0
+        for h in heads:
+            for gb in h[1:3]:
+                gb = _f32c(gb)
+                C = gb.size(2)
+                o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
+                mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, res=None, rbs=0, y=_ptr(o), ybs=0, mean=mean, rstd=rstd,
+                                  amax=None, abs=0, C=C, eps=eps, relu=0))
+                outs.append(o)
+                saved += [gb, mean, rstd]
+                meta.append((c0, C))
+                c0 += C
         with _on(x.device):
-            for h in heads:
-                for gb in h[1:3]:
-                    gb = _f32c(gb)
-                    C = gb.size(2)
-                    o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
-                    mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
-                    rstd = torch.empty_like(mean)
-                    _lib.check(lib.ct_adain_fwd(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), None, 0, _ptr(o), 0, _ptr(mean), _ptr(rstd),
-                                                B, C, N, float(eps), 0, _stream()), "ct_adain_fwd")
-                    outs.append(o)
-                    saved += [gb, mean, rstd]
-                    meta.append((c0, C))
-                    c0 += C
+            _adain_group_fwd(items, B, N)
         assert c0 == Ct, "keys_bn + values_bn must cover the projections"
         ctx.save_for_backward(x, y, Wc, *saved)
         ctx.am = (am_w, am_x)
@@ -607,24 +643,24 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Ct = Wc.size(0)
         g_y = torch.empty_like(y)
-        lib = _lib.load()
-        g_gbs = []
+        g_gbs, items, keep = [], [], []
         slots = _amax_slots(B * Ct, x.device)           # [B][Ct]: every norm writes its channel range of every cloud
+        for i, (c0, C) in enumerate(ctx.meta):
+            gb, mean, rstd = saved[i * 3:(i + 1) * 3]
+            gy = gouts[i]
+            if gy is None:
+                gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
+            gybs = _batch_stride(gy, C, N)
+            if gybs is None:
+                gy, gybs = _f32c(gy), 0
+            keep.append(gy)
+            g_gb = torch.empty_like(gb)
+            items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
+                              gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, g_gb=g_gb,
+                              amax=None if slots is None else _ptr(slots) + 4 * c0, abs=Ct, C=C, relu=0))
+            g_gbs.append(g_gb)
         with _on(x.device):
-            for i, (c0, C) in enumerate(ctx.meta):
-                gb, mean, rstd = saved[i * 3:(i + 1) * 3]
-                gy = gouts[i]
-                if gy is None:
-                    gy = torch.zeros(B, C, N, device=x.device, dtype=torch.float32)
-                gybs = _batch_stride(gy, C, N)
-                if gybs is None:
-                    gy, gybs = _f32c(gy), 0
-                g_gb = torch.empty_like(gb)
-                _lib.check(lib.ct_adain_bwd_amax(_ptr(y) + c0 * N * 4, Ct * N, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy), gybs,
-                                                 _ptr(g_y) + c0 * N * 4, Ct * N, _ptr(g_gb),
-                                                 None if slots is None else _ptr(slots) + 4 * c0, Ct, B, C, N, 0, _stream()),
-                           "ct_adain_bwd")
-                g_gbs.append(g_gb)
+            _adain_group_bwd(items, B, N)
         g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True, am_g=slots)
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
@@ -645,19 +681,18 @@ class JoinAdaInReluFn(torch.autograd.Function):
         B, _, N = xs[0].shape
         Ct = sum(x.size(1) for x in xs)
         y = torch.empty(B, Ct, N, device=xs[0].device, dtype=torch.float32)
-        lib = _lib.load()
         slots = _amax_slots(B * Ct, y.device)
-        saved, c0 = [], 0
+        saved, items, c0 = [], [], 0
+        for x, gb in zip(xs, gbs):
+            C = x.size(1)
+            mean = torch.empty(B * C, device=y.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            items.append(dict(x=_ptr(x), xbs=0, gb=gb, res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N, mean=mean, rstd=rstd,
+                              amax=None if slots is None else _ptr(slots) + 4 * c0, abs=Ct, C=C, eps=eps, relu=1))
+            saved += [x, gb, mean, rstd]
+            c0 += C
         with _on(y.device):
-            for x, gb in zip(xs, gbs):
-                C = x.size(1)
-                mean = torch.empty(B * C, device=y.device, dtype=torch.float32)
-                rstd = torch.empty_like(mean)
-                _lib.check(lib.ct_adain_fwd_amax(_ptr(x), 0, _ptr(gb), None, 0, _ptr(y) + c0 * N * 4, Ct * N, _ptr(mean), _ptr(rstd),
-                                                 None if slots is None else _ptr(slots) + 4 * c0, Ct, B, C, N, float(eps), 1,
-                                                 _stream()), "ct_adain_fwd")
-                saved += [x, gb, mean, rstd]
-                c0 += C
+            _adain_group_fwd(items, B, N)
         tag_amax(y, slots)
         ctx.save_for_backward(*saved)
         ctx.n = n
@@ -670,18 +705,18 @@ class JoinAdaInReluFn(torch.autograd.Function):
         gybs = _batch_stride(gy, Ct, N)
         if gybs is None:
             gy, gybs = _f32c(gy), Ct * N
-        lib = _lib.load()
-        grads, c0 = [None, None], 0
+        grads, items, c0 = [None, None], [], 0
+        for i in range(n):
+            x, gb, mean, rstd = saved[i * 4:(i + 1) * 4]
+            C = x.size(1)
+            gx, g_gb = torch.empty_like(x), torch.empty_like(gb)
+            slots = _amax_slots(B * C, gx.device)
+            items.append(dict(x=_ptr(x), xbs=0, gb=gb, mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs, gx=_ptr(gx), gxbs=0,
+                              g_gb=g_gb, amax=_ptr(slots), abs=0, C=C, relu=1))
+            grads += [tag_amax(gx, slots), g_gb]
+            c0 += C
         with _on(gy.device):
-            for i in range(n):
-                x, gb, mean, rstd = saved[i * 4:(i + 1) * 4]
-                C = x.size(1)
-                gx, g_gb = torch.empty_like(x), torch.empty_like(gb)
-                slots = _amax_slots(B * C, gx.device)
-                _lib.check(lib.ct_adain_bwd_amax(_ptr(x), 0, _ptr(gb), _ptr(mean), _ptr(rstd), _ptr(gy) + c0 * N * 4, gybs, _ptr(gx), 0,
-                                                 _ptr(g_gb), _ptr(slots), 0, B, C, N, 1, _stream()), "ct_adain_bwd")
-                grads += [tag_amax(gx, slots), g_gb]
-                c0 += C
+            _adain_group_bwd(items, B, N)
         return tuple(grads)
 
 

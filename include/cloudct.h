@@ -296,6 +296,20 @@ int ct_adain_fwd(const float* x, long long x_batch_stride, const float* gamma_be
 int ct_adain_bwd(const float* x, long long x_batch_stride, const float* gamma_beta, const float* mean, const float* rstd,
                  const float* gy, long long gy_batch_stride, float* gx, long long gx_batch_stride, float* g_gamma_beta,
                  int B, int C, int N, int relu, ct_stream_t s);
+/* Several adaptive instance norms over the same (B, N) in ONE launch (n <= 8), as ct_bn_group_fwd / _bwd: fields as the
+ * arguments of ct_adain_fwd_amax / ct_adain_bwd_amax. */
+typedef struct {
+  const float* x; long long x_batch_stride; const float* gamma_beta; const float* residual; long long residual_batch_stride;
+  float* y; long long y_batch_stride; float* mean; float* rstd; float* amax_out; long long amax_batch_stride; int C; float eps;
+  int relu;
+} ct_adain_fwd_item;
+typedef struct {
+  const float* x; long long x_batch_stride; const float* gamma_beta; const float* mean; const float* rstd; const float* gy;
+  long long gy_batch_stride; float* gx; long long gx_batch_stride; float* g_gamma_beta; float* amax_out;
+  long long amax_batch_stride; int C; int relu;
+} ct_adain_bwd_item;
+int ct_adain_group_fwd(const ct_adain_fwd_item* items, int n, int B, int N, ct_stream_t s);
+int ct_adain_group_bwd(const ct_adain_bwd_item* items, int n, int B, int N, ct_stream_t s);
 /* The same two with amax_out (nullable): amax_out[b * amax_batch_stride + c] = max |y| / max |g_x| of row (b, c), a by-product of
  * the pass (amax_batch_stride 0 = C) — operand maxima for ct_pw_gemm, as ct_bn_relu_fwd_amax. */
 int ct_adain_fwd_amax(const float* x, long long x_batch_stride, const float* gamma_beta, const float* residual,
