@@ -89,5 +89,21 @@ class FakeLib:
         _bcn(gx, gxbs, B, C, N)[:] = (_vec(w, C) * rs)[None, :, None] * (g - m0[None, :, None] - xh * m1[None, :, None])
         return 0
 
+    # the *_amax entry points: the same passes plus the per-channel max |.| of what they wrote (cloudct.h)
+    def ct_bn_apply_fwd_amax(self, x, xbs, w, b, g_mean, g_m2, g_count, world, stride, rm, rv, nbt, res, rbs, y, ybs,
+                             save_mean, save_rstd, count_total, amax_out, B, C, N, eps, mom, relu, stream):
+        rc = self.ct_bn_apply_fwd(x, xbs, w, b, g_mean, g_m2, g_count, world, stride, rm, rv, nbt, res, rbs, y, ybs,
+                                  save_mean, save_rstd, count_total, B, C, N, eps, mom, relu, stream)
+        if amax_out:
+            _vec(amax_out, C)[:] = np.abs(_bcn(y, ybs, B, C, N)).max(axis=(0, 2))
+        return rc
+
+    def ct_bn_apply_bwd_amax(self, x, xbs, w, b, mean, rstd, gy, gybs, sum_g, sum_gx, count, gx, gxbs, amax_out, B, C, N, relu,
+                             stream):
+        rc = self.ct_bn_apply_bwd(x, xbs, w, b, mean, rstd, gy, gybs, sum_g, sum_gx, count, gx, gxbs, B, C, N, relu, stream)
+        if amax_out:
+            _vec(amax_out, C)[:] = np.abs(_bcn(gx, gxbs, B, C, N)).max(axis=(0, 2))
+        return rc
+
     def ct_strerror(self, status):
         return b"fake"
