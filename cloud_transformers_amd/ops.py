@@ -429,6 +429,9 @@ class LatticeFn(torch.autograd.Function):
                        "ct_lattice_fwd")
         ctx.save_for_backward(xyz, residual, R, shift, scales, ks, lattice)
         ctx.meta = (B, H, N, dim, kscale.shape if kscale is not None else None)
+        # a block uses one of (keys, tanh(keys)) downstream: the other's cotangent stays None instead of a zero tensor that a
+        # fill kernel writes and the backward kernel reads (ct_lattice_bwd takes either pointer as NULL)
+        ctx.set_materialize_grads(False)
         if with_stats:
             ctx.mark_non_differentiable(stats)
             return keys, lattice, stats
@@ -438,6 +441,8 @@ class LatticeFn(torch.autograd.Function):
     def backward(ctx, g_keys, g_lattice, _g_stats=None):
         xyz, residual, R, shift, scales, ks, lattice = ctx.saved_tensors
         B, H, N, dim, ks_shape = ctx.meta
+        if g_keys is None and g_lattice is None:
+            return (None,) * 8
         g_keys = _f32c(g_keys) if g_keys is not None else None
         g_lattice = _f32c(g_lattice) if g_lattice is not None else None
         g_xyz, g_res = torch.empty_like(xyz), torch.empty_like(residual)
