@@ -51,7 +51,7 @@ class AdainFwdItem(ctypes.Structure):
                 ("residual", ctypes.c_void_p), ("residual_batch_stride", ctypes.c_longlong), ("y", ctypes.c_void_p),
                 ("y_batch_stride", ctypes.c_longlong), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
                 ("amax_out", ctypes.c_void_p), ("amax_batch_stride", ctypes.c_longlong), ("C", ctypes.c_int), ("eps", ctypes.c_float),
-                ("relu", ctypes.c_int)]
+                ("relu", ctypes.c_int), ("gamma_beta_batch_stride", ctypes.c_longlong)]
 
 
 class AdainBwdItem(ctypes.Structure):
@@ -59,7 +59,8 @@ class AdainBwdItem(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_longlong), ("gamma_beta", ctypes.c_void_p),
                 ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("gy", ctypes.c_void_p), ("gy_batch_stride", ctypes.c_longlong),
                 ("gx", ctypes.c_void_p), ("gx_batch_stride", ctypes.c_longlong), ("g_gamma_beta", ctypes.c_void_p),
-                ("amax_out", ctypes.c_void_p), ("amax_batch_stride", ctypes.c_longlong), ("C", ctypes.c_int), ("relu", ctypes.c_int)]
+                ("amax_out", ctypes.c_void_p), ("amax_batch_stride", ctypes.c_longlong), ("C", ctypes.c_int), ("relu", ctypes.c_int),
+                ("gamma_beta_batch_stride", ctypes.c_longlong)]
 
 
 BN_GROUP_MAX = 8

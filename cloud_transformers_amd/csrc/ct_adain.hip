@@ -73,6 +73,7 @@ struct AdainArgs {
   // y next (ct_pw_gemm folds them like ct_amax_f32's partials), at no extra pass over y
   float* amax_out;
   long long amax_bs;
+  long long gbbs;            // batch stride of gamma_beta in floats (2*C when contiguous; larger for a slice of a stacked projection)
 };
 
 template <int NV>
@@ -108,8 +109,8 @@ __device__ __forceinline__ void adain_fwd_reg_body(const AdainArgs& a, float* __
     a.mean[row] = mu;
     a.rstd[row] = rs;
   }
-  const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
-  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float g = (a.gamma_beta[(size_t)b * a.gbbs + c] + 1.0f) * rs;
+  const float be = a.gamma_beta[(size_t)b * a.gbbs + a.C + c];
   const float lo = a.relu ? 0.0f : -INFINITY;
   float4* yr = reinterpret_cast<float4*>(y + (size_t)b * a.ybs + (size_t)c * a.N);
   const float4* rr = a.residual ? reinterpret_cast<const float4*>(a.residual + (size_t)b * a.rbs + (size_t)c * a.N) : nullptr;
@@ -157,8 +158,8 @@ __device__ __forceinline__ void adain_fwd_strided_body(const AdainArgs& a, float
     a.mean[row] = mu;
     a.rstd[row] = rs;
   }
-  const float g = (a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f) * rs;
-  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float g = (a.gamma_beta[(size_t)b * a.gbbs + c] + 1.0f) * rs;
+  const float be = a.gamma_beta[(size_t)b * a.gbbs + a.C + c];
   const float lo = a.relu ? 0.0f : -INFINITY;
   float* yr = y + (size_t)b * a.ybs + (size_t)c * a.N;
   const float* rr = a.residual ? a.residual + (size_t)b * a.rbs + (size_t)c * a.N : nullptr;
@@ -190,6 +191,7 @@ struct AdainBwdArgs {
   long long xbs, gybs, gxbs; // batch strides in floats
   float* amax_out;           // nullable: amax_out[b * amax_bs + c] = max |gx| of row (b, c) (see AdainArgs::amax_out)
   long long amax_bs;
+  long long gbbs;            // batch stride of gamma_beta (read) in floats; g_gamma_beta is written contiguous
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * ((gamma + 1) * rstd) + beta, same
@@ -204,9 +206,9 @@ __device__ __forceinline__ void adain_bwd_reg_body(const AdainBwdArgs& a, const 
   const int b = row / a.C, c = row - b * a.C;
   const int nq = a.N >> 2;
   const float mu = a.mean[row], rs = a.rstd[row];
-  const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float g1 = a.gamma_beta[(size_t)b * a.gbbs + c] + 1.0f;
   const float gfw = g1 * rs;                            // the forward's scale
-  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float be = a.gamma_beta[(size_t)b * a.gbbs + a.C + c];
   const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.xbs + (size_t)c * a.N);
   const float4* gr = reinterpret_cast<const float4*>(a.gy + (size_t)b * a.gybs + (size_t)c * a.N);
   float4 xh[NV], g[NV];
@@ -255,9 +257,9 @@ __device__ __forceinline__ void adain_bwd_strided_body(const AdainBwdArgs& a, co
   __shared__ float red[2][kWaves];
   const int b = row / a.C, c = row - b * a.C;
   const float mu = a.mean[row], rs = a.rstd[row];
-  const float g1 = a.gamma_beta[((size_t)b * 2 + 0) * a.C + c] + 1.0f;
+  const float g1 = a.gamma_beta[(size_t)b * a.gbbs + c] + 1.0f;
   const float gfw = g1 * rs;                            // the forward's scale
-  const float be = a.gamma_beta[((size_t)b * 2 + 1) * a.C + c];
+  const float be = a.gamma_beta[(size_t)b * a.gbbs + a.C + c];
   const float* xr = a.x + (size_t)b * a.xbs + (size_t)c * a.N;
   const float* gr = a.gy + (size_t)b * a.gybs + (size_t)c * a.N;
   float s[2] = {0.f, 0.f};
@@ -396,7 +398,8 @@ static int adain_fwd_impl(const float* x, long long x_batch_stride, const float*
   if (B < 0 || C < 0 || N < 0 || !(eps >= 0.0f)) return CT_EINVAL;
   if ((size_t)B * C == 0 || N == 0) return CT_OK;
   if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
-  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0, amax_out, amax_batch_stride ? amax_batch_stride : C};
+  AdainArgs a{x, gamma_beta, mean, rstd, B, C, N, eps, relu, 0, 0, residual, 0, amax_out, amax_batch_stride ? amax_batch_stride : C,
+              2LL * C};
   bool vec;
   const int rc = adain_fwd_prepare(a, y, x_batch_stride, y_batch_stride, residual_batch_stride, vec);
   if (rc != CT_OK) return rc;
@@ -415,8 +418,10 @@ extern "C" int ct_adain_group_fwd(const ct_adain_fwd_item* items, int n, int B, 
   for (int i = 0; i < n; ++i) {
     const ct_adain_fwd_item& it = items[i];
     if (it.C < 1 || !(it.eps >= 0.0f) || (it.amax_batch_stride != 0 && it.amax_batch_stride < it.C)) return CT_EINVAL;
+    if (it.gamma_beta_batch_stride != 0 && it.gamma_beta_batch_stride < 2LL * it.C) return CT_EINVAL;
     AdainArgs a{it.x, it.gamma_beta, it.mean, it.rstd, B, it.C, N, it.eps, it.relu, 0, 0, it.residual, 0, it.amax_out,
-                it.amax_batch_stride ? it.amax_batch_stride : it.C};
+                it.amax_batch_stride ? it.amax_batch_stride : it.C,
+                it.gamma_beta_batch_stride ? it.gamma_beta_batch_stride : 2LL * it.C};
     bool vec;
     const int rc = adain_fwd_prepare(a, it.y, it.x_batch_stride, it.y_batch_stride, it.residual_batch_stride, vec);
     if (rc != CT_OK) return rc;
@@ -481,7 +486,7 @@ static int adain_bwd_impl(const float* x, long long x_batch_stride, const float*
   if ((size_t)B * C > 0x7fffffffull) return CT_EINVAL;
   if (N == 0) return hipMemsetAsync(g_gamma_beta, 0, (size_t)B * 2 * C * sizeof(float), stream) == hipSuccess ? CT_OK : CT_ELAUNCH;
   AdainBwdArgs a{x, gamma_beta, mean, rstd, gy, gx, g_gamma_beta, B, C, N, relu, 0, 0, 0, amax_out,
-                 amax_batch_stride ? amax_batch_stride : C};
+                 amax_batch_stride ? amax_batch_stride : C, 2LL * C};
   bool vec;
   const int rc = adain_bwd_prepare(a, x_batch_stride, gy_batch_stride, gx_batch_stride, vec);
   if (rc != CT_OK) return rc;
@@ -499,8 +504,10 @@ extern "C" int ct_adain_group_bwd(const ct_adain_bwd_item* items, int n, int B, 
   for (int i = 0; i < n; ++i) {
     const ct_adain_bwd_item& it = items[i];
     if (it.C < 1 || (it.amax_batch_stride != 0 && it.amax_batch_stride < it.C)) return CT_EINVAL;
+    if (it.gamma_beta_batch_stride != 0 && it.gamma_beta_batch_stride < 2LL * it.C) return CT_EINVAL;
     AdainBwdArgs a{it.x, it.gamma_beta, it.mean, it.rstd, it.gy, it.gx, it.g_gamma_beta, B, it.C, N, it.relu, 0, 0, 0, it.amax_out,
-                   it.amax_batch_stride ? it.amax_batch_stride : it.C};
+                   it.amax_batch_stride ? it.amax_batch_stride : it.C,
+                   it.gamma_beta_batch_stride ? it.gamma_beta_batch_stride : 2LL * it.C};
     bool vec;
     const int rc = adain_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.gx_batch_stride, vec);
     if (rc != CT_OK) return rc;

@@ -391,6 +391,33 @@ class MultiHeadUnionAdaIn(_UnionBase):
             for f, w, d, h in zip(features_dims, tensor_sizes, tensor_dims, heads)])
 
     def forward(self, x, style, orig_pcd):
+        norms = self._style_norms(style)
+        try:
+            return self._forward(x, style, orig_pcd)
+        finally:
+            for m in norms:
+                m._gb = None
+
+    def _style_norms(self, style):
+        """Project the style vector for every AdaIn1dUpd of the block at once (ops.StyleProjFn) and hand each norm its slice for
+        the span of this forward; returns the norms to reset."""
+        if not (style.is_cuda and style.dtype == torch.float32 and style.dim() == 2):
+            return []
+        mods = self.__dict__.get("_adain_norms")
+        if mods is None:
+            mods = [m for m in self.modules() if type(m) is AdaIn1dUpd]
+            self.__dict__["_adain_norms"] = mods
+        mods = [m for m in mods if m.linear.in_features == style.size(1) and m.linear.bias is not None]
+        if len(mods) < 2:
+            return []
+        args = []
+        for m in mods:
+            args += [m.linear.weight, m.linear.bias]
+        for m, gb in zip(mods, ops.StyleProjFn.apply(style, *args)):
+            m._gb = gb
+        return mods
+
+    def _forward(self, x, style, orig_pcd):
         x = self.prenorm(x)
         residual = forward_style(self.shortcut, x, style)
         pres, stats = [], []
@@ -405,7 +432,7 @@ class MultiHeadUnionAdaIn(_UnionBase):
         if fusable:        # the heads' AdaIN + ReLU write straight into their channel ranges of the concatenation
             args = []
             for n, p in zip(afters, pres):
-                args += [p, n[0].linear(style).reshape(-1, 2, n[0].num_features)]
+                args += [p, n[0].gamma_beta(style)]
             joined = ops.JoinAdaInReluFn.apply(len(pres), afters[0][0].instance_norm.eps, *args)
         else:
             joined = torch.cat([forward_style(n, p, style) for n, p in zip(afters, pres)], dim=1)
@@ -429,7 +456,6 @@ class MultiHeadUnionAdaIn(_UnionBase):
             if vb[0].instance_norm.eps != e or (eps is not None and eps != e):
                 return None
             eps = e
-            args += [kvp[0].weight, kb[0].linear(style).reshape(-1, 2, kb[0].num_features),
-                     vb[0].linear(style).reshape(-1, 2, vb[0].num_features)]
+            args += [kvp[0].weight, kb[0].gamma_beta(style), vb[0].gamma_beta(style)]
         outs = ops.UnionKeysValuesAdaInFn.apply(len(atts), x, eps, *args)
         return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(atts))]

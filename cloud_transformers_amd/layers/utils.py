@@ -84,10 +84,19 @@ class AdaIn1dUpd(nn.Module):
         self.instance_norm = nn.InstanceNorm1d(num_features, eps=1e-5, affine=False)
         self.linear = nn.Linear(num_latent, num_features * 2)
 
+    _gb = None     # set by a union block for the span of its forward: this norm's slice of the block's stacked style projection
+
+    def gamma_beta(self, z):
+        """[B,2,C] scale / bias predicted from the style vector: the block's stacked projection when one is in flight
+        (MultiHeadUnionAdaIn.forward, ops.StyleProjFn), else this layer's own Linear."""
+        if self._gb is not None:
+            return self._gb
+        return self.linear(z).reshape(-1, 2, self.num_features)
+
     def forward(self, x, z, relu=False, residual=None):
         """`relu=True` folds the ReLU that follows this layer in the blocks' `after` stacks into the same
         kernel (forward_style passes it and skips the nn.ReLU); `residual` is added to the result in the same pass."""
-        gamma_beta = self.linear(z).reshape(-1, 2, self.num_features)
+        gamma_beta = self.gamma_beta(z)
         if x.dtype == torch.float32 and x.dim() == 3:
             return ops.adain(x, gamma_beta, self.instance_norm.eps, relu, residual)    # one HIP launch (ct_adain_fwd); raises off the GPU
         if not x.is_cuda:

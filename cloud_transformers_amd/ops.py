@@ -521,8 +521,8 @@ class AdaInFn(torch.autograd.Function):
         xbs = _batch_stride(x, C, N)
         if xbs is None:
             x, xbs = x.contiguous(), 0
-        gamma_beta = _f32c(gamma_beta)
         assert gamma_beta.shape == (B, 2, C)
+        gamma_beta, gbbs = _gb_arg(gamma_beta, B, C)
         rbs = 0
         if residual is not None:
             rbs = _batch_stride(residual, C, N)
@@ -531,15 +531,15 @@ class AdaInFn(torch.autograd.Function):
         y = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
         mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        lib = _lib.load()
         slots = _amax_slots(B * C, x.device)
         with _on(x.device):
-            _lib.check(lib.ct_adain_fwd_amax(_ptr(x), xbs, _ptr(gamma_beta), _ptr(residual), rbs, _ptr(y), 0, _ptr(mean), _ptr(rstd),
-                                             _ptr(slots), 0, B, C, N, float(eps), int(bool(relu)), _stream()), "ct_adain_fwd")
+            _adain_group_fwd([dict(x=_ptr(x), xbs=xbs, gb=gamma_beta, gbbs=gbbs, res=_ptr(residual), rbs=rbs, y=_ptr(y), ybs=0, mean=mean,
+                                   rstd=rstd, amax=_ptr(slots), abs=0, C=C, eps=eps, relu=bool(relu))], B, N)
         tag_amax(y, slots)
         ctx.save_for_backward(x, gamma_beta, mean, rstd)
         ctx.relu = int(bool(relu))
         ctx.xbs = xbs
+        ctx.gbbs = gbbs
         ctx.has_residual = residual is not None
         return y
 
@@ -551,12 +551,11 @@ class AdaInFn(torch.autograd.Function):
         if gybs is None:
             gy, gybs = _f32c(gy), 0
         gx = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
-        g_gb = torch.empty_like(gamma_beta)
-        lib = _lib.load()
+        g_gb = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
         slots = _amax_slots(B * C, x.device)
         with _on(x.device):
-            _lib.check(lib.ct_adain_bwd_amax(_ptr(x), ctx.xbs, _ptr(gamma_beta), _ptr(mean), _ptr(rstd), _ptr(gy), gybs, _ptr(gx), 0,
-                                             _ptr(g_gb), _ptr(slots), 0, B, C, N, ctx.relu, _stream()), "ct_adain_bwd")
+            _adain_group_bwd([dict(x=_ptr(x), xbs=ctx.xbs, gb=gamma_beta, gbbs=ctx.gbbs, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
+                                   gx=_ptr(gx), gxbs=0, g_gb=g_gb, amax=_ptr(slots), abs=0, C=C, relu=ctx.relu)], B, N)
         tag_amax(gx, slots)
         return gx, g_gb, None, None, (gy if ctx.has_residual else None)
 
@@ -567,40 +566,92 @@ def adain(x, gamma_beta, eps=1e-5, relu=False, residual=None):
     return AdaInFn.apply(x, gamma_beta, eps, relu, residual)
 
 
+class StyleProjFn(torch.autograd.Function):
+    """The style projections of ALL adaptive instance norms of a block — `linear_i(style)` for every AdaIn1dUpd
+    (layers/utils.py:90; layers/multihead_ct_adain.py: keys_bn / values_bn of each head, the heads' `after` norms, the union's `after`
+    and shortcut norms) — as ONE product with the weights stacked: seven [B,L] x [L,2C_i] library GEMMs of 8-15 us, their 21
+    backward products and the six accumulations of the style cotangent become 3 + 4 launches.  Arguments: style [B,L], then
+    (weight [2C_i,L], bias [2C_i]) per norm.  Returns one [B,2,C_i] VIEW per norm into the stacked result (strides (sum, C_i, 1):
+    the AdaIN kernels read it where it lies, `_gb_arg`)."""
+
+    @staticmethod
+    def forward(ctx, style, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        W = torch.cat(ws, dim=0)
+        out = torch.addmm(torch.cat(bs, dim=0), style, W.t())              # [B, sum 2C_i]
+        ctx.save_for_backward(style, W)
+        ctx.sizes = [w.size(0) for w in ws]
+        outs, o = [], 0
+        for d in ctx.sizes:
+            outs.append(out[:, o:o + d].unflatten(1, (2, d // 2)))
+            o += d
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        style, W = ctx.saved_tensors
+        B = style.size(0)
+        parts = [(g.reshape(B, d) if g is not None else style.new_zeros(B, d)) for g, d in zip(gouts, ctx.sizes)]
+        g = torch.cat(parts, dim=1)                                           # [B, sum 2C_i]
+        g_style = g @ W if ctx.needs_input_grad[0] else None
+        g_W, g_b = g.t() @ style, g.sum(0)
+        grads, o = [g_style], 0
+        for d in ctx.sizes:                       # row ranges of the stacked gradients: dense views, no copies
+            grads += [g_W[o:o + d], g_b[o:o + d]]
+            o += d
+        return tuple(grads)
+
+
+def _gb_arg(gb, B, C):
+    """gamma_beta [B,2,C] for the AdaIN kernels without a copy: (tensor, batch stride in floats, 0 = contiguous).  A column
+    range of a stacked style projection [B, sum 2*C_i] viewed as [B,2,C] has strides (sum, C, 1): the kernels take the sum."""
+    if gb.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % gb.dtype)
+    if gb.dim() == 3 and gb.shape == (B, 2, C) and gb.stride(2) == 1 and gb.stride(1) == C and (B == 1 or gb.stride(0) >= 2 * C):
+        return gb, (0 if B == 1 or gb.stride(0) == 2 * C else gb.stride(0))
+    return gb.contiguous(), 0
+
+
 def _adain_group_fwd(items, B, N):
     """ct_adain_fwd_amax of every item — in ONE launch when there are several (ct_adain_group_fwd).  items: dicts with x (ptr),
     xbs, gb, res, rbs, y (ptr), ybs, mean, rstd, amax (ptr or None), abs (amax batch stride), C, eps, relu."""
     lib = _lib.load()
-    if 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH and B > 0 and N > 0 and all(it["C"] > 0 for it in items):
-        arr = (_lib.AdainFwdItem * len(items))()
-        for e, it in zip(arr, items):
+    if B == 0 or N == 0:
+        return
+    items = [it for it in items if it["C"] > 0]
+    step = _lib.BN_GROUP_MAX if BN_GROUP_LAUNCH else 1
+    for i0 in range(0, len(items), step):
+        chunk = items[i0:i0 + step]
+        arr = (_lib.AdainFwdItem * len(chunk))()
+        for e, it in zip(arr, chunk):
             e.x, e.x_batch_stride, e.gamma_beta, e.residual, e.residual_batch_stride = it["x"], it["xbs"], _ptr(it["gb"]), it["res"], it["rbs"]
             e.y, e.y_batch_stride, e.mean, e.rstd = it["y"], it["ybs"], _ptr(it["mean"]), _ptr(it["rstd"])
             e.amax_out, e.amax_batch_stride, e.C, e.eps, e.relu = it["amax"], it["abs"], it["C"], float(it["eps"]), int(it["relu"])
-        _lib.check(lib.ct_adain_group_fwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_adain_group_fwd")
-        return
-    for it in items:
-        _lib.check(lib.ct_adain_fwd_amax(it["x"], it["xbs"], _ptr(it["gb"]), it["res"], it["rbs"], it["y"], it["ybs"], _ptr(it["mean"]),
-                                         _ptr(it["rstd"]), it["amax"], it["abs"], B, it["C"], N, float(it["eps"]), int(it["relu"]),
-                                         _stream()), "ct_adain_fwd")
+            e.gamma_beta_batch_stride = it.get("gbbs", 0)
+        _lib.check(lib.ct_adain_group_fwd(ctypes.addressof(arr), len(chunk), B, N, _stream()), "ct_adain_group_fwd")
 
 
 def _adain_group_bwd(items, B, N):
     """ct_adain_bwd_amax of every item, in ONE launch when there are several.  items: dicts with x (ptr), xbs, gb, mean, rstd,
     gy (ptr), gybs, gx (ptr), gxbs, g_gb, amax, abs, C, relu."""
     lib = _lib.load()
-    if 1 < len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH and B > 0 and N > 0 and all(it["C"] > 0 for it in items):
-        arr = (_lib.AdainBwdItem * len(items))()
-        for e, it in zip(arr, items):
+    if B == 0:
+        return
+    if N == 0:
+        for it in items:
+            it["g_gb"].zero_()
+        return
+    items = [it for it in items if it["C"] > 0]
+    step = _lib.BN_GROUP_MAX if BN_GROUP_LAUNCH else 1
+    for i0 in range(0, len(items), step):
+        chunk = items[i0:i0 + step]
+        arr = (_lib.AdainBwdItem * len(chunk))()
+        for e, it in zip(arr, chunk):
             e.x, e.x_batch_stride, e.gamma_beta, e.mean, e.rstd = it["x"], it["xbs"], _ptr(it["gb"]), _ptr(it["mean"]), _ptr(it["rstd"])
             e.gy, e.gy_batch_stride, e.gx, e.gx_batch_stride, e.g_gamma_beta = it["gy"], it["gybs"], it["gx"], it["gxbs"], _ptr(it["g_gb"])
             e.amax_out, e.amax_batch_stride, e.C, e.relu = it["amax"], it["abs"], it["C"], int(it["relu"])
-        _lib.check(lib.ct_adain_group_bwd(ctypes.addressof(arr), len(items), B, N, _stream()), "ct_adain_group_bwd")
-        return
-    for it in items:
-        _lib.check(lib.ct_adain_bwd_amax(it["x"], it["xbs"], _ptr(it["gb"]), _ptr(it["mean"]), _ptr(it["rstd"]), it["gy"], it["gybs"],
-                                         it["gx"], it["gxbs"], _ptr(it["g_gb"]), it["amax"], it["abs"], B, it["C"], N, int(it["relu"]),
-                                         _stream()), "ct_adain_bwd")
+            e.gamma_beta_batch_stride = it.get("gbbs", 0)
+        _lib.check(lib.ct_adain_group_bwd(ctypes.addressof(arr), len(chunk), B, N, _stream()), "ct_adain_group_bwd")
 
 
 class UnionKeysValuesAdaInFn(torch.autograd.Function):
@@ -621,13 +672,13 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         outs, saved, meta, items, c0 = [], [], [], [], 0
         for h in heads:
             for gb in h[1:3]:
-                gb = _f32c(gb)
                 C = gb.size(2)
+                gb, gbbs = _gb_arg(gb, B, C)
                 o = torch.empty(B, C, N, device=x.device, dtype=torch.float32)
                 mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
                 rstd = torch.empty_like(mean)
-                items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, res=None, rbs=0, y=_ptr(o), ybs=0, mean=mean, rstd=rstd,
-                                  amax=None, abs=0, C=C, eps=eps, relu=0))
+                items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, gbbs=gbbs, res=None, rbs=0, y=_ptr(o), ybs=0, mean=mean,
+                                  rstd=rstd, amax=None, abs=0, C=C, eps=eps, relu=0))
                 outs.append(o)
                 saved += [gb, mean, rstd]
                 meta.append((c0, C))
@@ -659,8 +710,8 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
             if gybs is None:
                 gy, gybs = _f32c(gy), 0
             keep.append(gy)
-            g_gb = torch.empty_like(gb)
-            items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
+            g_gb = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
+            items.append(dict(x=_ptr(y) + c0 * N * 4, xbs=Ct * N, gb=gb, gbbs=_gb_arg(gb, B, C)[1], mean=mean, rstd=rstd, gy=_ptr(gy), gybs=gybs,
                               gx=_ptr(g_y) + c0 * N * 4, gxbs=Ct * N, g_gb=g_gb,
                               amax=None if slots is None else _ptr(slots) + 4 * c0, abs=Ct, C=C, relu=0))
             g_gbs.append(g_gb)
@@ -681,7 +732,7 @@ class JoinAdaInReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n, eps, *args):
         xs = [_f32c(args[2 * i]) for i in range(n)]
-        gbs = [_f32c(args[2 * i + 1]) for i in range(n)]
+        gbs = [_gb_arg(args[2 * i + 1], xs[i].size(0), xs[i].size(1))[0] for i in range(n)]
         _dev(*xs)
         B, _, N = xs[0].shape
         Ct = sum(x.size(1) for x in xs)
@@ -692,8 +743,8 @@ class JoinAdaInReluFn(torch.autograd.Function):
             C = x.size(1)
             mean = torch.empty(B * C, device=y.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
-            items.append(dict(x=_ptr(x), xbs=0, gb=gb, res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N, mean=mean, rstd=rstd,
-                              amax=None if slots is None else _ptr(slots) + 4 * c0, abs=Ct, C=C, eps=eps, relu=1))
+            items.append(dict(x=_ptr(x), xbs=0, gb=gb, gbbs=_gb_arg(gb, B, C)[1], res=None, rbs=0, y=_ptr(y) + c0 * N * 4, ybs=Ct * N,
+                              mean=mean, rstd=rstd, amax=None if slots is None else _ptr(slots) + 4 * c0, abs=Ct, C=C, eps=eps, relu=1))
             saved += [x, gb, mean, rstd]
             c0 += C
         with _on(y.device):
@@ -714,9 +765,10 @@ class JoinAdaInReluFn(torch.autograd.Function):
         for i in range(n):
             x, gb, mean, rstd = saved[i * 4:(i + 1) * 4]
             C = x.size(1)
-            gx, g_gb = torch.empty_like(x), torch.empty_like(gb)
+            gx, g_gb = torch.empty_like(x), torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
             slots = _amax_slots(B * C, gx.device)
-            items.append(dict(x=_ptr(x), xbs=0, gb=gb, mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs, gx=_ptr(gx), gxbs=0,
+            items.append(dict(x=_ptr(x), xbs=0, gb=gb, gbbs=_gb_arg(gb, B, C)[1], mean=mean, rstd=rstd, gy=_ptr(gy) + c0 * N * 4, gybs=gybs,
+                              gx=_ptr(gx), gxbs=0,
                               g_gb=g_gb, amax=_ptr(slots), abs=0, C=C, relu=1))
             grads += [tag_amax(gx, slots), g_gb]
             c0 += C

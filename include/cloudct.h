@@ -302,11 +302,14 @@ typedef struct {
   const float* x; long long x_batch_stride; const float* gamma_beta; const float* residual; long long residual_batch_stride;
   float* y; long long y_batch_stride; float* mean; float* rstd; float* amax_out; long long amax_batch_stride; int C; float eps;
   int relu;
+  long long gamma_beta_batch_stride;   /* floats between clouds in gamma_beta (0 = 2*C: contiguous [B,2,C]); larger for a column
+                                          range of a stacked style projection [B, sum 2*C_i] */
 } ct_adain_fwd_item;
 typedef struct {
   const float* x; long long x_batch_stride; const float* gamma_beta; const float* mean; const float* rstd; const float* gy;
   long long gy_batch_stride; float* gx; long long gx_batch_stride; float* g_gamma_beta; float* amax_out;
   long long amax_batch_stride; int C; int relu;
+  long long gamma_beta_batch_stride;   /* as in ct_adain_fwd_item (g_gamma_beta is written contiguous [B,2,C]) */
 } ct_adain_bwd_item;
 int ct_adain_group_fwd(const ct_adain_fwd_item* items, int n, int B, int N, ct_stream_t s);
 int ct_adain_group_bwd(const ct_adain_bwd_item* items, int n, int B, int N, ct_stream_t s);

@@ -284,3 +284,37 @@ def test_heads_on_side_streams_equal_the_serial_block(kind, monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(out_s.detach(), want[0])
     np.testing.assert_allclose(xs.grad.cpu().numpy(), want[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_stacked_style_projection_equals_the_norms_own_linears(monkeypatch):
+    """MultiHeadUnionAdaIn with ops.StyleProjFn (one stacked product for the style projections of all its AdaIN norms, the
+    kernels reading their column ranges of the result in place) against the same block with every norm's own Linear:
+    output, input / style cotangents and every parameter gradient (the Linear weights' and biases' included)."""
+    from cloud_transformers_amd.layers import multihead_ct as M
+    torch.manual_seed(31)
+    B, D, N, L = 3, 32, 512, 24
+    blk = M.MultiHeadUnionAdaIn(D, [4, 4], [16, 8], [2, 3], [4, 2], model_dim_out=48, n_latent=L).cuda().train()
+    x0 = torch.randn(B, D, N, device="cuda")
+    pcd = torch.rand(B, 3, N, device="cuda") * 2 - 1
+    s0 = torch.randn(B, L, device="cuda")
+    cot = torch.randn(B, 48, N, device="cuda")
+
+    def run():
+        blk.zero_grad(set_to_none=True)
+        x, st = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        out, _ = blk(x, st, pcd)
+        (out * cot).sum().backward()
+        return out.detach(), x.grad, st.grad, {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+
+    got = run()
+    assert any("linear.weight" in n for n in got[3])
+    monkeypatch.setattr(M.MultiHeadUnionAdaIn, "_style_norms", lambda self, style: [])
+    want = run()
+    assert got[3].keys() == want[3].keys()
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[1].cpu().numpy(), want[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got[2].cpu().numpy(), want[2].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for n in want[3]:
+        if n.endswith("conv.0.bias"):
+            continue        # a bias in front of an instance norm: its true gradient is 0, both runs hold rounding noise of ~1e-4
+        np.testing.assert_allclose(got[3][n].cpu().numpy(), want[3][n].cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=n)
