@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) lattice_stats_kernel(const float* stat_pa
 }
 
 // grid = (ceil(N/256), H, B).  Point-wise output: the cotangent gp of the moved point, stored per head in g_res;
-// lattice_bwd_finish_kernel then sums it over the heads into g_xyz and scales g_res by kscale in place (g_xyz used
+// the finish half of lattice_bwd_tail_kernel then sums it over the heads into g_xyz and scales g_res by kscale in place (g_xyz used
 // to be accumulated with B*3*N*H device-scope float atomics, most of this pass's time).  Parameter cotangents (g_R 9, g_shift 3, g_scales dim, g_kscale 1 per head) are
 // reduced per workgroup and added with one atomic each.
 // kBwdPts points per thread.  With __shfl_xor reductions (96 ds_bpermute per thread for the 16 parameter partials) four points
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gp[c] = R[c * 3 + 0] * gq[0] + R[c * 3 + 1] * gq[1] + R[c * 3 + 2] * gq[2];
-        g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = gp[c];      // unscaled: lattice_bwd_finish_kernel
+        g_res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] = gp[c];      // unscaled: lattice_bwd_tail_kernel (finish)
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) lattice_bwd_kernel(LatticeArgs a, const f
   if (threadIdx.x < 16) {
     const int i = threadIdx.x;
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (parts) {        // workspace: this workgroup's 16 partials, summed in a fixed order by lattice_param_sum_kernel
+    if (parts) {        // workspace: this workgroup's 16 partials, summed in a fixed order by lattice_bwd_tail_kernel (parameter sums)
       parts[(((size_t)b * gridDim.x + blockIdx.x) * a.H + h) * 16 + i] = v;
     } else if (i < 9) atomicAdd(&g_R[h * 9 + i], v);
     else if (i < 12) atomicAdd(&g_shift[h * 3 + (i - 9)], v);
@@ -188,11 +188,10 @@ __global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_R, float* g_
 // parameter cotangents from the per-workgroup partials [B * nbx][H][16].  One workgroup per head: its 256 threads are
 // 16 partial indices x 16 lanes over the workgroups (coalesced 64-byte rows), combined by a fixed-order tree in LDS.
 // The residual scale is one scalar for all heads: workgroup 0 also sums partial 15 of every (workgroup, head).
-__global__ void __launch_bounds__(256) lattice_param_sum_kernel(const float* parts, int nwg, int H, int dim, float* g_R, float* g_shift,
-                                                                float* g_scales, float* g_kscale) {
+__device__ __forceinline__ void lattice_param_sum_body(const float* parts, int nwg, int H, int dim, float* g_R, float* g_shift,
+                                                       float* g_scales, float* g_kscale, const int h) {
   __shared__ float red[16][17];
   __shared__ float kred[256];
-  const int h = blockIdx.x;
   const int i = threadIdx.x & 15, wl = threadIdx.x >> 4;
   float s = 0.0f;
   for (int w = wl; w < nwg; w += 16) s += parts[((size_t)w * H + h) * 16 + i];
@@ -220,9 +219,9 @@ __global__ void __launch_bounds__(256) lattice_param_sum_kernel(const float* par
 }
 
 // g_xyz[b,c,n] = sum_h gp[b,h,c,n];  g_res[b,h,c,n] = kscale * gp[b,h,c,n]  (in place).  One thread per (b, c, n).
-__global__ void __launch_bounds__(256) lattice_bwd_finish_kernel(float* g_res, float* g_xyz, const float* kscale, int B, int H, int N) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // over (c, n)
-  const int b = blockIdx.y;
+__device__ __forceinline__ void lattice_bwd_finish_body(float* g_res, float* g_xyz, const float* kscale, int B, int H, int N, const int bx,
+                                                        const int b) {
+  const size_t i = (size_t)bx * blockDim.x + threadIdx.x;                 // over (c, n)
   if (i >= (size_t)3 * N) return;
   const float ks = kscale ? kscale[0] : 1.0f;
   float* p = g_res + (size_t)b * H * 3 * N + i;
@@ -233,6 +232,21 @@ __global__ void __launch_bounds__(256) lattice_bwd_finish_kernel(float* g_res, f
     if (kscale) p[(size_t)h * 3 * N] = ks * v;
   }
   g_xyz[(size_t)b * 3 * N + i] = s;
+}
+
+// The two tails of the backward in ONE launch (they do not depend on each other; each is a 5-6 us launch of a few dozen
+// workgroups): workgroups [0, nsum) are lattice_param_sum's (one per head; nsum = 0 without a workspace), the rest are
+// lattice_bwd_finish's (nfx per cloud).
+__global__ void __launch_bounds__(256) lattice_bwd_tail_kernel(const float* parts, int nwg, int nsum, int H, int dim, float* g_R, float* g_shift,
+                                                               float* g_scales, float* g_kscale, float* g_res, float* g_xyz,
+                                                               const float* kscale, int B, int N, int nfx) {
+  const int blk = blockIdx.x;
+  if (blk < nsum) {
+    lattice_param_sum_body(parts, nwg, H, dim, g_R, g_shift, g_scales, g_kscale, blk);
+  } else {
+    const int f = blk - nsum;
+    lattice_bwd_finish_body(g_res, g_xyz, kscale, B, H, N, f % nfx, f / nfx);
+  }
 }
 
 // so3 exponential map of the per-head rotation parameters (Rodrigues; the map the reference imports from
@@ -341,11 +355,9 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
   if (!parts) hipLaunchKernelGGL(lattice_zero_kernel, dim3((H * 9 + 255) / 256), dim3(256), 0, st, g_R, g_shift, g_scales, g_kscale, H, dim);
   hipLaunchKernelGGL(lattice_bwd_kernel, dim3(nbx, H, B), dim3(256), 0, st, a, lattice, g_lattice, g_keys, g_xyz,
                      g_residual, g_R, g_shift, g_scales, g_kscale, parts);
-  hipLaunchKernelGGL(lattice_bwd_finish_kernel, dim3((unsigned)(((size_t)3 * N + 255) / 256), B), dim3(256), 0, st, g_residual, g_xyz,
-                     kscale, B, H, N);
-  if (parts)
-    hipLaunchKernelGGL(lattice_param_sum_kernel, dim3(H), dim3(256), 0, st, parts, B * nbx, H, dim, g_R, g_shift,
-                       g_scales, g_kscale);
+  const int nfx = (int)(((size_t)3 * N + 255) / 256), nsum = parts ? H : 0;
+  hipLaunchKernelGGL(lattice_bwd_tail_kernel, dim3((unsigned)(nsum + nfx * B)), dim3(256), 0, st, parts, B * nbx, nsum, H, dim, g_R, g_shift,
+                     g_scales, g_kscale, g_residual, g_xyz, kscale, B, N, nfx);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
