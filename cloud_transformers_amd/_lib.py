@@ -265,6 +265,8 @@ SIGNATURES = {
     "ct_emd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ct_amax_f32": (_i, [_vp, _ll, _vp, _vp]),
     "ct_amax_len": (_i, []),
+    "ct_pw_prep_weight_partials": (_i, [_i, _i]),
+    "ct_pw_prep_weight": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "ct_pw_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
 }

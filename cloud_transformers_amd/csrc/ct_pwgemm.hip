@@ -474,6 +474,37 @@ constexpr int kPwZTarget = CT_PW_ZTARGET;
 constexpr int kPwAmaxLen = 512;       // = kPwThreads: one partial maximum per GEMM thread
 constexpr int kPwAmaxMax = 4096;      // what a producer may leave instead (per channel, per (cloud, channel))
 
+// The same with the weight's partial maxima (one per 32x32 tile, <= kPwAmaxMax tiles): what a layer's forward needs of its
+// weight for all three products, in one launch.
+__global__ void __launch_bounds__(256) pw_prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, unsigned* __restrict__ amax,
+                                                             int R, int C) {
+  __shared__ float tile[32][33];
+  __shared__ unsigned wave_max[4];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < R && c < C) {
+      const float v = w[(size_t)r * C + c];
+      tile[ty + 8 * i][tx] = v;
+      m = max(m, __float_as_uint(v) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) amax[blockIdx.y * gridDim.x + blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+  if (wt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (r < R && c < C) wt[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+    }
+  }
+}
+
 struct PwPlan {
   int M, N, K, Z, ksplit, Kc, tilesM, tilesN;
   size_t ws;
@@ -482,7 +513,7 @@ struct PwPlan {
 static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
   if (B < 1 || Co < 1 || Ci < 1 || N < 1 || (Co & 3) || (Ci & 3) || (N & 3)) return false;
   if (mode == CT_PW_FWD) { p.M = Co; p.N = N; p.K = Ci; }
-  else if (mode == CT_PW_DGRAD) { p.M = Ci; p.N = N; p.K = Co; }
+  else if (mode == CT_PW_DGRAD || mode == CT_PW_DGRAD_T) { p.M = Ci; p.N = N; p.K = Co; }
   else if (mode == CT_PW_WGRAD) { p.M = Co; p.N = Ci; p.K = N; }
   else return false;
   p.tilesM = (p.M + kPwTile - 1) / kPwTile;
@@ -538,6 +569,24 @@ int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s) {
 
 int ct_amax_len(void) { return kPwAmaxLen; }
 
+// partial maxima ct_pw_prep_weight writes for a [Co, Ci] weight (one per 32x32 tile), 0 when there would be more than ct_pw_gemm folds
+int ct_pw_prep_weight_partials(int Co, int Ci) {
+  if (Co < 1 || Ci < 1) return 0;
+  const long long n = (long long)((Co + 31) / 32) * ((Ci + 31) / 32);
+  return n <= kPwAmaxMax ? (int)n : 0;
+}
+
+// W f32[Co,Ci] -> its partial maxima amax f32[ct_pw_prep_weight_partials] and, when wt != NULL, W^T f32[Ci,Co] (the A operand
+// of CT_PW_DGRAD_T), in one launch
+int ct_pw_prep_weight(const float* w, float* wt, float* amax, int Co, int Ci, ct_stream_t s) {
+  if (!w || !amax || ct_pw_prep_weight_partials(Co, Ci) == 0) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(pw_prep_weight_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, (hipStream_t)s, w, wt, (unsigned*)amax, Co,
+                     Ci);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   PwPlan p;
   return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
@@ -567,6 +616,9 @@ int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float
     hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, st, a, (float*)workspace, Co, Ci);
     CT_CHECK_LAUNCH();
     g.A = (const float*)workspace;
+    g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
+    rc = pw_launch<true, false>(g, blocks, st);
+  } else if (mode == CT_PW_DGRAD_T) {  // a IS W^T [Ci][Co] (ct_pw_prep_weight wrote it in the layer's forward)
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
     rc = pw_launch<true, false>(g, blocks, st);
   } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous

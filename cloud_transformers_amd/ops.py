@@ -78,7 +78,7 @@ def _pad_args(pad, B, N):
 # ---------------------------------------------------------------------------
 # Pointwise-convolution GEMMs (ct_pw_gemm: fp32 in / out, split-f16 on the matrix pipes)
 # ---------------------------------------------------------------------------
-PW_FWD, PW_DGRAD, PW_WGRAD = 0, 1, 2
+PW_FWD, PW_DGRAD, PW_WGRAD, PW_DGRAD_T = 0, 1, 2, 3
 # "split16": this library's kernels; "lib": rocBLAS fp32 through torch.bmm (the round-2 path, kept as the A/B switch and
 # for shapes the kernel does not take: a dimension that is not a multiple of 4)
 PW_GEMM = os.environ.get("CLOUDCT_PW_GEMM", "split16")
@@ -148,7 +148,7 @@ def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
     dev = b.device
     if mode == PW_FWD:
         out = torch.empty(B, Co, N, device=dev, dtype=torch.float32)
-    elif mode == PW_DGRAD:
+    elif mode in (PW_DGRAD, PW_DGRAD_T):
         out = torch.empty(B, Ci, N, device=dev, dtype=torch.float32)
     else:
         out = torch.empty(Co, Ci, device=dev, dtype=torch.float32)
@@ -161,19 +161,37 @@ def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
     return out
 
 
-def pw_forward(W, x):
-    """y[b] = W x[b] for W [Co,Ci], x [B,Ci,N] (both contiguous float32 on the device); returns (y, amax_W, amax_x) — the
-    scales are reused by the gradients — or (y, None, None) from the library GEMM."""
+def prep_weight(W, transpose):
+    """(partial maxima of |W|, W^T or None) in ONE launch (ct_pw_prep_weight): what the three products of a layer need of its
+    weight; falls back to amax() + no transpose for weights with more 32x32 tiles than ct_pw_gemm folds."""
+    lib = _lib.load()
+    Co, Ci = W.shape
+    n = lib.ct_pw_prep_weight_partials(Co, Ci)
+    if n == 0:
+        return amax(W), None
+    am = torch.empty(n, device=W.device, dtype=torch.float32)
+    Wt = torch.empty(Ci, Co, device=W.device, dtype=torch.float32) if transpose else None
+    with _on(W.device):
+        _lib.check(lib.ct_pw_prep_weight(_ptr(W), _ptr(Wt), _ptr(am), Co, Ci, _stream()), "ct_pw_prep_weight")
+    return am, Wt
+
+
+def pw_forward(W, x, need_dgrad=False):
+    """y[b] = W x[b] for W [Co,Ci], x [B,Ci,N] (both contiguous float32 on the device); returns (y, amax_W, amax_x, W^T) — the
+    scales and, with need_dgrad, the transposed weight are reused by the gradients — or (y, None, None, None) from the library
+    GEMM."""
     Co, Ci = W.shape
     B, _, N = x.shape
     if not pw_eligible(Co, Ci, N, PW_FWD):
-        return torch.bmm(W.unsqueeze(0).expand(B, -1, -1), x), None, None
-    am_w, am_x = amax(W), amax_of(x)
-    return pw_gemm(PW_FWD, W, x, am_w, am_x, B, Co, Ci, N), am_w, am_x
+        return torch.bmm(W.unsqueeze(0).expand(B, -1, -1), x), None, None, None
+    am_w, Wt = prep_weight(W, need_dgrad and pw_eligible(Co, Ci, N, PW_DGRAD))
+    am_x = amax_of(x)
+    return pw_gemm(PW_FWD, W, x, am_w, am_x, B, Co, Ci, N), am_w, am_x, Wt
 
 
-def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None):
-    """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous); am_g: g_y's maxima where the caller has them."""
+def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=None):
+    """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous); am_g: g_y's maxima where the caller has them; Wt:
+    the transposed weight pw_forward made (else the data gradient writes its own through its workspace)."""
     Co, Ci = W.shape
     B, _, N = x.shape
     mine_x = need_x and pw_eligible(Co, Ci, N, PW_DGRAD)
@@ -181,7 +199,9 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None):
     if am_g is None and (mine_x or mine_w):
         am_g = amax_of(g_y)
     g_x = g_w = None
-    if mine_x:
+    if mine_x and Wt is not None and am_w is not None:
+        g_x = pw_gemm(PW_DGRAD_T, Wt, g_y, am_w, am_g, B, Co, Ci, N)
+    elif mine_x:
         g_x = pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
     elif need_x:
         g_x = torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y)
@@ -668,7 +688,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)
         Ct = Wc.size(0)
-        y, am_w, am_x = pw_forward(Wc, x)
+        y, am_w, am_x, Wt = pw_forward(Wc, x, ctx.needs_input_grad[1])
         outs, saved, meta, items, c0 = [], [], [], [], 0
         for h in heads:
             for gb in h[1:3]:
@@ -687,7 +707,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
             _adain_group_fwd(items, B, N)
         assert c0 == Ct, "keys_bn + values_bn must cover the projections"
         ctx.save_for_backward(x, y, Wc, *saved)
-        ctx.am = (am_w, am_x)
+        ctx.am = (am_w, am_x, Wt)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
         return tuple(outs)
@@ -717,7 +737,7 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
             g_gbs.append(g_gb)
         with _on(x.device):
             _adain_group_bwd(items, B, N)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True, am_g=slots)
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True, am_g=slots, Wt=ctx.am[2])
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
@@ -1121,7 +1141,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         B, Cin, N = x.shape
         Wc = torch.cat([h[0][:, :, 0] for h in heads], dim=0)               # [sum Co, Cin]
         Ct = Wc.size(0)
-        y, am_w, am_x = pw_forward(Wc, x)                                   # [B, sum Co, N]
+        y, am_w, am_x, Wt = pw_forward(Wc, x, ctx.needs_input_grad[2])      # [B, sum Co, N]
         outs, items, meta, c0 = [], [], [], 0
         for h in heads:
             for (w, b, rm, rv, nbt, eps, mom) in (h[1:8], h[8:15]):
@@ -1140,7 +1160,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
         for it, (mean, rstd) in zip(items, stats):
             saved += [it["w"], it["b"], mean, rstd]
         ctx.save_for_backward(x, y, Wc, count, *saved)
-        ctx.am = (am_w, am_x)
+        ctx.am = (am_w, am_x, Wt)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
         ctx.group = group
@@ -1168,7 +1188,7 @@ class UnionKeysValuesFn(torch.autograd.Function):
                               amax=None if slots is None else _ptr(slots) + 4 * c0))
         with _on(x.device):
             bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True, am_g=slots)   # g_Wc [sum Co, Cin]
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True, am_g=slots, Wt=ctx.am[2])   # g_Wc [sum Co, Cin]
         grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]

@@ -451,8 +451,13 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
 #define CT_PW_FWD 0
 #define CT_PW_DGRAD 1
 #define CT_PW_WGRAD 2
+#define CT_PW_DGRAD_T 3 /* as CT_PW_DGRAD with a = W^T f32[Ci,Co] already (ct_pw_prep_weight): no workspace */
 int ct_amax_f32(const float* x, int64_t n, float* amax, ct_stream_t s);
 int ct_amax_len(void);
+/* a layer's weight for all three products in one launch: its partial maxima (ct_pw_prep_weight_partials(Co, Ci) of them, 0 =
+ * too many: use ct_amax_f32) and, when wt != NULL, W^T for CT_PW_DGRAD_T */
+int ct_pw_prep_weight_partials(int Co, int Ci);
+int ct_pw_prep_weight(const float* w, float* wt, float* amax, int Co, int Ci, ct_stream_t s);
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N);
 int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a,
                const float* amax_b, int n_amax_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,

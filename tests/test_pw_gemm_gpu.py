@@ -168,8 +168,9 @@ def test_batchnorm_kernels_leave_the_channel_maxima_of_what_they_write():
 
 
 def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
-    """BatchNorm+ReLU -> PointwiseConv1d -> BatchNorm+ReLU, forward and backward: the only ct_amax_f32 passes left are the
-    weight's and the first input's; results equal the ones computed with a pass over every operand."""
+    """BatchNorm+ReLU -> PointwiseConv1d -> BatchNorm+ReLU, forward and backward: no ct_amax_f32 pass is left (x and g_y come
+    with their producers' maxima, the weight's come out of ct_pw_prep_weight with its transpose); results equal the ones computed
+    with a pass over every operand."""
     from cloud_transformers_amd import ops
     from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
     torch.manual_seed(2)
@@ -190,7 +191,7 @@ def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
     real = ops.amax
     monkeypatch.setattr(ops, "amax", lambda t: (calls.append(tuple(t.shape)), real(t))[1])
     got = run()
-    assert sorted(calls) == [(256, C)], calls          # the weight only: x and g_y came with their maxima
+    assert calls == [], calls
     monkeypatch.setattr(ops, "amax_of", lambda t: real(t))
     want = run()
     for a, b in zip(got, want):
@@ -264,3 +265,18 @@ def test_syncbn_apply_kernels_leave_the_channel_maxima():
                                         sums.data_ptr(), sums.data_ptr() + 4 * C, count.data_ptr(), gx.data_ptr(), 0, gam.data_ptr(),
                                         B, C, N, 1, st), "apply_bwd")
     assert torch.equal(gam, gx.abs().amax(dim=(0, 2)))
+
+
+def test_prepared_weight_gives_the_same_data_gradient():
+    """ct_pw_prep_weight (partial maxima + W^T in one launch) and CT_PW_DGRAD_T against ct_amax_f32 + CT_PW_DGRAD: same bits."""
+    from cloud_transformers_amd import ops
+    torch.manual_seed(9)
+    for (B, Co, Ci, N) in [(2, 208, 512, 1024), (3, 52, 36, 260), (1, 640, 132, 512)]:
+        W = torch.randn(Co, Ci, device="cuda") * 0.3
+        gy = torch.randn(B, Co, N, device="cuda") * 1e-2
+        am, Wt = ops.prep_weight(W, True)
+        assert torch.equal(Wt, W.t().contiguous()) and float(am.max()) == float(W.abs().max())
+        am_g = ops.amax(gy)
+        a = ops.pw_gemm(ops.PW_DGRAD_T, Wt, gy, am, am_g, B, Co, Ci, N)
+        b = ops.pw_gemm(ops.PW_DGRAD, W, gy, ops.amax(W), am_g, B, Co, Ci, N)
+        assert torch.equal(a, b)
