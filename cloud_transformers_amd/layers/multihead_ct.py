@@ -267,18 +267,21 @@ class MultiHeadAdaIn(_MHCTCore):
         return result, stats
 
 
-HEAD_STREAMS = os.environ.get("CLOUDCT_HEAD_STREAMS", "0") == "1"
+# "auto" (default): only while a HIP graph is being captured — a replayed graph gains 3-4 % from the overlap, eager launches pay
+# for the stream switches on the host (the eager classifier step is 14 % slower with them); "1": always; "0": never
+HEAD_STREAMS = {"0": False, "1": True}.get(os.environ.get("CLOUDCT_HEAD_STREAMS", "auto"), "auto")
 _side_streams = {}
 
 
 def _run_heads(calls, ref):
     """[f() for f in calls] — the per-head chains of a union block (lattice, Splat, grouped conv, Slice of each head: independent
-    until the concatenation).  With CLOUDCT_HEAD_STREAMS=1 and a HIP tensor `ref`, head i > 0 runs on its own side stream, forked
+    until the concatenation).  When enabled (HEAD_STREAMS above) head i > 0 runs on its own side stream, forked
     from the current stream and joined before the results are used: the heads' kernels are many and small (a 3D head's raster
     kernels launch 128 workgroups on 256 CUs), so two chains side by side fill the chip and hide each other's launch gaps.
     Autograd replays every op's backward on the stream of its forward, so the backward chains overlap the same way; a HIP-graph
     capture records the fork and join as graph dependencies."""
-    if not (HEAD_STREAMS and len(calls) > 1 and ref.is_cuda):
+    on = HEAD_STREAMS if HEAD_STREAMS != "auto" else (ref.is_cuda and torch.cuda.is_current_stream_capturing())
+    if not (on and len(calls) > 1 and ref.is_cuda):
         return [f() for f in calls]
     cur = torch.cuda.current_stream(ref.device)
     key = (ref.device.index, len(calls))
