@@ -84,6 +84,17 @@ PW_FWD, PW_DGRAD, PW_WGRAD, PW_DGRAD_T = 0, 1, 2, 3
 PW_GEMM = os.environ.get("CLOUDCT_PW_GEMM", "split16")
 
 
+PW_BWD_STREAMS = os.environ.get("CLOUDCT_PW_BWD_STREAMS", "1") != "0"
+_pw_side = {}
+
+
+def _pw_side_stream(device):
+    s = _pw_side.get(device.index)
+    if s is None:
+        s = _pw_side[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
 def pw_eligible(Co, Ci, N, mode=None):
     """Whether ct_pw_gemm takes the product; with `mode`, whether it also beats the library GEMM there: an output-row
     extent under one 128-row tile leaves half the MFMA rows idle (tools/pw_gemm_bench.py: 0.7-0.95x at 64 rows)."""
@@ -199,16 +210,32 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=N
     if am_g is None and (mine_x or mine_w):
         am_g = amax_of(g_y)
     g_x = g_w = None
-    if mine_x and Wt is not None and am_w is not None:
-        g_x = pw_gemm(PW_DGRAD_T, Wt, g_y, am_w, am_g, B, Co, Ci, N)
-    elif mine_x:
-        g_x = pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
-    elif need_x:
-        g_x = torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y)
-    if mine_w:
-        g_w = pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax_of(x), B, Co, Ci, N)
-    elif need_w:
-        g_w = torch.bmm(g_y, x.transpose(1, 2)).sum(0)
+
+    def dgrad():
+        if mine_x and Wt is not None and am_w is not None:
+            return pw_gemm(PW_DGRAD_T, Wt, g_y, am_w, am_g, B, Co, Ci, N)
+        if mine_x:
+            return pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
+        return torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y) if need_x else None
+
+    def wgrad():
+        if mine_w:
+            return pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax_of(x), B, Co, Ci, N)
+        return torch.bmm(g_y, x.transpose(1, 2)).sum(0) if need_w else None
+
+    # the two gradients are independent and neither is a whole number of rounds of the chip's workgroup slots (1024 + 672
+    # workgroups on 512 slots at 848 x 512): inside a HIP-graph capture they go to two streams and fill each other's tails
+    if PW_BWD_STREAMS and mine_x and mine_w and g_y.is_cuda and torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream(g_y.device)
+        side = _pw_side_stream(g_y.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g_x = dgrad()
+        g_w = wgrad()
+        cur.wait_stream(side)
+        g_x.record_stream(cur)
+    else:
+        g_x, g_w = dgrad(), wgrad()
     return g_x, g_w
 
 
