@@ -288,6 +288,7 @@ def _run_heads(calls, ref):
     sides = _side_streams.get(key)
     if sides is None:
         sides = _side_streams[key] = [torch.cuda.Stream(device=ref.device) for _ in range(len(calls) - 1)]
+        ops.forked_streams.update(s.cuda_stream for s in sides)        # nothing running on them forks again (ops.pw_backward)
     outs = [None] * len(calls)
     for i, side in enumerate(sides, start=1):
         side.wait_stream(cur)

@@ -86,6 +86,9 @@ PW_GEMM = os.environ.get("CLOUDCT_PW_GEMM", "split16")
 
 PW_BWD_STREAMS = os.environ.get("CLOUDCT_PW_BWD_STREAMS", "1") != "0"
 _pw_side = {}
+# streams that are themselves forks inside a capture (the heads' side streams of layers.multihead_ct._run_heads): work on them
+# does not fork again — a second level of forks shared by two concurrent chains crashed hipStreamEndCapture
+forked_streams = set()
 
 
 def _pw_side_stream(device):
@@ -225,7 +228,8 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=N
 
     # the two gradients are independent and neither is a whole number of rounds of the chip's workgroup slots (1024 + 672
     # workgroups on 512 slots at 848 x 512): inside a HIP-graph capture they go to two streams and fill each other's tails
-    if PW_BWD_STREAMS and mine_x and mine_w and g_y.is_cuda and torch.cuda.is_current_stream_capturing():
+    if (PW_BWD_STREAMS and mine_x and mine_w and g_y.is_cuda and torch.cuda.is_current_stream_capturing()
+            and torch.cuda.current_stream(g_y.device).cuda_stream not in forked_streams):
         cur = torch.cuda.current_stream(g_y.device)
         side = _pw_side_stream(g_y.device)
         side.wait_stream(cur)
