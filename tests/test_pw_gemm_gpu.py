@@ -7,6 +7,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+def _needs_split16():
+    from cloud_transformers_amd import ops
+    if ops.PW_GEMM != "split16":
+        pytest.skip("the producers leave operand maxima only for ct_pw_gemm (CLOUDCT_PW_GEMM=split16)")
+
+
 # relative to sum_k |a_k b_k|: three f16 terms carry 2^-21 of each product; fp32 accumulation adds ~sqrt(K) 2^-24
 BOUND = 2.0e-6
 
@@ -144,6 +150,7 @@ def test_pointwise_layer_against_float64_conv1d(bias):
 def test_batchnorm_kernels_leave_the_channel_maxima_of_what_they_write():
     """ct_bn_relu_fwd_amax / _bwd_amax: max |y| (after ReLU and skip) and max |g_x| per channel, bit for bit the maxima of the
     tensors they wrote — the operand scale of the pointwise GEMM that reads them next, without a pass over them."""
+    _needs_split16()
     from cloud_transformers_amd import ops
     torch.manual_seed(1)
     for (B, C, N, relu, res) in [(4, 96, 1024, True, True), (2, 40, 260, False, False), (8, 16, 8192, True, False)]:
@@ -171,6 +178,7 @@ def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
     """BatchNorm+ReLU -> PointwiseConv1d -> BatchNorm+ReLU, forward and backward: no ct_amax_f32 pass is left (x and g_y come
     with their producers' maxima, the weight's come out of ct_pw_prep_weight with its transpose); results equal the ones computed
     with a pass over every operand."""
+    _needs_split16()
     from cloud_transformers_amd import ops
     from cloud_transformers_amd.layers.pointwise import PointwiseConv1d
     torch.manual_seed(2)
@@ -199,6 +207,7 @@ def test_block_level_convs_reuse_the_producers_maxima(monkeypatch):
 
 
 def test_adain_kernels_leave_the_row_maxima_of_what_they_write():
+    _needs_split16()
     from cloud_transformers_amd import ops
     torch.manual_seed(3)
     for (B, C, N, relu, res) in [(2, 96, 4096, True, True), (3, 40, 260, False, False)]:
