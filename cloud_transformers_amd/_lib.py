@@ -68,6 +68,7 @@ CT_OK = 0
 REDUCE = {"max": 0, "sum": 1}
 PAD_NONE, PAD_F32, PAD_I32 = 0, 1, 2
 BWD_ACCUMULATE_KEYS = 1
+TICKETS_BYTES = 65536
 DEBUG_NO_HOT = 1
 DEBUG_FORCE_HOT = 2
 
@@ -131,6 +132,11 @@ def build(force=False, verbose=False):
     Safe when several processes call it at once (the ranks `launch.spawn_ranks` / torchrun start on a fresh checkout):
     the compile runs under an exclusive file lock into a per-process temporary name, staleness is re-checked under the
     lock (a rank that waited finds the library its sibling built), and the finished file is renamed into place."""
+    if os.environ.get("CLOUDCT_LIB"):
+        # an experiment library named by the caller: use it as it is, never relink the product objects over it
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("CLOUDCT_LIB=%s does not exist" % LIB_PATH)
+        return LIB_PATH
     if not force and not _stale():
         return LIB_PATH
     import fcntl
@@ -207,6 +213,9 @@ SIGNATURES = {
     "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_slice_bwd_ws": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_tickets_init": (_i, [_vp, _vp]),
+    "ct_slice_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_splat_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_keys": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
@@ -252,6 +261,7 @@ SIGNATURES = {
     "ct_mhct_core_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_mhct_core_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_mhct_core_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_mhct_core_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_mhct_core_bwd_fused_supported": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_mhct_core_bwd_fused_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_mhct_core_bwd_fused": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),

@@ -1139,6 +1139,14 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
                      const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
                      float* g_b, void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim,
                      const int* W, ct_stream_t s) {
+  return ct_mhct_core_bwd_tk(keys, feat, pad, pad_dtype, conv_w, z, y, g_out, g_feat, g_keys, g_w, g_b, workspace,
+                             workspace_bytes, nullptr, B, H, C, N, dim, W, s);
+}
+
+int ct_mhct_core_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                        const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
+                        float* g_b, void* workspace, size_t workspace_bytes, void* tickets, int B, int H, int C, int N, int dim,
+                        const int* W, ct_stream_t s) {
   if (!keys || !feat || !conv_w || !z || !y || !g_out || !g_feat || !g_keys || !g_w) return CT_EINVAL;
   if (!ct_mhct_core_supported(B, H, C, N, dim, W)) return CT_EINVAL;
   const size_t need = ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, W);
@@ -1150,13 +1158,13 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
   float* g_z = (float*)((char*)workspace + grid_bytes);
   void* sub = (char*)workspace + 2 * grid_bytes;
   const size_t sub_bytes = workspace_bytes - 2 * grid_bytes;
-  int rc = ct_slice_bwd_ws(keys, y, pad, pad_dtype, g_out, g_y, g_keys, sub, sub_bytes, B, H, C, N, dim, W, s);
+  int rc = ct_slice_bwd_tk(keys, y, pad, pad_dtype, g_out, g_y, g_keys, sub, sub_bytes, tickets, B, H, C, N, dim, W, s);
   if (rc != CT_OK) return rc;
   rc = ct_gconv_bwd_data(g_y, conv_w, g_z, B, H, C, C, dim, W, s);
   if (rc != CT_OK) return rc;
   rc = ct_gconv_bwd_weight(z, g_y, g_w, g_b, sub, sub_bytes, B, H, C, C, dim, W, s);
   if (rc != CT_OK) return rc;
-  return ct_splat_bwd_ex(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys, sub, sub_bytes, B, H, C, N, dim, W,
+  return ct_splat_bwd_tk(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys, sub, sub_bytes, tickets, B, H, C, N, dim, W,
                          CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS, s);
 }
 

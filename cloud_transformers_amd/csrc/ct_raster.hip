@@ -61,6 +61,12 @@ struct RasterArgs {
   int accumulate;       // hot Splat(max) backward: g_pos += result instead of g_pos = result
   int nseg;             // fused Slice backward: point segments per (b,h) plane (grid.z = B * nseg); a.N = points per segment,
   int Nrow;             //   Nrow = length of a row of the point-sized tensors (= N when nseg == 1)
+  // in-kernel folds of the partials (ct_raster_hot.h, arrive_last): arrival tickets (null: the partials are added by
+  // sum_parts launches), where the folded g_keys / g_grid go, and whether the g_keys fold adds to what is there
+  unsigned* tickets;
+  float* fold_gpos;
+  float* fold_grid;
+  int fold_acc;
 };
 
 template <int DIM, bool FROM_KEYS>
@@ -1515,6 +1521,13 @@ bool hot_bwd_plan(int B, int H, int C, int G, size_t per_ch, size_t fixed, long 
   return true;
 }
 
+// arrival tickets cover the launch: one word per (plane, segment) for the g_keys folds, one per (plane, chunk group) for the
+// g_grid folds, each kind in its half of the CT_TICKETS_BYTES buffer (ct_raster_hot.h: kTicketHalf)
+bool tickets_cover(const void* tickets, long long planes, int ncg, int nseg) {
+  const long long half = CT_TICKETS_BYTES / 8;
+  return tickets != nullptr && ((uintptr_t)tickets & 3) == 0 && planes * nseg <= half && planes * ncg <= half;
+}
+
 bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
   return hot_enabled() && (a.N & 3) == 0 && (G & 3) == 0 && (a.C & 3) == 0 && (ptr_bits & 15) == 0 &&
          ((long long)a.B * a.H >= 32 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
@@ -1582,7 +1595,7 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   int ncg = 1;
   const int nseg = slice_bwd_segments(B, H, C, N, g.G, 2);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
-  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
   return (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
 }
 
@@ -1596,14 +1609,14 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
-  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
   const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
   const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
   if (nseg > 1 && (!ws || ws_bytes < (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0) + (size_t)nseg * grid_n * 4)) return CT_EINVAL;
   if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
     // no scratch for the partial sums: one group per plane if there are planes enough to be worth it
     if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
-    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
+    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 2) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
     ncg = 1;
   }
   a.tile_in = grid;
@@ -1614,12 +1627,20 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   float* const grid_parts = nseg > 1 ? (float*)((char*)ws + (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0)) : nullptr;
   if (nseg > 1) a.tile_out = grid_parts;
   a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+  // with arrival tickets the plane's last workgroup adds the partials itself: no sum_parts launches behind the kernel
+  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg);
+  if (!fold) a.tickets = nullptr;
+  a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
 #define CT_MK_SLICE_BWD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true>
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   note(nseg > 1 ? "slice_bwd_fused_segments" : ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
+  if (fold) {
+    note("folded");
+    return CT_OK;
+  }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
@@ -1638,10 +1659,11 @@ int run_scatter_add_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
   HotPlan hp;
-  if (!hot_chunks(a.C, (size_t)g.G * 4, (size_t)(g.G + a.C + 1) * 4, hp)) return CT_EINVAL;
+  if (!hot_chunks(a.C, (size_t)g.G * 4, (size_t)(g.G + a.C + 2) * 4, hp)) return CT_EINVAL;
   int ncg = 1;
-  hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 4, (size_t)(g.G + a.C + 1) * 4, kHalfCuLdsBytes, hp, ncg);   // no g_keys: groups are free
+  hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 4, (size_t)(g.G + a.C + 2) * 4, kHalfCuLdsBytes, hp, ncg);   // no g_keys: groups are free
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
+  a.tickets = nullptr;
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
 #define CT_MK_SCATTER_ADD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, false>
@@ -1689,10 +1711,13 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   float* const out = a.g_pos;
   const int accumulate = a.accumulate;
   const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
+  if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
     a.gpos_stride = gpos_n;
     a.accumulate = 0;
+    a.fold_gpos = out; a.fold_acc = accumulate;
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
@@ -1701,6 +1726,10 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
   note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");
+  if (fold) {
+    note("folded");
+    return CT_OK;
+  }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
@@ -1742,7 +1771,7 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   int ncg = 1;
   const int nseg = slice_bwd_segments(B, H, C, N, g.G, 3);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
-  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
   return (ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
 }
 
@@ -1756,13 +1785,13 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   HotPlan hp;
   int ncg = 1;
-  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
+  if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
   const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
   const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
   if (nseg > 1 && (!ws || ws_bytes < (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0) + (size_t)nseg * grid_n * 4)) return CT_EINVAL;
   if (ncg > 1 && (!ws || ws_bytes < (size_t)ncg * gpos_n * 4)) {
     if ((long long)a.B * a.H < 128 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
-    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 1) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
+    if (!hot_chunks(a.C, (size_t)g.G * 8, (size_t)(g.G + a.C + 2) * 4, hp, CT_FUSED_LDS_BUDGET)) return CT_EINVAL;
     ncg = 1;
   }
   a.tile_in = grid;
@@ -1773,6 +1802,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   float* const grid_parts = nseg > 1 ? (float*)((char*)ws + (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0)) : nullptr;
   if (nseg > 1) a.tile_out = grid_parts;
   a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg);     // see the 2D form
+  if (!fold) a.tickets = nullptr;
+  a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
   if (nq <= kHotThreads)
@@ -1780,6 +1812,10 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   else
     CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 2>), (slice_bwd_fused3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
   note(nseg > 1 ? "slice_bwd_fused3_segments" : ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
+  if (fold) {
+    note("folded");
+    return CT_OK;
+  }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
@@ -1822,10 +1858,13 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   float* const out = a.g_pos;
   const int accumulate = a.accumulate;
   const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
+  if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
     a.gpos_stride = gpos_n;
     a.accumulate = 0;
+    a.fold_gpos = out; a.fold_acc = accumulate;
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
@@ -1833,6 +1872,10 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   // chunks makes the 3D kernel spill
   CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, hot_threads(nq), hp.lds, st, a, g);
   note(ncg > 1 ? "splat_max_bwd_hot3_groups" : "splat_max_bwd_hot3");
+  if (fold) {
+    note("folded");
+    return CT_OK;
+  }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
     if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
@@ -2095,7 +2138,8 @@ int splat_fwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
 template <bool FROM_KEYS>
 int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype, const float* grid,
                    const float* g_grid, float* g_feat, float* g_pos, void* ws, size_t ws_bytes,
-                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st, int flags = 0) {
+                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st, int flags = 0,
+                   void* tickets = nullptr) {
   if (!valid_common(B, H, C, N, dim, W) || !feat || !g_grid || !g_feat || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   note_reset();
   if (flags & CT_BWD_ACCUMULATE_KEYS) {
@@ -2108,6 +2152,7 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
       RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
       a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = grid; a.tile_in2 = g_grid;
       a.accumulate = 1;
+      a.tickets = (unsigned*)tickets;
       const int r = dim == 2 ? run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st) : run_splat_max_bwd<3, FROM_KEYS>(a, W, ws, head, st);
       if (r != CT_EINVAL) return r;
     }
@@ -2135,6 +2180,7 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
   if (reduce == CT_REDUCE_MAX0) {
     if (!grid) return CT_EINVAL;
     a.tile_in = grid; a.tile_in2 = g_grid;
+    a.tickets = (unsigned*)tickets;
     return dim == 2 ? run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, ws_bytes, st)
                     : run_splat_max_bwd<3, FROM_KEYS>(a, W, ws, ws_bytes, st);
   } else if (reduce == CT_REDUCE_SUM) {
@@ -2166,11 +2212,12 @@ int slice_fwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
 template <bool FROM_KEYS>
 int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, const float* g_out,
                    float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st,
-                   void* ws = nullptr, size_t ws_bytes = 0) {
+                   void* ws = nullptr, size_t ws_bytes = 0, void* tickets = nullptr) {
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = g_out; a.tile_out = g_grid;
+  a.tickets = (unsigned*)tickets;          // only the hot kernels (run_slice_bwd_hot) fold; every other path ignores them
   // (A single fused kernel — grid tile + accumulator tile of a whole (b,h) plane in LDS, one
   //  1024-thread workgroup per CU — was built twice and measured SLOWER than the pair below
   //  (105-124 us vs 92-99 us on the headline shape): the pass is co-bound by LDS atomics/reads
@@ -2317,6 +2364,29 @@ int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int p
   if (!keys) return CT_EINVAL;
   PosSrc pos = {keys, nullptr, nullptr};
   return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes);
+}
+
+int ct_tickets_init(void* tickets, ct_stream_t s) {
+  if (!tickets || ((uintptr_t)tickets & 3) != 0) return CT_EINVAL;
+  return hipMemsetAsync(tickets, 0, CT_TICKETS_BYTES, (hipStream_t)s) == hipSuccess ? CT_OK : CT_ELAUNCH;
+}
+
+int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                    float* g_grid, float* g_keys, void* ws, size_t ws_bytes, void* tickets, int B, int H, int C, int N, int dim,
+                    const int* W, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes,
+                              tickets);
+}
+
+int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,
+                    const float* g_grid, float* g_feat, float* g_keys, void* ws, size_t ws_bytes, void* tickets,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s) {
+  if (!keys || (flags & ~CT_BWD_ACCUMULATE_KEYS)) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
+                              B, H, C, N, dim, W, reduce, (hipStream_t)s, flags, tickets);
 }
 
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out, float* g_grid,

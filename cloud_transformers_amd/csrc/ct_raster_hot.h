@@ -69,6 +69,101 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 
 typedef float ct_f2 __attribute__((ext_vector_type(2)));
 
+// ---------------------------------------------------------------------------
+// Partial results of a (b, h) plane's workgroups, folded INSIDE the producing kernel (no sum_parts launch behind it).
+// Few-plane launches deal a plane's channel chunks (ncg groups) or its points (nseg segments) to several workgroups; every
+// group leaves a partial g_keys (every segment a partial g_grid tile) in the caller's workspace.  With arrival tickets
+// (RasterArgs::tickets: zeroed once by ct_tickets_init, self-resetting) the workgroup whose ticket is the plane's last
+// adds the partials in ascending order — the order, and so the bits, of sum_parts_kernel.  Hand-off as in ct_mhct.hip /
+// MI355X_MICROARCH.md "Valid forms": write-through (sc1) stores of the partials -> every storing wave's vmcnt(0) ->
+// workgroup barrier -> one relaxed agent-scope add -> the workgroup whose add returned the last value takes an agent
+// acquire, waits for it, joins the barrier -> plain loads.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void st_sc1_4(float* p, float4 v) {
+  const ct_f4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+// a partial that another workgroup will read goes out write-through, everything else as a streaming store
+__device__ __forceinline__ void st_part4(float* p, float4 v, bool handoff) {
+  if (handoff) st_sc1_4(p, v);
+  else st_stream4(p, v);
+}
+
+constexpr int kTicketWords = CT_TICKETS_BYTES / 4;
+constexpr int kTicketHalf = kTicketWords / 2;       // [0, half): g_keys folds, [half, 2 half): g_grid folds
+
+// All threads of the workgroup call this after their partial stores.  Returns (block-uniform) bit 0: this workgroup is
+// the last of `nk` to arrive at ticket `tk` (null: not taking part), bit 1: the same for `tg` / `ng`.
+__device__ __forceinline__ unsigned arrive_last(unsigned* tk, unsigned nk, unsigned* tg, unsigned ng, unsigned* s_flag,
+                                                bool plain_stores = false) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (plain_stores) {       // partials written with ordinary stores (kept in this XCD's L2): one agent-scope release
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    unsigned f = 0;
+    if (tk && __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk - 1u) {
+      f |= 1u;
+      __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // everybody has arrived: ready for the next launch
+    }
+    if (tg && __hip_atomic_fetch_add(tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u) {
+      f |= 2u;
+      __hip_atomic_store(tg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (f) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = f;
+  }
+  __syncthreads();
+  return *s_flag;
+}
+
+// out[i] (= old +) parts[i] + parts[stride + i] + ... (k copies, ascending), n4 float4 — sum_parts_kernel's arithmetic
+__device__ __forceinline__ void fold_rows(const float* parts, size_t stride, int k, float* out, int n4, bool acc) {
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    float4 s = ((const float4*)parts)[i];
+    for (int j = 1; j < k; ++j) {
+      const float4 t = ((const float4*)(parts + (size_t)j * stride))[i];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (acc) {
+      const float4 o = ((const float4*)out)[i];
+      s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
+    }
+    ((float4*)out)[i] = s;
+  }
+}
+
+// Workgroup -> (chunk group, point segment, head, cloud).  The launch order is x-fastest and consecutive workgroups go to
+// the 8 XCDs in turn (observed; speed only), so the `per` = ncg * nseg workgroups of a plane — which share its keys, its
+// conv tile and the partials the last of them folds — are given linear ids congruent mod 8: one XCD, one L2.
+struct WgCoord {
+  int cgi, seg, h, b;
+};
+__device__ __forceinline__ WgCoord wg_coord(int ncg, int nseg, int H, int B) {
+  WgCoord w;
+  const unsigned per = (unsigned)(ncg * nseg), planes = (unsigned)(H * B);
+  if (per > 1 && (planes & 7u) == 0) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned grp = L / (8u * per), r = L - grp * 8u * per;
+    const unsigned plane = grp * 8u + (r & 7u), k = r >> 3;
+    w.cgi = (int)(k % (unsigned)ncg);
+    w.seg = (int)(k / (unsigned)ncg);
+    w.h = (int)(plane % (unsigned)H);
+    w.b = (int)(plane / (unsigned)H);
+  } else {
+    w.cgi = blockIdx.x;
+    w.h = blockIdx.y;
+    w.b = blockIdx.z / nseg;
+    w.seg = blockIdx.z - w.b * nseg;
+  }
+  return w;
+}
+
 
 // per-axis terms and corner weights of one 2D point
 struct Pt2 {
@@ -152,12 +247,16 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
   // blockIdx.z = (cloud, point segment): with more points per plane than a workgroup's registers hold (N > 4096) or too
   // few planes, a plane's points are dealt to a.nseg workgroups, each scattering into its own partial tile (summed
   // afterwards in a fixed order: still bitwise reproducible); rows are Nr floats long, this segment starts at `so`
-  const int h = blockIdx.y, nsg = a.nseg > 0 ? a.nseg : 1, b = blockIdx.z / nsg, seg = blockIdx.z - b * nsg;
+  const int nsg = a.nseg > 0 ? a.nseg : 1;
+  const WgCoord wg = wg_coord(a.ncg, nsg, a.H, a.B);
+  const int h = wg.h, b = wg.b, seg = wg.seg;
   const size_t bh = (size_t)b * a.H + h;
   const int Nr = a.Nrow > 0 ? a.Nrow : a.N;          // (0: a caller that knows no segments)
   const size_t so = (size_t)seg * a.N;
   const int tid = threadIdx.x;
   const int off[4] = {0, W1, 1, W1 + 1};
+  // partials another workgroup folds (tickets) are stored write-through
+  const bool fold_keys = GATHER && a.tickets != nullptr && a.ncg > 1, fold_grid = a.tickets != nullptr && nsg > 1;
   int n0[QPT], n0c[QPT];
   bool active[QPT];
 #pragma unroll
@@ -214,7 +313,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 
   // Few (b,h) planes (the zoo's H16 blocks): the chunks of a plane are dealt to a.ncg workgroups (blockIdx.x), each
   // writing its partial g_keys to its own slice of the workspace (summed afterwards in a fixed order).
-  const int cgi = blockIdx.x;
+  const int cgi = wg.cgi;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);            // multiple of 4
@@ -421,8 +520,8 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
         oa = make_float4(__int_as_float(lo[0]), __int_as_float(lo[1]), __int_as_float(lo[2]), __int_as_float(lo[3]));
         ob = make_float4(__int_as_float(hw[0]), __int_as_float(hw[1]), __int_as_float(hw[2]), __int_as_float(hw[3]));
       }
-      st_stream4(gout + (size_t)(2 * pr) * G + cell, oa);
-      st_stream4(gout + (size_t)(2 * pr + 1) * G + cell, ob);
+      st_part4(gout + (size_t)(2 * pr) * G + cell, oa, fold_grid);
+      st_part4(gout + (size_t)(2 * pr + 1) * G + cell, ob, fold_grid);
       if (more) w[0] = w[1] = make_int4(0, 0, 0, 0);
     }
 #else
@@ -435,7 +534,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       float4 o;
       if (fixed) o = make_float4((float)r.x * q, (float)r.y * q, (float)r.z * q, (float)r.w * q);
       else o = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
-      st_stream4(gout + ((size_t)t << 2), o);
+      st_part4(gout + ((size_t)t << 2), o, fold_grid);
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
 #endif
@@ -451,8 +550,26 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
       oy.x = gs[u][0][1] * ct_key_mask(ty.x); oy.y = gs[u][1][1] * ct_key_mask(ty.y);
       oy.z = gs[u][2][1] * ct_key_mask(ty.z); oy.w = gs[u][3][1] * ct_key_mask(ty.w);
       float* gp = a.g_pos + (size_t)cgi * a.gpos_stride;
-      st_stream4(gp + (bh * 2 + 0) * Nr + so + n0[u], ox);
-      st_stream4(gp + (bh * 2 + 1) * Nr + so + n0[u], oy);
+      st_part4(gp + (bh * 2 + 0) * Nr + so + n0[u], ox, fold_keys);
+      st_part4(gp + (bh * 2 + 1) * Nr + so + n0[u], oy, fold_keys);
+    }
+  }
+  if (fold_keys || fold_grid) {       // kernel-uniform
+    unsigned* s_flag = s_k + 1;
+    const unsigned f = arrive_last(fold_keys ? a.tickets + (bh * nsg + seg) : nullptr, (unsigned)a.ncg,
+                                   fold_grid ? a.tickets + kTicketHalf + (bh * a.ncg + cgi) : nullptr, (unsigned)nsg, s_flag);
+    if (f & 1u) {      // this segment's g_keys: the chunk groups' partials, ascending
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fold_rows(a.g_pos + (bh * 2 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * Nr + so, N >> 2, false);
+    }
+    if (f & 2u) {      // this chunk group's g_grid tiles: the segments' partials, ascending
+      const size_t grid_n = (size_t)a.B * a.H * a.C * G;
+      for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+        const int c0 = chunk * CC, cc = min(CC, a.C - c0);
+        const size_t o = (bh * a.C + c0) * (size_t)G;
+        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, false);
+      }
     }
   }
 }
@@ -572,12 +689,11 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
 
 template <bool HAS_PAD, bool CLAIMS, int WT, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const GridW<2>& g, float4* ZG, int* s_cnt,
-                                                    size_t bh, int b, float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
+                                                    size_t bh, int b, int cgi, float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
   const int G = WT ? WT * WT : g.G, CC = a.CC, N = a.N;
   const int tid = threadIdx.x;
   const int nq = N >> 2;
-  int nz = 0, nm = 0;
-  const int cgi = blockIdx.x;                     // chunk group (see slice_bwd_fused_kernel)
+  int nz = 0, nm = 0;                             // cgi: chunk group (see slice_bwd_fused_kernel)
   float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
@@ -631,8 +747,13 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
           oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
         }
-        *(float4*)px = ox;
-        *(float4*)py = oy;
+        if (a.tickets != nullptr && a.ncg > 1 && chunk + a.ncg >= a.nchunks) {
+          st_sc1_4(px, ox);      // the finished partial, handed to the workgroup that folds the plane (arrive_last)
+          st_sc1_4(py, oy);
+        } else {
+          *(float4*)px = ox;
+          *(float4*)py = oy;
+        }
       }
     }
   }
@@ -653,9 +774,11 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
-  const int h = blockIdx.y, b = blockIdx.z;
+  const WgCoord wg = wg_coord(a.ncg, 1, a.H, a.B);
+  const int h = wg.h, b = wg.b;
   const size_t bh = (size_t)b * a.H + h;
   const int N = a.N;
+  const bool fold_keys = a.tickets != nullptr && a.ncg > 1;
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;       // ordered before use by the barriers of the pass
   float gs[QPT ? QPT : 1][4][2];
 #pragma unroll
@@ -663,13 +786,13 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
   bool tie = false;
-  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, gs, tie);
+  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, gs, tie);
   if (tie) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
-    splat_bwd_plane_pass<HAS_PAD, true, WT, QPT>(a, g, ZG, s_cnt, bh, b, gs, tie);
+    splat_bwd_plane_pass<HAS_PAD, true, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, gs, tie);
   }
   if constexpr (QPT > 0) {
 #pragma unroll
@@ -682,16 +805,28 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
                                 gs[u][2][0] * ct_key_mask(tx.z), gs[u][3][0] * ct_key_mask(tx.w));
         float4 oy = make_float4(gs[u][0][1] * ct_key_mask(ty.x), gs[u][1][1] * ct_key_mask(ty.y),
                                 gs[u][2][1] * ct_key_mask(ty.z), gs[u][3][1] * ct_key_mask(ty.w));
-        float* px = a.g_pos + (size_t)blockIdx.x * a.gpos_stride + (bh * 2 + 0) * N + n0;
-        float* py = a.g_pos + (size_t)blockIdx.x * a.gpos_stride + (bh * 2 + 1) * N + n0;
+        float* px = a.g_pos + (size_t)wg.cgi * a.gpos_stride + (bh * 2 + 0) * N + n0;
+        float* py = a.g_pos + (size_t)wg.cgi * a.gpos_stride + (bh * 2 + 1) * N + n0;
         if (a.accumulate) {
           const float4 qx = *(const float4*)px, qy = *(const float4*)py;
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
           oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
         }
-        *(float4*)px = ox;
-        *(float4*)py = oy;
+        if (fold_keys) {
+          st_sc1_4(px, ox);
+          st_sc1_4(py, oy);
+        } else {
+          *(float4*)px = ox;
+          *(float4*)py = oy;
+        }
       }
+    }
+  }
+  if (fold_keys) {       // kernel-uniform: the chunk groups' partial g_keys, added by the plane's last workgroup
+    if (arrive_last(a.tickets + bh, (unsigned)a.ncg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fold_rows(a.g_pos + (bh * 2 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * N, N >> 2, a.fold_acc != 0);
     }
   }
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void load_keys3(const float* keys, size_t bh, int N, 
 }
 
 __device__ __forceinline__ void store_gkeys3(float* gpos, size_t bh, int N, int n0, const float (&gs)[4][3], const float (&k)[3][4],
-                                             bool accumulate) {
+                                             bool accumulate, bool handoff = false /* write-through: read by another workgroup */) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     float4 o = make_float4(gs[0][j] * ct_key_mask(k[j][0]), gs[1][j] * ct_key_mask(k[j][1]),
@@ -48,7 +48,8 @@ __device__ __forceinline__ void store_gkeys3(float* gpos, size_t bh, int N, int 
       const float4 q = *(const float4*)p;
       o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
     }
-    *(float4*)p = o;
+    if (handoff) st_sc1_4(p, o);
+    else *(float4*)p = o;
   }
 }
 
@@ -64,7 +65,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
   int* cnt = acc + (size_t)CC * G;
   unsigned* s_max = (unsigned*)(cnt + G);
   unsigned* s_k = s_max + a.C;
-  const int h = blockIdx.y, nsg = a.nseg > 0 ? a.nseg : 1, b = blockIdx.z / nsg, seg = blockIdx.z - b * nsg;      // point segments: see slice_bwd_fused_kernel
+  const int nsg = a.nseg > 0 ? a.nseg : 1;                      // point segments, placement, folds: see slice_bwd_fused_kernel
+  const WgCoord wg = wg_coord(a.ncg, nsg, a.H, a.B);
+  const int h = wg.h, b = wg.b, seg = wg.seg;
+  const bool fold_keys = a.tickets != nullptr && a.ncg > 1, fold_grid = a.tickets != nullptr && nsg > 1;
   const size_t bh = (size_t)b * a.H + h;
   const int Nr = a.Nrow > 0 ? a.Nrow : a.N;          // (0: a caller that knows no segments)
   const int so = seg * a.N;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 #pragma unroll
   for (int i = 0; i < 4; ++i) gs[0][i][0] = gs[0][i][1] = gs[0][i][2] = 0.0f;
 
-  const int cgi = blockIdx.x;
+  const int cgi = wg.cgi;
   float* const gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
@@ -274,7 +278,9 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (!kKeepGs && active[u]) store_gkeys3(gpos, bh, Nr, so + n0c[u], gs[0], k, chunk > cgi || cq > 0);
+        if (!kKeepGs && active[u])      // (the workgroup's last share of a quad is the finished partial: handed off when folded)
+          store_gkeys3(gpos, bh, Nr, so + n0c[u], gs[0], k, chunk > cgi || cq > 0,
+                       fold_keys && chunk + a.ncg >= a.nchunks && cq == (cc >> 2) - 1);
       }
       if (any_float) {
 #pragma unroll 1
@@ -332,8 +338,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
         oa = make_float4(__int_as_float(lo[0]), __int_as_float(lo[1]), __int_as_float(lo[2]), __int_as_float(lo[3]));
         ob = make_float4(__int_as_float(hw[0]), __int_as_float(hw[1]), __int_as_float(hw[2]), __int_as_float(hw[3]));
       }
-      st_stream4(gout + (size_t)(2 * pr) * G + cell, oa);
-      st_stream4(gout + (size_t)(2 * pr + 1) * G + cell, ob);
+      st_part4(gout + (size_t)(2 * pr) * G + cell, oa, fold_grid);
+      st_part4(gout + (size_t)(2 * pr + 1) * G + cell, ob, fold_grid);
       if (more) w[0] = w[1] = make_int4(0, 0, 0, 0);
     }
 #else
@@ -346,7 +352,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
       float4 o;
       if (fixed) o = make_float4((float)r.x * q, (float)r.y * q, (float)r.z * q, (float)r.w * q);
       else o = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
-      st_stream4(gout + ((size_t)t << 2), o);
+      st_part4(gout + ((size_t)t << 2), o, fold_grid);
       if (more) ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
     }
 #endif
@@ -355,7 +361,25 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
     if (active[0]) {
       float k[3][4];
       load_keys3(a.pos.keys, bh, Nr, so + n0[0], k);
-      store_gkeys3(gpos, bh, Nr, so + n0[0], gs[0], k, false);
+      store_gkeys3(gpos, bh, Nr, so + n0[0], gs[0], k, false, fold_keys);
+    }
+  }
+  if (fold_keys || fold_grid) {       // kernel-uniform (see slice_bwd_fused_kernel)
+    unsigned* s_flag = s_k + 1;
+    const unsigned f = arrive_last(fold_keys ? a.tickets + (bh * nsg + seg) : nullptr, (unsigned)a.ncg,
+                                   fold_grid ? a.tickets + kTicketHalf + (bh * a.ncg + cgi) : nullptr, (unsigned)nsg, s_flag);
+    if (f & 1u) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        fold_rows(a.g_pos + (bh * 3 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * Nr + so, N >> 2, false);
+    }
+    if (f & 2u) {
+      const size_t grid_n = (size_t)a.B * a.H * a.C * G;
+      for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+        const int c0 = chunk * CC, cc = min(CC, a.C - c0);
+        const size_t o = (bh * a.C + c0) * (size_t)G;
+        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, false);
+      }
     }
   }
 }
@@ -465,12 +489,11 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
 
 template <bool HAS_PAD, bool CLAIMS, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const GridW<3>& g, float4* ZG, int* s_cnt, size_t bh,
-                                                     int b, const int (&off)[8], float (&gs_reg)[QPT ? QPT : 1][4][3], bool& tie) {
+                                                     int b, int cgi, const int (&off)[8], float (&gs_reg)[QPT ? QPT : 1][4][3], bool& tie) {
   const int G = g.G, CC = a.CC, N = a.N;
   const int tid = threadIdx.x;
   const int nq = N >> 2;
   int nz = 0, nm = 0;
-  const int cgi = blockIdx.x;
   float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
@@ -505,7 +528,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
         splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, k, off, gs, nm);
-        store_gkeys3(gpos, bh, N, q << 2, gs, k, chunk > cgi);
+        store_gkeys3(gpos, bh, N, q << 2, gs, k, chunk > cgi, a.tickets != nullptr && a.ncg > 1 && chunk + a.ncg >= a.nchunks);
       }
     }
   }
@@ -526,9 +549,11 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
-  const int h = blockIdx.y, b = blockIdx.z;
+  const WgCoord wg = wg_coord(a.ncg, 1, a.H, a.B);
+  const int h = wg.h, b = wg.b;
   const size_t bh = (size_t)b * a.H + h;
   const int N = a.N;
+  const bool fold_keys = a.tickets != nullptr && a.ncg > 1;
   int off[8];
   corner_offsets3(g, off);
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -538,13 +563,13 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
   bool tie = false;
-  splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, off, gs, tie);
+  splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, off, gs, tie);
   if (tie) {
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
-    splat_bwd_plane_pass3<HAS_PAD, true, QPT>(a, g, ZG, s_cnt, bh, b, off, gs, tie);
+    splat_bwd_plane_pass3<HAS_PAD, true, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, off, gs, tie);
   }
   if constexpr (QPT > 0) {
 #pragma unroll
@@ -553,8 +578,15 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
       if (n0 < N) {
         float k[3][4];
         load_keys3(a.pos.keys, bh, N, n0, k);
-        store_gkeys3(a.g_pos + (size_t)blockIdx.x * a.gpos_stride, bh, N, n0, gs[u], k, a.accumulate != 0);
+        store_gkeys3(a.g_pos + (size_t)wg.cgi * a.gpos_stride, bh, N, n0, gs[u], k, a.accumulate != 0, fold_keys);
       }
+    }
+  }
+  if (fold_keys) {       // kernel-uniform (see splat_max_bwd_hot_kernel)
+    if (arrive_last(a.tickets + bh, (unsigned)a.ncg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        fold_rows(a.g_pos + (bh * 3 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * N, N >> 2, a.fold_acc != 0);
     }
   }
 }

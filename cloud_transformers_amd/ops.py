@@ -283,6 +283,24 @@ class PositionsFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # fused (keys-based) Splat / Slice — the hot path
 # ---------------------------------------------------------------------------
+RASTER_TICKETS = os.environ.get("CLOUDCT_TICKETS", "1") != "0"      # "0": the two-launch form (A/B, debugging)
+_tickets = {}
+
+
+def raster_tickets(device):
+    """The arrival tickets of the backward raster passes (include/cloudct.h: ct_slice_bwd_tk / ct_splat_bwd_tk) for the
+    CURRENT stream of `device`: a zeroed CT_TICKETS_BYTES buffer kept for the life of the process.  The kernels leave it zero,
+    so it is initialised once; launches that share a buffer must be ordered, hence one buffer per stream (the heads of a
+    union block run side by side on their own streams, and autograd replays every backward on its forward's stream)."""
+    if not RASTER_TICKETS:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(_lib.TICKETS_BYTES // 4, device=device, dtype=torch.int32)
+    return t
+
+
 class SplatKeysFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, keys, feat, pad, W, H, reduce):
@@ -317,9 +335,9 @@ class SplatKeysFn(torch.autograd.Function):
         ws_bytes = lib.ct_splat_bwd_workspace_bytes(B, H, C, N, dim, Wa, _lib.REDUCE[reduce])
         ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
         with _on(feat.device):
-            _lib.check(lib.ct_splat_bwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid), _ptr(g_grid),
-                                        _ptr(g_feat), _ptr(g_keys), _ptr(ws), ws_bytes,
-                                        B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_bwd")
+            _lib.check(lib.ct_splat_bwd_tk(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid), _ptr(g_grid),
+                                           _ptr(g_feat), _ptr(g_keys), _ptr(ws), ws_bytes, _ptr(raster_tickets(feat.device)),
+                                           B, H, C, N, dim, Wa, _lib.REDUCE[reduce], 0, _stream()), "ct_splat_bwd_tk")
         return g_keys, g_feat, None, None, None, None
 
 
@@ -357,9 +375,10 @@ class SliceKeysFn(torch.autograd.Function):
         ws_bytes = lib.ct_slice_bwd_workspace_bytes(B, H, C, N, dim, Wa)
         ws = torch.empty(ws_bytes, device=grid.device, dtype=torch.uint8) if ws_bytes else None
         with _on(grid.device):
-            _lib.check(lib.ct_slice_bwd_ws(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
-                                           _ptr(g_grid), _ptr(g_keys), _ptr(ws), ws_bytes, B, H, C, N, dim, Wa, _stream()),
-                       "ct_slice_bwd_ws")
+            _lib.check(lib.ct_slice_bwd_tk(_ptr(keys), _ptr(grid), _ptr(padt), pad_code, _ptr(g_out),
+                                           _ptr(g_grid), _ptr(g_keys), _ptr(ws), ws_bytes, _ptr(raster_tickets(grid.device)),
+                                           B, H, C, N, dim, Wa, _stream()),
+                       "ct_slice_bwd_tk")
         return g_keys, g_grid, None, None, None
 
 
@@ -1481,9 +1500,9 @@ class MhctCoreFn(torch.autograd.Function):
         nws = lib.ct_mhct_core_bwd_workspace_bytes(B, H, C, N, dim, Wa)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         with _on(dev):
-            _lib.check(lib.ct_mhct_core_bwd(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(z), _ptr(y),
-                                            _ptr(g_out), _ptr(g_feat), _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(ws), nws,
-                                            B, H, C, N, dim, Wa, _stream()), "ct_mhct_core_bwd")
+            _lib.check(lib.ct_mhct_core_bwd_tk(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(weight), _ptr(z), _ptr(y),
+                                               _ptr(g_out), _ptr(g_feat), _ptr(g_keys), _ptr(g_w), _ptr(g_b), _ptr(ws), nws,
+                                               _ptr(raster_tickets(dev)), B, H, C, N, dim, Wa, _stream()), "ct_mhct_core_bwd_tk")
         return g_keys, g_feat, None, g_w, g_b, None, None
 
 

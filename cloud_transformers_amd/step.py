@@ -20,7 +20,7 @@ class SplatSliceStep:
     second backward accumulates into the first one's result inside its own store.
     """
 
-    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max"):
+    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True):
         assert keys.is_cuda and feat.is_cuda and cot.is_cuda
         self.W = sizes_of(tensor_size, dim)
         self.H, self.dim, self.reduce = heads, dim, reduce
@@ -43,6 +43,9 @@ class SplatSliceStep:
         nws2 = self.lib.ct_slice_bwd_workspace_bytes(self.B, self.H, self.C, self.N, dim, self.Wa)
         self.ws2 = torch.empty(nws2, device=dev, dtype=torch.uint8) if nws2 else None
         self.nws2 = nws2
+        # arrival tickets (ct_tickets_init contract: zero once, the kernels leave them zero): the sums over a plane's
+        # workgroups happen inside the backward kernels — one launch per pass on the few-plane shapes too
+        self.tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device=dev, dtype=torch.int32) if tickets else None
 
     # the four passes, individually callable (bench.py times them one by one)
     def splat_fwd(self):
@@ -67,18 +70,18 @@ class SplatSliceStep:
                    "ct_slice_bwd_keys")
 
     def slice_bwd(self):
-        _lib.check(self.lib.ct_slice_bwd_ws(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
-                                            _ptr(self.g_z), _ptr(self.g_keys_buf), _ptr(self.ws2), self.nws2,
+        _lib.check(self.lib.ct_slice_bwd_tk(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
+                                            _ptr(self.g_z), _ptr(self.g_keys_buf), _ptr(self.ws2), self.nws2, _ptr(self.tickets),
                                             self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
-                   "ct_slice_bwd_ws")
+                   "ct_slice_bwd_tk")
 
     def splat_bwd(self):
         """accumulates its key cotangent into g_keys_buf (call after slice_bwd, which overwrites it)"""
-        _lib.check(self.lib.ct_splat_bwd_ex(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
-                                            _ptr(self.g_feat), _ptr(self.g_keys_buf), _ptr(self.ws), self.nws,
+        _lib.check(self.lib.ct_splat_bwd_tk(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
+                                            _ptr(self.g_feat), _ptr(self.g_keys_buf), _ptr(self.ws), self.nws, _ptr(self.tickets),
                                             self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red,
                                             _lib.BWD_ACCUMULATE_KEYS, _stream()),
-                   "ct_splat_bwd_ex")
+                   "ct_splat_bwd_tk")
 
     # one entry per ABI call
     PASSES = ("splat_fwd", "slice_fwd", "slice_bwd", "splat_bwd")

@@ -124,6 +124,24 @@ size_t ct_slice_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const i
 int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int pad_dtype,
                     const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
                     int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+/* Arrival tickets: ct_slice_bwd_ws / ct_splat_bwd_ex with the sums over a plane's workgroups done INSIDE the kernel.
+ * Where a (b,h) plane is shared by several workgroups (few planes: channel-chunk groups, point segments) each leaves a
+ * partial g_keys / g_grid in `workspace`; without tickets a second small launch adds them.  With `tickets` — a device
+ * buffer of CT_TICKETS_BYTES that is ZERO on entry (ct_tickets_init once after allocation) — every workgroup takes a
+ * ticket of its plane when its partials are out and the holder of the last ticket adds them, in the same fixed order
+ * (same bits as the two-launch form), and resets the ticket: the buffer is zero again when the kernel ends.  One
+ * launch per pass instead of two or three.  The buffer carries state between launches: launches that share it must be
+ * ordered (one buffer per stream), and it must be re-initialised after a launch that faulted.  tickets == NULL: exactly
+ * ct_slice_bwd_ws / ct_splat_bwd_ex.  Same workspace sizes, same results. */
+#define CT_TICKETS_BYTES 65536
+int ct_tickets_init(void* tickets, ct_stream_t s);
+int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                    const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
+                    void* tickets, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype,
+                    const float* grid, const float* g_grid, float* g_feat, float* g_keys,
+                    void* workspace, size_t workspace_bytes, void* tickets,
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s);
 /* The two halves of ct_slice_bwd, for callers that need only one cotangent
  * (autograd's needs_input_grad) and for per-kernel timing: each is one launch. */
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out,
@@ -382,6 +400,11 @@ int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int 
                      const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
                      float* g_b, void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim,
                      const int* W, ct_stream_t s);
+/* the same with arrival tickets (ct_tickets_init; NULL = none) handed to its Slice / Splat backward passes */
+int ct_mhct_core_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
+                        const float* z, const float* y, const float* g_out, float* g_feat, float* g_keys, float* g_w,
+                        float* g_b, void* workspace, size_t workspace_bytes, void* tickets, int B, int H, int C, int N,
+                        int dim, const int* W, ct_stream_t s);
 /* The LDS-resident BACKWARD of the core, for the grid whose five tiles fit a CU (2D 16x16 with 16 features per head:
  * ct_mhct_core_bwd_fused_supported): nothing of the forward is read back — one workgroup per plane recomputes z and conv(z)
  * from the points and walks Slice backward -> conv^T / filter cotangent -> Splat backward in LDS (ct_mhct_core_fwd may then be
