@@ -215,7 +215,7 @@ SIGNATURES = {
     "ct_slice_bwd_ws": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_tickets_init": (_i, [_vp, _vp]),
     "ct_slice_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
-    "ct_splat_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _vp]),
+    "ct_splat_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_keys": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),

@@ -139,7 +139,8 @@ __device__ __forceinline__ constexpr int off_compact(int v) {
 // needs no write-back of this L2 before it may read them (MI355X_MICROARCH.md, publish-large: 3.0 vs 8.2 us per 64 KB)
 __device__ __forceinline__ void st_sc1_f4(float* p, float4 v) {
   const ct_f4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  // s_nop 1: the wait states of "vector write to the data registers of a >8-byte store" (invisible to the compiler in asm)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
 __device__ __forceinline__ int wave_sum_int(int v) {
@@ -1132,7 +1133,9 @@ size_t ct_mhct_core_bwd_workspace_bytes(int B, int H, int C, int N, int dim, con
   const size_t sp = ct_splat_bwd_ex_workspace_bytes(B, H, C, N, dim, W, CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS);
   if (wg > sub) sub = wg;
   if (sp > sub) sub = sp;                    // the three passes run one after the other: they share the scratch
-  return 2 * grid_bytes + sub;
+  // + Slice's key cotangent, which the Splat backward adds to its own (ct_splat_bwd_tk: a tensor of its own)
+  const size_t keys_bytes = ((size_t)B * H * dim * N * 4 + 255) & ~(size_t)255;
+  return 2 * grid_bytes + keys_bytes + sub;
 }
 
 int ct_mhct_core_bwd(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* conv_w,
@@ -1154,18 +1157,20 @@ int ct_mhct_core_bwd_tk(const float* keys, const float* feat, const void* pad, i
   size_t G = 1;
   for (int j = 0; j < dim; ++j) G *= (size_t)W[j];
   const size_t grid_bytes = ((size_t)B * H * C * G * 4 + 255) & ~(size_t)255;
+  const size_t keys_bytes = ((size_t)B * H * dim * N * 4 + 255) & ~(size_t)255;
   float* g_y = (float*)workspace;
   float* g_z = (float*)((char*)workspace + grid_bytes);
-  void* sub = (char*)workspace + 2 * grid_bytes;
-  const size_t sub_bytes = workspace_bytes - 2 * grid_bytes;
-  int rc = ct_slice_bwd_tk(keys, y, pad, pad_dtype, g_out, g_y, g_keys, sub, sub_bytes, tickets, B, H, C, N, dim, W, s);
+  float* g_keys_slice = (float*)((char*)workspace + 2 * grid_bytes);
+  void* sub = (char*)workspace + 2 * grid_bytes + keys_bytes;
+  const size_t sub_bytes = workspace_bytes - 2 * grid_bytes - keys_bytes;
+  int rc = ct_slice_bwd_tk(keys, y, pad, pad_dtype, g_out, g_y, g_keys_slice, sub, sub_bytes, tickets, B, H, C, N, dim, W, s);
   if (rc != CT_OK) return rc;
   rc = ct_gconv_bwd_data(g_y, conv_w, g_z, B, H, C, C, dim, W, s);
   if (rc != CT_OK) return rc;
   rc = ct_gconv_bwd_weight(z, g_y, g_w, g_b, sub, sub_bytes, B, H, C, C, dim, W, s);
   if (rc != CT_OK) return rc;
-  return ct_splat_bwd_tk(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys, sub, sub_bytes, tickets, B, H, C, N, dim, W,
-                         CT_REDUCE_MAX0, CT_BWD_ACCUMULATE_KEYS, s);
+  return ct_splat_bwd_tk(keys, feat, pad, pad_dtype, z, g_z, g_feat, g_keys_slice, g_keys, sub, sub_bytes, tickets, B, H, C, N,
+                         dim, W, CT_REDUCE_MAX0, s);
 }
 
 int ct_mhct_core_bwd_fused_supported(int B, int H, int C, int N, int dim, const int* W) {

@@ -66,7 +66,8 @@ struct RasterArgs {
   unsigned* tickets;
   float* fold_gpos;
   float* fold_grid;
-  int fold_acc;
+  const float* fold_add;  // the g_keys fold adds these rows (the incoming key cotangent) to the sum, or null
+  const float* gpos_add;  // hot Splat(max) backward: g_pos = gpos_add + result (may alias g_pos: in place), or null
 };
 
 template <int DIM, bool FROM_KEYS>
@@ -1440,7 +1441,7 @@ int pick_nsplit(int B, int H, int nchunks, int N) {
 
 // out[i] (+)= sum_k parts[k*stride + i] (ascending k): the partial g_keys of the channel-chunk groups
 template <typename V>
-__global__ void __launch_bounds__(256) sum_parts_kernel(const V* parts, V* out, size_t n, size_t stride, int k, int acc) {
+__global__ void __launch_bounds__(256) sum_parts_kernel(const V* parts, V* out, size_t n, size_t stride, int k, const V* add) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   V s = parts[i];
@@ -1448,20 +1449,21 @@ __global__ void __launch_bounds__(256) sum_parts_kernel(const V* parts, V* out, 
     const V t = parts[(size_t)j * stride + i];
     if constexpr (sizeof(V) == 16) { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; } else { s += t; }
   }
-  if (acc) {
-    const V o = out[i];
+  if (add) {
+    const V o = add[i];
     if constexpr (sizeof(V) == 16) { s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w; } else { s = o + s; }
   }
   out[i] = s;
 }
 
-int launch_sum_parts(const float* parts, float* out, size_t n, size_t stride, int k, int acc, hipStream_t st) {
+// out = (add +) parts[0] + parts[1] + ... ; add may be out itself (accumulate in place) or null
+int launch_sum_parts(const float* parts, float* out, size_t n, size_t stride, int k, const float* add, hipStream_t st) {
   CT_CLEAR_ERROR();
-  if (((n | stride) & 3) == 0 && ((((uintptr_t)parts) | ((uintptr_t)out)) & 15) == 0)
+  if (((n | stride) & 3) == 0 && ((((uintptr_t)parts) | ((uintptr_t)out) | ((uintptr_t)add)) & 15) == 0)
     hipLaunchKernelGGL(sum_parts_kernel<float4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float4*)parts,
-                       (float4*)out, n / 4, stride / 4, k, acc);
+                       (float4*)out, n / 4, stride / 4, k, (const float4*)add);
   else
-    hipLaunchKernelGGL(sum_parts_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, parts, out, n, stride, k, acc);
+    hipLaunchKernelGGL(sum_parts_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, parts, out, n, stride, k, add);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
@@ -1643,12 +1645,12 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, nullptr, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   if (nseg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, 0, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, nullptr, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1688,13 +1690,56 @@ int run_splat_sum_bwd_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   return CT_OK;
 }
 
-// can the hot Splat(max) backward take this call, and does it keep g_keys in registers (may accumulate)?
-bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<2>& g, HotPlan& hp, int& ncg, bool& single) {
+// Point segments of the hot Splat(max) backward (ct_raster_hot.h: splat_max_bwd_hot_kernel): nseg workgroups per plane, each
+// walking all chunks for its own points.  1 = none.  Needs arrival tickets (the plane's tie test) and an incoming key
+// cotangent that does not alias the output.  Chosen where one workgroup per plane leaves the chip empty (few planes) or the
+// cloud outgrows a workgroup's registers (2D: N > 4096), as long as re-staging the plane's tiles per segment stays within
+// ~4x the segment's own point traffic (nseg * G <= 4 N: fine for 8^3 .. 64^2 / 16^3 at the zoo's sizes, not for 128^2).
+// CLOUDCT_SPLAT_BWD_NSEG = 1: off, n > 1: that many where legal (A/B runs).
+int splat_bwd_segments(int B, int H, int C, int N, int G, int dim, size_t lds_per_wg) {
+  static const int forced = [] {
+    const char* e = getenv("CLOUDCT_SPLAT_BWD_NSEG");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1) return 1;
+  auto legal = [&](int ns) { return ns >= 1 && ns <= 64 && N % (4 * ns) == 0 && N / ns >= 256 && (long long)ns * G <= 4ll * N; };
+  if (forced > 1) return legal(forced) ? forced : 1;
+  const long long planes = (long long)B * H;
+  const long long target = lds_per_wg > (size_t)kHalfCuLdsBytes ? 256 : 512;
+  int nseg = 1;
+  while (planes * nseg < target && legal(2 * nseg) && N / (2 * nseg) >= 1024) nseg *= 2;
+  while (dim == 2 && N / nseg > 8 * kHotThreads && legal(2 * nseg)) nseg *= 2;      // the register form: <= 4096 points
+  return nseg;
+}
+
+// can the hot Splat(max) backward take this call?  ncg: chunk groups (partial g_keys through the workspace); nseg: point
+// segments (preferred where legal: nothing to add up); single: one group whose threads own their quads
+template <int DIM>
+bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<DIM>& g, HotPlan& hp, int& ncg, int& nseg, bool& single) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
-                         (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
+                         (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2 | (uintptr_t)a.gpos_add;
+  nseg = 1;
   if (!hot_shape_ok(a, g.G, bits)) return false;
+  // segments first: every workgroup stages every chunk, so the chunks are as fat as LDS allows (no chunk groups)
+  if (a.tickets != nullptr && tickets_cover(a.tickets, (long long)a.B * a.H, 1, 1) && (a.gpos_add == nullptr || a.gpos_add != a.g_pos)) {
+    HotPlan sp;
+    if (hot_chunks(a.C, (size_t)g.G * 8, 16, sp)) {
+      const int ns = splat_bwd_segments(a.B, a.H, a.C, a.N, g.G, DIM, sp.lds);
+      if (ns > 1) {
+        hp = sp; ncg = 1; nseg = ns; single = true;
+        return true;
+      }
+    }
+  }
   if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
-  single = (a.N >> 2) <= 2 * kHotThreads;
+  if constexpr (DIM == 2) {
+    single = (a.N >> 2) <= 2 * kHotThreads;
+  } else {
+    // a workgroup walks all N points of its plane: with fewer workgroups than CUs (16^3 at B2 H16: 128) the generic
+    // kernel's thinner single-channel chunks win (72 vs 147 us)
+    if ((long long)a.B * a.H * ncg < 256 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return false;
+    single = true;       // (the loop form: every thread owns its quads' rows)
+  }
   return true;
 }
 
@@ -1706,22 +1751,32 @@ size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
 }
 
-int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, int ncg, void* ws, hipStream_t st) {
+int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, int ncg, int nseg, void* ws, hipStream_t st) {
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
   float* const out = a.g_pos;
-  const int accumulate = a.accumulate;
+  const float* const add = a.gpos_add;
   const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+#define CT_MK_SPLAT_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
+  if (nseg > 1) {       // point segments: ncg == 1, tickets present (splat_bwd_hot_plan)
+    a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+    dim3 wgrid(1, a.H, a.B * nseg);
+    const int nq = a.N >> 2;
+    if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+    else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
+    else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
+    note("splat_max_bwd_hot_segments");
+    return CT_OK;
+  }
   const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
   if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
     a.gpos_stride = gpos_n;
-    a.accumulate = 0;
-    a.fold_gpos = out; a.fold_acc = accumulate;
+    a.gpos_add = nullptr;
+    a.fold_gpos = out; a.fold_add = add;
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
-#define CT_MK_SPLAT_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
   if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
@@ -1732,7 +1787,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, add, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1818,12 +1873,12 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, 0, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, ncg, nullptr, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   if (nseg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, 0, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, nseg, nullptr, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -1833,18 +1888,6 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
 // chunk): with the 12 values of a quad kept in registers across chunks — and the corner setup of all four points hoisted
 // out of the channel loop by the compiler — it spilled 170-450 registers and lost to the generic kernel (118 vs 72 us on
 // 16^3 C16 B8 N4096); now 53 us.
-bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<3>& g, HotPlan& hp, int& ncg, bool& single) {
-  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos |
-                         (uintptr_t)a.tile_in | (uintptr_t)a.tile_in2;
-  if (!hot_shape_ok(a, g.G, bits)) return false;
-  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
-  // a workgroup walks all N points of its plane: with fewer workgroups than CUs (16^3 at B2 H16: 128) the generic
-  // kernel's thinner single-channel chunks win (72 vs 147 us)
-  if ((long long)a.B * a.H * ncg < 256 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return false;
-  single = false;
-  return true;
-}
-
 size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   HotPlan hp;
   int ncg = 1;
@@ -1853,18 +1896,25 @@ size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   return ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0;
 }
 
-int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, int ncg, void* ws, hipStream_t st) {
+int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, int ncg, int nseg, void* ws, hipStream_t st) {
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = ncg;
   float* const out = a.g_pos;
-  const int accumulate = a.accumulate;
+  const float* const add = a.gpos_add;
   const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  if (nseg > 1) {       // point segments (see the 2D form)
+    a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
+    dim3 wgrid(1, a.H, a.B * nseg);
+    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, hot_threads(a.N >> 2), hp.lds, st, a, g);
+    note("splat_max_bwd_hot3_segments");
+    return CT_OK;
+  }
   const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
   if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
     a.gpos_stride = gpos_n;
-    a.accumulate = 0;
-    a.fold_gpos = out; a.fold_acc = accumulate;
+    a.gpos_add = nullptr;
+    a.fold_gpos = out; a.fold_add = add;
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
@@ -1878,7 +1928,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   }
   if (ncg > 1) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts((const float*)ws, out, gpos_n, gpos_n, ncg, add, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -2003,15 +2053,17 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if constexpr (FROM_KEYS) {
     HotPlan hp;
     bool single = false;
-    int ncg = 1;
-    if (splat_bwd_hot_plan(a, g, hp, ncg, single)) {
+    int ncg = 1, nseg = 1;
+    if (splat_bwd_hot_plan<DIM>(a, g, hp, ncg, nseg, single)) {
       const size_t need = ncg > 1 ? (size_t)ncg * a.B * a.H * DIM * a.N * 4 : 0;
-      // several groups: the partial sums go through the workspace and the final sum may accumulate; one group: the
-      // kernel accumulates in its own store when every thread owns its quads (`single`)
-      if (need <= ws_bytes && (ws || !need) && (ncg > 1 || single || !a.accumulate) && ((uintptr_t)ws & 15) == 0)
-        return run_splat_max_bwd_hot(a, g, hp, ncg, ws, st);
+      // several groups: the partial sums go through the workspace and the final sum adds the incoming cotangent; one
+      // group (or point segments): the kernel adds it in its own store — every thread owns its rows
+      if (need <= ws_bytes && (ws || !need) && ((uintptr_t)ws & 15) == 0)
+        return run_splat_max_bwd_hot(a, g, hp, ncg, nseg, ws, st);
     }
+    a.tickets = nullptr;
   }
+  if (a.gpos_add != nullptr && a.gpos_add != a.g_pos) return CT_EINVAL;     // only the hot kernels add from another tensor
   // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
   const bool two = (size_t)g.G * 8 <= (size_t)kMaxLdsBytes;
   Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, two ? 2 : 1);
@@ -2036,7 +2088,7 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
   if (r != CT_OK) return r;
   if (parts) {
     CT_CLEAR_ERROR();
-    if (launch_sum_parts((const float*)ws, g_pos_out, gpos_n, gpos_n, ncg, accumulate, st) != CT_OK) return CT_ELAUNCH;
+    if (launch_sum_parts((const float*)ws, g_pos_out, gpos_n, gpos_n, ncg, accumulate ? g_pos_out : nullptr, st) != CT_OK) return CT_ELAUNCH;
     CT_CHECK_LAUNCH();
   }
   return CT_OK;
@@ -2135,29 +2187,33 @@ int splat_fwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
                   : run_scatter<3, FROM_KEYS>(a, W, reduce == CT_REDUCE_SUM, st);
 }
 
+// g_pos_add: null (g_pos = result), g_pos itself (g_pos += result: CT_BWD_ACCUMULATE_KEYS) or another tensor of the same
+// shape (g_pos = g_pos_add + result: ct_splat_bwd_tk — the form the point segments of the hot kernel need)
 template <bool FROM_KEYS>
 int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype, const float* grid,
                    const float* g_grid, float* g_feat, float* g_pos, void* ws, size_t ws_bytes,
-                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st, int flags = 0,
-                   void* tickets = nullptr) {
+                   int B, int H, int C, int N, int dim, const int* W, int reduce, hipStream_t st,
+                   const float* g_pos_add = nullptr, void* tickets = nullptr) {
   if (!valid_common(B, H, C, N, dim, W) || !feat || !g_grid || !g_feat || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   note_reset();
-  if (flags & CT_BWD_ACCUMULATE_KEYS) {
-    // g_pos += result.  The hot Splat(max) backward does it in its own store; every other path computes into
-    // the tail of the workspace and adds.
+  if (g_pos_add != nullptr) {
+    // The hot Splat(max) backward adds in its own store; every other path computes the plain result — into the tail of the
+    // workspace when the sum is in place — and adds.
+    const bool in_place = g_pos_add == g_pos;
     const size_t gpos_n = (size_t)B * H * (FROM_KEYS ? dim : (1 << dim)) * N;
-    if (!ws || ws_bytes < gpos_n * 4) return CT_EWORKSPACE;
-    const size_t head = ws_bytes - gpos_n * 4;
+    if (in_place && (!ws || ws_bytes < gpos_n * 4)) return CT_EWORKSPACE;
+    const size_t head = in_place ? ws_bytes - gpos_n * 4 : ws_bytes;
     if (reduce == CT_REDUCE_MAX0 && grid) {
       RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
       a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = grid; a.tile_in2 = g_grid;
-      a.accumulate = 1;
+      a.accumulate = in_place ? 1 : 0;
+      a.gpos_add = g_pos_add;
       a.tickets = (unsigned*)tickets;
       const int r = dim == 2 ? run_splat_max_bwd<2, FROM_KEYS>(a, W, ws, head, st) : run_splat_max_bwd<3, FROM_KEYS>(a, W, ws, head, st);
       if (r != CT_EINVAL) return r;
     }
     if constexpr (FROM_KEYS) {
-      if (reduce == CT_REDUCE_SUM && dim == 2) {
+      if (reduce == CT_REDUCE_SUM && dim == 2 && in_place) {
         RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
         a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = g_grid;
         a.accumulate = 1;
@@ -2165,12 +2221,13 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
         if (r != CT_EINVAL) return r;
       }
     }
-    float* tmp = (float*)((char*)ws + head);
+    float* tmp = in_place ? (float*)((char*)ws + head) : g_pos;
     const int r = splat_bwd_impl<FROM_KEYS>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, tmp, ws, head, B, H, C, N, dim, W,
-                                            reduce, st, 0);
+                                            reduce, st, nullptr, tickets);
     if (r != CT_OK) return r;
     CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, g_pos, (const float*)tmp, gpos_n);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((gpos_n + 255) / 256)), dim3(256), 0, st, g_pos,
+                       in_place ? (const float*)tmp : g_pos_add, gpos_n);
     CT_CHECK_LAUNCH();
     note("add_inplace");
     return CT_OK;
@@ -2327,7 +2384,7 @@ int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int p
   if (!keys || (flags & ~CT_BWD_ACCUMULATE_KEYS)) return CT_EINVAL;
   PosSrc pos = {keys, nullptr, nullptr};
   return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
-                              B, H, C, N, dim, W, reduce, (hipStream_t)s, flags);
+                              B, H, C, N, dim, W, reduce, (hipStream_t)s, (flags & CT_BWD_ACCUMULATE_KEYS) ? g_keys : nullptr);
 }
 
 void ct_debug_set_flags(unsigned flags) { t_dbg_flags = flags; }
@@ -2381,12 +2438,12 @@ int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int p
 }
 
 int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,
-                    const float* g_grid, float* g_feat, float* g_keys, void* ws, size_t ws_bytes, void* tickets,
-                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s) {
-  if (!keys || (flags & ~CT_BWD_ACCUMULATE_KEYS)) return CT_EINVAL;
+                    const float* g_grid, float* g_feat, const float* g_keys_add, float* g_keys, void* ws, size_t ws_bytes,
+                    void* tickets, int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
   PosSrc pos = {keys, nullptr, nullptr};
   return splat_bwd_impl<true>(pos, feat, pad, pad_dtype, grid, g_grid, g_feat, g_keys, ws, ws_bytes,
-                              B, H, C, N, dim, W, reduce, (hipStream_t)s, flags, tickets);
+                              B, H, C, N, dim, W, reduce, (hipStream_t)s, g_keys_add, tickets);
 }
 
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out, float* g_grid,

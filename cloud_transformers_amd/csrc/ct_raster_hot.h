@@ -81,7 +81,9 @@ typedef float ct_f2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void st_sc1_4(float* p, float4 v) {
   const ct_f4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  // (the two wait states are the hazard the compiler cannot see behind inline asm: a vector write to the data registers of
+  //  a store of more than 8 bytes right behind it — it corrupted single lanes of g_keys until the s_nop went in)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 // a partial that another workgroup will read goes out write-through, everything else as a streaming store
 __device__ __forceinline__ void st_part4(float* p, float4 v, bool handoff) {
@@ -122,16 +124,16 @@ __device__ __forceinline__ unsigned arrive_last(unsigned* tk, unsigned nk, unsig
   return *s_flag;
 }
 
-// out[i] (= old +) parts[i] + parts[stride + i] + ... (k copies, ascending), n4 float4 — sum_parts_kernel's arithmetic
-__device__ __forceinline__ void fold_rows(const float* parts, size_t stride, int k, float* out, int n4, bool acc) {
+// out[i] = (add[i] +) parts[i] + parts[stride + i] + ... (k copies, ascending), n4 float4 — sum_parts_kernel's arithmetic
+__device__ __forceinline__ void fold_rows(const float* parts, size_t stride, int k, float* out, int n4, const float* add) {
   for (int i = threadIdx.x; i < n4; i += blockDim.x) {
     float4 s = ((const float4*)parts)[i];
     for (int j = 1; j < k; ++j) {
       const float4 t = ((const float4*)(parts + (size_t)j * stride))[i];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    if (acc) {
-      const float4 o = ((const float4*)out)[i];
+    if (add != nullptr) {
+      const float4 o = ((const float4*)add)[i];
       s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
     }
     ((float4*)out)[i] = s;
@@ -561,14 +563,14 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
     if (f & 1u) {      // this segment's g_keys: the chunk groups' partials, ascending
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        fold_rows(a.g_pos + (bh * 2 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * Nr + so, N >> 2, false);
+        fold_rows(a.g_pos + (bh * 2 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * Nr + so, N >> 2, nullptr);
     }
     if (f & 2u) {      // this chunk group's g_grid tiles: the segments' partials, ascending
       const size_t grid_n = (size_t)a.B * a.H * a.C * G;
       for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
         const int c0 = chunk * CC, cc = min(CC, a.C - c0);
         const size_t o = (bh * a.C + c0) * (size_t)G;
-        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, false);
+        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, nullptr);
       }
     }
   }
@@ -583,7 +585,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 //     the first tied contribution to compare-and-swap the cell's z word to 0 wins (single winner, as
 //     torch_scatter's backward; which of the tied contributions is unspecified).
 //   QPT > 0: every thread owns at most QPT quads (N <= 4*QPT*blockDim): g_keys stays in registers across the
-//     chunks and may be ACCUMULATED into the destination (a.accumulate) — a block's keys feed Splat and Slice.
+//     chunks and is added to an incoming cotangent in the same store (a.gpos_add) — a block's keys feed Splat and Slice.
 //   QPT == 0: any N; the partial g_keys of the chunks go through memory.
 //   grid = (1, H, B)
 // ---------------------------------------------------------------------------
@@ -592,22 +594,30 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 // a feature is that very NaN.
 constexpr unsigned kNoMatch = 0x7FFFFFFFu;
 
+// rows of the point-sized tensors as one workgroup sees them: Nr floats long, the workgroup's points start at `so`
+// (point segments: RasterArgs::nseg; Nr = N, so = 0 without them)
+struct PtRows {
+  int Nr;
+  size_t so;
+  bool wt;      // results another workgroup may have to overwrite (a segmented plane with ties) go out write-through
+};
+
 template <bool HAS_PAD, bool CLAIMS, int WT>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
-                                               int c0, int cc, int n0, const float (&kx)[4], const float (&ky)[4],
+                                               int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
                                                float (&gs)[4][2], int& nm) {
-  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
   // 4 channels (two {z,z,g,g} pairs) per step: the corner weights of a point are computed once per 4 channels.
   // (Requesting the next step's rows before this step is processed was measured: the 16 extra registers spill, 73 -> 102 us.)
   for (int cg0 = 0; cg0 < cc; cg0 += 4) {
     float fv[4][4];          // [channel][point]
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
-      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)N;      // wave-uniform
+      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so;      // wave-uniform
       const float4 t = ld_stream4(row + n0);
       fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
     }
@@ -683,18 +693,22 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
     }
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj)
-      st_stream4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)N + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]));
+      st_part4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]), R.wt);
   }
 }
 
+// one pass over the workgroup's points (N of them, rows R) and its chunks; cgi: chunk group (see slice_bwd_fused_kernel)
 template <bool HAS_PAD, bool CLAIMS, int WT, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const GridW<2>& g, float4* ZG, int* s_cnt,
-                                                    size_t bh, int b, int cgi, float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
-  const int G = WT ? WT * WT : g.G, CC = a.CC, N = a.N;
+                                                    size_t bh, int b, int cgi, int N, const PtRows& R,
+                                                    float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
+  const int G = WT ? WT * WT : g.G, CC = a.CC;
   const int tid = threadIdx.x;
   const int nq = N >> 2;
-  int nz = 0, nm = 0;                             // cgi: chunk group (see slice_bwd_fused_kernel)
+  int nz = 0, nm = 0;
   float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
+  const float* keyx = a.pos.keys + (bh * 2 + 0) * R.Nr + R.so;
+  const float* keyy = a.pos.keys + (bh * 2 + 1) * R.Nr + R.so;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
     const int cc = min(CC, a.C - c0);            // multiple of 4
@@ -718,37 +732,41 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int q = tid + u * (int)blockDim.x;
         if (q < nq) {
           const int n0 = q << 2;
-          const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
-          const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+          const float4 tx = *(const float4*)(keyx + n0);
+          const float4 ty = *(const float4*)(keyy + n0);
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
-          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, kx, ky, gs_reg[u], nm);
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm);
         }
       }
     } else {
       for (int q = tid; q < nq; q += blockDim.x) {
         const int n0 = q << 2;
-        const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
-        const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+        const float4 tx = *(const float4*)(keyx + n0);
+        const float4 ty = *(const float4*)(keyy + n0);
         const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
         float gs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
-        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, kx, ky, gs, nm);
-        // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns
-        // these addresses)
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm);
+        // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns these
+        // addresses); the first chunk starts from the incoming cotangent where there is one (a.gpos_add)
         float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
                                 gs[2][0] * ct_key_mask(kx[2]), gs[3][0] * ct_key_mask(kx[3]));
         float4 oy = make_float4(gs[0][1] * ct_key_mask(ky[0]), gs[1][1] * ct_key_mask(ky[1]),
                                 gs[2][1] * ct_key_mask(ky[2]), gs[3][1] * ct_key_mask(ky[3]));
-        float* px = gpos + (bh * 2 + 0) * N + n0;
-        float* py = gpos + (bh * 2 + 1) * N + n0;
-        if (chunk > cgi) {
-          const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+        float* px = gpos + (bh * 2 + 0) * R.Nr + R.so + n0;
+        float* py = gpos + (bh * 2 + 1) * R.Nr + R.so + n0;
+        if (chunk > cgi || a.gpos_add != nullptr) {
+          const float* ax = chunk > cgi ? px : a.gpos_add + (bh * 2 + 0) * R.Nr + R.so + n0;
+          const float* ay = chunk > cgi ? py : a.gpos_add + (bh * 2 + 1) * R.Nr + R.so + n0;
+          const float4 qx = *(const float4*)ax, qy = *(const float4*)ay;
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
           oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
         }
-        if (a.tickets != nullptr && a.ncg > 1 && chunk + a.ncg >= a.nchunks) {
-          st_sc1_4(px, ox);      // the finished partial, handed to the workgroup that folds the plane (arrive_last)
+        // handed to another workgroup — the finished partial of a chunk group that is folded (arrive_last), the results of a
+        // segment that a tie may force the plane's last workgroup to overwrite: write-through
+        if (chunk + a.ncg >= a.nchunks && (R.wt || (a.tickets != nullptr && a.ncg > 1))) {
+          st_sc1_4(px, ox);
           st_sc1_4(py, oy);
         } else {
           *(float4*)px = ox;
@@ -769,15 +787,27 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
   }
 }
 
+// Point segments (a.nseg > 1): the plane's points are dealt to nseg workgroups, each walking ALL chunks for its own points —
+// no partial g_keys, nothing to fold, nseg times the workgroups (the decoders' 32 planes fill the chip; the zoo's 128 planes
+// need no chunk groups).  What a segment cannot know alone is whether the PLANE has exact ties (matches are counted per
+// segment, non-zero cells per plane): every segment adds its matches to the plane's word in the ticket buffer, takes a
+// ticket, and the holder of the last ticket compares; on a tie (duplicated points: rare) it redoes the whole plane with
+// single-winner claims, overwriting what the segments wrote — which is why their results went out write-through and
+// why the incoming key cotangent (a.gpos_add) must not alias the output then.
 template <bool HAS_PAD, int WT, int QPT>
 __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g) {
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
-  const WgCoord wg = wg_coord(a.ncg, 1, a.H, a.B);
+  const int nsg = a.nseg > 0 ? a.nseg : 1;
+  const WgCoord wg = wg_coord(a.ncg, nsg, a.H, a.B);
   const int h = wg.h, b = wg.b;
   const size_t bh = (size_t)b * a.H + h;
   const int N = a.N;
+  PtRows R;
+  R.Nr = a.Nrow > 0 ? a.Nrow : a.N;
+  R.so = (size_t)wg.seg * a.N;
+  R.wt = nsg > 1;
   const bool fold_keys = a.tickets != nullptr && a.ncg > 1;
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;       // ordered before use by the barriers of the pass
   float gs[QPT ? QPT : 1][4][2];
@@ -786,33 +816,34 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
   bool tie = false;
-  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, gs, tie);
-  if (tie) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
+  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, gs, tie);
+  if (tie && nsg == 1) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
-    splat_bwd_plane_pass<HAS_PAD, true, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, gs, tie);
+    splat_bwd_plane_pass<HAS_PAD, true, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, gs, tie);
   }
   if constexpr (QPT > 0) {
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
       const int n0 = ((int)threadIdx.x + u * (int)blockDim.x) << 2;
       if (n0 < N) {
-        const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
-        const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+        const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * R.Nr + R.so + n0);
+        const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * R.Nr + R.so + n0);
         float4 ox = make_float4(gs[u][0][0] * ct_key_mask(tx.x), gs[u][1][0] * ct_key_mask(tx.y),
                                 gs[u][2][0] * ct_key_mask(tx.z), gs[u][3][0] * ct_key_mask(tx.w));
         float4 oy = make_float4(gs[u][0][1] * ct_key_mask(ty.x), gs[u][1][1] * ct_key_mask(ty.y),
                                 gs[u][2][1] * ct_key_mask(ty.z), gs[u][3][1] * ct_key_mask(ty.w));
-        float* px = a.g_pos + (size_t)wg.cgi * a.gpos_stride + (bh * 2 + 0) * N + n0;
-        float* py = a.g_pos + (size_t)wg.cgi * a.gpos_stride + (bh * 2 + 1) * N + n0;
-        if (a.accumulate) {
-          const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+        const size_t ox_off = (bh * 2 + 0) * R.Nr + R.so + n0, oy_off = (bh * 2 + 1) * R.Nr + R.so + n0;
+        float* px = a.g_pos + (size_t)wg.cgi * a.gpos_stride + ox_off;
+        float* py = a.g_pos + (size_t)wg.cgi * a.gpos_stride + oy_off;
+        if (a.gpos_add != nullptr) {
+          const float4 qx = *(const float4*)(a.gpos_add + ox_off), qy = *(const float4*)(a.gpos_add + oy_off);
           ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
           oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
         }
-        if (fold_keys) {
+        if (fold_keys || R.wt) {
           st_sc1_4(px, ox);
           st_sc1_4(py, oy);
         } else {
@@ -826,7 +857,29 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
     if (arrive_last(a.tickets + bh, (unsigned)a.ncg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        fold_rows(a.g_pos + (bh * 2 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * N, N >> 2, a.fold_acc != 0);
+        fold_rows(a.g_pos + (bh * 2 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 2 + j) * N, N >> 2,
+                  a.fold_add != nullptr ? a.fold_add + (bh * 2 + j) * N : nullptr);
+    }
+  }
+  if (nsg > 1) {         // kernel-uniform: the plane's tie test across its segments
+    unsigned* matches = a.tickets + kTicketHalf + bh;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(matches, (unsigned)s_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counted before the ticket is taken
+    }
+    const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
+    if (last) {          // block-uniform
+      if (threadIdx.x == 0) {
+        s_cnt[3] = (int)__hip_atomic_load(matches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (s_cnt[3] != s_cnt[0]) {       // the plane has exact ties: all of it again, with claims, by this workgroup
+        PtRows Rall;
+        Rall.Nr = R.Nr; Rall.so = 0; Rall.wt = false;
+        float gs0[1][4][2];
+        splat_bwd_plane_pass<HAS_PAD, true, WT, 0>(a, g, ZG, s_cnt, bh, b, 0, R.Nr, Rall, gs0, tie);
+      }
     }
   }
 }

@@ -38,14 +38,15 @@ __device__ __forceinline__ void load_keys3(const float* keys, size_t bh, int N, 
 }
 
 __device__ __forceinline__ void store_gkeys3(float* gpos, size_t bh, int N, int n0, const float (&gs)[4][3], const float (&k)[3][4],
-                                             bool accumulate, bool handoff = false /* write-through: read by another workgroup */) {
+                                             bool accumulate, bool handoff = false /* write-through: read by another workgroup */,
+                                             const float* add = nullptr /* accumulate from these rows instead of gpos's own */) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     float4 o = make_float4(gs[0][j] * ct_key_mask(k[j][0]), gs[1][j] * ct_key_mask(k[j][1]),
                            gs[2][j] * ct_key_mask(k[j][2]), gs[3][j] * ct_key_mask(k[j][3]));
     float* p = gpos + (bh * 3 + j) * N + n0;
     if (accumulate) {
-      const float4 q = *(const float4*)p;
+      const float4 q = *(const float4*)(add != nullptr ? add + (bh * 3 + j) * N + n0 : p);
       o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
     }
     if (handoff) st_sc1_4(p, o);
@@ -371,14 +372,14 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
     if (f & 1u) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        fold_rows(a.g_pos + (bh * 3 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * Nr + so, N >> 2, false);
+        fold_rows(a.g_pos + (bh * 3 + j) * Nr + so, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * Nr + so, N >> 2, nullptr);
     }
     if (f & 2u) {
       const size_t grid_n = (size_t)a.B * a.H * a.C * G;
       for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
         const int c0 = chunk * CC, cc = min(CC, a.C - c0);
         const size_t o = (bh * a.C + c0) * (size_t)G;
-        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, false);
+        fold_rows(a.tile_out + o, grid_n, nsg, a.fold_grid + o, (cc * G) >> 2, nullptr);
       }
     }
   }
@@ -389,17 +390,17 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 // ---------------------------------------------------------------------------
 template <bool HAS_PAD, bool CLAIMS>
 __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW<3>& g, float4* ZG, size_t bh, int b, int c0,
-                                                int cc, int n0, const float (&k)[3][4], const int (&off)[8], float (&gs)[4][3],
-                                                int& nm) {
-  const int G = g.G, N = a.N;
+                                                int cc, int n0, const PtRows& R, const float (&k)[3][4], const int (&off)[8],
+                                                float (&gs)[4][3], int& nm) {
+  const int G = g.G;
   float pv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+  for (int i = 0; i < 4; ++i) pv[i] = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
   for (int cg0 = 0; cg0 < cc; cg0 += 4) {
     float fv[4][4];
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
-      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)N;
+      const float* row = a.src + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so;
       const float4 t = ld_stream4(row + n0);
       fv[cj][0] = t.x; fv[cj][1] = t.y; fv[cj][2] = t.z; fv[cj][3] = t.w;
     }
@@ -483,14 +484,15 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
     }
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj)
-      st_stream4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)N + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]));
+      st_part4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]), R.wt);
   }
 }
 
 template <bool HAS_PAD, bool CLAIMS, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const GridW<3>& g, float4* ZG, int* s_cnt, size_t bh,
-                                                     int b, int cgi, const int (&off)[8], float (&gs_reg)[QPT ? QPT : 1][4][3], bool& tie) {
-  const int G = g.G, CC = a.CC, N = a.N;
+                                                     int b, int cgi, int N, const PtRows& R, const int (&off)[8],
+                                                     float (&gs_reg)[QPT ? QPT : 1][4][3], bool& tie) {
+  const int G = g.G, CC = a.CC;
   const int tid = threadIdx.x;
   const int nq = N >> 2;
   int nz = 0, nm = 0;
@@ -516,19 +518,23 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
         const int q = tid + u * (int)blockDim.x;
         if (q < nq) {
           float k[3][4];
-          load_keys3(a.pos.keys, bh, N, q << 2, k);
-          splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, k, off, gs_reg[u], nm);
+          load_keys3(a.pos.keys, bh, R.Nr, (int)R.so + (q << 2), k);
+          splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs_reg[u], nm);
         }
       }
     } else {
       for (int q = tid; q < nq; q += blockDim.x) {
         float k[3][4];
-        load_keys3(a.pos.keys, bh, N, q << 2, k);
+        load_keys3(a.pos.keys, bh, R.Nr, (int)R.so + (q << 2), k);
         float gs[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-        splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, k, off, gs, nm);
-        store_gkeys3(gpos, bh, N, q << 2, gs, k, chunk > cgi, a.tickets != nullptr && a.ncg > 1 && chunk + a.ncg >= a.nchunks);
+        splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs, nm);
+        // a chunk adds to the workgroup's own rows; the first starts from the incoming cotangent where there is one
+        // (a.gpos_add); the finished rows go out write-through where another workgroup reads or overwrites them
+        store_gkeys3(gpos, bh, R.Nr, (int)R.so + (q << 2), gs, k, chunk > cgi || a.gpos_add != nullptr,
+                     chunk + a.ncg >= a.nchunks && (R.wt || (a.tickets != nullptr && a.ncg > 1)),
+                     chunk > cgi ? nullptr : a.gpos_add);
       }
     }
   }
@@ -549,10 +555,15 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
-  const WgCoord wg = wg_coord(a.ncg, 1, a.H, a.B);
+  const int nsg = a.nseg > 0 ? a.nseg : 1;               // point segments and their tie test: see splat_max_bwd_hot_kernel
+  const WgCoord wg = wg_coord(a.ncg, nsg, a.H, a.B);
   const int h = wg.h, b = wg.b;
   const size_t bh = (size_t)b * a.H + h;
   const int N = a.N;
+  PtRows R;
+  R.Nr = a.Nrow > 0 ? a.Nrow : a.N;
+  R.so = (size_t)wg.seg * a.N;
+  R.wt = nsg > 1;
   const bool fold_keys = a.tickets != nullptr && a.ncg > 1;
   int off[8];
   corner_offsets3(g, off);
@@ -563,13 +574,13 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
   bool tie = false;
-  splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, off, gs, tie);
-  if (tie) {
+  splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, off, gs, tie);
+  if (tie && nsg == 1) {
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
-    splat_bwd_plane_pass3<HAS_PAD, true, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, off, gs, tie);
+    splat_bwd_plane_pass3<HAS_PAD, true, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, off, gs, tie);
   }
   if constexpr (QPT > 0) {
 #pragma unroll
@@ -577,8 +588,9 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
       const int n0 = ((int)threadIdx.x + u * (int)blockDim.x) << 2;
       if (n0 < N) {
         float k[3][4];
-        load_keys3(a.pos.keys, bh, N, n0, k);
-        store_gkeys3(a.g_pos + (size_t)wg.cgi * a.gpos_stride, bh, N, n0, gs[u], k, a.accumulate != 0, fold_keys);
+        load_keys3(a.pos.keys, bh, R.Nr, (int)R.so + n0, k);
+        store_gkeys3(a.g_pos + (size_t)wg.cgi * a.gpos_stride, bh, R.Nr, (int)R.so + n0, gs[u], k, a.gpos_add != nullptr,
+                     fold_keys || R.wt, a.gpos_add);
       }
     }
   }
@@ -586,7 +598,29 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
     if (arrive_last(a.tickets + bh, (unsigned)a.ncg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        fold_rows(a.g_pos + (bh * 3 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * N, N >> 2, a.fold_acc != 0);
+        fold_rows(a.g_pos + (bh * 3 + j) * N, a.gpos_stride, a.ncg, a.fold_gpos + (bh * 3 + j) * N, N >> 2,
+                  a.fold_add != nullptr ? a.fold_add + (bh * 3 + j) * N : nullptr);
+    }
+  }
+  if (nsg > 1) {         // kernel-uniform: the plane's tie test across its segments
+    unsigned* matches = a.tickets + kTicketHalf + bh;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(matches, (unsigned)s_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
+    if (last) {
+      if (threadIdx.x == 0) {
+        s_cnt[3] = (int)__hip_atomic_load(matches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (s_cnt[3] != s_cnt[0]) {
+        PtRows Rall;
+        Rall.Nr = R.Nr; Rall.so = 0; Rall.wt = false;
+        float gs0[1][4][3];
+        splat_bwd_plane_pass3<HAS_PAD, true, 0>(a, g, ZG, s_cnt, bh, b, 0, R.Nr, Rall, off, gs0, tie);
+      }
     }
   }
 }

@@ -336,8 +336,8 @@ class SplatKeysFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, device=feat.device, dtype=torch.uint8) if ws_bytes else None
         with _on(feat.device):
             _lib.check(lib.ct_splat_bwd_tk(_ptr(keys), _ptr(feat), _ptr(padt), pad_code, _ptr(grid), _ptr(g_grid),
-                                           _ptr(g_feat), _ptr(g_keys), _ptr(ws), ws_bytes, _ptr(raster_tickets(feat.device)),
-                                           B, H, C, N, dim, Wa, _lib.REDUCE[reduce], 0, _stream()), "ct_splat_bwd_tk")
+                                           _ptr(g_feat), None, _ptr(g_keys), _ptr(ws), ws_bytes, _ptr(raster_tickets(feat.device)),
+                                           B, H, C, N, dim, Wa, _lib.REDUCE[reduce], _stream()), "ct_splat_bwd_tk")
         return g_keys, g_feat, None, None, None, None
 
 

@@ -14,10 +14,10 @@ class SplatSliceStep:
     """out = Slice(keys, Splat(keys, feat)); backward from the cotangent `cot`.
 
     forward : z = ct_splat_fwd(keys, feat);  out = ct_slice_fwd(keys, z)
-    backward: g_z, g_keys  = ct_slice_bwd(keys, z, cot)
-              g_feat, g_keys += ct_splat_bwd_ex(keys, feat, z, g_z, CT_BWD_ACCUMULATE_KEYS)
+    backward: g_z, g_keys_slice = ct_slice_bwd_tk(keys, z, cot)
+              g_feat, g_keys = ct_splat_bwd_tk(keys, feat, z, g_z, add = g_keys_slice)
     The keys feed both ops, so their two key cotangents are summed (what autograd does in the module path); the
-    second backward accumulates into the first one's result inside its own store.
+    second backward adds the first one's result inside its own store.
     """
 
     def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True):
@@ -32,7 +32,8 @@ class SplatSliceStep:
         self.out = torch.empty_like(self.feat)
         self.g_z = torch.empty_like(self.z)
         self.g_feat = torch.empty_like(self.feat)
-        self.g_keys_buf = torch.empty_like(self.keys)
+        self.g_keys_buf = torch.empty_like(self.keys)        # Slice's key cotangent
+        self.g_keys_out = torch.empty_like(self.keys)        # + Splat's (a second tensor: see ct_splat_bwd_tk)
         self.lib = _lib.load()
         self.Wa = _lib.int_array(self.W)
         self.red = _lib.REDUCE[reduce]
@@ -76,11 +77,11 @@ class SplatSliceStep:
                    "ct_slice_bwd_tk")
 
     def splat_bwd(self):
-        """accumulates its key cotangent into g_keys_buf (call after slice_bwd, which overwrites it)"""
+        """g_keys_out = g_keys_buf (Slice's key cotangent: call after slice_bwd) + Splat's"""
         _lib.check(self.lib.ct_splat_bwd_tk(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z), _ptr(self.g_z),
-                                            _ptr(self.g_feat), _ptr(self.g_keys_buf), _ptr(self.ws), self.nws, _ptr(self.tickets),
-                                            self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red,
-                                            _lib.BWD_ACCUMULATE_KEYS, _stream()),
+                                            _ptr(self.g_feat), _ptr(self.g_keys_buf), _ptr(self.g_keys_out), _ptr(self.ws), self.nws,
+                                            _ptr(self.tickets), self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red,
+                                            _stream()),
                    "ct_splat_bwd_tk")
 
     # one entry per ABI call
@@ -115,7 +116,7 @@ class SplatSliceStep:
 
     def g_keys(self):
         """d(out . cot)/d(keys) after run(): Slice's and Splat's key cotangents, already summed"""
-        return self.g_keys_buf
+        return self.g_keys_out
 
     # algorithmic (compulsory) HBM bytes of the fused formulation, SURVEY.md §8(d)
     def algorithmic_bytes(self):

@@ -138,10 +138,16 @@ int ct_tickets_init(void* tickets, ct_stream_t s);
 int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int pad_dtype,
                     const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
                     void* tickets, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+/* ct_splat_bwd_tk: g_keys = g_keys_add + (key cotangent of this Splat); g_keys_add NULL: g_keys = the cotangent;
+ * g_keys_add == g_keys: in place, as CT_BWD_ACCUMULATE_KEYS.  With tickets AND a g_keys_add that is not g_keys (or NULL) a
+ * plane's POINTS may be dealt to several workgroups (point segments: no partial sums at all, every workgroup walks all
+ * channel chunks for its points); the plane's exact-tie test then runs across them through the tickets, and a plane
+ * that has ties is redone by its last workgroup from g_keys_add — which is why it must not alias the output.
+ * workspace: ct_splat_bwd_ex_workspace_bytes(..., CT_BWD_ACCUMULATE_KEYS if g_keys_add else 0). */
 int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype,
-                    const float* grid, const float* g_grid, float* g_feat, float* g_keys,
+                    const float* grid, const float* g_grid, float* g_feat, const float* g_keys_add, float* g_keys,
                     void* workspace, size_t workspace_bytes, void* tickets,
-                    int B, int H, int C, int N, int dim, const int* W, int reduce, int flags, ct_stream_t s);
+                    int B, int H, int C, int N, int dim, const int* W, int reduce, ct_stream_t s);
 /* The two halves of ct_slice_bwd, for callers that need only one cotangent
  * (autograd's needs_input_grad) and for per-kernel timing: each is one launch. */
 int ct_slice_bwd_grid(const float* keys, const void* pad, int pad_dtype, const float* g_out,

@@ -15,7 +15,7 @@ for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
         keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
         feat = torch.randn(B, H * C, N, device="cuda")
         cot = torch.randn(B, H * C, N, device="cuda")
-        st = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
+        st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets="--no-tickets" not in sys.argv)
         for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks
             st.run()
         torch.cuda.synchronize()
