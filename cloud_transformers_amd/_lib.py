@@ -208,12 +208,14 @@ SIGNATURES = {
     "ct_splat_bwd_ex_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip, _i, _i]),
     "ct_splat_bwd_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _i, _i, _vp]),
     "ct_debug_set_flags": (None, [ctypes.c_uint]),
+    "ct_debug_set_nseg": (None, [_i]),
     "ct_debug_last_launch": (ctypes.c_char_p, []),
     "ct_slice_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _ip]),
     "ct_slice_bwd_ws": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_tickets_init": (_i, [_vp, _vp]),
+    "ct_splat_bwd_tk_segments": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_slice_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),

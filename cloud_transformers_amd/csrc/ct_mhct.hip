@@ -1163,6 +1163,8 @@ int ct_mhct_core_bwd_tk(const float* keys, const float* feat, const void* pad, i
   float* g_keys_slice = (float*)((char*)workspace + 2 * grid_bytes);
   void* sub = (char*)workspace + 2 * grid_bytes + keys_bytes;
   const size_t sub_bytes = workspace_bytes - 2 * grid_bytes - keys_bytes;
+  // (a second key-cotangent tensor only where the Splat backward's point segments want one: else Slice writes g_keys, Splat adds in place)
+  if (tickets == nullptr || ct_splat_bwd_tk_segments(B, H, C, N, dim, W) <= 1) g_keys_slice = g_keys;
   int rc = ct_slice_bwd_tk(keys, y, pad, pad_dtype, g_out, g_y, g_keys_slice, sub, sub_bytes, tickets, B, H, C, N, dim, W, s);
   if (rc != CT_OK) return rc;
   rc = ct_gconv_bwd_data(g_y, conv_w, g_z, B, H, C, C, dim, W, s);

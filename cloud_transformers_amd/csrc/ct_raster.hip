@@ -1235,6 +1235,7 @@ __global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
 // a mutex (writers: every Splat / Slice entry point; the reader gets a copy in a buffer of its own thread).
 // ---------------------------------------------------------------------------
 std::atomic<unsigned> t_dbg_flags{0};
+std::atomic<int> t_dbg_nseg{0};          // ct_debug_set_nseg: point segments of the hot Splat(max) backward (0: automatic)
 std::mutex t_last_mu;
 char t_last[256] = "";
 
@@ -1530,6 +1531,11 @@ bool tickets_cover(const void* tickets, long long planes, int ncg, int nseg) {
   return tickets != nullptr && ((uintptr_t)tickets & 3) == 0 && planes * nseg <= half && planes * ncg <= half;
 }
 
+// Is the in-kernel fold worth it?  The plane's LAST workgroup adds all of the plane's partials alone (~60-100 GB/s) while
+// a sum_parts launch spreads them over the chip: measured equal at ~128-192 KiB per fold (B8 N4096 heads: +-1 us), 1-5 us
+// better below (N2048), and 10-40 us WORSE at the decoders' 0.5-1.5 MiB (B2 N16384: 39 -> 49, 67 -> 106 us).
+bool fold_pays(size_t bytes_per_fold) { return bytes_per_fold <= 192 * 1024; }
+
 bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
   return hot_enabled() && (a.N & 3) == 0 && (G & 3) == 0 && (a.C & 3) == 0 && (ptr_bits & 15) == 0 &&
          ((long long)a.B * a.H >= 32 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
@@ -1630,7 +1636,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   if (nseg > 1) a.tile_out = grid_parts;
   a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
   // with arrival tickets the plane's last workgroup adds the partials itself: no sum_parts launches behind the kernel
-  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg);
+  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg) &&
+                    fold_pays(ncg > 1 ? (size_t)ncg * 2 * a.N * 4 : 0) &&
+                    fold_pays(nseg > 1 ? (size_t)nseg * ((a.C + ncg - 1) / ncg) * g.G * 4 : 0);
   if (!fold) a.tickets = nullptr;
   a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(ncg, a.H, a.B * nseg);
@@ -1695,17 +1703,26 @@ int run_splat_sum_bwd_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
 // cotangent that does not alias the output.  Chosen where one workgroup per plane leaves the chip empty (few planes) or the
 // cloud outgrows a workgroup's registers (2D: N > 4096), as long as re-staging the plane's tiles per segment stays within
 // ~4x the segment's own point traffic (nseg * G <= 4 N: fine for 8^3 .. 64^2 / 16^3 at the zoo's sizes, not for 128^2).
-// CLOUDCT_SPLAT_BWD_NSEG = 1: off, n > 1: that many where legal (A/B runs).
+// CLOUDCT_SPLAT_BWD_NSEG / ct_debug_set_nseg = 1: off, n > 1: that many where legal (A/B runs, tests of the 3D form).
 int splat_bwd_segments(int B, int H, int C, int N, int G, int dim, size_t lds_per_wg) {
-  static const int forced = [] {
+  static const int env_forced = [] {
     const char* e = getenv("CLOUDCT_SPLAT_BWD_NSEG");
     return e ? atoi(e) : 0;
   }();
+  const int dbg = t_dbg_nseg.load(std::memory_order_relaxed);
+  const int forced = dbg ? dbg : env_forced;
   if (forced == 1) return 1;
   auto legal = [&](int ns) { return ns >= 1 && ns <= 64 && N % (4 * ns) == 0 && N / ns >= 256 && (long long)ns * G <= 4ll * N; };
   if (forced > 1) return legal(forced) ? forced : 1;
+  // Measured (tools/zoo_sweep.py, B8 N4096 / B2 N16384, H16): 16^2 C16 29.2 -> 23.5 / 39.1 -> 24.0 us; but 8^3 C32 56.6 -> 72.6,
+  // 16^3 C16 59 -> 75, 64^2 C16 47 -> 58: a segment's threads walk ALL channels, so there are nchunks-times fewer waves in
+  // flight than with chunk groups, and every segment re-stages every chunk.  Automatic only where the plane's tiles are one
+  // small chunk (all channels' {z, g_z} within 32 KiB) and the cloud is long enough for >= 1024 points per segment.
+  if ((size_t)C * G * 8 > 32 * 1024 || N < 4096) return 1;
+  // ~256 workgroups: B8 N4096 nseg 2 / 4 / 8 = 20.3 / 22.1 / 27.1 us, B2 N16384 nseg 4 / 8 / 16 = 31.3 / 20.1 / 23.1 (tools/dev/nseg_sweep.py)
   const long long planes = (long long)B * H;
-  const long long target = lds_per_wg > (size_t)kHalfCuLdsBytes ? 256 : 512;
+  const long long target = 256;
+  (void)lds_per_wg;
   int nseg = 1;
   while (planes * nseg < target && legal(2 * nseg) && N / (2 * nseg) >= 1024) nseg *= 2;
   while (dim == 2 && N / nseg > 8 * kHotThreads && legal(2 * nseg)) nseg *= 2;      // the register form: <= 4096 points
@@ -1767,7 +1784,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
     note("splat_max_bwd_hot_segments");
     return CT_OK;
   }
-  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
+  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1) && fold_pays((size_t)ncg * 2 * a.N * 4);
   if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
@@ -1857,7 +1874,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   float* const grid_parts = nseg > 1 ? (float*)((char*)ws + (ncg > 1 ? (size_t)ncg * gpos_n * 4 : 0)) : nullptr;
   if (nseg > 1) a.tile_out = grid_parts;
   a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
-  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg);     // see the 2D form
+  const bool fold = (ncg > 1 || nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, nseg) &&     // see the 2D form
+                    fold_pays(ncg > 1 ? (size_t)ncg * 3 * a.N * 4 : 0) &&
+                    fold_pays(nseg > 1 ? (size_t)nseg * ((a.C + ncg - 1) / ncg) * g.G * 4 : 0);
   if (!fold) a.tickets = nullptr;
   a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(ncg, a.H, a.B * nseg);
@@ -1908,7 +1927,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
     note("splat_max_bwd_hot3_segments");
     return CT_OK;
   }
-  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1);      // see run_slice_bwd_hot
+  const bool fold = ncg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, ncg, 1) && fold_pays((size_t)ncg * 3 * a.N * 4);
   if (!fold) a.tickets = nullptr;
   if (ncg > 1) {
     a.g_pos = (float*)ws;
@@ -2213,10 +2232,10 @@ int splat_bwd_impl(PosSrc pos, const float* feat, const void* pad, int pad_dtype
       if (r != CT_EINVAL) return r;
     }
     if constexpr (FROM_KEYS) {
-      if (reduce == CT_REDUCE_SUM && dim == 2 && in_place) {
+      if (reduce == CT_REDUCE_SUM && dim == 2) {
         RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
         a.pos = pos; a.src = feat; a.dst = g_feat; a.g_pos = g_pos; a.tile_in = g_grid;
-        a.accumulate = 1;
+        a.gpos_add = g_pos_add;
         const int r = run_splat_sum_bwd_hot(a, make_grid<2>(W), st);
         if (r != CT_EINVAL) return r;
       }
@@ -2421,6 +2440,18 @@ int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int p
   if (!keys) return CT_EINVAL;
   PosSrc pos = {keys, nullptr, nullptr};
   return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes);
+}
+
+void ct_debug_set_nseg(int nseg) { t_dbg_nseg.store(nseg, std::memory_order_relaxed); }
+
+int ct_splat_bwd_tk_segments(int B, int H, int C, int N, int dim, const int* W) {
+  if (!valid_common(B, H, C, N, dim, W) || !hot_enabled() || (N & 3) || (C & 3)) return 1;
+  long long G = 1;
+  for (int j = 0; j < dim; ++j) G *= W[j];
+  if ((G & 3) || ((long long)B * H < 32 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) || (long long)B * H > CT_TICKETS_BYTES / 8) return 1;
+  HotPlan sp;
+  if (!hot_chunks(C, (size_t)G * 8, 16, sp)) return 1;
+  return splat_bwd_segments(B, H, C, N, (int)G, dim, sp.lds);
 }
 
 int ct_tickets_init(void* tickets, ct_stream_t s) {

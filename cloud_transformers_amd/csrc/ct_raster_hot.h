@@ -869,10 +869,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
     }
     const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
     if (last) {          // block-uniform
-      if (threadIdx.x == 0) {
-        s_cnt[3] = (int)__hip_atomic_load(matches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      // (read and reset in ONE atomic: a load could be served from a line an earlier launch left in this XCD's L2)
+      if (threadIdx.x == 0) s_cnt[3] = (int)__hip_atomic_exchange(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       if (s_cnt[3] != s_cnt[0]) {       // the plane has exact ties: all of it again, with claims, by this workgroup
         PtRows Rall;
@@ -961,7 +959,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
 // ---------------------------------------------------------------------------
 // KS: Splat(sum) backward in one pass (linear op: g_feat = Slice(g_grid), corner cotangents gw = sum_c g_grid * feat):
 //   the g_grid tile of ALL channels of the plane channel-interleaved in LDS, one ds_read_b128 per (point, corner,
-//   4 channels) feeds both results; g_keys is written once (or accumulated, a.accumulate).
+//   4 channels) feeds both results; g_keys is written once (added to an incoming cotangent: a.gpos_add).
 //   grid = (nsplit, H, B)
 // ---------------------------------------------------------------------------
 template <bool HAS_PAD, int WT>
@@ -1051,8 +1049,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_sum_bwd_kernel(RasterArg
                             gs[2][1] * ct_key_mask(ky[2]), gs[3][1] * ct_key_mask(ky[3]));
     float* px = a.g_pos + (bh * 2 + 0) * N + n0;
     float* py = a.g_pos + (bh * 2 + 1) * N + n0;
-    if (a.accumulate) {
-      const float4 qx = *(const float4*)px, qy = *(const float4*)py;
+    if (a.gpos_add != nullptr) {       // the incoming key cotangent (may be these very rows: in place)
+      const float4 qx = *(const float4*)(a.gpos_add + (bh * 2 + 0) * N + n0), qy = *(const float4*)(a.gpos_add + (bh * 2 + 1) * N + n0);
       ox.x += qx.x; ox.y += qx.y; ox.z += qx.z; ox.w += qx.w;
       oy.x += qy.x; oy.y += qy.y; oy.z += qy.z; oy.w += qy.w;
     }

@@ -610,10 +610,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
     }
     const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
     if (last) {
-      if (threadIdx.x == 0) {
-        s_cnt[3] = (int)__hip_atomic_load(matches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (threadIdx.x == 0) s_cnt[3] = (int)__hip_atomic_exchange(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       if (s_cnt[3] != s_cnt[0]) {
         PtRows Rall;

@@ -33,7 +33,7 @@ class SplatSliceStep:
         self.g_z = torch.empty_like(self.z)
         self.g_feat = torch.empty_like(self.feat)
         self.g_keys_buf = torch.empty_like(self.keys)        # Slice's key cotangent
-        self.g_keys_out = torch.empty_like(self.keys)        # + Splat's (a second tensor: see ct_splat_bwd_tk)
+        self.g_keys_out = self.g_keys_buf                    # + Splat's: added in place ...
         self.lib = _lib.load()
         self.Wa = _lib.int_array(self.W)
         self.red = _lib.REDUCE[reduce]
@@ -47,6 +47,8 @@ class SplatSliceStep:
         # arrival tickets (ct_tickets_init contract: zero once, the kernels leave them zero): the sums over a plane's
         # workgroups happen inside the backward kernels — one launch per pass on the few-plane shapes too
         self.tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device=dev, dtype=torch.int32) if tickets else None
+        if tickets and reduce == "max" and self.lib.ct_splat_bwd_tk_segments(self.B, self.H, self.C, self.N, dim, self.Wa) > 1:
+            self.g_keys_out = torch.empty_like(self.keys)    # ... or into a second tensor where point segments pay (ct_splat_bwd_tk)
 
     # the four passes, individually callable (bench.py times them one by one)
     def splat_fwd(self):

@@ -108,6 +108,8 @@ int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int p
 #define CT_DEBUG_FORCE_HOT 2   /* use them for every eligible layout, however few (b,h) planes there are */
 void ct_debug_set_flags(unsigned flags);
 const char* ct_debug_last_launch(void);
+/* point segments of the hot Splat(max) backward (ct_splat_bwd_tk): 0 automatic, 1 never, n > 1: n wherever legal */
+void ct_debug_set_nseg(int nseg);
 
 /* Slice.forward  (layers/cloud_transform.py:190-227): out f32[B,H*C,N].
  * Slice backward (autograd of torch.gather = scatter-add, :216-221):
@@ -144,6 +146,9 @@ int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int p
  * channel chunks for its points); the plane's exact-tie test then runs across them through the tickets, and a plane
  * that has ties is redone by its last workgroup from g_keys_add — which is why it must not alias the output.
  * workspace: ct_splat_bwd_ex_workspace_bytes(..., CT_BWD_ACCUMULATE_KEYS if g_keys_add else 0). */
+/* > 1: with tickets and a g_keys_add that is not g_keys, ct_splat_bwd_tk(reduce = max) deals the points of a plane of this
+ * shape to that many workgroups — worth a second key-cotangent tensor; 1: it would not (adding in place is as good). */
+int ct_splat_bwd_tk_segments(int B, int H, int C, int N, int dim, const int* W);
 int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype,
                     const float* grid, const float* g_grid, float* g_feat, const float* g_keys_add, float* g_keys,
                     void* workspace, size_t workspace_bytes, void* tickets,

@@ -50,12 +50,18 @@ def test_folded_sums_equal_the_two_launch_form_bit_for_bit(shape):
     folded = False
     for it in range(4):
         _refresh(tk, 100 + it)             # (shared input tensors: `two` sees the same data)
-        tk.run()
-        two.run()
+        for st in (tk, two):
+            st.splat_fwd()
+            st.slice_fwd()
+            st.slice_bwd()
         torch.cuda.synchronize()
-        for name in ("z", "out", "g_z", "g_feat", "g_keys_buf"):
+        for name in ("z", "out", "g_z", "g_keys_buf"):            # (g_keys_buf: Slice's key cotangent, before Splat adds its own)
             a, b = getattr(tk, name), getattr(two, name)
             assert torch.equal(a, b), (name, it, float((a - b).abs().max()))
+        tk.splat_bwd()
+        two.splat_bwd()
+        torch.cuda.synchronize()
+        assert torch.equal(tk.g_feat, two.g_feat), (it, float((tk.g_feat - two.g_feat).abs().max()))
         a, b = tk.g_keys_out, two.g_keys_out
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (it, float((a - b).abs().max()))
         assert int(tk.tickets.abs().sum()) == 0, "tickets not reset"
@@ -64,7 +70,7 @@ def test_folded_sums_equal_the_two_launch_form_bit_for_bit(shape):
         folded = folded or any("folded" in t or "segments" in t for t in tags.values())
         assert int(tk.tickets.abs().sum()) == 0
     B, N, H, C, W, dim = shape
-    if B * H < 256 and C >= 16:            # every such shape shares planes between workgroups in at least one pass
+    if B * H < 256 and C >= 16 and N <= 4096:     # (longer clouds: partials beyond the fold's size bound, two launches)
         assert folded, tags
 
 
@@ -88,7 +94,7 @@ def test_two_streams_side_by_side_keep_their_own_tickets():
         b_two.run()
         torch.cuda.synchronize()
         for t, r in ((a_tk, a_two), (b_tk, b_two)):
-            for name in ("g_z", "g_feat", "g_keys_buf"):
+            for name in ("g_z", "g_feat"):
                 assert torch.equal(getattr(t, name), getattr(r, name)), (name, it)
             assert float((t.g_keys_out - r.g_keys_out).abs().max()) <= 2e-6 * float(r.g_keys_out.abs().max()), it
             assert int(t.tickets.abs().sum()) == 0
@@ -159,6 +165,7 @@ def test_ties_across_point_segments_route_to_a_single_winner(shape, dup):
     ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
     tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device="cuda", dtype=torch.int32)
     lib.ct_debug_set_flags(_lib.DEBUG_FORCE_HOT)
+    lib.ct_debug_set_nseg(4)          # (automatic only for small 2D tiles: force the segmented form, 3D too)
     try:
         outs = []
         for tk in (tickets, None):       # segments + tickets, then the one-workgroup-per-plane form
@@ -170,6 +177,7 @@ def test_ties_across_point_segments_route_to_a_single_winner(shape, dup):
             outs.append((g_feat.cpu(), g_keys.cpu(), lib.ct_debug_last_launch().decode()))
     finally:
         lib.ct_debug_set_flags(0)
+        lib.ct_debug_set_nseg(0)
     assert "segments" in outs[0][2], outs[0][2]
     assert "segments" not in outs[1][2], outs[1][2]
     assert int(tickets.abs().sum()) == 0
@@ -191,7 +199,10 @@ def test_ties_across_point_segments_route_to_a_single_winner(shape, dup):
         # between the two forms, the gradient mass of each duplicated pair may not
         (gf_s, gk_s, _), (gf_1, gk_1, _) = outs
         assert torch.equal(gf_s[1:], gf_1[1:]) and torch.equal(gf_s[0, C:], gf_1[0, C:])
+        assert not torch.isnan(gf_s).any() and not torch.isnan(gk_s).any()
         pair = lambda t, lo: t[0, :lo, :64] + t[0, :lo, half:half + 64]
         assert float((pair(gf_s, C) - pair(gf_1, C)).abs().max()) <= 1e-5 * float(gf_1.abs().max())
-        assert float(((gk_s - gk_1)[1:]).abs().max()) <= 2e-6 * float(gk_1.abs().max())
+        if B > 1:
+            assert float(((gk_s - gk_1)[1:]).abs().max()) <= 2e-6 * float(gk_1.abs().max())
+        assert float(((gk_s - gk_1)[0, dim:]).abs().max()) <= 2e-6 * float(gk_1.abs().max())
         assert float((pair(gk_s, dim) - pair(gk_1, dim)).abs().max()) <= 1e-4 * float(gk_1.abs().max())
