@@ -71,6 +71,8 @@ BWD_ACCUMULATE_KEYS = 1
 TICKETS_BYTES = 65536
 DEBUG_NO_HOT = 1
 DEBUG_FORCE_HOT = 2
+DEBUG_NO_BAND = 4
+DEBUG_FORCE_BAND = 8
 
 _lock = threading.Lock()
 _lib = None

@@ -1144,6 +1144,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
 
 #include "ct_raster_hot.h"
 #include "ct_raster_hot3d.h"
+#include "ct_raster_band.h"
 
 // ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
@@ -1953,6 +1954,59 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   return CT_OK;
 }
 
+// ---- banded kernels (ct_raster_band.h): four-channel heads on grids too large for the hot kernels ----
+// R rows per band: as many as keep two workgroups per CU (else one), but bands enough to fill the chip's 512 slots.
+template <int DIM>
+bool band_plan(const RasterArgs& a, const GridW<DIM>& g, uintptr_t ptr_bits, int& R, int& nb, size_t& lds) {
+  const int S = g.G / g.W[0];
+  if (!hot_enabled() || a.C != 4 || (a.N & 3) != 0 || (S & 3) != 0 || (ptr_bits & 15) != 0 || g.W[0] < 4) return false;
+  const size_t fixed = (size_t)(kBandCnt + 8) * 4 + band_ring_bytes<DIM>();
+  auto bytes = [&](int r) { return (size_t)(r + 2) * S * 32 + fixed; };
+  int r = (int)(((size_t)kHalfCuLdsBytes - fixed) / ((size_t)S * 32)) - 2;
+  if (r < 2) r = (int)(((size_t)kBigLdsBytes - fixed) / ((size_t)S * 32)) - 2;
+  if (r < 1) return false;
+  const long long planes = (long long)a.B * a.H;
+  const int want_nb = (int)((512 + planes - 1) / planes);
+  const int r_fill = (g.W[0] + want_nb - 1) / want_nb;
+  if (r > r_fill) r = r_fill < 2 ? 2 : r_fill;
+  if (r > g.W[0]) r = g.W[0];
+  R = r;
+  nb = (g.W[0] + r - 1) / r;
+  lds = bytes(r);
+  return lds <= (size_t)kBigLdsBytes;
+}
+
+template <int DIM>
+int run_band_slice_bwd(RasterArgs a, const float* grid, float* g_pos, const GridW<DIM>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos;
+  int R, nb;
+  size_t lds;
+  if (!band_plan<DIM>(a, g, bits, R, nb, lds)) return CT_EINVAL;
+  a.tile_in = grid; a.g_pos = g_pos;
+  a.nsplit = R; a.ncg = nb; a.tickets = nullptr;
+  dim3 wgrid(nb, a.H, a.B);
+  if (a.pad_dtype != CT_PAD_NONE) CT_LAUNCH((band_slice_bwd_kernel<DIM, true>), wgrid, kBandThreads, lds, st, a, g);
+  else CT_LAUNCH((band_slice_bwd_kernel<DIM, false>), wgrid, kBandThreads, lds, st, a, g);
+  note(DIM == 2 ? "band_slice_bwd" : "band_slice_bwd3");
+  return CT_OK;
+}
+
+// (needs an incoming key cotangent that is not the output: a band with exact ties is redone from it)
+template <int DIM>
+int run_band_splat_bwd(RasterArgs a, const GridW<DIM>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.g_pos | (uintptr_t)a.tile_in |
+                         (uintptr_t)a.tile_in2 | (uintptr_t)a.gpos_add;
+  int R, nb;
+  size_t lds;
+  if ((a.gpos_add != nullptr && a.gpos_add == a.g_pos) || !band_plan<DIM>(a, g, bits, R, nb, lds)) return CT_EINVAL;
+  a.nsplit = R; a.ncg = nb; a.tickets = nullptr;
+  dim3 wgrid(nb, a.H, a.B);
+  if (a.pad_dtype != CT_PAD_NONE) CT_LAUNCH((band_splat_bwd_kernel<DIM, true>), wgrid, kBandThreads, lds, st, a, g);
+  else CT_LAUNCH((band_splat_bwd_kernel<DIM, false>), wgrid, kBandThreads, lds, st, a, g);
+  note(DIM == 2 ? "band_splat_bwd" : "band_splat_bwd3");
+  return CT_OK;
+}
+
 // y += x
 __global__ void __launch_bounds__(256) add_inplace_kernel(float* y, const float* x, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2070,6 +2124,10 @@ template <int DIM, bool FROM_KEYS>
 int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
   if constexpr (FROM_KEYS) {
+    if (t_dbg_flags & CT_DEBUG_FORCE_BAND) {
+      const int r = run_band_splat_bwd<DIM>(a, g, st);
+      if (r != CT_EINVAL) return r;
+    }
     HotPlan hp;
     bool single = false;
     int ncg = 1, nseg = 1;
@@ -2081,8 +2139,12 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
         return run_splat_max_bwd_hot(a, g, hp, ncg, nseg, ws, st);
     }
     a.tickets = nullptr;
+    if (!(t_dbg_flags & CT_DEBUG_NO_BAND)) {
+      const int r = run_band_splat_bwd<DIM>(a, g, st);
+      if (r != CT_EINVAL) return r;
+    }
   }
-  if (a.gpos_add != nullptr && a.gpos_add != a.g_pos) return CT_EINVAL;     // only the hot kernels add from another tensor
+  if (a.gpos_add != nullptr && a.gpos_add != a.g_pos) return CT_EINVAL;     // only the hot / banded kernels add from another tensor
   // z and g_z tiles both in LDS when two single-channel tiles fit the 64 KiB budget
   const bool two = (size_t)g.G * 8 <= (size_t)kMaxLdsBytes;
   Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, two ? 2 : 1);
@@ -2119,8 +2181,16 @@ template <int DIM>
 int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
   if ((g.G & 3) != 0) return CT_EINVAL;
+  if (t_dbg_flags & CT_DEBUG_FORCE_BAND) {       // tests: the banded kernel on grids the hot kernels would take
+    const int r = run_band_slice_bwd<DIM>(a, grid, g_pos, g, st);
+    if (r != CT_EINVAL) return r;
+  }
   {
     const int r = run_slice_bwd_hot(a, grid, g_pos, g, ws, ws_bytes, st);
+    if (r != CT_EINVAL) return r;
+  }
+  if (!(t_dbg_flags & CT_DEBUG_NO_BAND)) {
+    const int r = run_band_slice_bwd<DIM>(a, grid, g_pos, g, st);
     if (r != CT_EINVAL) return r;
   }
   // gather side: tile + [CC] maxima + [G] counters in LDS
@@ -2450,7 +2520,11 @@ int ct_splat_bwd_tk_segments(int B, int H, int C, int N, int dim, const int* W) 
   for (int j = 0; j < dim; ++j) G *= W[j];
   if ((G & 3) || ((long long)B * H < 32 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) || (long long)B * H > CT_TICKETS_BYTES / 8) return 1;
   HotPlan sp;
-  if (!hot_chunks(C, (size_t)G * 8, 16, sp)) return 1;
+  if ((t_dbg_flags & CT_DEBUG_FORCE_BAND) && C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4) return 2;
+  if (!hot_chunks(C, (size_t)G * 8, 16, sp)) {
+    // the banded kernels (ct_raster_band.h) redo a band with exact ties from the incoming cotangent: a second tensor too
+    return (C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4 && !(t_dbg_flags & CT_DEBUG_NO_BAND)) ? 2 : 1;
+  }
   return splat_bwd_segments(B, H, C, N, (int)G, dim, sp.lds);
 }
 
