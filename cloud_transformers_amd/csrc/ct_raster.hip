@@ -127,6 +127,30 @@ __device__ __forceinline__ void store_gpos(float* g_pos, size_t bh, int N, int n
   }
 }
 
+// Workgroup -> (x, head, cloud) of a grid (X, H, B) whose X workgroups per (b, h) plane share that plane's keys (and, for
+// the scatter / gather pairs, its feature rows or its tile).  The launch order is x-fastest and consecutive workgroups go to
+// the 8 XCDs in turn (observed; speed only), so a plane's workgroups are given linear ids congruent mod 8: one XCD, one
+// L2 — what the plane's second and later workgroups re-read is then served there instead of from HBM (the single-channel
+// kernels of the C4 heads moved 1.6-3.1x the algorithmic bytes, profiles/r3_zoo_counters.txt).
+struct BlockXHB {
+  int x, h, b;
+};
+__device__ __forceinline__ BlockXHB block_xhb() {
+  BlockXHB r;
+  const unsigned X = gridDim.x, planes = gridDim.y * gridDim.z;
+  if (X > 1 && (planes & 7u) == 0) {
+    const unsigned L = blockIdx.x + X * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned grp = L / (8u * X), rem = L - grp * 8u * X;
+    const unsigned plane = grp * 8u + (rem & 7u);
+    r.x = (int)(rem >> 3);
+    r.h = (int)(plane % gridDim.y);
+    r.b = (int)(plane / gridDim.y);
+  } else {
+    r.x = blockIdx.x; r.h = blockIdx.y; r.b = blockIdx.z;
+  }
+  return r;
+}
+
 __device__ __forceinline__ void lds_fill_zero(float* tile, int count) {
   for (int i = threadIdx.x; i < count; i += blockDim.x) tile[i] = 0.0f;
 }
@@ -173,7 +197,8 @@ template <int DIM, bool FROM_KEYS, bool SUM, bool LDS_TILE>
 __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x, h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -246,7 +271,8 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_kernel(
   int* acc = (int*)lds;
   float* s_q = lds + (size_t)a.CC * g.G;      // [CC] per-channel max, then quantum (< 0: float atomics)
   float* s_iq = s_q + a.CC;                   // [CC] 1 / quantum
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x, h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -337,7 +363,8 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
   int* acc = (int*)lds;
   float* s_q = lds + (size_t)a.CC * g.G;      // [CC] quantum (< 0: float fallback)
   float* s_iq = s_q + a.CC;                   // [CC] 1 / quantum
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x, h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -413,7 +440,8 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
   constexpr int CG = DIM == 2 ? 4 : 2;
   extern __shared__ __align__(16) float lds[];
   int* acc = (int*)lds;
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x, h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -559,7 +587,8 @@ __global__ void __launch_bounds__(1024, CT_FXREG_WAVES) scatter_add_fx_reg_kerne
   __shared__ float redg[16 * CG];   // per-wave maxima of the CG channels of a group
   __shared__ float qs[CCR];     // quantum per channel; < 0 marks a float (non-finite) channel
   int* acc = (int*)lds;
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x, h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -696,8 +725,9 @@ template <int DIM, bool FROM_KEYS, bool LDS_TILE>
 __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
-  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x / a.nsplit, sp = blk.x % a.nsplit;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
@@ -738,8 +768,9 @@ template <int DIM, bool FROM_KEYS, bool LDS_TILE>
 __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) gather_gw_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
-  const int cg = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int cg = blk.x / a.nsplit, sp = blk.x % a.nsplit;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int per = (a.N + a.nsplit - 1) / a.nsplit;
   const int n_beg = sp * per, n_end = min(a.N, n_beg + per);
@@ -794,8 +825,9 @@ template <int DIM, bool FROM_KEYS, bool LDS_TILE, bool GZ_LDS>
 __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) splat_max_bwd_kernel(RasterArgs a, GridW<DIM> g) {
   constexpr int V = 1 << DIM;
   extern __shared__ __align__(16) float lds[];
-  const int cg = blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int cg = blk.x;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const bool atomic = a.atomic_gpos != 0;
   bool first = true;
@@ -887,8 +919,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
   constexpr bool kDst = MODE != QM_GATHER_GW;       // writes a point-sized output
   constexpr bool kGw = MODE != QM_GATHER;           // produces g_keys
   extern __shared__ __align__(16) float lds[];
-  const int cgi = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();
+  const int cgi = blk.x / a.nsplit, sp = blk.x % a.nsplit;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   constexpr bool has_pad = HAS_PAD;            // compile-time: no per-element select on the no-padding path
   const bool atomic = a.atomic_gpos != 0;
@@ -1956,10 +1989,16 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
 
 // ---- banded kernels (ct_raster_band.h): four-channel heads on grids too large for the hot kernels ----
 // R rows per band: as many as keep two workgroups per CU (else one), but bands enough to fill the chip's 512 slots.
+// Measured on the zoo's C4 heads (tools/zoo_sweep.py, B8 N4096 / B2 N16384): 128^2 Slice backward 34 -> 52 / 37 -> 41 us, Splat
+// backward 29 -> 57 / 36 -> 36; 32^3 73 -> 179 and 57 -> 227: every band streams the WHOLE plane's keys (and g_out, for the
+// maxima) through L2 and the scattered 4-byte fetches move 64-byte sectors, nb x the point traffic where the single-channel
+// kernels re-read only the keys (C x).  So the bands serve what nothing else serves well: grids whose single-channel tile
+// exceeds a CU's LDS (> 40K cells: 256^2, 64^3 ...), which otherwise run on global atomics, nondeterministically.
 template <int DIM>
 bool band_plan(const RasterArgs& a, const GridW<DIM>& g, uintptr_t ptr_bits, int& R, int& nb, size_t& lds) {
   const int S = g.G / g.W[0];
   if (!hot_enabled() || a.C != 4 || (a.N & 3) != 0 || (S & 3) != 0 || (ptr_bits & 15) != 0 || g.W[0] < 4) return false;
+  if ((size_t)g.G * 4 <= (size_t)kBigLdsBytes && !(t_dbg_flags & CT_DEBUG_FORCE_BAND)) return false;
   const size_t fixed = (size_t)(kBandCnt + 8) * 4 + band_ring_bytes<DIM>();
   auto bytes = [&](int r) { return (size_t)(r + 2) * S * 32 + fixed; };
   int r = (int)(((size_t)kHalfCuLdsBytes - fixed) / ((size_t)S * 32)) - 2;
@@ -2522,8 +2561,9 @@ int ct_splat_bwd_tk_segments(int B, int H, int C, int N, int dim, const int* W) 
   HotPlan sp;
   if ((t_dbg_flags & CT_DEBUG_FORCE_BAND) && C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4) return 2;
   if (!hot_chunks(C, (size_t)G * 8, 16, sp)) {
-    // the banded kernels (ct_raster_band.h) redo a band with exact ties from the incoming cotangent: a second tensor too
-    return (C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4 && !(t_dbg_flags & CT_DEBUG_NO_BAND)) ? 2 : 1;
+    // the banded kernels (ct_raster_band.h: grids beyond a CU's LDS) redo a band with exact ties from the incoming
+    // cotangent: a second tensor too
+    return (C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4 && (size_t)G * 4 > (size_t)kBigLdsBytes && !(t_dbg_flags & CT_DEBUG_NO_BAND)) ? 2 : 1;
   }
   return splat_bwd_segments(B, H, C, N, (int)G, dim, sp.lds);
 }

@@ -1,7 +1,9 @@
-"""Banded backward kernels of the four-channel heads (csrc/ct_raster_band.h: Slice backward fused, Splat(max) backward) —
-the zoo's 128^2 C4 / 32^3 C4 shapes, whose grids do not fit a CU.  Against the oracle on shapes it handles whole (the
-kernels forced onto small grids: several bands, a short last band, padding masks, ragged scan rounds, exact ties inside a
-band and across the row two bands share), and against the kernels they replace at the zoo's full sizes.
+"""Banded backward kernels of four-channel heads (csrc/ct_raster_band.h: Slice backward fused, Splat(max) backward): the
+dispatch gives them the 2D grids whose single-channel tile exceeds a CU's LDS (256^2 ...: otherwise global atomics); on the
+zoo's 128^2 C4 / 32^3 C4 heads they were measured slower than the single-channel kernels and run only when forced.
+Against the oracle on shapes it handles whole (forced onto small grids: several bands, a short last band, padding masks,
+ragged scan rounds, exact ties inside a band and across the row two bands share), and against the other kernel families
+at full sizes.
 
 Bars: g_grid within 1e-4 of each channel's max (fixed-point scatter-add, per-channel quantum), g_feat / g_keys within
 1e-4 (oracle) resp. 1e-5 (other kernel family) of the tensor's max; ties: one winner per (cell, channel)."""
@@ -141,14 +143,16 @@ def test_banded_splat_backward_with_exact_ties(dim):
     assert float(gf[..., half:].abs().max()) == 0.0
 
 
-ZOO = [(8, 4096, 16, 4, (128, 128)), (2, 16384, 16, 4, (128, 128)), (8, 4096, 16, 4, (32, 32, 32)), (2, 16384, 16, 4, (32, 32, 32)),
-       (8, 2048, 16, 4, (128, 128))]
+# the zoo's C4 heads (forced: their single-channel tiles fit LDS and the single-channel kernels are faster there, see
+# band_plan) and two grids beyond a CU's LDS, which the banded kernels take by default instead of global atomics
+ZOO = [(8, 4096, 16, 4, (128, 128), True), (2, 16384, 16, 4, (128, 128), True), (8, 4096, 16, 4, (32, 32, 32), True),
+       (2, 16384, 16, 4, (32, 32, 32), True), (2, 8192, 4, 4, (256, 256), False), (1, 8192, 4, 4, (512, 256), False)]
 
 
 @pytest.mark.parametrize("shape", ZOO, ids=lambda s: "B%dN%dH%dC%d_%s" % (s[0], s[1], s[2], s[3], "x".join(map(str, s[4]))))
-def test_banded_kernels_at_zoo_sizes_against_the_kernels_they_replace(shape):
+def test_banded_kernels_at_full_sizes_against_the_other_kernel_families(shape):
     mod, lib = _libs()
-    B, N, H, C, W = shape
+    B, N, H, C, W, forced = shape
     W, dim = list(W), len(W)
     torch.manual_seed(7)
     keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
@@ -156,8 +160,9 @@ def test_banded_kernels_at_zoo_sizes_against_the_kernels_they_replace(shape):
     cot_grid = torch.randn(B, H * C, *W, device="cuda")
     cot_pts = torch.randn(B, H * C, N, device="cuda")
     add = torch.randn(B, H * dim, N, device="cuda")
-    got, tags = run_bwd(keys, feat, cot_grid, cot_pts, add, None, W, H, dim, 0)
-    assert tags[0].startswith("band_slice_bwd") and tags[1].startswith("band_splat_bwd"), tags       # the default dispatch
+    fl = mod.DEBUG_FORCE_BAND if forced else 0
+    got, tags = run_bwd(keys, feat, cot_grid, cot_pts, add, None, W, H, dim, fl)
+    assert tags[0].startswith("band_slice_bwd") and tags[1].startswith("band_splat_bwd"), tags
     ref, rtags = run_bwd(keys, feat, cot_grid, cot_pts, add, None, W, H, dim, mod.DEBUG_NO_BAND)
     assert "band" not in rtags[0] and "band" not in rtags[1], rtags
     assert torch.equal(got[0], ref[0])
@@ -165,6 +170,6 @@ def test_banded_kernels_at_zoo_sizes_against_the_kernels_they_replace(shape):
     for name, a, r in zip(("g_keys_slice", "g_feat", "g_keys"), got[2:], ref[2:]):
         assert relerr(a, r) <= 1e-5, (name, relerr(a, r))
     # run to run: bitwise (fixed-point sums, every point and every cell owned by one workgroup)
-    again, _ = run_bwd(keys, feat, cot_grid, cot_pts, add, None, W, H, dim, 0)
+    again, _ = run_bwd(keys, feat, cot_grid, cot_pts, add, None, W, H, dim, fl)
     for a, r in zip(got, again):
         assert torch.equal(a, r)
