@@ -68,7 +68,28 @@ struct RasterArgs {
   float* fold_grid;
   const float* fold_add;  // the g_keys fold adds these rows (the incoming key cotangent) to the sum, or null
   const float* gpos_add;  // hot Splat(max) backward: g_pos = gpos_add + result (may alias g_pos: in place), or null
+  // Slice backward's statistics (per-channel max |src*pad|, contributions per cell) when N is split over workgroups: each
+  // split writes its own pair per channel here ([nsplit][B*H*C][2] words, plain stores) and the scatter kernel combines them
+  // (max of the maxima, sum of the per-split K) — instead of atomics on slots that a zero_slots launch had to clear first
+  unsigned* stats;
 };
+
+// (M, K) of channel `ch` of plane bh as the scatter kernels need them: from the partial statistics (a.stats) or from the
+// two slot words at the head of the channel's output tile
+__device__ __forceinline__ float stats_MK(const RasterArgs& a, size_t bh, int ch, const float* tile, int G) {
+  if (a.stats != nullptr) {
+    const size_t per = (size_t)a.B * a.H * a.C;
+    unsigned m = 0u, k = 0u;
+    for (int sp = 0; sp < a.nsplit; ++sp) {
+      const unsigned* w = a.stats + ((size_t)sp * per + bh * a.C + ch) * 2;
+      m = max(m, w[0]);      // non-negative floats order like their bit patterns
+      k += w[1];
+    }
+    return __uint_as_float(m) * (float)k;
+  }
+  const unsigned* slot = (const unsigned*)(tile + (size_t)ch * G);
+  return __uint_as_float(slot[0]) * (float)slot[1];
+}
 
 template <int DIM, bool FROM_KEYS>
 struct PointPos {
@@ -374,8 +395,7 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
   // One quantum PER CHANNEL (its own max |src*pad| from its slot, K of the plane): channels of a head may differ by
   // orders of magnitude, and a shared quantum would cost the quiet ones their precision.
   for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
-    const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
-    const float MK = __uint_as_float(slot[0]) * (float)slot[1];
+    const float MK = stats_MK(a, bh, c0 + ch, a.tile_out + (bh * a.C) * (size_t)g.G, g.G);
     const bool fixed = MK < 1e37f;
     int ex = 0;
     if (fixed && MK > 0.0f) (void)frexpf(MK, &ex);
@@ -452,8 +472,7 @@ __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatt
   if (ADD) {
     // per channel: its own max |src*pad| (slot 0) and the plane's max contributions per cell (slot 1)
     for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
-      const unsigned* slot = (const unsigned*)(gout + (size_t)ch * g.G);
-      const float MK = __uint_as_float(slot[0]) * (float)slot[1];
+      const float MK = stats_MK(a, bh, c0 + ch, a.tile_out + (bh * a.C) * (size_t)g.G, g.G);
       const bool fx = MK < 1e37f;
       int ex = 0;
       if (fx && MK > 0.0f) (void)frexpf(MK, &ex);
@@ -1156,18 +1175,22 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
       // workgroups the slots were zeroed and are combined atomically: max for M, and for K the SUM of
       // the per-split maxima (an upper bound of the true per-cell maximum, which is all K has to be).
       const bool split = a.nsplit > 1;
+      // a.stats: this split's own pair per channel (no atomics, nothing to clear beforehand: see RasterArgs::stats)
+      unsigned* mine = a.stats != nullptr ? a.stats + ((size_t)sp * a.B * a.H * a.C + bh * a.C) * 2 : nullptr;
       if (first) {
         if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&s_cnt[0], kmax);   // s_cnt[0] now holds max over waves
         __syncthreads();
         const unsigned kall = (unsigned)s_cnt[0];
         for (int ch = threadIdx.x; ch < a.C; ch += blockDim.x) {
           unsigned* kslot = (unsigned*)(a.tile_out + (bh * a.C + ch) * (size_t)g.G) + 1;
-          if (split) atomicAdd(kslot, kall);
+          if (mine != nullptr) mine[2 * ch + 1] = kall;
+          else if (split) atomicAdd(kslot, kall);
           else *kslot = kall;
         }
       }
       for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
-        if (split) atomicMax(slots + (size_t)ch * g.G, s_max[ch * 32]);
+        if (mine != nullptr) mine[2 * (c0 + ch)] = s_max[ch * 32];
+        else if (split) atomicMax(slots + (size_t)ch * g.G, s_max[ch * 32]);
         else slots[(size_t)ch * g.G] = s_max[ch * 32];
       }
     }
@@ -2215,6 +2238,13 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
 }
 
 
+// splits of N of the gather + statistics kernel of the two-kernel Slice backward (few planes: more workgroups)
+int slice_bwd_stats_nsplit(int B, int H, int N) {
+  int ns = 1;
+  while ((long long)B * H * ns < 256 && (N >> 2) / (ns * 2) >= 128) ns *= 2;
+  return ns;
+}
+
 // Slice backward, hot path: returns CT_EINVAL when the shape is not eligible.
 template <int DIM>
 int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int* W, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2255,17 +2285,23 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   if (pg.lds_bytes + extra > (size_t)kBigLdsBytes) return CT_EINVAL;
   ga.cnt_mask = cnt - 1;
   ga.CC = pg.CC; ga.nchunks = pg.nchunks; ga.ncg = 1; ga.atomic_gpos = 0;
-  ga.nsplit = 1;
-  while ((long long)a.B * a.H * ga.nsplit < 256 && (a.N >> 2) / (ga.nsplit * 2) >= 128) ga.nsplit *= 2;
+  ga.nsplit = slice_bwd_stats_nsplit(a.B, a.H, a.N);
+  const size_t stats_bytes = (size_t)ga.nsplit * a.B * a.H * a.C * 2 * 4;
+  unsigned* stats = nullptr;
   if (ga.nsplit > 1) {
-    // statistics are combined across the splits with atomics: zero their slots (first two words of
-    // every channel tile of g_grid) first
-    // (a kernel rather than hipMemset2DAsync: the 2-D memset node crashed HIP-graph capture on ROCm 7.0/7.2)
-    const size_t rows = (size_t)a.B * a.H * a.C;
-    CT_CLEAR_ERROR();
-    hipLaunchKernelGGL(zero_slots_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a.tile_out, (size_t)g.G, rows);
-    CT_CHECK_LAUNCH();
+    if (ws != nullptr && ws_bytes >= stats_bytes && ((uintptr_t)ws & 3) == 0) {
+      stats = (unsigned*)ws;             // every split writes its own statistics: nothing to clear, no atomics
+    } else {
+      // no scratch: the statistics are combined across the splits with atomics on the slots (first two words of every
+      // channel tile of g_grid), which a launch has to zero first
+      // (a kernel rather than hipMemset2DAsync: the 2-D memset node crashed HIP-graph capture on ROCm 7.0/7.2)
+      const size_t rows = (size_t)a.B * a.H * a.C;
+      CT_CLEAR_ERROR();
+      hipLaunchKernelGGL(zero_slots_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a.tile_out, (size_t)g.G, rows);
+      CT_CHECK_LAUNCH();
+    }
   }
+  ga.stats = stats;
   dim3 ggrid(ga.nsplit, a.H, a.B);
   if constexpr (DIM == 2)
     CT_LAUNCH_QUAD((2, QM_GATHER_GW, CT_QUAD_CG, CT_QUAD_THREADS, true), ggrid, quad_threads(a.N, ga.nsplit), pg.lds_bytes + extra, st, ga, g);
@@ -2274,9 +2310,10 @@ int run_slice_bwd_fast(RasterArgs a, const float* grid, float* g_pos, const int*
   // scatter side
   RasterArgs sa = a;
   sa.CC = ps.CC; sa.nchunks = ps.nchunks;
+  sa.stats = stats; sa.nsplit = ga.nsplit;
   const int sthreads = ps.threads;   // (finer chunks / smaller workgroups were measured: no gain)
   dim3 sgrid(sa.nchunks, a.H, a.B);
-  note(ga.nsplit > 1 ? "slice_bwd_gw_stats_nsplit" : "slice_bwd_gw_stats");
+  note(ga.nsplit > 1 ? (stats != nullptr ? "slice_bwd_gw_stats_parts" : "slice_bwd_gw_stats_nsplit") : "slice_bwd_gw_stats");
   if (scatter_quad_ok(sa, true, g.G)) {
     const int qt = scatter_quad_threads(DIM, a.N);
     if (sa.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, true, true>), sgrid, qt, (size_t)sa.CC * g.G * 4 + (size_t)sa.CC * 8, st, sa, g);
@@ -2540,7 +2577,11 @@ int ct_slice_bwd(const float* keys, const float* grid, const void* pad, int pad_
 
 size_t ct_slice_bwd_workspace_bytes(int B, int H, int C, int N, int dim, const int* W) {
   if (!valid_common(B, H, C, N, dim, W)) return 0;
-  return dim == 2 ? slice_bwd_hot_workspace(B, H, C, N, make_grid<2>(W)) : slice_bwd_hot_workspace(B, H, C, N, make_grid<3>(W));
+  const size_t hot = dim == 2 ? slice_bwd_hot_workspace(B, H, C, N, make_grid<2>(W)) : slice_bwd_hot_workspace(B, H, C, N, make_grid<3>(W));
+  // the two-kernel form's per-split statistics (run_slice_bwd_fast): [nsplit][B*H*C][2] words
+  const int ns = slice_bwd_stats_nsplit(B, H, N);
+  const size_t stats = ns > 1 ? (size_t)ns * B * H * C * 8 : 0;
+  return hot > stats ? hot : stats;
 }
 
 int ct_slice_bwd_ws(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,

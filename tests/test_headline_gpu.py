@@ -218,7 +218,7 @@ def test_fixed_point_scatter_add_keeps_every_channels_precision(family, flags):
         tag = lib.ct_debug_last_launch().decode()
         # (few planes: the channel chunks of a plane are dealt to several workgroups — "..._groups")
         # ("+folded": the groups' partial g_keys added inside the kernel, arrival tickets — tests/test_tickets_gpu.py)
-        assert tag.replace("+folded", "") == ("slice_bwd_fused_groups" if family == "hot" else "slice_bwd_gw_stats_nsplit+scatter_quad_add"), tag
+        assert tag.replace("+folded", "") == ("slice_bwd_fused_groups" if family == "hot" else "slice_bwd_gw_stats_parts+scatter_quad_add"), tag
     flags(0)
     assert _per_channel_err(z, ref, C) <= 1e-4, _per_channel_err(z, ref, C)
     assert _per_channel_err(grid.grad, ref, C) <= 1e-4, _per_channel_err(grid.grad, ref, C)
