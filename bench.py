@@ -329,6 +329,10 @@ def run_ddp_step(args):
     from torch import nn
     rank, local_rank, world, dist = init_rank()
     import torch.distributed as tdist
+    if world == 1:
+        # one rank: keep the norms' statistics exchange ON (a one-rank RCCL group), so that the step enqueues — and this
+        # line times — what every rank of an N-GPU step enqueues: 76 collectives + the bucketed gradient all-reduce
+        os.environ.setdefault("CLOUDCT_SYNCBN_FORCE", "1")
     if dist is None:            # DDP needs a process group even for one rank
         from cloud_transformers_amd.launch import free_port
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -349,16 +353,59 @@ def run_ddp_step(args):
     labels = torch.randint(13, (B, N), device="cuda")
     lossf = nn.CrossEntropyLoss()
 
-    def one():
-        opt.zero_grad(set_to_none=True)
+    from cloud_transformers_amd import ops
+
+    def fwd_bwd():
         loss = lossf(ddp(cloud), labels)
         loss.backward()                                # bucketed gradient all-reduce overlaps with this
+        return loss
+
+    def one_eager():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
         opt.step()
         return loss
 
-    for _ in range(max(1, args.warmup)):
+    # forward + loss + backward as ONE HIP graph, DDP's bucketed all-reduce and the norms' statistics exchanges captured
+    # with the kernels (RCCL collectives capture like launches).  DDP wants 11 eager iterations first (its reducer rebuilds
+    # the buckets after the first and settles); they run on a side stream, as torch's capture recipe asks.  The optimizer
+    # steps outside the graph.  --no-graph: the eager step (host-bound: ~3 000 launches through Python / ctypes).
+    graph, graph_error = None, None
+    collectives = None
+    if args.no_graph:
+        for _ in range(max(1, args.warmup)):
+            one_eager()
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(11, args.warmup)):
+                one_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        barrier(dist)
+        try:
+            opt.zero_grad(set_to_none=True)
+            c0 = ops.sync_stats_collectives()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                static_loss = fwd_bwd()
+            collectives = ops.sync_stats_collectives() - c0        # enqueued once, at capture; replayed every step
+        except Exception as e:      # noqa: BLE001  (a failed capture leaves the eager path usable: nothing was launched)
+            graph, graph_error = None, "%s: %s" % (type(e).__name__, e)
+            if rank == 0:
+                print("bench: HIP-graph capture of the DDP step failed (%s); timing the eager step" % graph_error, flush=True)
+            torch.cuda.synchronize()
+
+    def one():
+        if graph is None:
+            return one_eager()
+        graph.replay()
+        opt.step()
+        return static_loss
+
+    for _ in range(3):
         one()
-    from cloud_transformers_amd import ops
     coll0 = ops.sync_stats_collectives()
     barrier(dist)
     torch.cuda.synchronize()
@@ -368,6 +415,8 @@ def run_ddp_step(args):
     torch.cuda.synchronize()
     barrier(dist)
     dt = max_over_ranks(dist, time.perf_counter() - t0)
+    if collectives is None:
+        collectives = (ops.sync_stats_collectives() - coll0) / args.steps
     # every rank must hold the same parameters and running statistics after the steps (same initial weights, averaged
     # gradients, job-wide batch statistics): one float64 checksum per rank, gathered
     with torch.no_grad():
@@ -389,7 +438,11 @@ def run_ddp_step(args):
                                    % (nbytes / 4e6, B, N),
                        "per_gpu_batch": B, "parallelism": "dp%d" % world, "world_size_seen": world,
                        "gradient_allreduce_MB_per_step": nbytes / 1e6,
-                       "norm_statistics_collectives_per_step": (ops.sync_stats_collectives() - coll0) / args.steps,
+                       "norm_statistics_collectives_per_step": collectives,
+                       "norm_statistics_exchange": "forced on at world size 1 (CLOUDCT_SYNCBN_FORCE)" if (world == 1 and ops.SYNC_STATS_FORCE)
+                                                   else ("on" if world > 1 else "off (one rank: plain batch norm)"),
+                       "step": "HIP graph (forward + loss + backward, collectives captured) + optimizer" if graph is not None
+                               else ("eager" + (" (graph capture failed: %s)" % graph_error if graph_error else "")),
                        "params_equal_across_ranks": spread <= 1e-9, "param_checksum_spread": spread,
                        "loss": float(loss.detach())},
         }

@@ -9,8 +9,11 @@ package's layers and checkpoints stay interchangeable.
 * checkpoints: `<exp>/<name>_<epoch_name>_<n>.t7` holding a plain `state_dict()` (train_util.py:74-80); parameter names of
   this package's modules equal the reference's, so released weights load with `strict=True`; `restore_exp_fix` drops the
   `module.` prefix DistributedDataParallel adds (train_util.py:98-117).
-* data: real dataset readers (h5 / S3DIS rooms / GRNet) are out of scope; `SyntheticClouds` produces batches
-  of the shapes and dtypes those loaders yield.
+* data: `SyntheticClouds` produces batches of the shapes and dtypes the reference loaders yield (no files needed); with
+  `data.kind` in the config (or `Trainer(dataset=...)`) the loop runs on `data/datasets.py`'s readers instead — `scanobjectnn`
+  (datasets/scanobjectnn.py: `data.path` = the .h5 / .npz file) and `s3dis` (datasets/s3dis_v2.py: `data.path` = the
+  indoor3d_sem_seg_hdf5_data directory), items equal to the reference loaders' under the same seeds.  The remaining dataset
+  variants (s3dis_closer*, GRNet completion, image_point) stay out of scope.
 """
 import copy
 import datetime
@@ -168,6 +171,24 @@ class SyntheticClouds(torch.utils.data.Dataset):
         return pts, lab, (pts[:, 2] > 0).float()
 
 
+def make_dataset(cfg, task, n_classes, length=64, channels=3, train=True):
+    """The dataset `data.kind` of the config names: "synthetic" (default), "scanobjectnn" or "s3dis" (data/datasets.py)."""
+    data = cfg["data"]
+    kind = str(data.get("kind", "synthetic")).lower()
+    if kind == "synthetic":
+        return SyntheticClouds(task, data["num_points"], n_classes, length=length, channels=channels)
+    from .data import datasets as D
+    if kind == "scanobjectnn":
+        assert task == "classification", "ScanObjectNN items are (points, label, mask): the classification task"
+        return D.ScanObjectNN(data["path"], train=train, subsample=data.get("num_points"), center=data.get("center", True),
+                              normalize=data.get("normalize", True))
+    if kind == "s3dis":
+        assert task == "segmentation", "S3DIS blocks are (points, labels): the segmentation task"
+        return D.Indoor3DSemSeg(data["path"], data["num_points"], train=train, aug=bool(data.get("aug", train)),
+                                test_area=data.get("test_area", "Area_5"), data_precent=float(data.get("data_precent", 1.0)))
+    raise ValueError("data.kind must be synthetic, scanobjectnn or s3dis (got %r)" % kind)
+
+
 class Trainer:
     """The reference scripts' loop: model file + YAML config -> DDP(+SyncBN) model, optimizer, scheduler, steps with
     loss reduction to rank 0, `.t7` checkpoints every `train.save_each` iterations.
@@ -178,7 +199,7 @@ class Trainer:
     `n_classes` is then the size of the partial cloud)."""
 
     def __init__(self, cfg, task, n_classes, device=None, dist=None, exp_name="exp", dataset_length=64, make_dirs=True,
-                 channels=3):
+                 channels=3, dataset=None):
         self.cfg = cfg = copy.deepcopy(cfg)
         self.task, self.dist = task, dist
         self.rank = dist.get_rank() if parallel._active(dist) else 0
@@ -215,10 +236,13 @@ class Trainer:
                 for g in self.optimizer.param_groups:
                     g["lr"] = cfg["restore"]["new_lr"]
         self.scheduler = make_scheduler(self.optimizer, tr["scheduler"]) if "scheduler" in tr else None
-        data = SyntheticClouds(task, cfg["data"]["num_points"], n_classes, length=dataset_length, channels=channels)
+        # `dataset`: any torch Dataset whose items have the task's layout; else what `data.kind` of the config names
+        data = dataset if dataset is not None else make_dataset(cfg, task, n_classes, length=dataset_length, channels=channels)
         self.sampler = torch.utils.data.distributed.DistributedSampler(data) if parallel._active(dist) else None
         self.loader = torch.utils.data.DataLoader(data, batch_size=cfg["data"]["batch_size"], shuffle=self.sampler is None,
-                                                  num_workers=0, sampler=self.sampler, drop_last=True)
+                                                  num_workers=int(cfg["data"].get("num_workers", 0)), sampler=self.sampler,
+                                                  drop_last=bool(cfg["data"].get("drop_last", True)),
+                                                  worker_init_fn=worker_init_fn)
         self.ce, self.bce = nn.CrossEntropyLoss(), nn.BCEWithLogitsLoss()
         self.iters = 0
 
@@ -243,7 +267,8 @@ class Trainer:
         pts, label, mask = batch
         logits, mask_pred = self.model(pts.permute(0, 2, 1)[:, :, None].to(self.device))
         w = float(self.cfg["train"].get("seg_weight", 0.5))
-        return self.ce(logits, label.to(self.device)) + w * self.bce(mask_pred.reshape(mask.shape[0], -1), mask.to(self.device))
+        return (self.ce(logits, label.to(self.device).long())
+                + w * self.bce(mask_pred.reshape(mask.shape[0], -1), mask.to(self.device).float()))     # (ScanObjectNN's mask is int64)
 
     def save(self):
         if self.rank == 0 and self.exp_dir is not None:
@@ -258,52 +283,67 @@ class Trainer:
         self.optimizer.zero_grad()
         return loss.detach()
 
+    # DistributedDataParallel needs this many eager iterations before a capture (its reducer rebuilds the buckets after the
+    # first one and settles its bookkeeping; torch notes/cuda.rst "Usage with DistributedDataParallel")
+    DDP_WARMUP = 11
+
     def _capture(self, batch):
         """forward + loss + backward of one batch shape as ONE HIP graph on static input buffers (every libcloudct launch
-        goes to torch's current stream, so the whole step captures); the optimizer step stays outside.  The blocks' eager
-        launch rate is host-bound (~250 launches per block through Python / ctypes: the segmenter step 30.8 ms eager vs
-        24.8 ms graphed, profiles/r3_tools_output.txt)."""
-        self._static = [t.to(self.device).clone() for t in batch]
+        goes to torch's current stream, so the whole step captures — under DistributedDataParallel with its bucketed
+        gradient all-reduce and the norms' statistics exchanges: RCCL collectives are captured like kernels); the optimizer
+        step stays outside.  The blocks' eager launch rate is host-bound (~250 launches per block through Python / ctypes:
+        the segmenter step 30.8 ms eager vs 24.8 ms graphed, profiles/r3_tools_output.txt).  Returns the record of the
+        capture: (graph, static inputs, static loss, the gradient tensors the graph writes)."""
+        static = [t.to(self.device).clone() for t in batch]
         buffers = [b.clone() for b in self.model.buffers()]          # the warm-up passes must not count as training steps
+        params = [p for p in self.model.parameters() if p.requires_grad]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
+            for _ in range(self.DDP_WARMUP if parallel._active(self.dist) else 2):
                 self.optimizer.zero_grad(set_to_none=True)
-                self._loss(self._static).backward()
+                self._loss(static).backward()
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             for b, saved in zip(self.model.buffers(), buffers):
                 b.copy_(saved)
-        self.optimizer.zero_grad(set_to_none=True)                   # the graph re-creates the gradients in place
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_loss = self._loss(self._static)
-            self._static_loss.backward()
-        self._graph_shapes = [tuple(t.shape) for t in batch]
+        self.optimizer.zero_grad(set_to_none=True)                   # the graph creates its own gradient tensors
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            static_loss = self._loss(static)
+            static_loss.backward()
+        return graph, static, static_loss, [p.grad for p in params]
 
     def _graph_step(self, batch):
-        if self._graph is None:
-            self._capture(batch)
-        if [tuple(t.shape) for t in batch] != self._graph_shapes:    # a ragged last batch: run it eagerly
-            return self._eager_step(batch)
-        for dst, src in zip(self._static, batch):
+        """One step by graph replay.  A graph is captured per batch SHAPE (a ragged last batch, `data.drop_last: false`,
+        gets its own); every graph owns the gradient tensors it writes, so the parameters' `.grad` are pointed at the
+        replayed graph's before the optimizer steps — stepping with another graph's (stale) gradients, or dropping the
+        captured tensors with zero_grad(), would silently stop the training."""
+        key = tuple(tuple(t.shape) for t in batch)
+        rec = self._graphs.get(key)
+        if rec is None:
+            rec = self._graphs[key] = self._capture(batch)
+        graph, static, static_loss, grads = rec
+        for dst, src in zip(static, batch):
             dst.copy_(src, non_blocking=True)
-        self._graph.replay()
+        graph.replay()
+        for p, g in zip((p for p in self.model.parameters() if p.requires_grad), grads):
+            p.grad = g
         self.optimizer.step()
-        return self._static_loss.detach().clone()
+        return static_loss.detach().clone()
 
     def fit(self, max_iters=None, hip_graph=None, log_each=None):
         """Runs `train.num_epochs` epochs (or `max_iters` steps); returns the rank-0 loss history.
 
         `hip_graph` (default: `train.hip_graph` of the config, else False): replay forward + loss + backward as one HIP graph
-        (single process only: under DDP the gradient all-reduce is not captured, the step stays eager).  Losses stay on the
+        (under DistributedDataParallel too: the gradient all-reduce and the norms' statistics exchanges are captured with
+        the kernels, after DDP's warm-up iterations).  Losses stay on the
         device and are read back every `log_each` steps (default `train.log_each`, else 10) in ONE transfer — no host
         synchronisation per step (the reference reads the loss every step: train_segmentation.py:180-186)."""
         tr = self.cfg["train"]
-        use_graph = bool(tr.get("hip_graph", False) if hip_graph is None else hip_graph) and not parallel._active(self.dist)
+        use_graph = bool(tr.get("hip_graph", False) if hip_graph is None else hip_graph)
         log_each = int(tr.get("log_each", 10) if log_each is None else log_each)
-        self._graph = None
+        self._graphs = {}
         history, pending = [], []
 
         def flush():

@@ -860,6 +860,9 @@ def sync_stats_collectives():
     return _sync_stats_collectives
 
 
+SYNC_STATS_FORCE = os.environ.get("CLOUDCT_SYNCBN_FORCE", "0") == "1"
+
+
 def _sync_group(bn):
     """The process group a norm module exchanges its batch statistics over, or None: a plain BatchNorm1d, no process
     group initialised, or a SyncBatchNorm whose group has a single rank (torch's own SyncBatchNorm then runs the plain
@@ -870,7 +873,9 @@ def _sync_group(bn):
     if not (dist.is_available() and dist.is_initialized()):
         return None
     pg = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    return pg if dist.get_world_size(pg) > 1 else None
+    # (SYNC_STATS_FORCE: keep the exchange path on in a one-rank group too — what a multi-rank step enqueues, collectives
+    #  included, then runs and is timed on a single GPU: bench.py --mode ddp-step, tests/test_ddp_gpu.py)
+    return pg if dist.get_world_size(pg) > 1 or SYNC_STATS_FORCE else None
 
 
 def norms_share_group(bns):

@@ -71,3 +71,28 @@ def test_two_rank_ddp_step_on_rccl():
     assert line["n_gpus"] == 2 and cfg["world_size_seen"] == 2
     assert cfg["norm_statistics_collectives_per_step"] == 76
     assert cfg["params_equal_across_ranks"], cfg["param_checksum_spread"]
+
+
+def test_one_rank_ddp_step_graphed_with_the_statistics_exchange_forced_on():
+    """`bench.py --mode ddp-step` at one rank, in a child process (its own RCCL group): forward + loss + backward of the
+    S3DIS-shaped segmenter under DistributedDataParallel + SyncBatchNorm captured as ONE HIP graph, with the norms'
+    statistics exchange forced on (CLOUDCT_SYNCBN_FORCE: a one-rank group would otherwise skip it) — the same 76
+    collectives per step and the bucketed gradient all-reduce a multi-rank step enqueues, captured and replayed; the eager
+    step of the same process (--no-graph) must produce the same loss after the same number of steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for extra in ([], ["--no-graph"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "ddp-step", "--steps", "4", "--warmup", "2",
+                            "--batch", "2", "--points", "1024"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    g, e = lines
+    assert g["config"]["step"].startswith("HIP graph"), g["config"]["step"]
+    assert e["config"]["step"].startswith("eager"), e["config"]["step"]
+    for line in lines:
+        assert line["config"]["norm_statistics_collectives_per_step"] == 76, line["config"]
+        assert "forced" in line["config"]["norm_statistics_exchange"]

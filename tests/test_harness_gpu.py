@@ -107,3 +107,34 @@ def test_graph_captured_step_follows_the_eager_trajectory(tmp_path):
     eager, graphed = hists
     assert abs(eager[0] - graphed[0]) <= 1e-4 * abs(eager[0])                  # first step: identical weights and inputs
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)      # then the same trajectory
+
+
+def test_graphed_fit_survives_a_ragged_last_batch(tmp_path):
+    """`data.drop_last: false` with a dataset that is not a multiple of the batch: the last batch of every epoch has another
+    shape.  It gets a graph of its own; every graph owns the gradient tensors it writes and the step points the parameters'
+    `.grad` at the replayed graph's — the run must keep training after the odd batch (an eager fallback that dropped the
+    captured gradient tensors would leave every later step a no-op) and follow the eager trajectory."""
+    from cloud_transformers_amd import harness as H
+    (tmp_path / "segmenter.py").write_text(MODEL)
+    cfg_path = tmp_path / "s3dis.yaml"
+    text = CONFIG.format(root=str(tmp_path)).replace("save_each: 3", "save_each: 100000").replace("num_epochs: 1", "num_epochs: 3")
+    cfg_path.write_text(text.replace("    num_points: 512", "    num_points: 512\n    drop_last: false"))
+    hists, finals = [], []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        tr = H.Trainer(H.load_config(cfg_path), "segmentation", n_classes=13, device=torch.device("cuda", 0), dataset_length=5,
+                       channels=6, make_dirs=False)                     # batches of 2, 2, 1 per epoch
+        hists.append(tr.fit(hip_graph=graph, log_each=4))
+        assert len(hists[-1]) == 9
+        if graph:
+            assert len(tr._graphs) == 2
+        finals.append(torch.cat([p.detach().flatten() for p in tr.model.parameters()]))
+    eager, graphed = hists
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)
+    # the weights moved in every epoch, also after the odd batch: both runs end close to each other and far from the start
+    torch.manual_seed(0)
+    start = torch.cat([p.detach().flatten() for p in H.Trainer(H.load_config(cfg_path), "segmentation", n_classes=13,
+                                                               device=torch.device("cuda", 0), dataset_length=5, channels=6,
+                                                               make_dirs=False).model.parameters()])
+    moved = float((finals[1] - start).norm())
+    assert moved > 0 and float((finals[1] - finals[0]).norm()) <= 0.2 * moved, (moved, float((finals[1] - finals[0]).norm()))
