@@ -346,6 +346,14 @@ def run_ddp_step(args):
     B, N = args.batch, args.points
     torch.manual_seed(0)                               # same initial weights on every rank
     net = Segmenter().cuda()
+    # Everything DDP runs on ONE side stream — its construction (the reducer stashes the parameters' AccumulateGrad nodes,
+    # which remember the stream they were made on: its gradient hooks, and with them the bucketed all-reduce, run THERE),
+    # the warm-up iterations, the capture and the replays: torch's recipe for capturing DDP (notes/cuda.rst).  A step
+    # captured on another stream than the hooks' would enqueue the all-reduce outside the capture (and RCCL's watchdog
+    # then dies on "event last recorded in a capturing stream").
+    work_stream = torch.cuda.Stream()
+    work_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(work_stream)
     ddp = data_parallel(net, local_rank)
     opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
     torch.manual_seed(1234 + rank)                     # its own shard of the batch
@@ -376,19 +384,15 @@ def run_ddp_step(args):
         for _ in range(max(1, args.warmup)):
             one_eager()
     else:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(11, args.warmup)):
-                one_eager()
-        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(max(11, args.warmup)):
+            one_eager()
         torch.cuda.synchronize()
         barrier(dist)
         try:
             opt.zero_grad(set_to_none=True)
             c0 = ops.sync_stats_collectives()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, stream=work_stream, capture_error_mode="thread_local"):
                 static_loss = fwd_bwd()
             collectives = ops.sync_stats_collectives() - c0        # enqueued once, at capture; replayed every step
         except Exception as e:      # noqa: BLE001  (a failed capture leaves the eager path usable: nothing was launched)

@@ -645,6 +645,115 @@ extern "C" int ct_bn_group_bwd(const ct_bn_bwd_item* items, int n, int B, int N,
   return bn_bwd_launch_table(t, vec_all, (hipStream_t)s);
 }
 
+// ---- the norms of a group around ONE statistics exchange (SyncBatchNorm): each phase of all items in ONE launch ----
+// Buffer layouts (Ct = sum of the items' C, item i's channels start at c0_i):
+//   local / every rank's block of `gathered` (stride 2 Ct + 1): [mean: Ct | sum (x - mean)^2: Ct | count: 1]
+//   sums: [sum g': Ct | sum g' xhat: Ct]
+static int bn_group_fwd_table(const ct_bn_fwd_item* items, int n, int B, int N, int mode, float* local, const float* gathered,
+                              int world, float* count_out, BnTable& t, bool& vec_all) {
+  if (!items || n < 1 || n > kBnMaxItems) return CT_EINVAL;
+  int Ct = 0;
+  for (int i = 0; i < n; ++i) Ct += items[i].C;
+  const long long stride = 2ll * Ct + 1;
+  t.n = n;
+  vec_all = true;
+  int c0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_bn_fwd_item& it = items[i];
+    if (!it.x || it.C < 1) return CT_EINVAL;
+    BnArgs a{};
+    bool vec;
+    int rc;
+    if (mode == 1) {          // local statistics only: nothing but `local` is written
+      a = BnArgs{it.x, nullptr, nullptr, nullptr, nullptr, local + c0, local + Ct + c0, B, it.C, N, 0.0f, 0.0f, 0, 0, 0, nullptr, 0,
+                 nullptr, 1, i == 0 ? local + 2 * Ct : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+      rc = bn_fwd_prepare(a, const_cast<float*>(it.x), it.x_batch_stride, it.x_batch_stride, 0, vec);
+      t.y[i] = const_cast<float*>(it.x);
+    } else {
+      if (!it.weight || !it.bias || !it.y || !it.save_mean || !it.save_rstd || !(it.eps >= 0.0f)) return CT_EINVAL;
+      if ((it.running_mean == nullptr) != (it.running_var == nullptr)) return CT_EINVAL;
+      a = BnArgs{it.x, it.weight, it.bias, it.running_mean, it.running_var, it.save_mean, it.save_rstd, B, it.C, N, it.eps,
+                 it.momentum, it.relu, 0, 0, it.residual, 0, it.num_batches_tracked, 2, i == 0 ? count_out : nullptr,
+                 gathered + c0, gathered + Ct + c0, gathered + 2 * Ct, world, stride, it.amax_out};
+      rc = bn_fwd_prepare(a, it.y, it.x_batch_stride, it.y_batch_stride, it.residual_batch_stride, vec);
+      t.y[i] = it.y;
+    }
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.cstart[i] = c0;
+    t.item[i] = a;
+    c0 += it.C;
+  }
+  t.cstart[n] = c0;
+  return CT_OK;
+}
+
+extern "C" int ct_bn_group_stats_fwd(const ct_bn_fwd_item* items, int n, int B, int N, float* local, ct_stream_t s) {
+  if (!local) return CT_EINVAL;
+  BnTable t{};
+  bool vec;
+  const int rc = bn_group_fwd_table(items, n, B, N, 1, local, nullptr, 0, nullptr, t, vec);
+  return rc != CT_OK ? rc : bn_fwd_launch_table(t, vec, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_group_apply_fwd(const ct_bn_fwd_item* items, int n, int B, int N, const float* gathered, int world,
+                                     float* count_total, ct_stream_t s) {
+  if (!gathered || world < 1) return CT_EINVAL;
+  BnTable t{};
+  bool vec;
+  const int rc = bn_group_fwd_table(items, n, B, N, 2, nullptr, gathered, world, count_total, t, vec);
+  return rc != CT_OK ? rc : bn_fwd_launch_table(t, vec, (hipStream_t)s);
+}
+
+static int bn_group_bwd_table(const ct_bn_bwd_item* items, int n, int B, int N, int mode, float* sums, const float* count,
+                              BnBwdTable& t, bool& vec_all) {
+  if (!items || n < 1 || n > kBnMaxItems || !sums) return CT_EINVAL;
+  int Ct = 0;
+  for (int i = 0; i < n; ++i) Ct += items[i].C;
+  t.n = n;
+  vec_all = true;
+  int c0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ct_bn_bwd_item& it = items[i];
+    if (!it.x || !it.weight || !it.bias || !it.save_mean || !it.save_rstd || !it.gy || it.C < 1) return CT_EINVAL;
+    BnBwdArgs a{};
+    bool vec;
+    int rc;
+    if (mode == 1) {          // this rank's two sums per channel (g_bias = sum g' -> sums[c], g_weight = sum g' xhat -> sums[Ct + c])
+      a = BnBwdArgs{it.x, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, const_cast<float*>(it.x), sums + Ct + c0, sums + c0,
+                    B, it.C, N, it.relu, 0, 0, 0, 1, nullptr, nullptr, nullptr, nullptr};
+      rc = bn_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.x_batch_stride, vec);
+    } else {
+      if (!it.gx || !count) return CT_EINVAL;
+      a = BnBwdArgs{it.x, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, it.gx, nullptr, nullptr, B, it.C, N, it.relu, 0, 0, 0,
+                    2, sums + c0, sums + Ct + c0, count, it.amax_out};
+      rc = bn_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.gx_batch_stride, vec);
+    }
+    if (rc != CT_OK) return rc;
+    vec_all = vec_all && vec;
+    t.cstart[i] = c0;
+    t.item[i] = a;
+    c0 += it.C;
+  }
+  t.cstart[n] = c0;
+  return CT_OK;
+}
+
+extern "C" int ct_bn_group_reduce_bwd(const ct_bn_bwd_item* items, int n, int B, int N, float* sums, ct_stream_t s) {
+  BnBwdTable t{};
+  bool vec;
+  const int rc = bn_group_bwd_table(items, n, B, N, 1, sums, nullptr, t, vec);
+  return rc != CT_OK ? rc : bn_bwd_launch_table(t, vec, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_group_apply_bwd(const ct_bn_bwd_item* items, int n, int B, int N, const float* sums, const float* count,
+                                     ct_stream_t s) {
+  BnBwdTable t{};
+  bool vec;
+  const int rc = bn_group_bwd_table(items, n, B, N, 2, const_cast<float*>(sums), count, t, vec);
+  return rc != CT_OK ? rc : bn_bwd_launch_table(t, vec, (hipStream_t)s);
+}
+
 extern "C" int ct_bn_relu_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias,
                               float* running_mean, float* running_var, long long* num_batches_tracked,
                               const float* residual, long long residual_batch_stride, float* y, long long y_batch_stride,

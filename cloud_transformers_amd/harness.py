@@ -219,8 +219,18 @@ class Trainer:
             convert_pointwise(model)      # the model file's plain nn.Conv1d(k=1) stems / heads onto the blocks' GEMM kernels
         if "restore" in cfg and "generator" in cfg["restore"]:
             restore_exp_fix([model], [cfg["restore"]["generator"]], device=self.device, verbose=self.rank == 0)
+        self._stream = None
         if parallel._active(dist):
-            model = parallel.data_parallel(model, self.device.index if self.device.type == "cuda" else None)
+            if self.device.type == "cuda":
+                # DDP's gradient hooks (and its bucketed all-reduce) run on the stream the wrapper was BUILT on: the training
+                # steps, and the capture of fit(hip_graph=True), use that same side stream (torch notes/cuda.rst, "Usage
+                # with DistributedDataParallel")
+                self._stream = torch.cuda.Stream(device=self.device)
+                self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._stream):
+                    model = parallel.data_parallel(model, self.device.index)
+            else:
+                model = parallel.data_parallel(model, None)
         self.model = model
         tr = cfg["train"]
         if "scale_lr" in tr:      # the learnable residual scales of the AdaIN blocks get their own rate
@@ -297,7 +307,7 @@ class Trainer:
         static = [t.to(self.device).clone() for t in batch]
         buffers = [b.clone() for b in self.model.buffers()]          # the warm-up passes must not count as training steps
         params = [p for p in self.model.parameters() if p.requires_grad]
-        side = torch.cuda.Stream()
+        side = self._stream if self._stream is not None else torch.cuda.Stream()      # (DDP: the stream it was built on)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.DDP_WARMUP if parallel._active(self.dist) else 2):
@@ -309,7 +319,7 @@ class Trainer:
                 b.copy_(saved)
         self.optimizer.zero_grad(set_to_none=True)                   # the graph creates its own gradient tensors
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, stream=self._stream, capture_error_mode="thread_local"):
             static_loss = self._loss(static)
             static_loss.backward()
         return graph, static, static_loss, [p.grad for p in params]
@@ -360,7 +370,13 @@ class Trainer:
             self.model.train()
             end = time.time()
             for batch in self.loader:
-                loss = self._graph_step(batch) if use_graph else self._eager_step(batch)
+                if self._stream is not None:            # under DDP every step runs on the wrapper's stream (see __init__)
+                    self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(self._stream):
+                        loss = self._graph_step(batch) if use_graph else self._eager_step(batch)
+                    torch.cuda.current_stream(self.device).wait_stream(self._stream)
+                else:
+                    loss = self._graph_step(batch) if use_graph else self._eager_step(batch)
                 if self.scheduler is not None:
                     self.scheduler.step()
                 reduced = parallel.reduce_loss_dict(self.dist, {"loss": loss})

@@ -923,6 +923,28 @@ def _bn_group_fwd(items, B, N, device, group):
     Ct = sum(it["C"] for it in items)
     stride = 2 * Ct + 1
     local = torch.empty(stride, device=device, dtype=torch.float32)
+    if len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH:
+        # every phase of the group in ONE launch: statistics -> all_gather -> normalise (2 launches + 1 collective per group)
+        arr = (_lib.BnFwdItem * len(items))()
+        outs = []
+        for e, it in zip(arr, items):
+            mean = torch.empty(it["C"], device=device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            e.x, e.x_batch_stride, e.weight, e.bias = it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"])
+            e.running_mean, e.running_var, e.num_batches_tracked = _ptr(it["rm"]), _ptr(it["rv"]), _ptr(it["nbt"])
+            e.residual, e.residual_batch_stride, e.y, e.y_batch_stride = it["res"], it["rbs"], it["y"], it["ybs"]
+            e.save_mean, e.save_rstd, e.amax_out = _ptr(mean), _ptr(rstd), it.get("amax")
+            e.C, e.eps, e.momentum, e.relu = it["C"], float(it["eps"]), float(it["mom"]), int(it["relu"])
+            outs.append((mean, rstd))
+        _lib.check(lib.ct_bn_group_stats_fwd(ctypes.addressof(arr), len(items), B, N, _ptr(local), _stream()), "ct_bn_group_stats_fwd")
+        gathered = torch.empty(world * stride, device=device, dtype=torch.float32)
+        work = dist.all_gather_into_tensor(gathered, local, group=group, async_op=True)
+        _sync_stats_collectives += 1
+        count = torch.empty(1, device=device, dtype=torch.float32)
+        work.wait()                   # stream-level wait (no host synchronisation with the RCCL backend)
+        _lib.check(lib.ct_bn_group_apply_fwd(ctypes.addressof(arr), len(items), B, N, _ptr(gathered), world, _ptr(count), _stream()),
+                   "ct_bn_group_apply_fwd")
+        return outs, count
     base, c0 = local.data_ptr(), 0
     for i, it in enumerate(items):
         _lib.check(lib.ct_bn_stats_fwd(it["x"], it["xbs"], base + 4 * c0, base + 4 * (Ct + c0),
@@ -983,6 +1005,25 @@ def _bn_group_bwd(items, B, N, device, group, count):
     import torch.distributed as dist
     Ct = sum(it["C"] for it in items)
     sums = torch.empty(2 * Ct, device=device, dtype=torch.float32)       # [sum g' | sum g' * xhat]
+    if len(items) <= _lib.BN_GROUP_MAX and BN_GROUP_LAUNCH:
+        arr = (_lib.BnBwdItem * len(items))()
+        for e, it in zip(arr, items):
+            e.x, e.x_batch_stride, e.weight, e.bias = it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"])
+            e.save_mean, e.save_rstd, e.gy, e.gy_batch_stride = _ptr(it["mean"]), _ptr(it["rstd"]), it["gy"], it["gybs"]
+            e.gx, e.gx_batch_stride, e.g_weight, e.g_bias, e.amax_out = it["gx"], it["gxbs"], None, None, it.get("amax")
+            e.C, e.relu = it["C"], int(it["relu"])
+        _lib.check(lib.ct_bn_group_reduce_bwd(ctypes.addressof(arr), len(items), B, N, _ptr(sums), _stream()), "ct_bn_group_reduce_bwd")
+        local = sums.clone()                                              # this rank's g_bias / g_weight
+        work = dist.all_reduce(sums, group=group, async_op=True)
+        _sync_stats_collectives += 1
+        work.wait()
+        _lib.check(lib.ct_bn_group_apply_bwd(ctypes.addressof(arr), len(items), B, N, _ptr(sums), _ptr(count), _stream()),
+                   "ct_bn_group_apply_bwd")
+        c0 = 0
+        for it in items:
+            out.append((local[Ct + c0:Ct + c0 + it["C"]], local[c0:c0 + it["C"]]))
+            c0 += it["C"]
+        return out
     sb, c0 = sums.data_ptr(), 0
     for it in items:
         _lib.check(lib.ct_bn_reduce_bwd(it["x"], it["xbs"], _ptr(it["w"]), _ptr(it["b"]), _ptr(it["mean"]), _ptr(it["rstd"]),

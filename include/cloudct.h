@@ -263,6 +263,22 @@ typedef struct {
 } ct_bn_bwd_item;
 int ct_bn_group_fwd(const ct_bn_fwd_item* items, int n, int B, int N, ct_stream_t s);
 int ct_bn_group_bwd(const ct_bn_bwd_item* items, int n, int B, int N, ct_stream_t s);
+/* The same group around ONE statistics exchange between ranks (SyncBatchNorm, train_segmentation.py:128): every phase of
+ * all n norms in one launch — 2 launches + 1 collective per group and direction instead of 2 n + 1.  Ct = sum of the items' C,
+ * item i's channels start at c0_i:
+ *   ct_bn_group_stats_fwd : local f32[2 Ct + 1] = [mean | sum (x - mean)^2 | count] of THIS rank's batch (only x, C and
+ *                           x_batch_stride of the items are read);
+ *   ct_bn_group_apply_fwd : gathered f32[world][2 Ct + 1] (the ranks' `local` blocks, one all_gather) -> y, save_mean,
+ *                           save_rstd, running statistics, amax_out of every item; count_total f32[1] = values per channel
+ *                           of the whole job;
+ *   ct_bn_group_reduce_bwd: sums f32[2 Ct] = [sum g' | sum g' xhat] of this rank (g_weight / g_bias / gx of the items unused);
+ *   ct_bn_group_apply_bwd : sums all-reduced over the ranks + count -> gx, amax_out of every item. */
+int ct_bn_group_stats_fwd(const ct_bn_fwd_item* items, int n, int B, int N, float* local, ct_stream_t s);
+int ct_bn_group_apply_fwd(const ct_bn_fwd_item* items, int n, int B, int N, const float* gathered, int world,
+                          float* count_total, ct_stream_t s);
+int ct_bn_group_reduce_bwd(const ct_bn_bwd_item* items, int n, int B, int N, float* sums, ct_stream_t s);
+int ct_bn_group_apply_bwd(const ct_bn_bwd_item* items, int n, int B, int N, const float* sums, const float* count,
+                          ct_stream_t s);
 /* The same two with amax_out f32[C] (nullable): max |y| (after ReLU and skip) / max |g_x| per channel, a by-product of the
  * pass — the operand maxima ct_pw_gemm needs for the pointwise convolution that reads y / g_x next (n_amax = C). */
 int ct_bn_relu_fwd_amax(const float* x, long long x_batch_stride, const float* weight, const float* bias,
