@@ -333,13 +333,14 @@ def run_ddp_step(args):
         # one rank: keep the norms' statistics exchange ON (a one-rank RCCL group), so that the step enqueues — and this
         # line times — what every rank of an N-GPU step enqueues: 76 collectives + the bucketed gradient all-reduce
         os.environ.setdefault("CLOUDCT_SYNCBN_FORCE", "1")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")       # torch's recipe for capturing collectives (notes/cuda.rst)
     if dist is None:            # DDP needs a process group even for one rank
         from cloud_transformers_amd.launch import free_port
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         dist = tdist
-    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks
+    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks, quiesce as parallel_quiesce
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from segmenter_step_bench import Segmenter
 
@@ -388,6 +389,7 @@ def run_ddp_step(args):
             one_eager()
         torch.cuda.synchronize()
         barrier(dist)
+        parallel_quiesce()
         try:
             opt.zero_grad(set_to_none=True)
             c0 = ops.sync_stats_collectives()

@@ -318,6 +318,9 @@ class Trainer:
             for b, saved in zip(self.model.buffers(), buffers):
                 b.copy_(saved)
         self.optimizer.zero_grad(set_to_none=True)                   # the graph creates its own gradient tensors
+        if parallel._active(self.dist):
+            parallel.barrier(self.dist)
+            parallel.quiesce()                                       # the process group's watchdog drops the warm-up's work items
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=self._stream, capture_error_mode="thread_local"):
             static_loss = self._loss(static)

@@ -22,6 +22,18 @@ def barrier(dist):
         dist.barrier()
 
 
+def quiesce(seconds=0.5):
+    """Before a HIP-graph capture that contains collectives: the device is idle (the caller synchronised), but the process
+    group's watchdog thread still holds the finished work items of the eager warm-up until its next poll (every 100 ms) and
+    queries their events then — which HIP refuses while the streams those events live on are capturing ("operation not
+    permitted on an event last recorded in a capturing stream": the watchdog then takes the process down).  Waiting out a
+    few polls lets it drop them first."""
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 def _device_for(dist):
     if _active(dist) and dist.get_backend() == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
