@@ -76,7 +76,7 @@ def test_two_rank_ddp_step_on_rccl():
 def test_one_rank_ddp_step_graphed_with_the_statistics_exchange_forced_on():
     """`bench.py --mode ddp-step` at one rank, in a child process (its own RCCL group): forward + loss + backward of the
     S3DIS-shaped segmenter under DistributedDataParallel + SyncBatchNorm captured as ONE HIP graph, with the norms'
-    statistics exchange forced on (CLOUDCT_SYNCBN_FORCE: a one-rank group would otherwise skip it) — the same 76
+    statistics exchange forced on (CLOUDCT_SYNCBN_FORCE: a one-rank group would otherwise skip it) — the blocks' 72
     collectives per step and the bucketed gradient all-reduce a multi-rank step enqueues, captured and replayed; the eager
     step of the same process (--no-graph) must produce the same loss after the same number of steps."""
     import json
@@ -88,11 +88,15 @@ def test_one_rank_ddp_step_graphed_with_the_statistics_exchange_forced_on():
     for extra in ([], ["--no-graph"]):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "ddp-step", "--steps", "4", "--warmup", "2",
                             "--batch", "2", "--points", "1024"] + extra, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        why = [l for l in r.stderr.splitlines() if not l.startswith("frame #") and l.strip()]
+        assert r.returncode == 0, "\n".join(why[-25:])[-4000:]
         lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
     g, e = lines
     assert g["config"]["step"].startswith("HIP graph"), g["config"]["step"]
     assert e["config"]["step"].startswith("eager"), e["config"]["step"]
     for line in lines:
-        assert line["config"]["norm_statistics_collectives_per_step"] == 76, line["config"]
+        # 6 per MultiHeadUnion block x 12; the 4 of the stem's / head's stock nn.SyncBatchNorm layers (76 in all at two ranks and
+        # more, test_two_rank_ddp_step_on_rccl) are skipped by torch itself in a one-rank group
+        assert line["config"]["norm_statistics_collectives_per_step"] == 72, line["config"]
         assert "forced" in line["config"]["norm_statistics_exchange"]
+    assert abs(g["config"]["loss"] - e["config"]["loss"]) <= 2e-2 * abs(e["config"]["loss"]), (g["config"]["loss"], e["config"]["loss"])
