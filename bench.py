@@ -382,7 +382,7 @@ def run_ddp_step(args):
     graph, graph_error = None, None
     collectives = None
     if args.no_graph:
-        for _ in range(max(1, args.warmup)):
+        for _ in range(max(11, args.warmup)):          # (as many as the graphed form: the two lines are comparable step for step)
             one_eager()
     else:
         for _ in range(max(11, args.warmup)):
