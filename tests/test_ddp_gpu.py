@@ -100,3 +100,35 @@ def test_one_rank_ddp_step_graphed_with_the_statistics_exchange_forced_on():
         assert line["config"]["norm_statistics_collectives_per_step"] == 72, line["config"]
         assert "forced" in line["config"]["norm_statistics_exchange"]
     assert abs(g["config"]["loss"] - e["config"]["loss"]) <= 2e-2 * abs(e["config"]["loss"]), (g["config"]["loss"], e["config"]["loss"])
+
+
+def test_harness_fit_graphs_the_ddp_step(tmp_path):
+    """harness.Trainer under DistributedDataParallel + SyncBatchNorm (one RCCL rank, the norms' statistics exchange forced
+    on): fit(hip_graph=True) captures forward + loss + backward with the collectives and follows the eager trajectory."""
+    from cloud_transformers_amd import harness as H
+    from cloud_transformers_amd import ops
+    from tests.test_harness_gpu import CONFIG, MODEL
+    (tmp_path / "segmenter.py").write_text(MODEL)
+    cfg_path = tmp_path / "s3dis.yaml"
+    cfg_path.write_text(CONFIG.format(root=str(tmp_path)).replace("save_each: 3", "save_each: 100000"))
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    forced = ops.SYNC_STATS_FORCE
+    ops.SYNC_STATS_FORCE = True
+    try:
+        hists = []
+        for graph in (False, True):
+            torch.manual_seed(0)
+            tr = H.Trainer(H.load_config(cfg_path), "segmentation", n_classes=13, device=torch.device("cuda", 0), dist=dist,
+                           dataset_length=16, channels=6, make_dirs=False)
+            assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+            c0 = ops.sync_stats_collectives()
+            hists.append(tr.fit(max_iters=5, hip_graph=graph, log_each=5))
+            assert ops.sync_stats_collectives() > c0                   # the exchange path ran (captured once when graphed)
+            assert len(hists[-1]) == 5
+        eager, graphed = hists
+        assert abs(eager[0] - graphed[0]) <= 1e-4 * abs(eager[0])
+        assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)
+    finally:
+        ops.SYNC_STATS_FORCE = forced
+        dist.destroy_process_group()
