@@ -33,7 +33,10 @@ typedef float pw_acc __attribute__((ext_vector_type(16)));
 constexpr int kPwTile = 128, kPwBK = 32, kPwThreads = 512, kPwR = 8;   // kPwR: operand elements per thread and K-step
 constexpr int kPwImg = kPwTile * kPwBK;                 // halves per image
 constexpr int kPwStage = 4 * kPwImg;                    // A_h, A_l, B_h, B_l
-constexpr int kPwLdsBytes = 2 * kPwStage * 2;           // two stages
+constexpr int kPwStageBytes = 2 * kPwStage * 2;         // two stages
+// behind the stages: the scale exponents of the tile's 128 A rows and 128 B rows / columns (kept to the epilogue) and the
+// scratch they are folded through
+constexpr int kPwLdsBytes = kPwStageBytes + (256 + 1024) * 4;
 
 struct PwArgs {
   const float* A; const float* B; float* C;
@@ -43,6 +46,10 @@ struct PwArgs {
   int tilesM, tilesN, ksplit, Kc;  // z = cloud * ksplit + chunk; the chunk sums k in [chunk*Kc, min(K, (chunk+1)*Kc))
   const float* amax_a; const float* amax_b;
   int n_amax_a, n_amax_b;          // partial maxima per operand (<= kPwAmaxMax)
+  // > 0: the operand's maxima are PER ROW of its k-contiguous arrangement, laid out [n_amax / rows][rows] (a producer's
+  // per-channel or per-(cloud, channel) maxima, ct_pw_prep_weight_rs's per-tile row / column maxima): every row gets its
+  // own power-of-two scale, which factors out of the row's (column's) outputs exactly
+  int rows_a, rows_b;
 #ifdef PW_STAMP
   unsigned long long* dbg;   // development builds: per-phase cycle sums of every wave (tools/dev/pw_stamp.py)
 #endif
@@ -132,7 +139,7 @@ __device__ __forceinline__ void pw_split2(float a0, float a1, float s, unsigned&
       "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
       "s_nop 0"
       : "=&v"(h), "=&v"(l)
-      : "v"(a0), "v"(a1), "s"(s));
+      : "v"(a0), "v"(a1), "v"(s));
 }
 
 // eight values -> the h and l fragments' 16 bytes
@@ -240,8 +247,39 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { ma = max(ma, fold[i]); mb = max(mb, fold[8 + i]); }
   __syncthreads();
-  const int ea = pw_scale_exp(ma), eb = pw_scale_exp(mb);
-  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
+  // Scale exponents.  Per tensor: s * max in [2^13, 2^14).  Per row (rows_a / rows_b: the operand's maxima are per row of
+  // its k-contiguous arrangement): the same with the row's own maximum — a channel 2^-20 below the tensor's maximum keeps
+  // its 22 bits instead of sinking into f16's subnormals — and the factor comes out of the row's outputs exactly.  A
+  // row-contiguous operand (x / g_y of forward and data gradient: k = channel) can only have ONE scale over k.
+  int* etab = (int*)((char*)pw_lds + kPwStageBytes);      // [128] A rows of the tile | [128] B rows (= output columns)
+  {
+    unsigned* scr = (unsigned*)(etab + 256);              // [4][128] A | [4][128] B
+    const int i = t & 127, part = t >> 7;
+    if (a.rows_a > 0) {
+      const int row = min(m0 + i, a.M - 1), nb = a.n_amax_a / a.rows_a;
+      unsigned m = 0u;
+      for (int j = part; j < nb; j += 4) m = max(m, __float_as_uint(a.amax_a[(size_t)j * a.rows_a + row]) & 0x7fffffffu);
+      scr[part * 128 + i] = m;
+    }
+    if (B_KMAJOR && a.rows_b > 0) {
+      const int row = min(n0 + i, a.N - 1), nb = a.n_amax_b / a.rows_b;
+      unsigned m = 0u;
+      for (int j = part; j < nb; j += 4) m = max(m, __float_as_uint(a.amax_b[(size_t)j * a.rows_b + row]) & 0x7fffffffu);
+      scr[512 + part * 128 + i] = m;
+    }
+    __syncthreads();
+    if (t < 128) {
+      etab[t] = a.rows_a > 0 ? pw_scale_exp(max(max(scr[t], scr[128 + t]), max(scr[256 + t], scr[384 + t]))) : pw_scale_exp(ma);
+    } else if (t < 256) {
+      const int u = t - 128;
+      etab[t] = (B_KMAJOR && a.rows_b > 0) ? pw_scale_exp(max(max(scr[512 + u], scr[640 + u]), max(scr[768 + u], scr[896 + u])))
+                                           : pw_scale_exp(mb);
+    }
+    __syncthreads();
+  }
+  // the staging thread's scale: a k-contiguous operand's thread owns (part of) ONE row of the tile
+  const float sa = ldexpf(1.f, etab[t >> 2]);
+  const float sb = ldexpf(1.f, B_KMAJOR ? etab[128 + (t >> 2)] : etab[128]);
 
   pw_acc acc[2];                                     // wave tile 64 x 32: rows 64*wm + 32*i, columns 32*wn
 #pragma unroll
@@ -374,13 +412,14 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
     for (int i = 0; i < 6; ++i) a.dbg[((size_t)blockIdx.x * 8 + w) * 6 + i] = tsum[i];
 #endif
   // D of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-  const float ia = ldexpf(1.f, -ea), ib = ldexpf(1.f, -eb);
+  const float ib = ldexpf(1.f, -etab[128 + 32 * wn + r]);
   const int col = n0 + 32 * wn + r;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int lr = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h, row = m0 + lr;
+      const float ia = ldexpf(1.f, -etab[lr]);
       if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][e] * ia * ib;
     }
 }
@@ -472,7 +511,7 @@ __global__ void __launch_bounds__(256) pw_transpose_kernel(const float* __restri
 #endif
 constexpr int kPwZTarget = CT_PW_ZTARGET;
 constexpr int kPwAmaxLen = 512;       // = kPwThreads: one partial maximum per GEMM thread
-constexpr int kPwAmaxMax = 4096;      // what a producer may leave instead (per channel, per (cloud, channel))
+constexpr int kPwAmaxMax = 32768;     // what a producer may leave instead (per channel, per (cloud, channel), per (column tile, row))
 
 // The same with the weight's partial maxima (one per 32x32 tile, <= kPwAmaxMax tiles): what a layer's forward needs of its
 // weight for all three products, in one launch.
@@ -503,6 +542,67 @@ __global__ void __launch_bounds__(256) pw_prep_weight_kernel(const float* __rest
       if (r < R && c < C) wt[(size_t)c * R + r] = tile[tx][ty + 8 * i];
     }
   }
+}
+
+// ct_pw_prep_weight_rs: W [R][C] -> W^T (optional), the per-row maxima of every 32-column tile rowmax[tile_c][R] and the
+// per-column maxima of every 32-row tile colmax[tile_r][C] — the per-row maxima of W and of W^T in the [n / rows][rows]
+// layout ct_pw_gemm_rs folds.  One launch, one read of W.
+__global__ void __launch_bounds__(256) pw_prep_weight_rs_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                unsigned* __restrict__ rowmax, unsigned* __restrict__ colmax, int R, int C) {
+  __shared__ float tile[32][33];
+  __shared__ unsigned cpart[8][32];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  unsigned cm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    unsigned m = 0;
+    if (r < R && c < C) {
+      const float v = w[(size_t)r * C + c];
+      tile[ty + 8 * i][tx] = v;
+      m = __float_as_uint(v) & 0x7fffffffu;
+    }
+    cm = max(cm, m);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));      // over the row's 32 columns (a half wave)
+    if (tx == 0 && r < R) rowmax[(size_t)blockIdx.x * R + r] = m;
+  }
+  cpart[ty][tx] = cm;
+  __syncthreads();
+  if (ty == 0 && c0 + tx < C) {
+    unsigned m = cpart[0][tx];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) m = max(m, cpart[j][tx]);
+    colmax[(size_t)blockIdx.y * C + c0 + tx] = m;
+  }
+  if (wt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (r < R && c < C) wt[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+    }
+  }
+}
+
+// ct_amax_rows_f32: out[c] = max over (b, n) of |x[b][c][n]| for x [B][C][N] — the per-row maxima of an activation the
+// weight gradient reads when no producer left them.  One workgroup per channel, 16-byte loads.
+__global__ void __launch_bounds__(256) pw_amax_rows_kernel(const float* __restrict__ x, int B, int C, int N, unsigned* __restrict__ out) {
+  typedef unsigned pw_u4 __attribute__((ext_vector_type(4)));
+  const int c = blockIdx.x, n4 = N >> 2;
+  unsigned m = 0;
+  for (int b = 0; b < B; ++b) {
+    const pw_u4* p = (const pw_u4*)(x + ((size_t)b * C + c) * N);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const pw_u4 v = __builtin_nontemporal_load(p + i);
+      m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+  }
+  __shared__ unsigned wave_max[4];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 }
 
 struct PwPlan {
@@ -592,17 +692,54 @@ size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
 }
 
+// per-row / per-column maxima of W [Co][Ci] for ct_pw_gemm_rs: rowmax f32[ceil(Ci/32)][Co], colmax f32[ceil(Co/32)][Ci];
+// wt f32[Ci][Co] = W^T or NULL
+int ct_pw_prep_weight_rs(const float* w, float* wt, float* rowmax, float* colmax, int Co, int Ci, ct_stream_t s) {
+  if (!w || !rowmax || !colmax || Co < 1 || Ci < 1) return CT_EINVAL;
+  if ((long long)((Ci + 31) / 32) * Co > kPwAmaxMax || (long long)((Co + 31) / 32) * Ci > kPwAmaxMax) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(pw_prep_weight_rs_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, (hipStream_t)s, w, wt,
+                     (unsigned*)rowmax, (unsigned*)colmax, Co, Ci);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_amax_rows_f32(const float* x, int B, int C, int N, float* amax, ct_stream_t s) {
+  if (!x || !amax || B < 1 || C < 1 || N < 4 || (N & 3) || ((uintptr_t)x & 15)) return CT_EINVAL;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(pw_amax_rows_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, B, C, N, (unsigned*)amax);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a, const float* amax_b,
                int n_amax_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci, int N, ct_stream_t s) {
+  return ct_pw_gemm_rs(mode, a, b, out, amax_a, n_amax_a, 0, amax_b, n_amax_b, 0, workspace, workspace_bytes, B, Co, Ci, N, s);
+}
+
+int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a, int rows_a,
+                  const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,
+                  int N, ct_stream_t s) {
   PwPlan p;
   if (!a || !b || !out || !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
   if ((amax_a && (n_amax_a < 1 || n_amax_a > kPwAmaxMax)) || (amax_b && (n_amax_b < 1 || n_amax_b > kPwAmaxMax))) return CT_EINVAL;
+  // per-row maxima: of the A operand's rows in the arrangement the kernel reads it in (W: Co rows; W^T: Ci; g_y: Co) and, for
+  // the weight gradient, of x's Ci rows; anything else about rows_* is an error, 0 = the maxima are partials of ONE maximum
+  {
+    const int want_a = (mode == CT_PW_FWD || mode == CT_PW_WGRAD) ? Co : Ci;
+    if (rows_a != 0 && (!amax_a || rows_a != want_a || n_amax_a % rows_a != 0)) return CT_EINVAL;
+    if (rows_b != 0 && (!amax_b || n_amax_b % rows_b != 0)) return CT_EINVAL;
+    if (mode == CT_PW_WGRAD) { if (rows_b != 0 && rows_b != Ci) return CT_EINVAL; }
+    else rows_b = 0;              // a row-contiguous operand has one scale: its maxima are folded into one
+    if (mode == CT_PW_DGRAD) rows_a = 0;      // (the maxima belong to W, the kernel reads the W^T this call writes)
+  }
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CT_EINVAL;
   if (p.ws && (!workspace || workspace_bytes < p.ws || ((uintptr_t)workspace & 15))) return CT_EWORKSPACE;
   CT_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)s;
   PwArgs g{};
   g.A = a; g.B = b; g.amax_a = amax_a; g.amax_b = amax_b; g.n_amax_a = n_amax_a; g.n_amax_b = n_amax_b;
+  g.rows_a = rows_a; g.rows_b = rows_b;
 #ifdef PW_STAMP
   g.dbg = g_pw_dbg;
 #endif

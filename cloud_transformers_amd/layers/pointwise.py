@@ -23,16 +23,18 @@ class _PointwiseConvFn(torch.autograd.Function):
         x = x.contiguous()
         w2 = weight[:, :, 0].contiguous()
         y, am_w, am_x, wt = ops.pw_forward(w2, x, ctx.needs_input_grad[0])
-        ctx.save_for_backward(x, w2, am_w, am_x, wt)
+        am_w = am_w if am_w is not None else (None, None)       # (row maxima, column maxima) of the weight
+        ctx.save_for_backward(x, w2, am_w[0], am_w[1], am_x, wt)
         ctx.has_bias = bias is not None
         return y if bias is None else y + bias[None, :, None]
 
     @staticmethod
     def backward(ctx, g_y):
-        x, w2, am_w, am_x, wt = ctx.saved_tensors
+        x, w2, am_wr, am_wc, am_x, wt = ctx.saved_tensors
         g_y = g_y.contiguous()
         g_b = None
-        g_x, g_w = ops.pw_backward(w2, x, g_y, am_w, am_x, ctx.needs_input_grad[0], ctx.needs_input_grad[1], Wt=wt)
+        g_x, g_w = ops.pw_backward(w2, x, g_y, None if am_wr is None else (am_wr, am_wc), am_x, ctx.needs_input_grad[0],
+                                   ctx.needs_input_grad[1], Wt=wt)
         if g_w is not None:
             g_w = g_w.unsqueeze(-1)                                           # [O, I, 1]
         if ctx.has_bias and ctx.needs_input_grad[2]:

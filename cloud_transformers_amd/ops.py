@@ -128,7 +128,7 @@ def amax(t):
     return out
 
 
-PW_AMAX_MAX = 4096      # partial maxima ct_pw_gemm folds per operand
+PW_AMAX_MAX = 32768     # partial maxima ct_pw_gemm folds per operand
 
 
 def _amax_slots(C, device):
@@ -140,19 +140,42 @@ def _amax_slots(C, device):
 
 
 def tag_amax(t, slots):
-    """Remember on tensor `t` the maxima its producer left in `slots` (valid until `t` is modified in place)."""
+    """Remember on tensor `t` [B, C, N] the maxima its producer left in `slots` (valid until `t` is modified in place).  The
+    producers write one maximum per channel (or per (cloud, channel)): kept as a 2-D [n / C, C] view — the shape is what tells
+    ct_pw_gemm_rs that these are PER-ROW maxima (a 1-D tensor holds partials of one maximum, ops.amax)."""
     if slots is not None:
+        C = t.shape[1] if t.dim() == 3 else 0
+        if C and slots.dim() == 1 and slots.numel() % C == 0:
+            slots = slots.view(-1, C)
         t._ct_amax = (slots, t._version)
     return t
 
 
-def amax_of(t):
+def amax_rows(t):
+    """Per-channel maxima of |t| for a contiguous float32 [B, C, N] tensor, as a [1, C] tensor (ct_amax_rows_f32): what the
+    weight gradient wants of an operand no producer left maxima for."""
+    B, C, N = t.shape
+    if C > PW_AMAX_MAX or N % 4 != 0:
+        return amax(t)
+    out = torch.empty(1, C, device=t.device, dtype=torch.float32)
+    with _on(t.device):
+        _lib.check(_lib.load().ct_amax_rows_f32(_ptr(t), B, C, N, _ptr(out), _stream()), "ct_amax_rows_f32")
+    return out
+
+
+def _rows_of(am, want):
+    """`want` when `am` holds per-row maxima of an operand with `want` rows (2-D [.., want]), else 0 (partials of one maximum)."""
+    return want if (am is not None and am.dim() == 2 and am.shape[1] == want) else 0
+
+
+def amax_of(t, rows=False):
     """The operand maxima of `t` for ct_pw_gemm: what its producer left behind if `t` is unchanged since (an in-place op
-    bumps `_version`), else a ct_amax_f32 pass over it."""
+    bumps `_version`), else a pass over it — ct_amax_rows_f32 (per channel) where the consumer can use per-row scales
+    (`rows`: the weight gradient), ct_amax_f32 otherwise."""
     tag = getattr(t, "_ct_amax", None)
     if tag is not None and tag[1] == t._version and tag[0].device == t.device:
         return tag[0]
-    return amax(t)
+    return amax_rows(t) if (rows and t.dim() == 3) else amax(t)
 
 
 def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
@@ -168,39 +191,44 @@ def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
         out = torch.empty(Co, Ci, device=dev, dtype=torch.float32)
     nbytes = lib.ct_pw_gemm_workspace_bytes(mode, B, Co, Ci, N)
     ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32) if nbytes else None
+    # per-row scales wherever the maxima are per row of the operand's k-contiguous arrangement (2-D: tag_amax, prep_weight)
+    rows_a = _rows_of(amax_a, Co if mode in (PW_FWD, PW_WGRAD) else Ci) if mode != PW_DGRAD else 0
+    rows_b = _rows_of(amax_b, Ci) if mode == PW_WGRAD else 0
     with _on(dev):
-        _lib.check(lib.ct_pw_gemm(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), 0 if amax_a is None else amax_a.numel(),
-                                  _ptr(amax_b), 0 if amax_b is None else amax_b.numel(), _ptr(ws), nbytes, B, Co, Ci, N,
-                                  _stream()), "ct_pw_gemm")
+        _lib.check(lib.ct_pw_gemm_rs(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), 0 if amax_a is None else amax_a.numel(), rows_a,
+                                     _ptr(amax_b), 0 if amax_b is None else amax_b.numel(), rows_b, _ptr(ws), nbytes, B, Co, Ci, N,
+                                     _stream()), "ct_pw_gemm_rs")
     return out
 
 
 def prep_weight(W, transpose):
-    """(partial maxima of |W|, W^T or None) in ONE launch (ct_pw_prep_weight): what the three products of a layer need of its
-    weight; falls back to amax() + no transpose for weights with more 32x32 tiles than ct_pw_gemm folds."""
+    """((row maxima of |W|, column maxima), W^T or None) in ONE launch (ct_pw_prep_weight_rs): what the three products of a layer
+    need of its weight — per-row scales for W in the forward ([tiles, Co]) and for W^T in the data gradient ([tiles, Ci]); falls
+    back to (amax(), None) and no transpose for weights with more maxima than ct_pw_gemm_rs folds."""
     lib = _lib.load()
     Co, Ci = W.shape
-    n = lib.ct_pw_prep_weight_partials(Co, Ci)
-    if n == 0:
-        return amax(W), None
-    am = torch.empty(n, device=W.device, dtype=torch.float32)
+    tc, tr = (Ci + 31) // 32, (Co + 31) // 32
+    if tc * Co > PW_AMAX_MAX or tr * Ci > PW_AMAX_MAX:
+        return (amax(W), None), None
+    rowmax = torch.empty(tc, Co, device=W.device, dtype=torch.float32)
+    colmax = torch.empty(tr, Ci, device=W.device, dtype=torch.float32)
     Wt = torch.empty(Ci, Co, device=W.device, dtype=torch.float32) if transpose else None
     with _on(W.device):
-        _lib.check(lib.ct_pw_prep_weight(_ptr(W), _ptr(Wt), _ptr(am), Co, Ci, _stream()), "ct_pw_prep_weight")
-    return am, Wt
+        _lib.check(lib.ct_pw_prep_weight_rs(_ptr(W), _ptr(Wt), _ptr(rowmax), _ptr(colmax), Co, Ci, _stream()), "ct_pw_prep_weight_rs")
+    return (rowmax, colmax), Wt
 
 
 def pw_forward(W, x, need_dgrad=False):
     """y[b] = W x[b] for W [Co,Ci], x [B,Ci,N] (both contiguous float32 on the device); returns (y, amax_W, amax_x, W^T) — the
-    scales and, with need_dgrad, the transposed weight are reused by the gradients — or (y, None, None, None) from the library
-    GEMM."""
+    maxima (amax_W: the pair (row maxima, column maxima) of prep_weight) and, with need_dgrad, the transposed weight are reused
+    by the gradients — or (y, None, None, None) from the library GEMM."""
     Co, Ci = W.shape
     B, _, N = x.shape
     if not pw_eligible(Co, Ci, N, PW_FWD):
         return torch.bmm(W.unsqueeze(0).expand(B, -1, -1), x), None, None, None
     am_w, Wt = prep_weight(W, need_dgrad and pw_eligible(Co, Ci, N, PW_DGRAD))
     am_x = amax_of(x)
-    return pw_gemm(PW_FWD, W, x, am_w, am_x, B, Co, Ci, N), am_w, am_x, Wt
+    return pw_gemm(PW_FWD, W, x, am_w[0], am_x, B, Co, Ci, N), am_w, am_x, Wt
 
 
 def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=None):
@@ -211,19 +239,24 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=N
     mine_x = need_x and pw_eligible(Co, Ci, N, PW_DGRAD)
     mine_w = need_w and pw_eligible(Co, Ci, N, PW_WGRAD)
     if am_g is None and (mine_x or mine_w):
-        am_g = amax_of(g_y)
+        am_g = amax_of(g_y, rows=mine_w)
+    if torch.is_tensor(am_w):            # (a caller that kept one maxima tensor of W: partials of its maximum)
+        am_w = (am_w, None)
     g_x = g_w = None
 
     def dgrad():
         if mine_x and Wt is not None and am_w is not None:
-            return pw_gemm(PW_DGRAD_T, Wt, g_y, am_w, am_g, B, Co, Ci, N)
+            # W^T's rows are W's columns: their maxima give the data gradient its per-row scales
+            return pw_gemm(PW_DGRAD_T, Wt, g_y, am_w[1] if am_w[1] is not None else am_w[0], am_g, B, Co, Ci, N)
         if mine_x:
-            return pw_gemm(PW_DGRAD, W, g_y, am_w if am_w is not None else amax(W), am_g, B, Co, Ci, N)
+            return pw_gemm(PW_DGRAD, W, g_y, am_w[0] if am_w is not None else amax(W), am_g, B, Co, Ci, N)
         return torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y) if need_x else None
 
     def wgrad():
         if mine_w:
-            return pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax_of(x), B, Co, Ci, N)
+            # both operands row-scaled where their maxima are per channel: a nearly-dead channel of g_y (or of x) keeps its
+            # 22 bits in its own row of g_W (include/cloudct.h, ct_pw_gemm_rs)
+            return pw_gemm(PW_WGRAD, g_y, x, am_g, am_x if am_x is not None else amax_of(x, rows=True), B, Co, Ci, N)
         return torch.bmm(g_y, x.transpose(1, 2)).sum(0) if need_w else None
 
     # the two gradients are independent and neither is a whole number of rounds of the chip's workgroup slots (1024 + 672
@@ -787,7 +820,8 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
             g_gbs.append(g_gb)
         with _on(x.device):
             _adain_group_bwd(items, B, N)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True, am_g=slots, Wt=ctx.am[2])
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True,
+                                am_g=None if slots is None else slots.view(-1, Ct), Wt=ctx.am[2])
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
@@ -1284,7 +1318,8 @@ class UnionKeysValuesFn(torch.autograd.Function):
                               amax=None if slots is None else _ptr(slots) + 4 * c0))
         with _on(x.device):
             bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
-        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True, am_g=slots, Wt=ctx.am[2])   # g_Wc [sum Co, Cin]
+        g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True,
+                                am_g=None if slots is None else slots.view(-1, g_y.shape[1]), Wt=ctx.am[2])   # g_Wc [sum Co, Cin]
         grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]

@@ -496,7 +496,7 @@ int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const 
  * amax_a / amax_b: device f32[n_amax_*] whose maximum is (an upper bound within ~2^10 of) max |.| of the
  * whole operand tensor; the GEMM folds them when it starts.  Either ct_amax_f32's ct_amax_len()
  * partial maxima, or what the kernel that produced the operand left behind (ct_bn_relu_fwd_amax /
- * _bwd_amax: one per channel; ct_adain_*_amax: one per (cloud, channel)); n_amax_* <= 4096.  NULL = scale 1 (the caller then guarantees
+ * _bwd_amax: one per channel; ct_adain_*_amax: one per (cloud, channel)); n_amax_* <= 32768.  NULL = scale 1 (the caller then guarantees
  * |values| < 65504).  Co, Ci, N multiples of 4,
  * 16-byte aligned pointers -> CT_EINVAL otherwise.  Workspace: ct_pw_gemm_workspace_bytes.
  * ---------------------------------------------------------------------- */
@@ -514,6 +514,28 @@ size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N);
 int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a,
                const float* amax_b, int n_amax_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,
                int N, ct_stream_t s);
+/* Per-ROW scales.  The split keeps 22 bits of an element relative to its SCALE, and f16's exponent range ends the story below
+ * ~2^-17 of it: with one scale per tensor an element 2^-17 .. 2^-24 below the tensor's maximum keeps 22 .. 15 bits, and below
+ * 2^-24 it is flushed.  Error bound of one output, eps = 2^-21, M_a / M_b the maxima the scales were taken from:
+ *     |err_ij| <= eps * sum_k |a_ik b_kj|  +  2^-38 * ( M_a * sum_k |b_kj|  +  M_b * sum_k |a_ik| ).
+ * The second term is invisible while the rows of an operand are of one magnitude (post-norm activations) and takes over for
+ * an output whose OWN operand row is tiny against its tensor: the weight gradient's row co sees only channel co of g_y — a
+ * nearly-dead channel group 2^-24 below the tensor's maximum came out at 1e-5 relative, 2^-26 at 7e-5 (rocBLAS fp32: 1e-7).
+ * ct_pw_gemm_rs takes the maxima PER ROW of an operand's k-contiguous arrangement — rows_a > 0: amax_a is
+ * f32[n_amax_a / rows_a][rows_a], rows_a = Co (CT_PW_FWD: rows of W; CT_PW_WGRAD: channels of g_y) or Ci (CT_PW_DGRAD_T: rows
+ * of W^T); rows_b = Ci for the channels of x in CT_PW_WGRAD — scales every row by its own power of two and takes the factor
+ * out of that row's (column's) outputs, exactly: M_a, M_b in the bound become the ROW's maxima, i.e. the bound holds relative to
+ * every output's own operands.  Both operands of the weight gradient can be row-scaled (its summed index is the point, not
+ * the channel); in the forward and the data gradient the activation's summed index IS the channel, so it keeps one scale
+ * (rows_b is ignored there) and its term of the bound stays M_b * sum_k |a_ik|: a contribution that is itself 2^-17 of the
+ * row's largest.  Producers of per-row maxima: ct_bn_relu_*_amax / ct_bn_apply_*_amax (per channel), ct_adain_*_amax (per
+ * (cloud, channel)), ct_amax_rows_f32 (x f32[B,C,N] -> f32[C]), ct_pw_prep_weight_rs (W -> rowmax f32[ceil(Ci/32)][Co] for
+ * CT_PW_FWD, colmax f32[ceil(Co/32)][Ci] for CT_PW_DGRAD_T, and W^T).  n_amax_* <= 32768.  rows_* = 0: ct_pw_gemm. */
+int ct_amax_rows_f32(const float* x, int B, int C, int N, float* amax, ct_stream_t s);
+int ct_pw_prep_weight_rs(const float* w, float* wt, float* rowmax, float* colmax, int Co, int Ci, ct_stream_t s);
+int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a, int rows_a,
+                  const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co,
+                  int Ci, int N, ct_stream_t s);
 
 #ifdef __cplusplus
 }

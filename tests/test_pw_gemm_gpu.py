@@ -289,3 +289,77 @@ def test_prepared_weight_gives_the_same_data_gradient():
         a = ops.pw_gemm(ops.PW_DGRAD_T, Wt, gy, am, am_g, B, Co, Ci, N)
         b = ops.pw_gemm(ops.PW_DGRAD, W, gy, ops.amax(W), am_g, B, Co, Ci, N)
         assert torch.equal(a, b)
+
+
+def _run_rs(mode, W, x, gy):
+    """The products with per-row maxima wherever the arrangement takes them (ct_pw_gemm_rs through ops.pw_gemm: 2-D maxima):
+    forward — rows of W; data gradient — rows of W^T; weight gradient — channels of g_y and of x."""
+    from cloud_transformers_amd import ops
+    Co, Ci = W.shape
+    B, _, N = x.shape
+    (rowmax, colmax), Wt = ops.prep_weight(W, True)
+    if mode == 0:
+        return ops.pw_gemm(0, W, x, rowmax, ops.amax_rows(x), B, Co, Ci, N)
+    if mode == 1:
+        return ops.pw_gemm(3, Wt, gy, colmax, ops.amax_rows(gy), B, Co, Ci, N)
+    return ops.pw_gemm(2, gy, x, ops.amax_rows(gy), ops.amax_rows(x), B, Co, Ci, N)
+
+
+@pytest.mark.parametrize("depth", [16, 20, 24, 28, 40])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_rows_far_below_the_tensor_maximum_keep_their_precision(mode, depth):
+    """Dynamic range INSIDE a tensor (include/cloudct.h, ct_pw_gemm_rs): whole rows of the k-contiguous operands 2^-depth below
+    the tensor's maximum — rows of W (forward), columns of W (data gradient), channels of g_y and of x (weight gradient: a
+    nearly-dead channel group).  With one scale per tensor such a row sinks into f16's subnormals (2^-24: 1e-5 relative,
+    2^-28: nothing left); with the row's own scale every output stays within the fp32-GEMM bound of ITS OWN operands."""
+    B, Co, Ci, N = 2, 256, 192, 1024
+    g = torch.Generator(device="cuda").manual_seed(17 + mode + depth)
+    W = torch.randn(Co, Ci, device="cuda", generator=g) / Ci ** 0.5
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    q = 2.0 ** -depth
+    if mode == 0:
+        W[5::7] *= q                      # output rows 5, 12, ... of y are tiny
+    elif mode == 1:
+        W[:, 3::5] *= q                   # output rows 3, 8, ... of g_x
+    else:
+        gy[:, 2::9] *= q                  # rows of g_W
+        x[:, 1::11] *= q                  # columns of g_W
+    out = _run_rs(mode, W, x, gy)
+    ref, mag = _ref(mode, W, x, gy)
+    err = (out.double() - ref).abs()
+    assert torch.isfinite(out).all()
+    assert bool((err <= BOUND * mag + 1e-44).all()), float((err / (mag + 1e-44)).max())
+    # ... and the per-tensor scale does lose them from 2^-24 on (what the bound in the header says; not a requirement)
+    if depth >= 28 and depth < 40:
+        flat = _run(mode if mode != 1 else 1, W, x, gy)
+        bad = float(((flat.double() - ref).abs() / (mag + 1e-44)).max())
+        assert bad > BOUND, bad
+
+
+def test_row_maxima_of_the_producers_reach_the_weight_gradient():
+    """The maxima the norm kernels leave are per channel: tag_amax keeps them 2-D and ops.pw_backward hands them to
+    ct_pw_gemm_rs as per-row maxima — a block whose cotangent has a nearly-dead channel group gets an exact weight gradient
+    through the autograd layer, without any extra pass over the tensors."""
+    _needs_split16()
+    from cloud_transformers_amd import ops
+    B, Co, Ci, N = 2, 256, 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    gy[:, 64:96] *= 2.0 ** -26
+    W = torch.randn(Co, Ci, device="cuda", generator=g) / Ci ** 0.5
+    # as a producer would: per-channel maxima in a slots buffer, tagged on the tensors
+    sx, sg = torch.empty(Ci, device="cuda"), torch.empty(Co, device="cuda")
+    sx.copy_(x.abs().amax(dim=(0, 2)))
+    sg.copy_(gy.abs().amax(dim=(0, 2)))
+    ops.tag_amax(x, sx)
+    ops.tag_amax(gy, sg)
+    assert ops.amax_of(x).shape == (1, Ci) and ops.amax_of(gy).shape == (1, Co)
+    y, am_w, am_x, Wt = ops.pw_forward(W, x, True)
+    g_x, g_w = ops.pw_backward(W, x, gy, am_w, am_x, True, True, Wt=Wt)
+    ref, mag = _ref(2, W, x, gy)
+    err = (g_w.double() - ref).abs()
+    assert bool((err <= BOUND * mag + 1e-44).all()), float((err / (mag + 1e-44)).max())
+    refx, magx = _ref(1, W, x, gy)
+    assert bool(((g_x.double() - refx).abs() <= BOUND * magx + 1e-44).all())
