@@ -279,16 +279,19 @@ def test_syncbn_apply_kernels_leave_the_channel_maxima():
 
 
 def test_prepared_weight_gives_the_same_data_gradient():
-    """ct_pw_prep_weight (partial maxima + W^T in one launch) and CT_PW_DGRAD_T against ct_amax_f32 + CT_PW_DGRAD: same bits."""
+    """ct_pw_prep_weight_rs (row / column maxima + W^T in one launch) and CT_PW_DGRAD_T against ct_amax_f32 + CT_PW_DGRAD: the
+    maxima are exact, and with the prepared maxima used as partials of ONE maximum (a flat view: one scale per tensor) the
+    two data gradients have the same bits."""
     from cloud_transformers_amd import ops
     torch.manual_seed(9)
     for (B, Co, Ci, N) in [(2, 208, 512, 1024), (3, 52, 36, 260), (1, 640, 132, 512)]:
         W = torch.randn(Co, Ci, device="cuda") * 0.3
         gy = torch.randn(B, Co, N, device="cuda") * 1e-2
-        am, Wt = ops.prep_weight(W, True)
-        assert torch.equal(Wt, W.t().contiguous()) and float(am.max()) == float(W.abs().max())
+        (rowmax, colmax), Wt = ops.prep_weight(W, True)
+        assert torch.equal(Wt, W.t().contiguous())
+        assert torch.equal(rowmax.amax(0), W.abs().amax(1)) and torch.equal(colmax.amax(0), W.abs().amax(0))
         am_g = ops.amax(gy)
-        a = ops.pw_gemm(ops.PW_DGRAD_T, Wt, gy, am, am_g, B, Co, Ci, N)
+        a = ops.pw_gemm(ops.PW_DGRAD_T, Wt, gy, colmax.reshape(-1), am_g, B, Co, Ci, N)
         b = ops.pw_gemm(ops.PW_DGRAD, W, gy, ops.amax(W), am_g, B, Co, Ci, N)
         assert torch.equal(a, b)
 
