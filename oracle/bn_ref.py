@@ -1,5 +1,6 @@
 """CPU stand-ins for the four statistics-exchange norm kernels of csrc/ct_bnorm.hip (ct_bn_stats_fwd, ct_bn_apply_fwd,
-ct_bn_reduce_bwd, ct_bn_apply_bwd), in float64 on the same raw pointers and strides.
+ct_bn_reduce_bwd, ct_bn_apply_bwd) and their group launches (ct_bn_group_stats_fwd ...), in float64 on the same raw pointers
+and strides.
 
 TEST INFRASTRUCTURE ONLY (tests/test_syncbn_gloo.py): they let the product's HOST logic — buffer layout, offsets,
 the one-all_gather / one-all_reduce exchange of cloud_transformers_amd/ops._bn_group_fwd / _bn_group_bwd — run on
@@ -104,6 +105,59 @@ class FakeLib:
         if amax_out:
             _vec(amax_out, C)[:] = np.abs(_bcn(gx, gxbs, B, C, N)).max(axis=(0, 2))
         return rc
+
+    # the group launches (ct_bn_group_stats_fwd / _apply_fwd / _reduce_bwd / _apply_bwd, cloudct.h): every phase of all the
+    # items of a group at once, on the group's buffers [mean: Ct | m2: Ct | count] resp. [sum g': Ct | sum g' xhat: Ct]
+    @staticmethod
+    def _items(items, n, cls):
+        return ctypes.cast(int(items), ctypes.POINTER(cls * n)).contents
+
+    def ct_bn_group_stats_fwd(self, items, n, B, N, local, stream):
+        from cloud_transformers_amd._lib import BnFwdItem
+        arr = self._items(items, n, BnFwdItem)
+        Ct = sum(it.C for it in arr)
+        c0 = 0
+        for i, it in enumerate(arr):
+            self.ct_bn_stats_fwd(it.x, it.x_batch_stride, local + 4 * c0, local + 4 * (Ct + c0), local + 4 * 2 * Ct if i == 0 else 0,
+                                 B, it.C, N, stream)
+            c0 += it.C
+        return 0
+
+    def ct_bn_group_apply_fwd(self, items, n, B, N, gathered, world, count_total, stream):
+        from cloud_transformers_amd._lib import BnFwdItem
+        arr = self._items(items, n, BnFwdItem)
+        Ct = sum(it.C for it in arr)
+        stride, c0 = 2 * Ct + 1, 0
+        for i, it in enumerate(arr):
+            self.ct_bn_apply_fwd_amax(it.x, it.x_batch_stride, it.weight, it.bias, gathered + 4 * c0, gathered + 4 * (Ct + c0),
+                                      gathered + 4 * 2 * Ct, world, stride, it.running_mean, it.running_var, it.num_batches_tracked,
+                                      it.residual, it.residual_batch_stride, it.y, it.y_batch_stride, it.save_mean, it.save_rstd,
+                                      count_total if i == 0 else 0, it.amax_out, B, it.C, N, it.eps, it.momentum, it.relu, stream)
+            c0 += it.C
+        return 0
+
+    def ct_bn_group_reduce_bwd(self, items, n, B, N, sums, stream):
+        from cloud_transformers_amd._lib import BnBwdItem
+        arr = self._items(items, n, BnBwdItem)
+        Ct = sum(it.C for it in arr)
+        c0 = 0
+        for it in arr:
+            self.ct_bn_reduce_bwd(it.x, it.x_batch_stride, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, it.gy_batch_stride,
+                                  sums + 4 * c0, sums + 4 * (Ct + c0), B, it.C, N, it.relu, stream)
+            c0 += it.C
+        return 0
+
+    def ct_bn_group_apply_bwd(self, items, n, B, N, sums, count, stream):
+        from cloud_transformers_amd._lib import BnBwdItem
+        arr = self._items(items, n, BnBwdItem)
+        Ct = sum(it.C for it in arr)
+        c0 = 0
+        for it in arr:
+            self.ct_bn_apply_bwd_amax(it.x, it.x_batch_stride, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, it.gy_batch_stride,
+                                      sums + 4 * c0, sums + 4 * (Ct + c0), count, it.gx, it.gx_batch_stride, it.amax_out, B, it.C, N,
+                                      it.relu, stream)
+            c0 += it.C
+        return 0
 
     def ct_strerror(self, status):
         return b"fake"
