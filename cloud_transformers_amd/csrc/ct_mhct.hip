@@ -60,6 +60,8 @@ struct CoreArgs {
   int B, H, N;
   int S, SC, SN;         // workgroups per plane = SC (blocks of output channels) x SN (point ranges)
   int planes, xcd_map;
+  int spin_limit;        // polls before a workgroup gives up on its partners (kSpinLimit; tests shorten it)
+  int fault;             // test hook: the last workgroup of plane 0 arrives late (its partners time out)
 };
 
 template <int DIM, int WT, int C>
@@ -398,6 +400,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
   __syncthreads();
 
   CT_STAMP(2);
+  bool aborted = false;
   // ---- X: merge the partial tiles of the plane's workgroups
   if (S > 1 && !(CT_CORE_ABL & 8)) {
     float* mine = a.xch + ((size_t)plane * S + s) * (size_t)(C * G);
@@ -408,12 +411,14 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores are done
     __syncthreads();
     if (tid == 0) {
+      if (a.fault && plane == 0 && s == S - 1)         // (test hook: a partner that arrives after the others gave up)
+        for (int i = 0; i < 64 * a.spin_limit; ++i) __builtin_amdgcn_s_sleep(8);
       __hip_atomic_fetch_add(a.flags + plane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int it = 0;
       bool ok = true;
       while (__hip_atomic_load(a.flags + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
         __builtin_amdgcn_s_sleep(4);
-        if (++it > kSpinLimit) {
+        if (++it > a.spin_limit) {
           ok = false;
           break;
         }
@@ -426,8 +431,12 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
       }
     }
     __syncthreads();
-    if (s_flag[0]) return;                       // block-uniform
-    for (int o = 1; o < S; ++o) {
+    aborted = s_flag[0] != 0;                    // block-uniform: this workgroup gave up waiting for its partners
+    // (an abort must not end the workgroup here: the plane's counters below, and the launch's occupancy counter at the end
+    //  of the kernel, count EVERY workgroup — one that left early would leave them non-zero for every later launch on this
+    //  workspace, which would then pass the barrier before its partners' tiles exist.  It skips the work, poisons its
+    //  share of the outputs with NaN, and still takes part in the counting.)
+    for (int o = 1; o < (aborted ? 0 : S); ++o) {
       const int so = (s + o) % S;
       const float* other = a.xch + ((size_t)plane * S + so) * (size_t)(C * G);
       for (int t = tid; t < (C * G) >> 2; t += kCoreThreads) {
@@ -452,7 +461,21 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
 
   CT_STAMP(3);
   // ---- side outputs of the merged tile: z (training) and the occupancy count; workgroup s takes C/S channels
-  if (a.z_save != nullptr || a.occ != nullptr) {
+  if (aborted) {          // a timed-out cluster: NaN where this workgroup's results would have gone (status word set above)
+    const float4 bad = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    const int cper = C / S, c_lo = s * cper;
+    if (a.z_save != nullptr)
+      for (int t = tid; t < (cper * G) >> 2; t += kCoreThreads) *(float4*)(a.z_save + (bh * C + c_lo) * (size_t)G + ((size_t)t << 2)) = bad;
+    const int nmt_a = (C / 16) / a.SC, per_a = (nq + a.SN - 1) / a.SN, qa0 = sn * per_a, qa1 = min(nq, qa0 + per_a);
+    for (int mi = 0; mi < nmt_a; ++mi) {
+      const int co0 = (sc * nmt_a + mi) * 16;
+      if (a.y_save != nullptr && sn == 0)
+        for (int t = tid; t < (16 * G) >> 2; t += kCoreThreads) *(float4*)(a.y_save + (bh * C + co0) * (size_t)G + ((size_t)t << 2)) = bad;
+      for (int c = 0; c < 16; ++c)
+        for (int qd = qa0 + tid; qd < qa1; qd += kCoreThreads) *(float4*)(a.out + (bh * C + co0 + c) * (size_t)N + ((size_t)qd << 2)) = bad;
+    }
+  }
+  if (!aborted && (a.z_save != nullptr || a.occ != nullptr)) {
     const int cper = C / S, c_lo = s * cper;
     int cnt = 0;
     for (int t = tid; t < (cper * G) >> 2; t += kCoreThreads) {
@@ -470,7 +493,7 @@ __global__ void __launch_bounds__(kCoreThreads) mhct_core_fwd_kernel(CoreArgs a)
 
   CT_STAMP(4);
   // ---- B + C per block of 16 output channels
-  const int nmt = (C / 16) / a.SC;
+  const int nmt = aborted ? 0 : (C / 16) / a.SC;
   const float* wh = a.w + (size_t)h * C * C * Gm::TAPS;
   for (int mi = 0; mi < nmt; ++mi) {
     const int co0 = (sc * nmt + mi) * 16;
@@ -1028,7 +1051,7 @@ int device_cus() {
   return cus;
 }
 
-std::atomic<unsigned> g_core_flags{0};     // test hook (ct_debug_set_core): bit 0 = no clusters, bits 8.. = forced cluster size
+std::atomic<unsigned> g_core_flags{0};     // test hook (ct_debug_set_core): bit 0 = no clusters, bit 1 = a late partner, bits 8.. = forced cluster size
 
 // workgroups per plane: enough to cover the chip once, S | N/4 ranges, C % S == 0, at most 8
 void core_split(int planes, int C, int N, int cu_div, int& S, int& SC, int& SN) {
@@ -1108,6 +1131,11 @@ int ct_mhct_core_fwd(const float* keys, const float* feat, const void* pad, int 
   a.B = B; a.H = H; a.N = N; a.planes = B * H;
   core_split(a.planes, C, N, kCoreShapes[core_shape_index(C, dim, W)].cu_div, a.S, a.SC, a.SN);
   a.xcd_map = (a.planes % 8 == 0) ? 1 : 0;
+  {
+    const unsigned dbg = g_core_flags.load(std::memory_order_relaxed);
+    a.fault = (dbg & 2u) ? 1 : 0;                  // ct_debug_set_core bit 1: fault injection (tests of the abort path)
+    a.spin_limit = a.fault ? 256 : kSpinLimit;
+  }
   int G = 1;
   for (int j = 0; j < dim; ++j) G *= W[j];
   size_t fo, so;

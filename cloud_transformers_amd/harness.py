@@ -360,6 +360,9 @@ class Trainer:
         history, pending = [], []
 
         def flush():
+            if self.device.type == "cuda":
+                from . import ops
+                ops.mhct_core_check()        # (the one place the loop waits for the device anyway: a cluster timeout raises here)
             if pending and self.rank == 0:
                 stamps, vals = zip(*pending)
                 for it, v in zip(stamps, torch.stack(vals).tolist()):      # one device-to-host copy for the interval

@@ -1504,9 +1504,10 @@ _core_ws = {}
 
 
 def mhct_core_workspace(device, B, H, C, N, W):
-    """The forward's exchange workspace for a shape, allocated and initialised (counters zeroed) ONCE per device and shape:
-    every launch leaves the counters zeroed, and launches on one stream are ordered, so the buffer is reused."""
-    key = (device.index, B, H, C, N, tuple(W))
+    """The forward's exchange workspace for a shape, allocated and initialised (counters zeroed) ONCE per device, STREAM and
+    shape: every launch leaves the counters zeroed, and launches on one stream are ordered, so the buffer is reused — two
+    blocks of one shape running side by side on two streams (the heads of a union block, user code) get a buffer each."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, B, H, C, N, tuple(W))
     ws = _core_ws.get(key)
     if ws is None:
         lib = _lib.load()
@@ -1517,6 +1518,30 @@ def mhct_core_workspace(device, B, H, C, N, W):
             _lib.check(lib.ct_mhct_core_workspace_init(_ptr(ws), n, B, H, C, N, len(W), Wa, _stream()), "ct_mhct_core_workspace_init")
         _core_ws[key] = ws
     return ws
+
+
+def mhct_core_check(raise_on_fault=True):
+    """Did a cluster of any ct_mhct_core_fwd launch so far give up waiting for its partners (include/cloudct.h: status word of
+    the workspace)?  Reads the status of every cached workspace — one small copy each, AFTER synchronising: call it at points
+    that wait for the device anyway (harness.fit's logging flush).  A workspace whose word is set is re-initialised; with
+    `raise_on_fault` the first such workspace raises (the affected launch wrote NaN where its results would have gone)."""
+    lib = _lib.load()
+    bad = []
+    for key, ws in list(_core_ws.items()):
+        dev_index, _stream_id, B, H, C, N, W = key
+        Wa = _lib.int_array(W)
+        st = ctypes.c_int(0)
+        with torch.cuda.device(dev_index):
+            _lib.check(lib.ct_mhct_core_status(_ptr(ws), ws.numel(), B, H, C, N, len(W), Wa, ctypes.byref(st),
+                                               torch.cuda.current_stream().cuda_stream), "ct_mhct_core_status")
+            if st.value != 0:
+                bad.append(key)
+                _lib.check(lib.ct_mhct_core_workspace_init(_ptr(ws), ws.numel(), B, H, C, N, len(W), Wa,
+                                                           torch.cuda.current_stream().cuda_stream), "ct_mhct_core_workspace_init")
+    if bad and raise_on_fault:
+        raise RuntimeError("ct_mhct_core_fwd: a cluster timed out waiting for its partners on %d workspace(s) %r; the affected "
+                           "outputs hold NaN.  The workspaces were re-initialised." % (len(bad), bad[:2]))
+    return bad
 
 
 class MhctCoreFn(torch.autograd.Function):

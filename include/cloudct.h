@@ -445,7 +445,12 @@ int ct_mhct_core_bwd_fused(const float* keys, const float* feat, const void* pad
                            const float* conv_b, const float* g_out, float* g_feat, float* g_keys, float* g_w, float* g_b,
                            void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
                            ct_stream_t s);
-/* Test hooks: bit 0 = one workgroup per plane (no clusters); bits 8.. = force that many workgroups per plane (1, 2, 4, 8).
+/* A cluster whose workgroup gives up waiting for its partners (never in a correct run: co-residency of a plane's workgroups
+ * rests on in-order dispatch and a grid of at most one workgroup per CU) sets the workspace's status word, writes NaN where
+ * its results would have gone, and still takes part in the counters' bookkeeping — the workspace stays usable, the failure
+ * cannot pass for a result; ct_mhct_core_status reads the word (callers check it at their flush points and re-initialise).
+ * Test hooks: bit 0 = one workgroup per plane (no clusters); bit 1 = fault injection: the last workgroup of plane 0 arrives
+ * late and its partners time out after a short spin; bits 8.. = force that many workgroups per plane (1, 2, 4, 8).
  * ct_mhct_core_status copies the workspace's status word to the host AFTER synchronising the stream (a test helper, the
  * only call of this library that waits for the device): 0 = no cluster gave up waiting for its partners. */
 void ct_debug_set_core(unsigned flags);

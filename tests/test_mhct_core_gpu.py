@@ -338,3 +338,53 @@ def test_core_autograd_function_matches_module_chain(core_flags):
         for a, b in zip(outs[0], outs[1]):
             if torch.is_tensor(a):
                 assert relerr(a, b) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 4096, 32, 8, 3), (8, 16, 4096, 16, 16, 2)], ids=["8^3C32", "16^2C16"])
+def test_a_cluster_timeout_is_loud_and_the_workspace_recovers(shape):
+    """a workgroup that gives up waiting for its partners used to return, leaving `out` unwritten and the plane's
+    counters non-zero for every later launch on the cached workspace.  Fault injection (ct_debug_set_core bit 1: the last
+    workgroup of plane 0 arrives late, its partners time out after a short spin): the status word is set, the timed-out
+    workgroups' share of the outputs is NaN (nothing else is), the counters are zero again — the NEXT launch on the same
+    workspace is correct without re-initialising — and ops.mhct_core_check() raises and re-initialises."""
+    from cloud_transformers_amd import ops
+    L, lib = _libs()
+    B, H, N, C, W, dim = shape
+    g = torch.Generator().manual_seed(3)
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    feat = torch.randn(B, H * C, N, generator=g)
+    w = torch.randn(H * C, C, *([3] * dim), generator=g) / (C * 3 ** dim) ** 0.5
+    bias = torch.randn(H * C, generator=g) * 0.1
+    cot = torch.randn(B, H * C, N, generator=g)
+    good = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False)
+    assert good["status"] == 0
+    Wa = L.int_array([W] * dim)
+    nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
+    ws = torch.zeros(nws, device="cuda", dtype=torch.uint8)
+    L.check(lib.ct_mhct_core_workspace_init(ops._ptr(ws), nws, B, H, C, N, dim, Wa, ops._stream()), "init")
+    lib.ct_debug_set_core(2)
+    try:
+        hurt = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False, ws=ws)
+    finally:
+        lib.ct_debug_set_core(0)
+    assert hurt["status"] == 1
+    nan = torch.isnan(hurt["out"])
+    assert nan.any() and not nan[1:].any() and not nan[0, C:].any()          # plane (0, 0) only
+    ok = ~nan
+    assert torch.equal(hurt["out"][ok], good["out"][ok])
+    # the same workspace, not re-initialised: counters are back at zero, the launch is right (the status word stays set until read)
+    again = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False, ws=ws)
+    assert torch.equal(again["out"], good["out"]) and again["occ"] == good["occ"]
+    # the product's check: raises once, re-initialises, then is quiet
+    key = (0, torch.cuda.current_stream().cuda_stream, B, H, C, N, tuple([W] * dim))
+    saved = ops._core_ws.get(key)
+    ops._core_ws[key] = ws
+    try:
+        with pytest.raises(RuntimeError, match="timed out"):
+            ops.mhct_core_check()
+        assert ops.mhct_core_check() == []
+    finally:
+        if saved is None:
+            del ops._core_ws[key]
+        else:
+            ops._core_ws[key] = saved
