@@ -231,6 +231,8 @@ SIGNATURES = {
     "ct_lattice_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_lattice_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ct_lattice_bwd": (_i, [_vp] * 15 + [_vp, _sz, _i, _i, _i, _i, _vp]),
+    "ct_lattice_so3_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "ct_lattice_so3_bwd": (_i, [_vp, _vp, _vp, _f] + [_vp] * 14 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_so3_exp_fwd": (_i, [_vp, _vp, _i, _f, _vp]),
     "ct_so3_exp_bwd": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "ct_adain_fwd": (_i, [_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

@@ -21,7 +21,31 @@ struct LatticeArgs {
   const float* scales;   // nullable
   const float* kscale;   // nullable
   int B, H, N, dim;
+  // ct_lattice_so3_fwd: the rotations come from their so3 parameters inside the launch (log_R non-null: R is an OUTPUT then,
+  // written by the head's first workgroup for the backward), and the key statistics are finished by the launch's last
+  // workgroup (ticket: a zeroed word the kernel leaves zeroed)
+  const float* log_R;
+  float* R_out;
+  float so3_eps;
+  unsigned* ticket;
+  float* key_stats;
+  double nkeys;
 };
+
+// Rodrigues' formula of one head in double (so3_exp_fwd_kernel's arithmetic): R[9] row-major
+__device__ __forceinline__ void so3_exp_one(const float* log_R, int h, float eps, float (&R)[9]) {
+  const double x = log_R[h * 3 + 0], y = log_R[h * 3 + 1], z = log_R[h * 3 + 2];
+  const double s = x * x + y * y + z * z;
+  const double th = sqrt(s > (double)eps ? s : (double)eps);
+  const double a = sin(th) / th, b = (1.0 - cos(th)) / (th * th);
+  const double v[3] = {x, y, z};
+  const double K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = (float)((i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * (v[i] * v[j] - (i == j ? s : 0.0)));
+}
 
 // wave64 sum over DPP (row_shr 1/2/4/8, row_bcast 15/31: no LDS traffic; ct_raster_hot.h has the integer forms), returned
 // wave-uniform.  The 16 parameter partials of the backward took 96 ds_bpermute per thread with __shfl_xor.
@@ -42,8 +66,22 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 // lattice_stats_kernel instead of two more passes over the keys.
 __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* keys, float* lattice, float* stat_parts) {
   __shared__ float red[4][2];
+  __shared__ float Rs[9];
+  __shared__ unsigned s_last;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
+  if (a.log_R != nullptr) {            // kernel-uniform: this head's rotation from its so3 parameters (one lane, double)
+    if (threadIdx.x == 0) {
+      float Rl[9];
+      so3_exp_one(a.log_R, h, a.so3_eps, Rl);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        Rs[i] = Rl[i];
+        if (blockIdx.x == 0 && b == 0) a.R_out[h * 9 + i] = Rl[i];
+      }
+    }
+    __syncthreads();
+  }
   float s1 = 0.0f, s2 = 0.0f;
   if (n < a.N) {
     const float ks = a.kscale ? a.kscale[0] : 1.0f;
@@ -51,7 +89,7 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       p[c] = a.xyz[((size_t)b * 3 + c) * a.N + n] + ks * a.res[((size_t)(b * a.H + h) * 3 + c) * a.N + n] + a.shift[h * 3 + c];
-    const float* R = a.R + h * 9;
+    const float* R = a.log_R != nullptr ? Rs : a.R + h * 9;
     for (int j = 0; j < a.dim; ++j) {
       float k = p[0] * R[0 * 3 + j] + p[1] * R[1 * 3 + j] + p[2] * R[2 * 3 + j];
       if (a.scales) k *= a.scales[h * a.dim + j];
@@ -71,7 +109,43 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
     __syncthreads();
     if (threadIdx.x < 2) {
       const size_t wg = ((size_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
-      stat_parts[wg * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (a.ticket != nullptr) __hip_atomic_store(stat_parts + wg * 2 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else stat_parts[wg * 2 + threadIdx.x] = v;
+    }
+    if (a.ticket != nullptr) {         // kernel-uniform: the launch's last workgroup reduces the partials (lattice_stats_kernel's sum)
+      const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+      if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's two write-through stores have left
+        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == total - 1u;
+        if (old == total - 1u) {
+          __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __syncthreads();
+      if (s_last) {
+        __shared__ double dred[2][4];
+        double t1 = 0.0, t2 = 0.0;
+        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+          t1 += (double)stat_parts[(size_t)i * 2 + 0];
+          t2 += (double)stat_parts[(size_t)i * 2 + 1];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          t1 += __shfl_xor(t1, o, 64);
+          t2 += __shfl_xor(t2, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { dred[0][threadIdx.x >> 6] = t1; dred[1][threadIdx.x >> 6] = t2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const double u1 = dred[0][0] + dred[0][1] + dred[0][2] + dred[0][3], u2 = dred[1][0] + dred[1][1] + dred[1][2] + dred[1][3];
+          const double mean = u1 / a.nkeys;
+          a.key_stats[0] = (float)mean;
+          a.key_stats[1] = (float)(a.nkeys > 1.0 ? (u2 - a.nkeys * mean * mean) / (a.nkeys - 1.0) : 0.0);
+        }
+      }
     }
   }
 }
@@ -188,10 +262,44 @@ __global__ void __launch_bounds__(256) lattice_zero_kernel(float* g_R, float* g_
 // parameter cotangents from the per-workgroup partials [B * nbx][H][16].  One workgroup per head: its 256 threads are
 // 16 partial indices x 16 lanes over the workgroups (coalesced 64-byte rows), combined by a fixed-order tree in LDS.
 // The residual scale is one scalar for all heads: workgroup 0 also sums partial 15 of every (workgroup, head).
+// g_log_R of one head from its g_R (so3_exp_bwd_kernel's arithmetic, double)
+__device__ __forceinline__ void so3_exp_bwd_one(const float* log_R, const float* gR, float* g_log_R, int h, float eps) {
+  const double x = log_R[h * 3 + 0], y = log_R[h * 3 + 1], z = log_R[h * 3 + 2];
+  const double v[3] = {x, y, z};
+  double G[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = gR[i];
+  const double s = x * x + y * y + z * z;
+  const bool live = s >= (double)eps;
+  const double th = sqrt(live ? s : (double)eps);
+  const double sn = sin(th), cs = cos(th);
+  const double a = sn / th, b = (1.0 - cs) / (th * th);
+  const double trG = G[0] + G[4] + G[8];
+  double Gv[3], GTv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Gv[i] = G[i * 3 + 0] * x + G[i * 3 + 1] * y + G[i * 3 + 2] * z;
+    GTv[i] = G[0 * 3 + i] * x + G[1 * 3 + i] * y + G[2 * 3 + i] * z;
+  }
+  const double gK[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};
+  const double dLda = -z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7];
+  const double dLdb = x * Gv[0] + y * Gv[1] + z * Gv[2] - s * trG;
+  double radial = 0.0;
+  if (live) {
+    const double da = (th * cs - sn) / (th * th);
+    const double db = (th * sn - 2.0 * (1.0 - cs)) / (th * th * th);
+    radial = (dLda * da + dLdb * db) / th;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g_log_R[h * 3 + i] = (float)(a * gK[i] + b * (Gv[i] + GTv[i] - 2.0 * trG * v[i]) + radial * v[i]);
+}
+
 __device__ __forceinline__ void lattice_param_sum_body(const float* parts, int nwg, int H, int dim, float* g_R, float* g_shift,
-                                                       float* g_scales, float* g_kscale, const int h) {
+                                                       float* g_scales, float* g_kscale, const int h, const float* log_R = nullptr,
+                                                       float* g_log_R = nullptr, float so3_eps = 0.0f) {
   __shared__ float red[16][17];
   __shared__ float kred[256];
+  __shared__ float gRs[9];
   const int i = threadIdx.x & 15, wl = threadIdx.x >> 4;
   float s = 0.0f;
   for (int w = wl; w < nwg; w += 16) s += parts[((size_t)w * H + h) * 16 + i];
@@ -201,9 +309,13 @@ __device__ __forceinline__ void lattice_param_sum_body(const float* parts, int n
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][i];
-    if (i < 9) g_R[h * 9 + i] = t;
+    if (i < 9) { g_R[h * 9 + i] = t; gRs[i] = t; }
     else if (i < 12) g_shift[h * 3 + (i - 9)] = t;
     else if (g_scales && (i - 12) < dim) g_scales[h * dim + (i - 12)] = t;
+  }
+  if (g_log_R != nullptr) {            // kernel-uniform: the head's so3 gradient right where its g_R was summed
+    __syncthreads();
+    if (threadIdx.x == 0) so3_exp_bwd_one(log_R, gRs, g_log_R, h, so3_eps);
   }
   if (g_kscale && h == 0) {
     float k = 0.0f;
@@ -239,10 +351,11 @@ __device__ __forceinline__ void lattice_bwd_finish_body(float* g_res, float* g_x
 // lattice_bwd_finish's (nfx per cloud).
 __global__ void __launch_bounds__(256) lattice_bwd_tail_kernel(const float* parts, int nwg, int nsum, int H, int dim, float* g_R, float* g_shift,
                                                                float* g_scales, float* g_kscale, float* g_res, float* g_xyz,
-                                                               const float* kscale, int B, int N, int nfx) {
+                                                               const float* kscale, int B, int N, int nfx, const float* log_R,
+                                                               float* g_log_R, float so3_eps) {
   const int blk = blockIdx.x;
   if (blk < nsum) {
-    lattice_param_sum_body(parts, nwg, H, dim, g_R, g_shift, g_scales, g_kscale, blk);
+    lattice_param_sum_body(parts, nwg, H, dim, g_R, g_shift, g_scales, g_kscale, blk, log_R, g_log_R, so3_eps);
   } else {
     const int f = blk - nsum;
     lattice_bwd_finish_body(g_res, g_xyz, kscale, B, H, N, f % nfx, f / nfx);
@@ -305,7 +418,7 @@ __global__ void so3_exp_bwd_kernel(const float* log_R, const float* g_R, float* 
 }
 
 bool valid(const LatticeArgs& a) {
-  return a.xyz && a.res && a.R && a.shift && a.B > 0 && a.H > 0 && a.N > 0 && (a.dim == 2 || a.dim == 3) &&
+  return a.xyz && a.res && (a.R || a.log_R) && a.shift && a.B > 0 && a.H > 0 && a.N > 0 && (a.dim == 2 || a.dim == 3) &&
          a.B <= 65535 && a.H <= 65535;
 }
 
@@ -318,10 +431,28 @@ size_t ct_lattice_fwd_workspace_bytes(int B, int H, int N) {
   return (size_t)B * H * ((N + 255) / 256) * 2 * sizeof(float);
 }
 
+// lattice + so3 exponential map + key statistics in ONE launch (see LatticeArgs): R f32[H,3,3] is written for the backward;
+// `ticket`: one zeroed 32-bit word the launch leaves zeroed (with key_stats; e.g. a word of a ct_tickets_init buffer)
+int ct_lattice_so3_fwd(const float* xyz, const float* residual, const float* log_R, float so3_eps, const float* shift,
+                       const float* scales, const float* kscale, float* R, float* keys, float* lattice, float* key_stats,
+                       void* workspace, size_t workspace_bytes, void* ticket, int B, int H, int N, int dim, ct_stream_t s) {
+  LatticeArgs a = {xyz, residual, nullptr, shift, scales, kscale, B, H, N, dim, log_R, R, so3_eps, (unsigned*)ticket, key_stats,
+                   (double)B * H * dim * N};
+  if (!log_R || !R || !(so3_eps > 0.0f) || !valid(a) || !keys || !lattice) return CT_EINVAL;
+  if (key_stats && (!ticket || !workspace || workspace_bytes < ct_lattice_fwd_workspace_bytes(B, H, N))) return CT_EWORKSPACE;
+  if (!key_stats) a.ticket = nullptr;
+  const int nbx = (N + 255) / 256;
+  CT_CLEAR_ERROR();
+  hipLaunchKernelGGL(lattice_fwd_kernel, dim3(nbx, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice,
+                     key_stats ? (float*)workspace : nullptr);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
 int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
                    const float* kscale, float* keys, float* lattice, float* key_stats, void* workspace, size_t workspace_bytes,
                    int B, int H, int N, int dim, ct_stream_t s) {
-  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
+  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0};
   if (!valid(a) || !keys || !lattice) return CT_EINVAL;
   if (key_stats && (!workspace || workspace_bytes < ct_lattice_fwd_workspace_bytes(B, H, N))) return CT_EWORKSPACE;
   const int nbx = (N + 255) / 256;
@@ -340,11 +471,38 @@ size_t ct_lattice_bwd_workspace_bytes(int B, int H, int N) {
   return (size_t)B * ((N + 256 * kBwdPts - 1) / (256 * kBwdPts)) * H * 16 * sizeof(float);
 }
 
+static int lattice_bwd_impl(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
+                            const float* kscale, const float* lattice, const float* g_lattice, const float* g_keys, float* g_xyz,
+                            float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, void* workspace,
+                            size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s, const float* log_R,
+                            float* g_log_R, float so3_eps);
+
 int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
                    const float* kscale, const float* lattice, const float* g_lattice, const float* g_keys, float* g_xyz,
                    float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, void* workspace,
                    size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s) {
-  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim};
+  return lattice_bwd_impl(xyz, residual, R, shift, scales, kscale, lattice, g_lattice, g_keys, g_xyz, g_residual, g_R, g_shift,
+                          g_scales, g_kscale, workspace, workspace_bytes, B, H, N, dim, s, nullptr, nullptr, 0.0f);
+}
+
+// ct_lattice_bwd + the so3 map's backward (g_log_R f32[H,3] from g_R, inside the tail launch: the workgroup that sums a
+// head's g_R finishes with its g_log_R); needs the workspace (the ordered parameter sums), R from ct_lattice_so3_fwd
+int ct_lattice_so3_bwd(const float* xyz, const float* residual, const float* log_R, float so3_eps, const float* R,
+                       const float* shift, const float* scales, const float* kscale, const float* lattice, const float* g_lattice,
+                       const float* g_keys, float* g_xyz, float* g_residual, float* g_log_R, float* g_R, float* g_shift,
+                       float* g_scales, float* g_kscale, void* workspace, size_t workspace_bytes, int B, int H, int N, int dim,
+                       ct_stream_t s) {
+  if (!log_R || !g_log_R || !(so3_eps > 0.0f) || !workspace) return CT_EINVAL;
+  return lattice_bwd_impl(xyz, residual, R, shift, scales, kscale, lattice, g_lattice, g_keys, g_xyz, g_residual, g_R, g_shift,
+                          g_scales, g_kscale, workspace, workspace_bytes, B, H, N, dim, s, log_R, g_log_R, so3_eps);
+}
+
+static int lattice_bwd_impl(const float* xyz, const float* residual, const float* R, const float* shift, const float* scales,
+                            const float* kscale, const float* lattice, const float* g_lattice, const float* g_keys, float* g_xyz,
+                            float* g_residual, float* g_R, float* g_shift, float* g_scales, float* g_kscale, void* workspace,
+                            size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s, const float* log_R,
+                            float* g_log_R, float so3_eps) {
+  LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0};
   if (!valid(a) || !lattice || (!g_lattice && !g_keys) || !g_xyz || !g_residual || !g_R || !g_shift) return CT_EINVAL;
   if ((scales != nullptr) != (g_scales != nullptr) || (kscale != nullptr) != (g_kscale != nullptr)) return CT_EINVAL;
   hipStream_t st = (hipStream_t)s;
@@ -357,7 +515,7 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
                      g_residual, g_R, g_shift, g_scales, g_kscale, parts);
   const int nfx = (int)(((size_t)3 * N + 255) / 256), nsum = parts ? H : 0;
   hipLaunchKernelGGL(lattice_bwd_tail_kernel, dim3((unsigned)(nsum + nfx * B)), dim3(256), 0, st, parts, B * nbx, nsum, H, dim, g_R, g_shift,
-                     g_scales, g_kscale, g_residual, g_xyz, kscale, B, N, nfx);
+                     g_scales, g_kscale, g_residual, g_xyz, kscale, B, N, nfx, log_R, g_log_R, so3_eps);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

@@ -29,6 +29,9 @@ from .pointwise import PointwiseConv1d
 from .utils import AdaIn1dUpd, PlaneTransformer, VolTransformer, so3_exponential_map
 
 
+LATTICE_SO3 = os.environ.get("CLOUDCT_LATTICE_SO3", "1") != "0"      # "0": so3 map and lattice as separate ops (A/B)
+
+
 def forward_style(module_list, input, z, residual=None):
     """Apply a Sequential in which AdaIN layers also take the style vector `z` (and add `residual` to the result).
     Dispatch is by class name, like the reference (multihead_ct_adain.py:11)."""
@@ -110,6 +113,10 @@ class _MHCTCore(nn.Module):
         """keys = transform(xyz + kscale * residual) per head; lattice = tanh(keys) — one fused HIP
         kernel each way (ct_lattice_fwd / _bwd); only the H 3x3 rotations are built by torch."""
         t = self.transform
+        if LATTICE_SO3 and t.log_R.dtype == torch.float32:
+            # the so3 map inside the lattice launches: 1 launch forward, 2 backward (ops.LatticeSo3Fn)
+            return ops.lattice_so3(orig_pcd, keys_res, t.log_R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim,
+                                   with_stats=True)
         R = so3_exponential_map(t.log_R)
         return ops.lattice(orig_pcd, keys_res, R, t.shift, t.scales if t.do_scales else None, kscale, self.tensor_dim,
                            with_stats=True)

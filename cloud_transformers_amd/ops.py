@@ -320,12 +320,12 @@ RASTER_TICKETS = os.environ.get("CLOUDCT_TICKETS", "1") != "0"      # "0": the t
 _tickets = {}
 
 
-def raster_tickets(device):
+def raster_tickets(device, force=False):
     """The arrival tickets of the backward raster passes (include/cloudct.h: ct_slice_bwd_tk / ct_splat_bwd_tk) for the
     CURRENT stream of `device`: a zeroed CT_TICKETS_BYTES buffer kept for the life of the process.  The kernels leave it zero,
     so it is initialised once; launches that share a buffer must be ordered, hence one buffer per stream (the heads of a
     union block run side by side on their own streams, and autograd replays every backward on its forward's stream)."""
-    if not RASTER_TICKETS:
+    if not RASTER_TICKETS and not force:
         return None
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _tickets.get(key)
@@ -568,6 +568,74 @@ def lattice(xyz, residual, R, shift, scales, kscale, dim, with_stats=False):
     """(keys, tanh(keys)) of an MHCT block; R = so3_exponential_map(log_R) [H,3,3].  with_stats: also a
     non-differentiable f32[2] = (mean, unbiased variance) of the keys, reduced inside the same launch."""
     return LatticeFn.apply(xyz, residual, R, shift, scales, kscale, dim, with_stats)
+
+
+class LatticeSo3Fn(torch.autograd.Function):
+    """LatticeFn with the so3 exponential map of the rotation parameters inside the launches (ct_lattice_so3_fwd / _bwd): the
+    forward is ONE launch (map + transform + tanh + key statistics, finished by the launch's last workgroup), the backward two
+    (the tail launch also turns g_R into g_log_R) — three launches per head and step where LatticeFn + So3ExpFn are six."""
+
+    @staticmethod
+    def forward(ctx, xyz, residual, log_R, shift, scales, kscale, dim, eps, with_stats=False):
+        _dev(xyz, residual, log_R, shift, scales, kscale)
+        xyz, residual, log_R, shift = _f32c(xyz), _f32c(residual), _f32c(log_R), _f32c(shift)
+        scales = _f32c(scales) if scales is not None else None
+        ks = _f32c(kscale).reshape(1) if kscale is not None else None
+        B, _, N = xyz.shape
+        H = log_R.shape[0]
+        assert xyz.shape[1] == 3 and residual.shape == (B, H * 3, N) and log_R.shape == (H, 3) and shift.shape == (H, 3)
+        dev = xyz.device
+        keys = torch.empty(B, H * dim, N, device=dev, dtype=torch.float32)
+        lattice = torch.empty_like(keys)
+        R = torch.empty(H, 3, 3, device=dev, dtype=torch.float32)
+        lib = _lib.load()
+        stats = ws = ticket = None
+        ws_bytes = 0
+        if with_stats:
+            stats = torch.empty(2, device=dev, dtype=torch.float32)
+            ws_bytes = lib.ct_lattice_fwd_workspace_bytes(B, H, N)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            tk = raster_tickets(dev, force=True)
+            ticket = tk.data_ptr() + (tk.numel() - 1) * 4          # the buffer's last word (the raster kernels use the front)
+        with _on(dev):
+            _lib.check(lib.ct_lattice_so3_fwd(_ptr(xyz), _ptr(residual), _ptr(log_R), float(eps), _ptr(shift), _ptr(scales), _ptr(ks),
+                                              _ptr(R), _ptr(keys), _ptr(lattice), _ptr(stats), _ptr(ws), ws_bytes, ticket, B, H, N, dim,
+                                              _stream()), "ct_lattice_so3_fwd")
+        ctx.save_for_backward(xyz, residual, log_R, R, shift, scales, ks, lattice)
+        ctx.meta = (B, H, N, dim, kscale.shape if kscale is not None else None, float(eps))
+        ctx.set_materialize_grads(False)
+        if with_stats:
+            ctx.mark_non_differentiable(stats)
+            return keys, lattice, stats
+        return keys, lattice
+
+    @staticmethod
+    def backward(ctx, g_keys, g_lattice, _g_stats=None):
+        xyz, residual, log_R, R, shift, scales, ks, lattice = ctx.saved_tensors
+        B, H, N, dim, ks_shape, eps = ctx.meta
+        if g_keys is None and g_lattice is None:
+            return (None,) * 9
+        g_keys = _f32c(g_keys) if g_keys is not None else None
+        g_lattice = _f32c(g_lattice) if g_lattice is not None else None
+        g_xyz, g_res = torch.empty_like(xyz), torch.empty_like(residual)
+        g_R, g_shift, g_log_R = torch.empty_like(R), torch.empty_like(shift), torch.empty_like(log_R)
+        g_scales = torch.empty_like(scales) if scales is not None else None
+        g_ks = torch.empty_like(ks) if ks is not None else None
+        lib = _lib.load()
+        with _on(xyz.device):
+            ws_bytes = lib.ct_lattice_bwd_workspace_bytes(B, H, N)
+            ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
+            _lib.check(lib.ct_lattice_so3_bwd(_ptr(xyz), _ptr(residual), _ptr(log_R), eps, _ptr(R), _ptr(shift), _ptr(scales), _ptr(ks),
+                                              _ptr(lattice), _ptr(g_lattice), _ptr(g_keys), _ptr(g_xyz), _ptr(g_res), _ptr(g_log_R),
+                                              _ptr(g_R), _ptr(g_shift), _ptr(g_scales), _ptr(g_ks), _ptr(ws), ws_bytes, B, H, N, dim,
+                                              _stream()), "ct_lattice_so3_bwd")
+        return (g_xyz, g_res, g_log_R, g_shift, g_scales, (g_ks.reshape(ks_shape) if g_ks is not None else None), None, None, None)
+
+
+def lattice_so3(xyz, residual, log_R, shift, scales, kscale, dim, eps=1e-4, with_stats=False):
+    """(keys, tanh(keys)[, key statistics]) of an MHCT block from the transformer's so3 parameters log_R [H,3]
+    (layers/utils.py:25-34,53-61; eps: pytorch3d's so3_exponential_map default)."""
+    return LatticeSo3Fn.apply(xyz, residual, log_R, shift, scales, kscale, dim, eps, with_stats)
 
 
 class So3ExpFn(torch.autograd.Function):

@@ -214,6 +214,23 @@ int ct_lattice_bwd(const float* xyz, const float* residual, const float* R, cons
                    const float* g_keys, float* g_xyz, float* g_residual, float* g_R, float* g_shift, float* g_scales,
                    float* g_kscale, void* workspace, size_t workspace_bytes, int B, int H, int N, int dim, ct_stream_t s);
 
+/* The transformer of a block in its fewest launches (layers/utils.py:25-34,53-61 with the so3 map of :29,56 inside):
+ *   ct_lattice_so3_fwd: R = so3_exponential_map(log_R, so3_eps) computed per head inside the lattice launch (R f32[H,3,3] is an
+ *     OUTPUT, kept for the backward) and the key statistics finished by the launch's last workgroup — ONE launch where
+ *     ct_so3_exp_fwd + ct_lattice_fwd are three.  `ticket`: one zero 32-bit word of device memory that the launch leaves zero
+ *     (needed with key_stats; launches that share it must be ordered: e.g. the last word of a ct_tickets_init buffer).
+ *   ct_lattice_so3_bwd: ct_lattice_bwd whose tail launch also turns every head's g_R into g_log_R f32[H,3] (the workgroup
+ *     that sums a head's g_R finishes with the so3 map's backward) — two launches where ct_lattice_bwd + ct_so3_exp_bwd are
+ *     three; g_R f32[H,3,3] is scratch the caller provides; the workspace is required. */
+int ct_lattice_so3_fwd(const float* xyz, const float* residual, const float* log_R, float so3_eps, const float* shift,
+                       const float* scales, const float* kscale, float* R, float* keys, float* lattice, float* key_stats,
+                       void* workspace, size_t workspace_bytes, void* ticket, int B, int H, int N, int dim, ct_stream_t s);
+int ct_lattice_so3_bwd(const float* xyz, const float* residual, const float* log_R, float so3_eps, const float* R,
+                       const float* shift, const float* scales, const float* kscale, const float* lattice,
+                       const float* g_lattice, const float* g_keys, float* g_xyz, float* g_residual, float* g_log_R, float* g_R,
+                       float* g_shift, float* g_scales, float* g_kscale, void* workspace, size_t workspace_bytes, int B, int H,
+                       int N, int dim, ct_stream_t s);
+
 /* so3 exponential map of the per-head rotation parameters — the third-party call of the transformers
  * (pytorch3d.transforms.so3.so3_exponential_map, layers/utils.py:6,29,56; eps = 1e-4 there):
  *   theta = sqrt(max(|v|^2, eps));  R = I + (sin theta / theta) K + ((1 - cos theta) / theta^2) K^2,  K = hat(v)

@@ -9,8 +9,9 @@ from oracle import ref_cpu as R
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused_so3", [False, True], ids=["so3-apart", "so3-inside"])
 @pytest.mark.parametrize("dim,use_scales,use_kscale", [(2, False, False), (3, True, False), (2, True, True), (3, False, True)])
-def test_lattice_fwd_bwd(dim, use_scales, use_kscale):
+def test_lattice_fwd_bwd(dim, use_scales, use_kscale, fused_so3):
     from cloud_transformers_amd import ops
     from cloud_transformers_amd.layers.utils import so3_exponential_map
     g = torch.Generator().manual_seed(10 * dim + use_scales + 2 * use_kscale)
@@ -35,7 +36,12 @@ def test_lattice_fwd_bwd(dim, use_scales, use_kscale):
     dl = [t.clone().cuda().requires_grad_(True) for t in (xyz, res, log_R, shift)]
     dsc = scales.clone().cuda().requires_grad_(True) if use_scales else None
     dks = kscale.clone().cuda().requires_grad_(True) if use_kscale else None
-    keys, lat = ops.lattice(dl[0], dl[1], so3_exponential_map(dl[2]), dl[3], dsc, dks, dim)
+    if fused_so3:        # ops.LatticeSo3Fn: the so3 map inside the launches, key statistics by the launch's last workgroup
+        keys, lat, stats = ops.lattice_so3(dl[0], dl[1], dl[2], dl[3], dsc, dks, dim, with_stats=True)
+        assert abs(float(stats[0]) - float(keys_ref.mean())) <= 1e-5 * max(1.0, abs(float(keys_ref.mean())))
+        assert abs(float(stats[1]) - float(keys_ref.var())) <= 1e-4 * float(keys_ref.var())
+    else:
+        keys, lat = ops.lattice(dl[0], dl[1], so3_exponential_map(dl[2]), dl[3], dsc, dks, dim)
     ((lat * cot_l.cuda()).sum() + (keys * cot_k.cuda()).sum()).backward()
 
     def close(a, b, name, tol=2e-5):
@@ -72,3 +78,20 @@ def test_so3_exp_map_matches_oracle():
     # rotations: R R^T = I
     eye = torch.eye(3, device="cuda").expand_as(Rc)
     assert float((Rc.detach() @ Rc.detach().transpose(1, 2) - eye).abs().max()) <= 1e-5
+
+
+def test_fused_lattice_statistics_over_repeated_launches():
+    """The ticket word of ct_lattice_so3_fwd resets itself: many launches on one stream, fresh inputs each, every launch's key
+    statistics equal the keys' own (a stale ticket or a partial read too early would show)."""
+    from cloud_transformers_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, N, dim = 8, 16, 4096, 3
+    for it in range(12):
+        xyz = torch.rand(B, 3, N, device="cuda", generator=g) * 2 - 1
+        res = torch.randn(B, H * 3, N, device="cuda", generator=g) * (0.1 + 0.05 * it)
+        log_R = torch.randn(H, 3, device="cuda", generator=g)
+        shift = torch.randn(H, 3, device="cuda", generator=g) * 0.1
+        keys, lat, stats = ops.lattice_so3(xyz, res, log_R, shift, None, None, dim, with_stats=True)
+        kd = keys.double()
+        assert abs(float(stats[0]) - float(kd.mean())) <= 1e-5
+        assert abs(float(stats[1]) - float(kd.var())) <= 1e-4 * float(kd.var()), it
