@@ -356,15 +356,19 @@ def test_a_cluster_timeout_is_loud_and_the_workspace_recovers(shape):
     w = torch.randn(H * C, C, *([3] * dim), generator=g) / (C * 3 ** dim) ** 0.5
     bias = torch.randn(H * C, generator=g) * 0.1
     cot = torch.randn(B, H * C, N, generator=g)
-    good = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False)
-    assert good["status"] == 0
-    Wa = L.int_array([W] * dim)
-    nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
-    ws = torch.zeros(nws, device="cuda", dtype=torch.uint8)
-    L.check(lib.ct_mhct_core_workspace_init(ops._ptr(ws), nws, B, H, C, N, dim, Wa, ops._stream()), "init")
-    lib.ct_debug_set_core(2)
+    force = 2 << 8                    # clusters of two workgroups per plane (the light 16^2 plane runs unclustered by itself)
+    lib.ct_debug_set_core(force)
     try:
+        good = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False)
+        assert good["status"] == 0
+        Wa = L.int_array([W] * dim)
+        nws = lib.ct_mhct_core_workspace_bytes(B, H, C, N, dim, Wa)
+        ws = torch.zeros(nws, device="cuda", dtype=torch.uint8)
+        L.check(lib.ct_mhct_core_workspace_init(ops._ptr(ws), nws, B, H, C, N, dim, Wa, ops._stream()), "init")
+        lib.ct_debug_set_core(force | 2)
         hurt = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False, ws=ws)
+        lib.ct_debug_set_core(force)
+        again = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False, ws=ws)
     finally:
         lib.ct_debug_set_core(0)
     assert hurt["status"] == 1
@@ -373,7 +377,6 @@ def test_a_cluster_timeout_is_loud_and_the_workspace_recovers(shape):
     ok = ~nan
     assert torch.equal(hurt["out"][ok], good["out"][ok])
     # the same workspace, not re-initialised: counters are back at zero, the launch is right (the status word stays set until read)
-    again = fused_core(keys, feat, w, bias, cot, None, W, H, dim, want_grids=False, ws=ws)
     assert torch.equal(again["out"], good["out"]) and again["occ"] == good["occ"]
     # the product's check: raises once, re-initialises, then is quiet
     key = (0, torch.cuda.current_stream().cuda_stream, B, H, C, N, tuple([W] * dim))
