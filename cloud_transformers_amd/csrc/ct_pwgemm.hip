@@ -23,6 +23,7 @@
 // (deterministic).  The per-tensor maxima arrive as partial maxima (ct_amax_f32's per-block ones, or what the kernel that
 // wrote the operand left per channel) and are folded when the kernel starts.  DESIGN.md §4.9 has the measurements.
 #include "ct_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 typedef _Float16 pw_h8 __attribute__((ext_vector_type(8)));
@@ -44,6 +45,7 @@ struct PwArgs {
   int lda, ldb, ldc;
   int M, N, K;                     // output rows / columns, summed extent per cloud
   int tilesM, tilesN, ksplit, Kc;  // z = cloud * ksplit + chunk; the chunk sums k in [chunk*Kc, min(K, (chunk+1)*Kc))
+  int Z;                           // clouds * ksplit
   const float* amax_a; const float* amax_b;
   int n_amax_a, n_amax_b;          // partial maxima per operand (<= kPwAmaxMax)
   // > 0: the operand's maxima are PER ROW of its k-contiguous arrangement, laid out [n_amax / rows][rows] (a producer's
@@ -140,6 +142,24 @@ __device__ __forceinline__ void pw_split2(float a0, float a1, float s, unsigned&
       "s_nop 0"
       : "=&v"(h), "=&v"(l)
       : "v"(a0), "v"(a1), "v"(s));
+}
+
+// Two such units with their instructions interleaved: every half-register write is followed by an instruction of the other
+// unit before it is read, so only the last one needs the wait state (s_nop issues in 4 cycles like a vector instruction:
+// MI355X_MICROARCH.md 'vector-instruction ISSUE cost').
+__device__ __forceinline__ void pw_split2x2(float a0, float a1, float sa, float b0, float b1, float sb, unsigned& ha, unsigned& la,
+                                            unsigned& hb, unsigned& lb) {
+  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+      "v_fma_mixlo_f16 %2, %7, %9, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
+      "v_fma_mixhi_f16 %2, %8, %9, 0\n\t"
+      "v_fma_mixlo_f16 %1, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %7, %9, -%2 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %8, %9, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(ha), "=&v"(la), "=&v"(hb), "=&v"(lb)
+      : "v"(a0), "v"(a1), "v"(sa), "v"(b0), "v"(b1), "v"(sb));
 }
 
 // eight values -> the h and l fragments' 16 bytes
@@ -420,9 +440,15 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
     for (int e = 0; e < 16; ++e) {
       const int lr = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h, row = m0 + lr;
       const float ia = ldexpf(1.f, -etab[lr]);
+#if defined(PW_ABL) && PW_ABL == 4
+      if (row < a.M && col < a.N && acc[i][e] == 12345.678f) C[(size_t)row * a.ldc + col] = acc[i][e] * ia * ib;
+#else
       if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][e] * ia * ib;
+#endif
     }
 }
+
+#include "ct_pwgemm2.h"
 
 // out[i] = sum_z slabs[z][i] in a fixed order: 32 float4 outputs x 8 z-groups per block, each group summed z ascending
 // (four loads in flight), the groups added in order through LDS
@@ -640,6 +666,73 @@ static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
   return true;
 }
 
+// The second kernel's plan (ct_pwgemm2.h): 128 x 256 tiles walked by one persistent workgroup per CU.  Weight gradient: the
+// number of k chunks per cloud that minimises rounds x (steps per chunk + what an item costs besides its steps) plus the
+// slabs' round trip.
+static int pw_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+static int g_pw_kernel = -1;      // -1: CLOUDCT_PW_KERNEL (1: the first kernel only, 2 / unset: the second where it applies)
+static bool pw2_enabled() {
+  if (g_pw_kernel < 0) {
+    const char* e = getenv("CLOUDCT_PW_KERNEL");
+    g_pw_kernel = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  return g_pw_kernel == 2;
+}
+static bool pw2_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
+  if (!pw2_enabled() || !pw_plan(mode, B, Co, Ci, N, p)) return false;
+  if (p.M + (mode == CT_PW_WGRAD ? p.N : 1) > k2TabMax) return false;
+  p.tilesM = (p.M + k2TM - 1) / k2TM;
+  p.tilesN = (p.N + k2TN - 1) / k2TN;
+  p.ksplit = 1;
+  p.Kc = (p.K + k2BK - 1) / k2BK * k2BK;
+  p.ws = 0;
+  const int ncu = pw_cu_count();
+  if (mode == CT_PW_WGRAD) {
+    const long long tiles = (long long)p.tilesM * p.tilesN * B;
+    double best = 1e30;
+    int best_ks = 1;
+    for (int ks = 1; ks <= 32; ++ks) {
+      const int kc = ((p.K + ks - 1) / ks + k2BK - 1) / k2BK * k2BK;
+      if (ks > 1 && kc < 8 * k2BK) break;
+      const int real = (p.K + kc - 1) / kc;
+      const long long items = tiles * real;
+      const double rounds = (double)((items + ncu - 1) / ncu);
+      const double z = (double)B * real;
+      const double cost = rounds * (kc / k2BK + 4) * 0.4 + (z > 1 ? z * Co * Ci * 8.0 / 4.0e6 : 0.0);      // us
+      if (cost < best) { best = cost; best_ks = real; p.Kc = kc; }
+    }
+    p.ksplit = best_ks;
+    if ((long long)B * p.ksplit > 1) p.ws = (size_t)B * p.ksplit * Co * Ci * sizeof(float);
+  }
+  if (mode == CT_PW_DGRAD) p.ws = (size_t)Co * Ci * sizeof(float);
+  p.Z = B * p.ksplit;
+  return (long long)p.tilesM * p.tilesN * p.Z <= 0x7fffffffLL;
+}
+
+template <bool BKM>
+static int pw2_launch(const PwArgs& a, hipStream_t st) {
+  auto k = pw2_gemm_kernel<BKM>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, k2LdsBytes) != hipSuccess) return CT_ELAUNCH;
+    attr = true;
+  }
+  const long long items = (long long)a.tilesM * a.tilesN * a.Z;
+  const int ncu = pw_cu_count();
+  const int blocks = items >= ncu ? ncu : (int)((items + 7) / 8 * 8);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(k2Threads), k2LdsBytes, st, a);
+  return CT_OK;
+}
+
 template <bool AK, bool BK>
 static int pw_launch(const PwArgs& a, int blocks, hipStream_t st) {
   auto k = pw_gemm_kernel<AK, BK>;
@@ -689,8 +782,12 @@ int ct_pw_prep_weight(const float* w, float* wt, float* amax, int Co, int Ci, ct
 
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   PwPlan p;
+  if (pw2_plan(mode, B, Co, Ci, N, p)) return p.ws;
   return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
 }
+
+// development: 1 = the first kernel (pw_gemm_kernel) only, 2 = the second (pw2_gemm_kernel) where it applies
+void ct_debug_set_pw_kernel(int which) { g_pw_kernel = which == 1 ? 1 : 2; }
 
 // per-row / per-column maxima of W [Co][Ci] for ct_pw_gemm_rs: rowmax f32[ceil(Ci/32)][Co], colmax f32[ceil(Co/32)][Ci];
 // wt f32[Ci][Co] = W^T or NULL
@@ -721,7 +818,9 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
                   const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,
                   int N, ct_stream_t s) {
   PwPlan p;
-  if (!a || !b || !out || !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
+  if (!a || !b || !out) return CT_EINVAL;
+  const bool v2 = pw2_plan(mode, B, Co, Ci, N, p);
+  if (!v2 && !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
   if ((amax_a && (n_amax_a < 1 || n_amax_a > kPwAmaxMax)) || (amax_b && (n_amax_b < 1 || n_amax_b > kPwAmaxMax))) return CT_EINVAL;
   // per-row maxima: of the A operand's rows in the arrangement the kernel reads it in (W: Co rows; W^T: Ci; g_y: Co) and, for
   // the weight gradient, of x's Ci rows; anything else about rows_* is an error, 0 = the maxima are partials of ONE maximum
@@ -743,26 +842,26 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
 #ifdef PW_STAMP
   g.dbg = g_pw_dbg;
 #endif
-  g.M = p.M; g.N = p.N; g.K = p.K; g.tilesM = p.tilesM; g.tilesN = p.tilesN; g.ksplit = p.ksplit; g.Kc = p.Kc;
+  g.M = p.M; g.N = p.N; g.K = p.K; g.tilesM = p.tilesM; g.tilesN = p.tilesN; g.ksplit = p.ksplit; g.Kc = p.Kc; g.Z = p.Z;
   const int blocks = p.tilesM * p.tilesN * p.Z;
   int rc;
   if (mode == CT_PW_FWD) {            // A = W [Co][Ci] (k contiguous), B = x[b] [Ci][N] (columns contiguous)
     g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Ci * N; g.C = out; g.ldc = N; g.c_zs = (long long)Co * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD) {   // A = W^T [Ci][Co] written to the workspace (k = co contiguous), B = g_y[b] [Co][N]
     hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, st, a, (float*)workspace, Co, Ci);
     CT_CHECK_LAUNCH();
     g.A = (const float*)workspace;
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD_T) {  // a IS W^T [Ci][Co] (ct_pw_prep_weight wrote it in the layer's forward)
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
   } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous
     g.lda = N; g.a_bs = (long long)Co * N; g.ldb = N; g.b_bs = (long long)Ci * N; g.ldc = Ci;
     g.C = p.ws ? (float*)workspace : out;
     g.c_zs = (long long)Co * Ci;
-    rc = pw_launch<true, true>(g, blocks, st);
+    rc = v2 ? pw2_launch<true>(g, st) : pw_launch<true, true>(g, blocks, st);
   }
   if (rc != CT_OK) return rc;
   CT_CHECK_LAUNCH();
