@@ -239,6 +239,14 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   // blocks that share an XCD (id % 8) take consecutive tiles: the M tiles of one [K, 128] operand panel run side by side on
   // one L2 (bijective form of the remap, cdna_hip_programming.md §5)
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rr = nwg & 7;
+#ifdef PW_PHASE
+  // experiment: the second workgroup of every CU (dispatch order: 32 workgroups per XCD fill its CUs once) starts half a
+  // tile late, so that one's prologue / epilogue falls into the other's K loop
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {
+    const int n = ((a.K < a.Kc ? a.K : a.Kc) / kPwBK) * PW_PHASE / 8128 + 1;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blockIdx.x >> 3);
   const int mt = id % a.tilesM, rest = id / a.tilesM, nt = rest % a.tilesN, z = rest / a.tilesN;
   const int cloud = z / a.ksplit, chunk = z - cloud * a.ksplit;
@@ -679,16 +687,29 @@ static int pw_cu_count() {
   }
   return n;
 }
-static int g_pw_kernel = -1;      // -1: CLOUDCT_PW_KERNEL (1: the first kernel only, 2 / unset: the second where it applies)
-static bool pw2_enabled() {
+// Which kernel: 0 = by measurement (below), 1 = the first kernel only, 2 = the second wherever it applies; env
+// CLOUDCT_PW_KERNEL read once, ct_debug_set_pw_kernel overrides.  Measured on the zoo's shapes (profiles/r4_pw_gemm_bench.txt):
+// the persistent 128x256 kernel wins the weight gradients of wide layers (Co, Ci >= 512: 848x512 105.9 vs 118.7 us, 592x512 81.9
+// vs 92.8, B2 N16384 104.9 vs 130.0) and forward / data gradient at K >= 1024 (117.1 vs 123.1, 130.0 vs 138.0); elsewhere the
+// two are within 5 % or the first kernel's smaller tiles fill the chip better (K or M <= 128: 24.7 vs 32.8 us).
+static int g_pw_kernel = -1;
+static int pw_kernel_choice() {
   if (g_pw_kernel < 0) {
     const char* e = getenv("CLOUDCT_PW_KERNEL");
-    g_pw_kernel = (e && atoi(e) == 1) ? 1 : 2;
+    const int v = e ? atoi(e) : 0;
+    g_pw_kernel = (v == 1 || v == 2) ? v : 0;
   }
-  return g_pw_kernel == 2;
+  return g_pw_kernel;
+}
+static bool pw2_wanted(int mode, int Co, int Ci) {
+  const int c = pw_kernel_choice();
+  if (c == 1) return false;
+  if (c == 2) return true;
+  if (mode == CT_PW_WGRAD) return Co >= 512 && Ci >= 512;
+  return (mode == CT_PW_FWD ? Ci : Co) >= 1024;
 }
 static bool pw2_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
-  if (!pw2_enabled() || !pw_plan(mode, B, Co, Ci, N, p)) return false;
+  if (!pw_plan(mode, B, Co, Ci, N, p) || !pw2_wanted(mode, Co, Ci)) return false;
   if (p.M + (mode == CT_PW_WGRAD ? p.N : 1) > k2TabMax) return false;
   p.tilesM = (p.M + k2TM - 1) / k2TM;
   p.tilesN = (p.N + k2TN - 1) / k2TN;
@@ -786,8 +807,8 @@ size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
 }
 
-// development: 1 = the first kernel (pw_gemm_kernel) only, 2 = the second (pw2_gemm_kernel) where it applies
-void ct_debug_set_pw_kernel(int which) { g_pw_kernel = which == 1 ? 1 : 2; }
+// test hook: 0 = by measurement, 1 = the first kernel (pw_gemm_kernel) only, 2 = the second (pw2_gemm_kernel) wherever it applies
+void ct_debug_set_pw_kernel(int which) { g_pw_kernel = (which == 1 || which == 2) ? which : 0; }
 
 // per-row / per-column maxima of W [Co][Ci] for ct_pw_gemm_rs: rowmax f32[ceil(Ci/32)][Co], colmax f32[ceil(Co/32)][Ci];
 // wt f32[Ci][Co] = W^T or NULL

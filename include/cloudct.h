@@ -474,9 +474,10 @@ void ct_debug_set_core(unsigned flags);
 /* Test hook of the grouped convolution: bit 0 = small-volume weight gradients take the vector-ALU kernel instead of the
  * matrix-core one (A/B measurements, tools/gconv64_bench.py). */
 void ct_debug_set_gconv(unsigned flags);
-/* Test hook of the pointwise GEMMs: 1 = every product on the first kernel (128x128 tiles, one tile per workgroup), 2 = the
- * persistent 128x256 kernel wherever it applies (the default; env CLOUDCT_PW_KERNEL read once).  ct_pw_gemm_workspace_bytes
- * follows the selection: set it before sizing a workspace. */
+/* Test hook of the pointwise GEMMs: 0 = the kernel measured faster for the shape (default), 1 = every product on the first
+ * kernel (128x128 tiles, one tile per workgroup), 2 = the persistent 128x256 kernel wherever it applies; env
+ * CLOUDCT_PW_KERNEL is read once for the initial value.  ct_pw_gemm_workspace_bytes follows the selection: set it before
+ * sizing a workspace. */
 void ct_debug_set_pw_kernel(int which);
 int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
                         int* host_status, ct_stream_t s);

@@ -7,6 +7,18 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=[1, 2], ids=["tile_per_workgroup", "persistent"])
+def _both_kernels(request):
+    """every test on both GEMM kernels (csrc/ct_pwgemm.hip: 128x128 tile per workgroup; csrc/ct_pwgemm2.h: persistent 128x256):
+    the library picks between them by shape, the hook forces one"""
+    from cloud_transformers_amd import _lib
+    lib = _lib.load()
+    lib.ct_debug_set_pw_kernel(request.param)
+    yield
+    lib.ct_debug_set_pw_kernel(0)
+
+
 def _needs_split16():
     from cloud_transformers_amd import ops
     if ops.PW_GEMM != "split16":
@@ -39,7 +51,7 @@ def _run(mode, W, x, gy):
 
 
 SHAPES = [(2, 208, 512, 1024), (1, 128, 64, 512), (3, 52, 36, 260), (2, 592, 256, 4096), (1, 4, 4, 4), (5, 132, 260, 36),
-          (8, 848, 512, 4096), (2, 512, 64, 16384)]
+          (8, 848, 512, 4096), (2, 512, 64, 16384), (1, 260, 44, 1028), (3, 128, 1056, 256), (1, 516, 520, 8196)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
