@@ -19,6 +19,7 @@
 //     HIGHEST bidder index (the reference: last writer, unspecified), so the
 //     result is deterministic and equal to oracle/emd_ref.c.
 #include "ct_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -39,6 +40,7 @@ struct EmdWs {
   int* max_idx;      // [B,n]
   int* unass_idx;    // [B,n]
   int* unass_cnt;    // [B]
+  int* sync;         // [B][3]: arrivals before Assign | arrivals at the end | entries of the list being written (emd_update_multi_kernel)
 };
 
 __device__ __forceinline__ int ld_coherent(const int* p) {
@@ -48,7 +50,7 @@ __device__ __forceinline__ float ld_coherent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void emd_init_kernel(EmdWs w, int* assignment, size_t total) {
+__global__ void emd_init_kernel(EmdWs w, int* assignment, size_t total, int nsync) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   assignment[i] = -1;
@@ -58,6 +60,7 @@ __global__ void emd_init_kernel(EmdWs w, int* assignment, size_t total) {
   w.max_idx[i] = -1;
   w.bid[i] = 0;
   w.bid_inc[i] = 0.0f;
+  if (i < (size_t)nsync) w.sync[i] = 0;
 }
 
 // One workgroup per batch.  do_assign: GetMax + Assign for the bids of the iteration
@@ -287,6 +290,134 @@ emd_update_kernel(EmdWs w, int* assignment, const float* xyz1, const float* xyz2
   }
 }
 
+// GetMax + Assign + the next unassigned list of one auction iteration on G workgroups per batch (grid = (G, B)): the
+// single-workgroup kernel above is pure latency at a few hundred entries, but a collapsed cloud (the completion network's
+// output early in training) keeps 6 000-8 000 bidders to the last iteration and the first iterations of any cloud have as many:
+// 44-104 us per launch on one workgroup.  Here a thread owns at most kMultiR list entries, the G workgroups of a batch meet
+// once — after GetMax's atomic maxima, before Assign reads them (arrival counter in the workspace, one spinning lane per
+// workgroup; every workgroup of the grid is resident: B * G <= the CU count, checked by the host) — and append to the new list
+// with one global atomic per workgroup.  The list's order is again free (see the fast path above).  A batch with at most
+// kMultiMin entries is handled by its first workgroup alone, without the meeting.
+#ifndef CT_EMD_MULTI_MIN
+#define CT_EMD_MULTI_MIN 4096
+#endif
+constexpr int kMultiR = 2, kSoloR = 4, kMultiMin = CT_EMD_MULTI_MIN;      // entries per thread: shared / alone (kSoloR * 1024 >= kMultiMin)
+static_assert(kSoloR * 1024 >= kMultiMin && kSoloR >= kMultiR, "entries per thread");
+__global__ void __launch_bounds__(1024)
+emd_update_multi_kernel(EmdWs w, int* assignment, int n, int gen) {
+  __shared__ int s_new, s_base;
+  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const size_t off = (size_t)b * n;
+  int* ass = assignment + off;
+  int* ass_inv = w.ass_inv + off;
+  int* bid = w.bid + off;
+  int* max_idx = w.max_idx + off;
+  float* bid_inc = w.bid_inc + off;
+  float* max_inc = w.max_inc + off;
+  float* price = w.price + off;
+  int* list = w.unass_idx + off;
+  int* arrive = w.sync + 3 * b;
+  int* done = arrive + 1;
+  int* newc = arrive + 2;
+  const int U = w.unass_cnt[b];
+  const bool solo = U <= kMultiMin;                  // the same for every workgroup of the batch
+  if (solo && g != 0) return;
+  if (threadIdx.x == 0) s_new = 0;
+  int j[kSoloR], t[kSoloR], prev[kSoloR], pos[kSoloR][2];
+  float bi[kSoloR], mi[kSoloR];
+  bool win[kSoloR];
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+    const int i = solo ? u * 1024 + (int)threadIdx.x : (g * kMultiR + u) * 1024 + (int)threadIdx.x;
+    j[u] = (i < U && (solo || u < kMultiR)) ? list[i] : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+    t[u] = j[u] >= 0 ? bid[j[u]] : 0;
+    bi[u] = j[u] >= 0 ? bid_inc[j[u]] : 0.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) mi[u] = j[u] >= 0 ? max_inc[t[u]] : 0.0f;       // written by the bid kernel
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+    if (j[u] >= 0 && (double)bi[u] - 1e-6 <= (double)mi[u] && (double)mi[u] <= (double)bi[u] + 1e-6)
+      atomicMax(&max_idx[t[u]], j[u]);
+  }
+  // this thread's maxima are performed (device-scope atomics: counted in vmcnt until acknowledged) — no agent-scope fence: on
+  // eight XCDs that is an L2 write-back, ~3 us per launch, and nothing but atomics has been written so far
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __threadfence_block();
+  __syncthreads();                                   // ... and everybody's entries are in registers: the list may be rewritten
+  if (!solo) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const int want = G * (gen + 1);
+      while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) win[u] = j[u] >= 0 && ld_coherent(&max_idx[t[u]]) == j[u];
+  // a target has one winner, so the winners touch disjoint targets and disjoint previous owners
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) prev[u] = win[u] ? ass_inv[t[u]] : -1;
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+    if (win[u]) {
+      if (prev[u] != -1) __hip_atomic_store(&ass[prev[u]], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ass_inv[t[u]] = j[u];
+      price[t[u]] += bi[u];
+      max_inc[t[u]] = -1e9f;
+      max_idx[t[u]] = -1;
+      __hip_atomic_store(&ass[j[u]], t[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the next list: an entry that did not win stays, an evicted owner joins; positions inside the workgroup by wave-aggregated
+  // LDS appends, the workgroup's run by one global atomic
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool add = k == 0 ? (j[u] >= 0 && !win[u]) : (win[u] && prev[u] != -1);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(add);
+      pos[u][k] = -1;
+      if (m == 0ull) continue;                       // wave-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_new, __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (add) pos[u][k] = base + __popcll(m & lt);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = solo ? 0 : __hip_atomic_fetch_add(newc, s_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int base = s_base;
+#pragma unroll
+  for (int u = 0; u < kSoloR; ++u) {
+    if (pos[u][0] >= 0) list[base + pos[u][0]] = j[u];
+    if (pos[u][1] >= 0) list[base + pos[u][1]] = prev[u];
+  }
+  if (solo) {                                        // (the counters advance as if all G workgroups had met)
+    if (threadIdx.x == 0) {
+      w.unass_cnt[b] = s_new;
+      __hip_atomic_fetch_add(arrive, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(done, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    // the last workgroup to get here publishes the list's length (a workgroup's run was added to newc — a returning atomic,
+    // s_base — before it arrives here, so every run is counted when the last arrival reads the sum)
+    const int d = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == G * (gen + 1) - 1) {
+      w.unass_cnt[b] = __hip_atomic_load(newc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(newc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 struct Top2 {
   float best, better;
   int idx;
@@ -349,19 +480,36 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   const int first = blockIdx.x * per_blk;
   const int mine = max(0, min(per_blk, U - first));
   if (mine == 0) return;                                        // block-uniform
-  int T = kBidThreads / per_blk;                                // lanes per bidder
+  // Many bidders per workgroup (>= kPairFrom: the first iterations, and every iteration of a collapsed cloud — 6 000-8 000
+  // bidders to the end): a lane group takes TWO bidders, reads each target once for both and does the arithmetic of the pair
+  // test on packed fp32 (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations, two lanes wide) — the dense regime is bound
+  // by one ds_read_b128 and ~9 vector instructions per (bidder, target) pair; this halves the first and nearly the second.
+#ifndef CT_EMD_PAIR_FROM
+#define CT_EMD_PAIR_FROM 16
+#endif
+  constexpr int kPairFrom = CT_EMD_PAIR_FROM;
+  const bool two = KTILE == 1024 && per_blk >= kPairFrom;       // block-uniform
+  const int groups = two ? (per_blk + 1) / 2 : per_blk;         // lane groups of this workgroup
+  int T = kBidThreads / groups;                                 // lanes per bidder (pair)
   T = T < 1 ? 1 : (T > 256 ? 256 : T);                         // (a tile holds 1024 targets: 4 per lane and step at most)
   T = 1 << (31 - __clz(T));                                     // power of two: a bidder is a lane group of a wave, or whole waves
   // nblk >= n/128 >= U/128  =>  per_blk <= 128  =>  T >= 4
   const int slot = threadIdx.x / T, sub = threadIdx.x % T;
-  const bool active = slot < mine;
-  int j = -1;
-  float x1 = 0, y1 = 0, z1 = 0;
+  const bool active = two ? 2 * slot < mine : slot < mine;
+  int j = -1, jb = -1;                                          // (jb: the pair's second bidder, -1 when the count is odd)
+  float x1 = 0, y1 = 0, z1 = 0, xb = 0, yb = 0, zb = 0;
   if (active) {
-    j = w.unass_idx[off + first + slot];
+    j = w.unass_idx[off + first + (two ? 2 * slot : slot)];
     x1 = xyz1[(off + j) * 3 + 0];
     y1 = xyz1[(off + j) * 3 + 1];
     z1 = xyz1[(off + j) * 3 + 2];
+    xb = x1; yb = y1; zb = z1;                                  // (an odd pair scans its first bidder twice; nothing is written for it)
+    if (two && 2 * slot + 1 < mine) {
+      jb = w.unass_idx[off + first + 2 * slot + 1];
+      xb = xyz1[(off + jb) * 3 + 0];
+      yb = xyz1[(off + jb) * 3 + 1];
+      zb = xyz1[(off + jb) * 3 + 2];
+    }
   }
   // software pipeline: tile t is scanned from LDS while tiles t+2 .. t+1+kDepth are in flight to registers
   float4 stage[kDepth][kPer];
@@ -384,7 +532,7 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   commit(0, stage[0]);
   if (kDepth < ntiles) fetch(kDepth, stage[0]);
   __syncthreads();
-  Top2 t2 = {-1e9f, -1e9f, 0x7fffffff};
+  Top2 t2 = {-1e9f, -1e9f, 0x7fffffff}, tb = {-1e9f, -1e9f, 0x7fffffff};
   // Candidate filter.  Only the bidder's two largest values matter, so a candidate below the second-best value the
   // bidder's lanes (of this wave) have seen so far can be dropped before its sqrt and its double-precision tail (2/3 of the
   // work): with thr that value, value = 3 - sqrt(d2) - price < thr  <=>  sqrt(d2) > 3 - thr - price, tested on the squared
@@ -392,14 +540,64 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
   // price alone rules the target out).  thr only uses earlier, lower-indexed targets, so a tie with it can never win the
   // lowest-index rule either: the result is bit-identical.  The slow path runs when ANY lane of the wave has a candidate
   // (wave-uniform branch); thr is refreshed from the lanes' running pairs after such a batch.
-  float cthr = 2e9f;                 // 3 - thr + margin; thr = -1e9 at the start: nothing is dropped
+  float cthr = 2e9f, cthb = 2e9f;    // 3 - thr + margin; thr = -1e9 at the start: nothing is dropped
   const int Tw = T < 64 ? T : 64;    // lanes of this wave that work for the same bidder
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  // second-best value over the bidder's lanes in this wave -> the filter's threshold (see the single-bidder scan below)
+  auto refresh = [&](const Top2& tt2) -> float {
+    float gb = tt2.best, g2 = tt2.better;
+    auto fold = [&](float ob, float o2) {
+      g2 = fmaxf(fminf(gb, ob), fmaxf(g2, o2));
+      gb = fmaxf(gb, ob);
+    };
+    if (Tw >= 2) fold(dpp_f32<0xB1>(gb), dpp_f32<0xB1>(g2));
+    if (Tw >= 4) fold(dpp_f32<0x4E>(gb), dpp_f32<0x4E>(g2));
+    if (Tw >= 8) fold(dpp_f32<0x141>(gb), dpp_f32<0x141>(g2));
+    if (Tw >= 16) fold(dpp_f32<0x140>(gb), dpp_f32<0x140>(g2));
+    if (Tw >= 32) fold(__shfl_xor(gb, 16, 64), __shfl_xor(g2, 16, 64));
+    if (Tw >= 64) fold(__shfl_xor(gb, 32, 64), __shfl_xor(g2, 32, 64));
+    return fabsf(g2) <= 32.0f ? 3.0f - g2 + 4e-5f : __builtin_inff();
+  };
   for (int t0 = 0; t0 < ntiles; t0 += kDepth) {
 #pragma unroll
     for (int r = 0; r < kDepth; ++r) {
       const int t = t0 + r;
       if (t < ntiles) {                                        // block-uniform
-        if (active) {
+        if (active && two) {
+          // two bidders per lane group: one LDS read per target, the pair test on packed fp32 (the operations and their
+          // order per bidder are those of the single-bidder scan: bit-identical values), ONE slow-path decision for both
+          const float4* tl = tile[t & 1];
+          const int k0 = t * kTile;
+          const f2 X = {x1, xb}, Y = {y1, yb}, Z = {z1, zb};
+          for (int k = sub; k < kTile; k += 4 * T) {
+            float4 q[4];
+            f2 d2[4];
+            unsigned long long keepa = 0ull, keepb = 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = tl[k + u * T];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const f2 qx = {q[u].x, q[u].x}, qy = {q[u].y, q[u].y}, qz = {q[u].z, q[u].z}, qw = {q[u].w, q[u].w};
+              const f2 x2 = qx - X, y2 = qy - Y, z2 = qz - Z;
+              d2[u] = __builtin_elementwise_fma(z2, z2, __builtin_elementwise_fma(y2, y2, x2 * x2));
+              const f2 cth = {cthr, cthb};
+              const f2 tt = cth - qw;
+              keepa |= __builtin_amdgcn_ballot_w64(!(d2[u].x > tt.x * fabsf(tt.x)));
+              keepb |= __builtin_amdgcn_ballot_w64(!(d2[u].y > tt.y * fabsf(tt.y)));
+            }
+            // the slow path per bidder of the pair (wave-uniform each): a candidate of one does not cost the other's chains
+            if (keepa != 0ull) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) top2_push(t2, (float)(3.0 - (double)sqrtf(d2[u].x) - (double)q[u].w), k0 + k + u * T);
+              cthr = refresh(t2);
+            }
+            if (keepb != 0ull) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) top2_push(tb, (float)(3.0 - (double)sqrtf(d2[u].y) - (double)q[u].w), k0 + k + u * T);
+              cthb = refresh(tb);
+            }
+          }
+        } else if (active) {
           const float4* tl = tile[t & 1];
           const int k0 = t * kTile;
           for (int k = sub; k < kTile; k += 4 * T) {           // kTile / T is a multiple of 4 (T <= 256)
@@ -462,6 +660,21 @@ emd_bid_kernel(EmdWs w, const float* __restrict__ xyz1, const float* __restrict_
     o.idx = __shfl_xor(t2.idx, m, 64);
     t2 = merge_top2(t2, o);
   }
+  if (two) {                         // block-uniform; a pair's lanes are part of one wave (groups >= 8: T <= 64)
+    for (int m = 1; m < Tw; m <<= 1) {
+      Top2 o;
+      o.best = __shfl_xor(tb.best, m, 64);
+      o.better = __shfl_xor(tb.better, m, 64);
+      o.idx = __shfl_xor(tb.idx, m, 64);
+      tb = merge_top2(tb, o);
+    }
+    if (active && sub == 0 && jb >= 0) {
+      const float inc = tb.best - tb.better + eps;
+      w.bid[off + jb] = tb.idx;
+      w.bid_inc[off + jb] = inc;
+      atomicMax((int*)&w.max_inc[off + tb.idx], __float_as_int(inc));
+    }
+  }
   if (T > 64) {                      // block-uniform: a bidder spans T/64 whole waves
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_best[wave] = t2.best; s_better[wave] = t2.better; s_idx[wave] = t2.idx; }
@@ -496,13 +709,25 @@ __global__ void emd_grad_kernel(const float* xyz1, const float* xyz2, const floa
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+int emd_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+int g_emd_single_update = -1;         // test hook (ct_debug_set_emd; env CLOUDCT_EMD_SINGLE_UPDATE read once): the update on one workgroup per batch
+
 }  // namespace
 
 extern "C" {
 
 size_t ct_emd_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 0) return 0;
-  return 7 * align256((size_t)B * n * 4) + align256((size_t)B * 4);
+  return 7 * align256((size_t)B * n * 4) + align256((size_t)B * 4) + align256((size_t)B * 12);
 }
 
 int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assignment, void* workspace,
@@ -522,16 +747,25 @@ int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assig
   w.bid = (int*)p; p += seg;
   w.max_idx = (int*)p; p += seg;
   w.unass_idx = (int*)p; p += seg;
-  w.unass_cnt = (int*)p;
+  w.unass_cnt = (int*)p; p += align256((size_t)B * 4);
+  w.sync = (int*)p;
   const size_t total = (size_t)B * n;
   CT_CLEAR_ERROR();
-  hipLaunchKernelGGL(emd_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (int*)assignment, total);
+  hipLaunchKernelGGL(emd_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (int*)assignment, total, 3 * B);
   hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n, 0, 0, 1, 0);
   const dim3 bid_grid(n / 64, B);
   constexpr int kBigTile = 4096;
   const bool big_ok = n % kBigTile == 0 && n >= 2 * kBigTile &&
                       hipFuncSetAttribute((const void*)emd_bid_kernel<kBigTile, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * kBigTile * (int)sizeof(float4)) == hipSuccess;
+  // the per-batch update on several workgroups (emd_update_multi_kernel): every list entry needs a thread's register slot and
+  // every workgroup of the grid must be resident for their meeting
+  int multi_g = (n + 1024 * kMultiR - 1) / (1024 * kMultiR), multi_gen = 0;
+  if (g_emd_single_update < 0) {
+    const char* e = getenv("CLOUDCT_EMD_SINGLE_UPDATE");
+    g_emd_single_update = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  if (multi_g > 16 || (long long)B * multi_g > emd_cu_count() || g_emd_single_update) multi_g = 1;
   for (int it = 0; it < iters; ++it) {
     const int last = it == iters - 1;
     // The host never learns the number of bidders, so from the sixth iteration on BOTH variants are launched and each batch
@@ -548,12 +782,17 @@ int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assig
       hipLaunchKernelGGL((emd_bid_kernel<kTile, 4>), bid_grid, dim3(kBidThreads), 2 * kTile * sizeof(float4), st, w, xyz1, xyz2, n, eps,
                          0, 0x7fffffff);
     }
-    hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n,
-                       1, last, last ? 0 : 1, last);
+    if (multi_g > 1 && !last)
+      hipLaunchKernelGGL(emd_update_multi_kernel, dim3(multi_g, B), dim3(1024), 0, st, w, (int*)assignment, n, multi_gen++);
+    else
+      hipLaunchKernelGGL(emd_update_kernel, dim3(B), dim3(1024), 0, st, w, (int*)assignment, xyz1, xyz2, dist, n,
+                         1, last, last ? 0 : 1, last);
   }
   CT_CHECK_LAUNCH();
   return CT_OK;
 }
+
+void ct_debug_set_emd(unsigned flags) { g_emd_single_update = (flags & 1u) ? 1 : 0; }
 
 int ct_emd_bwd(const float* xyz1, const float* xyz2, const float* g_dist, const int32_t* assignment,
                float* g_xyz1, int B, int n, ct_stream_t s) {

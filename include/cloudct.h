@@ -474,6 +474,9 @@ void ct_debug_set_core(unsigned flags);
 /* Test hook of the grouped convolution: bit 0 = small-volume weight gradients take the vector-ALU kernel instead of the
  * matrix-core one (A/B measurements, tools/gconv64_bench.py). */
 void ct_debug_set_gconv(unsigned flags);
+/* Test hook of the EMD auction: bit 0 = the per-batch update (GetMax, Assign, next list) on one workgroup per batch in every
+ * iteration (default: several workgroups per batch while the batch has more than 1024 unassigned points). */
+void ct_debug_set_emd(unsigned flags);
 /* Test hook of the pointwise GEMMs: 0 = the kernel measured faster for the shape (default), 1 = every product on the first
  * kernel (128x128 tiles, one tile per workgroup), 2 = the persistent 128x256 kernel wherever it applies; env
  * CLOUDCT_PW_KERNEL is read once for the initial value.  ct_pw_gemm_workspace_bytes follows the selection: set it before

@@ -121,3 +121,50 @@ def test_fuzz_matches_oracle_exactly(seed):
     dist, ass = emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), eps, iters)
     assert np.array_equal(ass.cpu().numpy(), ass_ref), float((ass.cpu().numpy() == ass_ref).mean())
     assert np.array_equal(dist.cpu().numpy(), d_ref)
+
+
+def _collapsed(B, n, seed):
+    """a cloud collapsed to a blob with duplicated points against a sphere shell: thousands of bidders stay unassigned through
+    every iteration (the completion network's output early in training, tools/dev/emd_inpainter_bidders.py) — the regime of
+    the two-bidders-per-lane scan and of the update kernel that runs on several workgroups per batch"""
+    rng = np.random.default_rng(seed)
+    a = (rng.standard_normal((B, n, 3)) * 0.02).astype(np.float32)
+    a[:, n // 2:] = a[:, :n // 2]                                   # every point twice: exact ties between bidders
+    g = rng.standard_normal((B, n, 3))
+    b = (0.4 * g / np.linalg.norm(g, axis=2, keepdims=True)).astype(np.float32)
+    return a, b
+
+
+@pytest.mark.parametrize("B,n,iters", [(2, 4096, 6), (1, 8192, 3), (2, 4096, 25)])
+def test_collapsed_cloud_matches_the_oracle(B, n, iters):
+    from cloud_transformers_amd.emd import emdModule
+    a, b = _collapsed(B, n, 5 + iters)
+    st, d_ref, ass_ref = emd_ref.forward(a, b, 0.005, iters)
+    assert st == 1
+    dist, ass = emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 0.005, iters)
+    assert np.array_equal(ass.cpu().numpy(), ass_ref)
+    assert np.array_equal(dist.cpu().numpy(), d_ref)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "collapsed"])
+def test_update_on_several_workgroups_equals_the_single_workgroup_update(kind):
+    """B2 n=16384 (eight workgroups per batch share the update while a batch has more than 4096 unassigned points; below that
+    its first workgroup works alone): assignments and distances bit for bit those of the one-workgroup-per-batch kernel, for
+    every iteration count up to where the uniform cloud has dropped below the threshold, and run to run"""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.emd import emdModule
+    lib = _lib.load()
+    B, n = 2, 16384
+    a, b = _clouds(B, n, 3) if kind == "uniform" else _collapsed(B, n, 4)
+    ac, bc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    for iters in (1, 2, 3, 5, 9, 30):
+        try:
+            lib.ct_debug_set_emd(1)
+            d1, a1 = emdModule()(ac, bc, 0.005, iters)
+        finally:
+            lib.ct_debug_set_emd(0)
+        d2, a2 = emdModule()(ac, bc, 0.005, iters)
+        d3, a3 = emdModule()(ac, bc, 0.005, iters)
+        assert torch.equal(a1, a2) and torch.equal(d1, d2), iters
+        assert torch.equal(a2, a3) and torch.equal(d2, d3), iters
+        assert int(a2.min()) >= 0
