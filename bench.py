@@ -120,10 +120,12 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def _time_oracle(args, batch, threads, budget, min_reps=3):
+def _time_oracle(args, batch, threads, budget, min_reps=3, reduce=None):
     """median seconds per fwd+bwd of the oracle at `batch` clouds with `threads` torch threads"""
     import torch
     from oracle import ref_cpu as R
+    if reduce is not None:
+        args = argparse.Namespace(**dict(vars(args), reduce=reduce))
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1234)
     keys = torch.tanh(torch.randn(batch, args.heads * args.dim, args.points, generator=g))
@@ -150,10 +152,18 @@ def cpu_baseline(args):
     before = torch.get_num_threads()
     cores = physical_cores()
     shape = "N=%d, H=%d, C=%d, %dD W=%d, reduce=%s" % (args.points, args.heads, args.feat, args.dim, args.grid, args.reduce)
-    t1, r1 = _time_oracle(args, 1, 1, args.cpu_seconds * 0.5)
-    tn, rn = _time_oracle(args, args.batch, cores, args.cpu_seconds * 0.5)
+    t1, r1 = _time_oracle(args, 1, 1, args.cpu_seconds * 0.4)
+    tn, rn = _time_oracle(args, args.batch, cores, args.cpu_seconds * 0.35)
+    # SURVEY 8(d) names both reductions of the reference's Splat: the other one (max -> torch_scatter's scatter_max, sum ->
+    # scatter_add_) on all cores beside the workload's own
+    other = "sum" if args.reduce == "max" else "max"
+    to, ro = _time_oracle(args, args.batch, cores, args.cpu_seconds * 0.25, reduce=other)
     torch.set_num_threads(before)
-    return {"value": args.batch * args.points / tn, "unit": "points/s", "cores": cores, "kind": "port",
+    other_rec = {"reduce": other, "value": args.batch * args.points / to, "unit": "points/s", "cores": cores, "batch": args.batch,
+                 "sample": "same workload with reduce=%s (%s), median of %d after a warm-up" %
+                           (other, "scatter_add_" if other == "sum" else "scatter_max", ro)}
+    return {"other_reduction": other_rec,
+            "value": args.batch * args.points / tn, "unit": "points/s", "cores": cores, "kind": "port",
             "batch": args.batch, "cpu_model": cpu_model(),
             "sample": "oracle/ref_cpu.splat_slice_step fwd+bwd, the whole workload (batch %d; %s), median of %d after a warm-up, "
                       "torch threads = %d physical cores" % (args.batch, shape, rn, cores),

@@ -5,7 +5,13 @@ tests/golden/zoo_segmenter_forward.npz, made by tests/golden/gen_zoo_forward.py.
 The golden stores no weights: both sides are `torch.manual_seed(seed)` + default initialisation, and this package's
 modules draw their parameters in the reference's order (tests/test_zoo_cpu.py::test_same_seed_same_weights).  The
 network below is this test's own statement of the architecture (stem, twelve MultiHeadUnion blocks cycling the three
-zoo head configurations, classifier head: model_zoo/s3dis/segmenter.py:14-75), built in the same order."""
+zoo head configurations, classifier head: model_zoo/s3dis/segmenter.py:14-75), built in the same order.
+
+WHAT COUNTS AS PARITY HERE.  The five whole-model tests (`test_*_smoke_whole_model_*`) are SMOKE tests: twelve blocks of
+argmax routing (Splat(max)) amplify a 1e-7 difference into a different winner now and then, so their bounds are statistical
+(median 3e-6, 97 % of the outputs within 1e-4, a loose cap on the rest) and nothing should be quoted from them as parity.
+The parity evidence for the blocks is the teacher-forced tests at the end of the file: each of the 12 + 12 blocks on the
+REFERENCE's own input activation, output and input gradient within 1e-4 of the reference's."""
 import numpy as np
 import pytest
 import torch
@@ -59,7 +65,7 @@ def _close(a, b, name, tol):
     assert err <= tol * max(1.0, np.abs(b).max()), (name, err, np.abs(b).max())
 
 
-def test_segmenter_eval_forward_and_input_gradient_match_the_reference():
+def test_segmenter_smoke_whole_model_eval_forward_and_input_gradient():
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_segmenter_forward.npz"))
     net = _model(int(gold["seed"])).eval()
     cloud = torch.from_numpy(gold["cloud"]).cuda().requires_grad_(True)
@@ -75,7 +81,7 @@ def test_segmenter_eval_forward_and_input_gradient_match_the_reference():
     assert np.median(err) <= 3e-6 and np.mean(err <= 1e-4) >= 0.97 and err.max() <= 2e-2, (np.median(err), np.mean(err <= 1e-4), err.max())
 
 
-def test_segmenter_training_mode_forward_matches_the_reference():
+def test_segmenter_smoke_whole_model_training_mode_forward():
     """Training mode (batch statistics).  Block by block the two implementations agree to ~1e-5, but twelve re-normalising
     blocks with learned keys amplify rounding differences (any two fp32 evaluations of this network drift apart the same
     way), so the tight comparison is on the activations after the first three blocks and the logits get a statistical bound."""
@@ -132,7 +138,7 @@ class Classifier(nn.Module):
         return self.class_head(vect), mask.unsqueeze(2)
 
 
-def test_classifier_eval_forward_and_input_gradient_match_the_reference():
+def test_classifier_smoke_whole_model_eval_forward_and_input_gradient():
     """Covers what the segmenter does not: MultiHeadPool (Splat-only heads), the grouped Res2D / Res3D blocks with their
     pooling (MFMA grouped conv at 16..64 channels per group), the dense heads."""
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_classifier_forward.npz"))
@@ -202,7 +208,7 @@ class Inpainter(nn.Module):
         return forward_style(self.final, torch.cat([x, noise], dim=1), z).unsqueeze(2)
 
 
-def test_inpainter_eval_forward_and_gradients_match_the_reference():
+def test_inpainter_smoke_whole_model_eval_forward_and_gradients():
     """The AdaIN path at model level: style vector from the encoder, fused AdaIN(+ReLU) kernels in the stem / head /
     blocks, MultiHeadUnionAdaIn with its learnable residual scale (perturbed away from its zero initial value)."""
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_inpainter_forward.npz"))
@@ -273,7 +279,7 @@ class ReconstructorDecoder(nn.Module):
         return forward_style(self.final, x, z).unsqueeze(2)
 
 
-def test_reconstructor_decoder_and_chamfer_loss_match_the_reference():
+def test_reconstructor_smoke_whole_model_decoder_and_chamfer_loss():
     """BASELINE configs[4] at model level: the AdaIN decoder from a style vector and the PCN-style Chamfer term of its
     training loss (train_image_reconstruction.py:173-178) on the HIP Chamfer kernels; and — on the reference's OWN input
     of the last decoder block and the cotangent at its output — that block's input gradient, tightly."""
