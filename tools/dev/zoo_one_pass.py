@@ -11,7 +11,7 @@ torch.manual_seed(0)
 keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
 feat = torch.randn(B, H * C, N, device="cuda")
 cot = torch.randn(B, H * C, N, device="cuda")
-st = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
+st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets="--no-tickets" not in sys.argv)
 for _ in range(50):
     st.run()
 torch.cuda.synchronize()

@@ -7,7 +7,11 @@ from cloud_transformers_amd.step import SplatSliceStep
 from bench import time_passes
 
 SHAPES = [(4, 128, 2), (4, 32, 3), (16, 64, 2), (16, 16, 3), (16, 16, 2), (32, 8, 3)]
-print("C W dim | B N | us per pass ... | step us | algorithmic MB | frac of 8 TB/s")
+print("C W dim | B N | mode | us per pass ... | step us | algorithmic MB | frac of 8 TB/s")
+# both modes per shape, one after the other on this box (boxes differ by up to 15 %: never compare rows of different runs):
+#   tickets = the round-4 path (arrival tickets: partial sums folded inside the producing kernels, point segments for Splat(max)
+#   backward, XCD-aware placement); plain = the same entry points without the ticket buffer (the round-3 launches + sum_parts)
+MODES = [("tickets", True)] if "--tickets-only" in sys.argv else [("plain", False)] if "--no-tickets" in sys.argv else [("tickets", True), ("plain", False)]
 for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
     for C, W, dim in SHAPES:
         torch.manual_seed(0)
@@ -15,12 +19,13 @@ for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
         keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
         feat = torch.randn(B, H * C, N, device="cuda")
         cot = torch.randn(B, H * C, N, device="cuda")
-        st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets="--no-tickets" not in sys.argv)
-        for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks
-            st.run()
-        torch.cuda.synchronize()
-        p = time_passes(st, iters=100)
-        tot = sum(p.values()) * 1e3
-        alg = st.algorithmic_bytes()["total"]
-        print(C, W, dim, "|", B, N, "|", {k: round(v * 1e3, 1) for k, v in p.items()}, "|", round(tot, 1), "|",
-              round(alg / 1e6, 1), "|", round(alg / (tot * 1e-6) / 8e12, 3), flush=True)
+        for name, tk in MODES:
+            st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets=tk)
+            for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks
+                st.run()
+            torch.cuda.synchronize()
+            p = time_passes(st, iters=100)
+            tot = sum(p.values()) * 1e3
+            alg = st.algorithmic_bytes()["total"]
+            print(C, W, dim, "|", B, N, "|", "%-7s" % name, "|", {k: round(v * 1e3, 1) for k, v in p.items()}, "|", round(tot, 1), "|",
+                  round(alg / 1e6, 1), "|", round(alg / (tot * 1e-6) / 8e12, 3), flush=True)
