@@ -687,11 +687,15 @@ static int pw_cu_count() {
   }
   return n;
 }
-// Which kernel: 0 = by measurement (below), 1 = the first kernel only, 2 = the second wherever it applies; env
-// CLOUDCT_PW_KERNEL read once, ct_debug_set_pw_kernel overrides.  Measured on the zoo's shapes (profiles/r4_pw_gemm_bench.txt):
-// the persistent 128x256 kernel wins the weight gradients of wide layers (Co, Ci >= 512: 848x512 105.9 vs 118.7 us, 592x512 81.9
-// vs 92.8, B2 N16384 104.9 vs 130.0) and forward / data gradient at K >= 1024 (117.1 vs 123.1, 130.0 vs 138.0); elsewhere the
-// two are within 5 % or the first kernel's smaller tiles fill the chip better (K or M <= 128: 24.7 vs 32.8 us).
+// Which kernel: 0 = default, 1 = the first kernel only, 2 = the second wherever it applies; env CLOUDCT_PW_KERNEL read once,
+// ct_debug_set_pw_kernel overrides.  Stand-alone (profiles/r4_pw_gemm_bench.txt) the persistent 128x256 kernel wins the weight
+// gradients of wide layers (848x512 105.9 vs 118.7 us, 592x512 81.9 vs 92.8, B2 N16384 104.9 vs 130.0) and forward / data
+// gradient at K >= 1024 (117.1 vs 123.1, 130.0 vs 138.0) and loses on thin shapes (K or M <= 128: 32.8 vs 24.7 us).  Inside the
+// training steps it wins nothing: a layer's data and weight gradients run on two streams and fill each other's partial rounds
+// of workgroup slots (ops.pw_backward), which a kernel that owns every CU with 147 KiB of LDS cannot — graphed steps with the
+// shape rule above / first kernel only / second everywhere, one box: segmenter 17.2 / 17.2 / 17.3 ms, classifier 15.2 / 15.1 /
+// 15.3, inpainter 32.6 / 31.6 / 32.5 (profiles/r4_model_steps.txt).  So the default is the first kernel; the second stays
+// built, tested (tests/test_pw_gemm_gpu.py runs every case on both) and selectable.
 static int g_pw_kernel = -1;
 static int pw_kernel_choice() {
   if (g_pw_kernel < 0) {
@@ -702,11 +706,8 @@ static int pw_kernel_choice() {
   return g_pw_kernel;
 }
 static bool pw2_wanted(int mode, int Co, int Ci) {
-  const int c = pw_kernel_choice();
-  if (c == 1) return false;
-  if (c == 2) return true;
-  if (mode == CT_PW_WGRAD) return Co >= 512 && Ci >= 512;
-  return (mode == CT_PW_FWD ? Ci : Co) >= 1024;
+  (void)mode; (void)Co; (void)Ci;
+  return pw_kernel_choice() == 2;
 }
 static bool pw2_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
   if (!pw_plan(mode, B, Co, Ci, N, p) || !pw2_wanted(mode, Co, Ci)) return false;

@@ -9,7 +9,7 @@ import csv
 import sys
 
 FAMILIES = [
-    ("pointwise-conv GEMMs on the f16 matrix pipes (ct_pwgemm: GEMM, weight prep, amax, slab sum)", ("pw_gemm", "pw_amax", "pw_reduce", "pw_transpose", "pw_prep")),
+    ("pointwise-conv GEMMs on the f16 matrix pipes (ct_pwgemm: GEMM, weight prep, amax, slab sum)", ("pw_gemm", "pw2_gemm", "pw_amax", "pw_reduce", "pw_transpose", "pw_prep")),
     ("library GEMM (rocBLAS / Tensile)", ("Cijk_", "gemm", "Gemm")),
     ("norms (ct_bnorm / ct_adain)", ("bn_", "adain_")),
     ("grouped conv (ct_gconv)", ("gconv",)),
