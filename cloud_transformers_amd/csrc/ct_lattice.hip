@@ -30,6 +30,7 @@ struct LatticeArgs {
   unsigned* ticket;
   float* key_stats;
   double nkeys;
+  int ppw;               // points of a row per workgroup of lattice_fwd_kernel (a multiple of 256)
 };
 
 // Rodrigues' formula of one head in double (so3_exp_fwd_kernel's arithmetic): R[9] row-major
@@ -68,7 +69,10 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
   __shared__ float red[4][2];
   __shared__ float Rs[9];
   __shared__ unsigned s_last;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // a workgroup walks `a.ppw` points of its (cloud, head) row, 256 at a time: the launch is a few hundred workgroups, not N / 256
+  // per row — every workgroup ends with ONE arrival on the launch's ticket, and 2 048 same-address atomics (B8 H16 N4096) took
+  // longer than the 17 MB the kernel moves (45 us; profiles/r4_model_breakdown.txt)
+  const int n_beg = blockIdx.x * a.ppw, n_end = min(a.N, n_beg + a.ppw);
   const int h = blockIdx.y, b = blockIdx.z;
   if (a.log_R != nullptr) {            // kernel-uniform: this head's rotation from its so3 parameters (one lane, double)
     if (threadIdx.x == 0) {
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) lattice_fwd_kernel(LatticeArgs a, float* 
     __syncthreads();
   }
   float s1 = 0.0f, s2 = 0.0f;
-  if (n < a.N) {
+  for (int n = n_beg + (int)threadIdx.x; n < n_end; n += 256) {
     const float ks = a.kscale ? a.kscale[0] : 1.0f;
     float p[3];
 #pragma unroll
@@ -426,6 +430,16 @@ bool valid(const LatticeArgs& a) {
 
 extern "C" {
 
+// workgroups per (cloud, head) row of lattice_fwd_kernel: about two rounds of the chip over the whole launch
+static int lattice_fwd_nbx(int B, int H, int N, int& ppw) {
+  const int rows = B * H, max_nbx = (N + 255) / 256;
+  int nbx = (512 + rows - 1) / rows;
+  if (nbx > max_nbx) nbx = max_nbx;
+  if (nbx < 1) nbx = 1;
+  ppw = ((N + nbx - 1) / nbx + 255) / 256 * 256;
+  return (N + ppw - 1) / ppw;
+}
+
 size_t ct_lattice_fwd_workspace_bytes(int B, int H, int N) {
   if (B <= 0 || H <= 0 || N <= 0) return 0;
   return (size_t)B * H * ((N + 255) / 256) * 2 * sizeof(float);
@@ -441,7 +455,7 @@ int ct_lattice_so3_fwd(const float* xyz, const float* residual, const float* log
   if (!log_R || !R || !(so3_eps > 0.0f) || !valid(a) || !keys || !lattice) return CT_EINVAL;
   if (key_stats && (!ticket || !workspace || workspace_bytes < ct_lattice_fwd_workspace_bytes(B, H, N))) return CT_EWORKSPACE;
   if (!key_stats) a.ticket = nullptr;
-  const int nbx = (N + 255) / 256;
+  const int nbx = lattice_fwd_nbx(B, H, N, a.ppw);
   CT_CLEAR_ERROR();
   hipLaunchKernelGGL(lattice_fwd_kernel, dim3(nbx, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice,
                      key_stats ? (float*)workspace : nullptr);
@@ -455,7 +469,7 @@ int ct_lattice_fwd(const float* xyz, const float* residual, const float* R, cons
   LatticeArgs a = {xyz, residual, R, shift, scales, kscale, B, H, N, dim, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0};
   if (!valid(a) || !keys || !lattice) return CT_EINVAL;
   if (key_stats && (!workspace || workspace_bytes < ct_lattice_fwd_workspace_bytes(B, H, N))) return CT_EWORKSPACE;
-  const int nbx = (N + 255) / 256;
+  const int nbx = lattice_fwd_nbx(B, H, N, a.ppw);
   CT_CLEAR_ERROR();
   hipLaunchKernelGGL(lattice_fwd_kernel, dim3(nbx, H, B), dim3(256), 0, (hipStream_t)s, a, keys, lattice,
                      key_stats ? (float*)workspace : nullptr);
