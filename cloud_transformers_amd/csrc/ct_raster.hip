@@ -1541,6 +1541,10 @@ struct HotPlan {
 };
 
 // channels per chunk: a multiple of 4 such that `fixed + CC * per_ch` bytes fit half a CU's LDS (else a whole CU's)
+// LDS of the Splat(max) backward kernels behind their tiles: four counters and, per four-channel group of the plane (<= 64), its
+// non-zero cells and its matches (ct_raster_hot.h: kTieGroups)
+constexpr size_t kSplatBwdFixed = 16 + 2 * 64 * 4;
+
 bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budget = kHalfCuLdsBytes) {
   if ((C & 3) != 0) return false;
   long long cc = (budget - (long long)fixed) / (long long)per_ch;
@@ -1797,7 +1801,7 @@ bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<DIM>& g, HotPlan& hp, i
   // segments first: every workgroup stages every chunk, so the chunks are as fat as LDS allows (no chunk groups)
   if (a.tickets != nullptr && tickets_cover(a.tickets, (long long)a.B * a.H, 1, 1) && (a.gpos_add == nullptr || a.gpos_add != a.g_pos)) {
     HotPlan sp;
-    if (hot_chunks(a.C, (size_t)g.G * 8, 16, sp)) {
+    if (hot_chunks(a.C, (size_t)g.G * 8, kSplatBwdFixed, sp)) {
       const int ns = splat_bwd_segments(a.B, a.H, a.C, a.N, g.G, DIM, sp.lds);
       if (ns > 1) {
         hp = sp; ncg = 1; nseg = ns; single = true;
@@ -1805,7 +1809,7 @@ bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<DIM>& g, HotPlan& hp, i
       }
     }
   }
-  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return false;
+  if (!hot_bwd_plan(a.B, a.H, a.C, g.G, (size_t)g.G * 8, kSplatBwdFixed, kHalfCuLdsBytes, hp, ncg)) return false;
   if constexpr (DIM == 2) {
     single = (a.N >> 2) <= 2 * kHotThreads;
   } else {
@@ -1821,7 +1825,7 @@ size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   HotPlan hp;
   int ncg = 1;
   if ((C & 3) || (N & 3) || (g.G & 3)) return 0;
-  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, kSplatBwdFixed, kHalfCuLdsBytes, hp, ncg)) return 0;
   return ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0;
 }
 
@@ -1968,7 +1972,7 @@ size_t splat_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   HotPlan hp;
   int ncg = 1;
   if ((C & 3) || (N & 3) || (g.G & 3)) return 0;
-  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, 16, kHalfCuLdsBytes, hp, ncg)) return 0;
+  if (!hot_bwd_plan(B, H, C, g.G, (size_t)g.G * 8, kSplatBwdFixed, kHalfCuLdsBytes, hp, ncg)) return 0;
   return ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0;
 }
 
@@ -2601,7 +2605,7 @@ int ct_splat_bwd_tk_segments(int B, int H, int C, int N, int dim, const int* W) 
   if ((G & 3) || ((long long)B * H < 32 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) || (long long)B * H > CT_TICKETS_BYTES / 8) return 1;
   HotPlan sp;
   if ((t_dbg_flags & CT_DEBUG_FORCE_BAND) && C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4) return 2;
-  if (!hot_chunks(C, (size_t)G * 8, 16, sp)) {
+  if (!hot_chunks(C, (size_t)G * 8, kSplatBwdFixed, sp)) {
     // the banded kernels (ct_raster_band.h: grids beyond a CU's LDS) redo a band with exact ties from the incoming
     // cotangent: a second tensor too
     return (C == 4 && ((G / W[0]) & 3) == 0 && W[0] >= 4 && (size_t)G * 4 > (size_t)kBigLdsBytes && !(t_dbg_flags & CT_DEBUG_NO_BAND)) ? 2 : 1;

@@ -602,10 +602,17 @@ struct PtRows {
   bool wt;      // results another workgroup may have to overwrite (a segmented plane with ties) go out write-through
 };
 
-template <bool HAS_PAD, bool CLAIMS, int WT>
+// groups of four channels a plane's tie test distinguishes (s_cnt[4 + i]: non-zero cells of group i, s_cnt[4 + kTieGroups + i]:
+// its matches): a plane with C > 4 * kTieGroups channels only has the plane-wide test
+constexpr int kTieGroups = 64;
+
+// DELTA (with CLAIMS): the redo of ONE four-channel group after an optimistic pass — its g_feat rows are rewritten with the
+// single-winner award, and gs receives only the difference to what the optimistic pass had added for these channels (the
+// awards of matches that lose their claim, negated).  nmp: the optimistic pass's per-group match counter of this chunk.
+template <bool HAS_PAD, bool CLAIMS, int WT, bool DELTA = false>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
                                                int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
-                                               float (&gs)[4][2], int& nm) {
+                                               float (&gs)[4][2], int& nm, unsigned* nmp = nullptr) {
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
@@ -614,6 +621,7 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
   // 4 channels (two {z,z,g,g} pairs) per step: the corner weights of a point are computed once per 4 channels.
   // (Requesting the next step's rows before this step is processed was measured: the 16 extra registers spill, 73 -> 102 us.)
   for (int cg0 = 0; cg0 < cc; cg0 += 4) {
+    const int nm_before = nm;
     float fv[4][4];          // [channel][point]
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
@@ -656,29 +664,41 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
             gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
           }
         } else {
+          // claims: a cell's z word is won by the first matching contribution that flips its sign bit (z > 0 in every non-empty
+          // cell: the zero floor of the forward), so a later contribution still sees WHAT the maximum was and knows that it
+          // matched and lost — which the redo of a single group needs (DELTA: the award the optimistic pass gave it is taken back)
+          constexpr unsigned kSign = 0x80000000u;
           unsigned ba[4], bb[4];
-          bool ma[4], mb[4];
+          bool ma[4], mb[4], la[4], lb[4];
           bool any = false;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             ba[v] = __float_as_uint(xa * p.cw[v]);
             bb[v] = __float_as_uint(xb * p.cw[v]);
-            ma[v] = ba[v] == __float_as_uint(zg[v].x);
-            mb[v] = bb[v] == __float_as_uint(zg[v].y);
-            any = any | ma[v] | mb[v];
+            const unsigned za = __float_as_uint(zg[v].x), zb = __float_as_uint(zg[v].y);
+            ma[v] = ba[v] == za && !(za & kSign);
+            mb[v] = bb[v] == zb && !(zb & kSign);
+            la[v] = (za & kSign) != 0u && ba[v] == (za ^ kSign);          // matched, already claimed by another contribution
+            lb[v] = (zb & kSign) != 0u && bb[v] == (zb ^ kSign);
+            any = any | ma[v] | mb[v] | (DELTA & (la[v] | lb[v]));
           }
           if (any) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-              // claim: the first tied contribution to swap the cell's z word to kNoMatch wins it
               unsigned* zw = (unsigned*)(Zp + off[v]);
-              const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : kNoMatch, kNoMatch);
-              const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : kNoMatch, kNoMatch);
+              const unsigned oa = atomicCAS(zw, ma[v] ? ba[v] : kNoMatch, ma[v] ? (ba[v] | kSign) : kNoMatch);
+              const unsigned ob = atomicCAS(zw + 1, mb[v] ? bb[v] : kNoMatch, mb[v] ? (bb[v] | kSign) : kNoMatch);
               const float ga = (ma[v] & (oa == ba[v])) ? zg[v].z : 0.0f;
               const float gb = (mb[v] & (ob == bb[v])) ? zg[v].w : 0.0f;
               gfa = __builtin_fmaf(ga, p.cw[v], gfa);
               gfb = __builtin_fmaf(gb, p.cw[v], gfb);
-              gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
+              if (DELTA) {      // what the optimistic pass added for a match that does not hold the claim, taken back
+                const float da = (la[v] | (ma[v] & (oa != ba[v]))) ? -zg[v].z : 0.0f;
+                const float db = (lb[v] | (mb[v] & (ob != bb[v]))) ? -zg[v].w : 0.0f;
+                gw[v] = __builtin_fmaf(db, xb, __builtin_fmaf(da, xa, gw[v]));
+              } else {
+                gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
+              }
             }
           }
         }
@@ -694,6 +714,9 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj)
       st_part4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]), R.wt);
+    // this group's matches into the thread's packed per-chunk counter (8 bits per four-channel group of the chunk: <= 4 groups,
+    // <= 2 quads x 64 products per thread and group); LDS adds per (quad, group) — even one per wave — cost 3.5 us of 68 on the headline
+    if (!CLAIMS && nmp != nullptr) *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
   }
 }
 
@@ -701,7 +724,7 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
 template <bool HAS_PAD, bool CLAIMS, int WT, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const GridW<2>& g, float4* ZG, int* s_cnt,
                                                     size_t bh, int b, int cgi, int N, const PtRows& R,
-                                                    float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie) {
+                                                    float (&gs_reg)[QPT ? QPT : 1][4][2], bool& tie, int* grp = nullptr) {
   const int G = WT ? WT * WT : g.G, CC = a.CC;
   const int tid = threadIdx.x;
   const int nq = N >> 2;
@@ -715,6 +738,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
     const float* gin = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
     __syncthreads();                              // readers of the previous chunk (or pass) are done
+    unsigned long long nzp = 0ull;
     for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
       const int cp = t / G, cell = t - cp * G;
       const size_t o = (size_t)(cp * 2) * G + cell;
@@ -723,9 +747,22 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
       const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
       ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
                           ld_stream(gin + o + G));
-      if (!CLAIMS) nz += (z0 != 0u) + (z1 != 0u);
+      if (!CLAIMS) {
+        const int nzt = (z0 != 0u) + (z1 != 0u);
+        nz += nzt;
+        nzp += (unsigned long long)(unsigned)nzt << (16 * ((cp >> 1) & 3));      // per four-channel group of the chunk (packed: see nmp)
+      }
+    }
+    if (!CLAIMS && grp != nullptr) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int v = wave_sum_i32((int)((nzp >> (16 * f)) & 0xffffu));
+        if ((tid & 63) == 0 && v) atomicAdd(grp + (c0 >> 2) + f, v);
+      }
     }
     __syncthreads();
+    unsigned nmp = 0u;
+    unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
     if constexpr (QPT > 0) {
 #pragma unroll
       for (int u = 0; u < QPT; ++u) {
@@ -735,7 +772,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float4 tx = *(const float4*)(keyx + n0);
           const float4 ty = *(const float4*)(keyy + n0);
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
-          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm);
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm);
         }
       }
     } else {
@@ -747,7 +784,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         float gs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
-        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm);
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm);
         // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns these
         // addresses); the first chunk starts from the incoming cotangent where there is one (a.gpos_add)
         float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
@@ -772,6 +809,13 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           *(float4*)px = ox;
           *(float4*)py = oy;
         }
+      }
+    }
+    if (pnm != nullptr) {                         // (all lanes are back here: threads without a quad add zeros)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int v = wave_sum_i32((int)((nmp >> (8 * f)) & 0xffu));
+        if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
     }
   }
@@ -816,7 +860,61 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = 0.0f;
   bool tie = false;
-  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, gs, tie);
+  // Exact ties are rare but not exotic: two different points whose products equal a cell's maximum bit for bit turn up in
+  // about one random B8 H64 C16 32^2 workload out of three (8.4 M (cell, channel) pairs, ~2e-7 each), duplicated points make
+  // them the rule.  Redoing the whole plane doubled its workgroup's time and, as the launch's tail, cost 68 -> 117 us on the
+  // headline.  With the plane's points in registers (QPT > 0) the test is kept per four-channel group — non-zero cells counted
+  // while the tile is staged, matches per group by one LDS add per quad and group — and only a tied group is redone
+  // (splat_bwd_quad<.., DELTA>): its tile pairs staged again, its g_feat rows rewritten with single-winner claims, g_keys
+  // corrected by the difference.
+  int* const grp = (QPT > 0 && QPT <= 2 && nsg == 1 && a.C <= 4 * kTieGroups && a.CC <= 16) ? s_cnt + 4 : nullptr;
+  if (grp != nullptr) {
+    for (int i = threadIdx.x; i < 2 * kTieGroups; i += blockDim.x) grp[i] = 0;
+  }
+#ifdef CT_EXP_CLAIMS_ONLY       // experiment: no optimistic pass, every plane with single-winner claims (the cost of a tie-proof single pass)
+  tie = nsg == 1;
+  if (nsg > 1)
+#endif
+  splat_bwd_plane_pass<HAS_PAD, false, WT, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, gs, tie, grp);
+#ifndef CT_EXP_CLAIMS_ONLY
+  if constexpr (QPT > 0) {
+    if (tie && grp != nullptr) {    // block-uniform
+      const int G = WT ? WT * WT : g.G;
+      const int tid = threadIdx.x, nq = N >> 2;
+      for (int gi = 0; gi < (a.C >> 2); ++gi) {
+        if (grp[gi] == grp[kTieGroups + gi]) continue;           // block-uniform (LDS words, written before the pass's last barrier)
+        const int cabs = gi << 2;                                 // the group's first channel
+        if ((cabs / a.CC) % a.ncg != wg.cgi) continue;            // (another chunk group's channels)
+        const float* zin = a.tile_in + (bh * a.C + cabs) * (size_t)G;
+        const float* gin = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
+        __syncthreads();
+        for (int t = tid; t < 2 * G; t += blockDim.x) {
+          const int cp = t / G, cell = t - cp * G;
+          const size_t o = (size_t)(cp * 2) * G + cell;
+          const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
+          ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
+                              ld_stream(gin + o + G));
+        }
+        __syncthreads();
+        const float* keyx = a.pos.keys + (bh * 2 + 0) * R.Nr + R.so;
+        const float* keyy = a.pos.keys + (bh * 2 + 1) * R.Nr + R.so;
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+          const int q = tid + u * (int)blockDim.x;
+          if (q < nq) {
+            const int n0 = q << 2;
+            const float4 tx = *(const float4*)(keyx + n0);
+            const float4 ty = *(const float4*)(keyy + n0);
+            const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+            int nm_unused = 0;
+            splat_bwd_quad<HAS_PAD, true, WT, true>(a, g, ZG, bh, b, cabs, 4, n0, R, kx, ky, gs[u], nm_unused);
+          }
+        }
+      }
+      tie = false;
+    }
+  }
+#endif
   if (tie && nsg == 1) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)

@@ -206,3 +206,48 @@ def test_ties_across_point_segments_route_to_a_single_winner(shape, dup):
             assert float(((gk_s - gk_1)[1:]).abs().max()) <= 2e-6 * float(gk_1.abs().max())
         assert float(((gk_s - gk_1)[0, dim:]).abs().max()) <= 2e-6 * float(gk_1.abs().max())
         assert float((pair(gk_s, dim) - pair(gk_1, dim)).abs().max()) <= 1e-4 * float(gk_1.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 4096, 8, 16, 32, 2), (4, 4096, 16, 16, 16, 2), (2, 2048, 8, 8, 32, 2), (1, 4096, 4, 32, 16, 2)],
+                         ids=lambda s: "B%dN%dH%dC%dW%dD%d" % s)
+@pytest.mark.parametrize("dup", ["three_points", "half_the_cloud"])
+def test_a_tied_channel_group_is_redone_alone(shape, dup):
+    """Splat(max) backward with the plane's points in registers keeps its tie test per four-channel group and redoes only a tied
+    group (ct_raster_hot.h: splat_bwd_quad<.., DELTA>: rows rewritten with single-winner claims, g_keys corrected by the
+    difference).  Against the generic kernels on the same data: duplicated points tie bit for bit, so per point only the SUM
+    over the copies is defined — it must agree; without duplicates everything must."""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.step import SplatSliceStep
+    lib = _lib.load()
+    B, N, H, C, W, dim = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda", generator=g))
+    feat = torch.randn(B, H * C, N, device="cuda", generator=g)
+    cot = torch.randn(B, H * C, N, device="cuda", generator=g)
+    half = N // 2
+    if dup == "half_the_cloud":
+        src = torch.arange(half, device="cuda")
+    else:
+        src = torch.tensor([5, 77, half - 1], device="cuda")           # isolated ties: three planes' worth of single tied groups
+    keys[..., half + src] = keys[..., src]
+    feat[..., half + src] = feat[..., src]
+    out = {}
+    for name, flags in (("hot", _lib.DEBUG_FORCE_HOT), ("generic", _lib.DEBUG_NO_HOT)):
+        lib.ct_debug_set_flags(flags)
+        try:
+            st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets=False)
+            st.run()
+            torch.cuda.synchronize()
+            out[name] = (st.g_feat.clone(), st.g_keys_out.clone(), st.launch_tags()["splat_bwd"])
+        finally:
+            lib.ct_debug_set_flags(0)
+    assert out["hot"][2].startswith("splat_max_bwd_hot") and "hot" not in out["generic"][2], (out["hot"][2], out["generic"][2])
+
+    def folded(t):          # a duplicated point and its copy as one
+        t = t.clone()
+        t[..., src] += t[..., half + src]
+        t[..., half + src] = 0
+        return t
+    for i, name in ((0, "g_feat"), (1, "g_keys")):
+        a, b = folded(out["hot"][i]), folded(out["generic"][i])
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
