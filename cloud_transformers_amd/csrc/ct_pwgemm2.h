@@ -157,6 +157,21 @@ __global__ void __launch_bounds__(k2Threads, 2) pw2_gemm_kernel(PwArgs a) {
     }
   };
   auto issue = [&](float (&xa)[8], float (&xb)[16]) { issue_a(xa); issue_b(xb, 0); issue_b(xb, 2); };
+  // one 16-byte load at a time (the step spreads the six over its MFMA half-groups: a wave that issues two back to back waits
+  // for the CU's vector-memory path behind the other seven waves' pairs)
+  auto issue_a1 = [&](float (&xa)[8], int q) {
+    const bool part = lkk + k2BK > lkend;
+    const float4 v = *(const float4*)(ua + (part ? poffa[q] : offa + 16u * q));
+    xa[4 * q] = v.x; xa[4 * q + 1] = v.y; xa[4 * q + 2] = v.z; xa[4 * q + 3] = v.w;
+  };
+  auto issue_b1 = [&](float (&xb)[16], int q) {
+    const bool part = lkk + k2BK > lkend;
+    unsigned o;
+    if constexpr (BKM) o = ((q >> 1) ? offb1 : offb0) + 16u * (q & 1);
+    else o = offb0 + (unsigned)q * (unsigned)ldb4;
+    const float4 v = *(const float4*)(ub + (part ? poffb[q] : o));
+    xb[4 * q] = v.x; xb[4 * q + 1] = v.y; xb[4 * q + 2] = v.z; xb[4 * q + 3] = v.w;
+  };
 
   // the first two K-steps' loads go out before anything else: the fold of the maxima below hides behind their round trip
   float ra0[8], rb0[16], ra1[8], rb1[16];
@@ -443,6 +458,13 @@ __global__ void __launch_bounds__(k2Threads, 2) pw2_gemm_kernel(PwArgs a) {
 #define PW2_STAMP(i) ((void)0)
 #define PW2_STAMP_SUM() ((void)0)
 #endif
+#define PW2_MH(F, X, Y, J)                                                                        \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    acc[J][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.Y[J], F.X[0], acc[J][0], 0, 0, 0);      \
+    acc[J][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.Y[J], F.X[1], acc[J][1], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
   int cs = 0;                                        // LDS stage of the step being multiplied
   // step s: MFMAs on stage cs; K-step s+2 (register set xa / xb) is split into stage cs+2 between them, then the set is
   // refilled with K-step s+4; the first fragments of step s+1 (stage cs+1) are fetched before the barrier
@@ -455,26 +477,37 @@ __global__ void __launch_bounds__(k2Threads, 2) pw2_gemm_kernel(PwArgs a) {
     PW2_STAMP(0);
     frags(st, 1, f1);
     mask_partial(xa, xb);
-    PW2_MF(f0, ah, bh);
+    PW2_MH(f0, ah, bh, 0);
     pair_a(xa, 0, hA, lA);
-    PW2_MF(f0, ah, bl);
+    PW2_MH(f0, ah, bh, 1);
     pair_a(xa, 2, hA, lA);
+    PW2_MH(f0, ah, bl, 0);
     write_a(wst, hA, lA);
-    issue_a(xa);
-    PW2_MF(f0, al, bh);
-    pair_b(xb, 0, 0, hB, lB); pair_b(xb, 0, 1, hB, lB);
-    issue_b(xb, 0);
+    issue_a1(xa, 0);
+    PW2_MH(f0, ah, bl, 1);
+    pair_b(xb, 0, 0, hB, lB);
+    issue_a1(xa, 1);
+    PW2_MH(f0, al, bh, 0);
+    pair_b(xb, 0, 1, hB, lB);
+    PW2_MH(f0, al, bh, 1);
+    issue_b1(xb, 0);
     PW2_STAMP(1);
-    PW2_MF(f1, ah, bh);
-    pair_b(xb, 1, 0, hB, lB); pair_b(xb, 1, 1, hB, lB);
-    issue_b(xb, 2);
-    next_load();
-    PW2_MF(f1, ah, bl);
+    PW2_MH(f1, ah, bh, 0);
+    pair_b(xb, 1, 0, hB, lB);
+    issue_b1(xb, 1);
+    PW2_MH(f1, ah, bh, 1);
+    pair_b(xb, 1, 1, hB, lB);
+    PW2_MH(f1, ah, bl, 0);
+    issue_b1(xb, 2);
     write_b(wst, hB, lB);
+    PW2_MH(f1, ah, bl, 1);
+    issue_b1(xb, 3);
+    next_load();
     next_split();
     PW2_STAMP(2);
+    PW2_MH(f1, al, bh, 0);
     frags(nst, 0, f0);
-    PW2_MF(f1, al, bh);
+    PW2_MH(f1, al, bh, 1);
     PW2_STAMP(3);
     __syncthreads();
     PW2_STAMP(4);
@@ -494,6 +527,7 @@ __global__ void __launch_bounds__(k2Threads, 2) pw2_gemm_kernel(PwArgs a) {
     step(ra1, rb1);
   } while (Cc.alive);
 #undef PW2_MF
+#undef PW2_MH
 #ifdef PW_STAMP
   if (a.dbg && lane == 0) {
     tsum[6] = tloop - tkernel;
