@@ -73,6 +73,8 @@ DEBUG_NO_HOT = 1
 DEBUG_FORCE_HOT = 2
 DEBUG_NO_BAND = 4
 DEBUG_FORCE_BAND = 8
+DEBUG_NO_SORTED = 16
+DEBUG_FORCE_SORTED = 32
 
 _lock = threading.Lock()
 _lib = None

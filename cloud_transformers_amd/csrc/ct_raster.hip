@@ -1201,6 +1201,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
 #include "ct_raster_hot.h"
 #include "ct_raster_hot3d.h"
 #include "ct_raster_band.h"
+#include "ct_raster_sorted.h"
 
 // ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
@@ -1668,6 +1669,22 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   return (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
 }
 
+// Sorted-plane kernels (ct_raster_sorted.h): one 1024-thread workgroup per (b, h) plane; every thread owns at most two items
+// (N / 4 + 3 G / 4 <= 2048), positions and counts fit 16 bits, the carve-up fits a CU's LDS.  Worth it only where there is a
+// plane per CU at least (the kernel does not split a plane).  CLOUDCT_SORTED=0/1 overrides the default.
+bool sorted_plane_ok(const RasterArgs& a, int G) {
+  static const int env = [] {
+    const char* e = getenv("CLOUDCT_SORTED");
+    return e ? atoi(e) : -1;
+  }();
+  const unsigned f = t_dbg_flags.load(std::memory_order_relaxed);
+  if ((f & CT_DEBUG_NO_SORTED) || (env == 0 && !(f & CT_DEBUG_FORCE_SORTED))) return false;
+  if (a.N > 4096 || (a.N & 3) || (a.C & 3) || (G & 3) || a.N / 4 + (3 * G) / 4 > kMaxItems) return false;
+  if (sort_lds(G, a.N, a.C).total > (size_t)kBigLdsBytes) return false;
+  if (f & CT_DEBUG_FORCE_SORTED) return true;
+  return (long long)a.B * a.H >= 256;
+}
+
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
@@ -1676,6 +1693,20 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
   // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
+  if (nseg == 1 && sorted_plane_ok(a, g.G)) {
+    // the plane's points sorted by base cell, items of <= 4 entries per thread (ct_raster_sorted.h)
+    a.tile_in = grid; a.g_pos = g_pos;
+    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = 1; a.nseg = 1; a.Nrow = 0; a.tickets = nullptr;
+    const SortLds L = sort_lds(g.G, a.N, a.C);
+#ifdef CT_SORT_STAGGER
+    { const char* e = getenv("CLOUDCT_SORT_STAGGER"); a.cnt_mask = e ? atoi(e) : 0; }
+#endif
+    dim3 wgrid(1, a.H, a.B);
+#define CT_MK_SLICE_BWD_SORTED(PADV, WTV) CT_HOT_KERNEL0(slice_bwd_sorted_kernel, PADV, WTV)
+    CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g);
+    note("slice_bwd_sorted");
+    return CT_OK;
+  }
   HotPlan hp;
   int ncg = 1;
   if (!hot_bwd_plan(a.B * nseg, a.H, a.C, g.G, (size_t)g.G * 8, (size_t)(g.G + a.C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return CT_EINVAL;
@@ -2468,6 +2499,12 @@ int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
 extern "C" {
 
 int ct_abi_version(void) { return CT_ABI_VERSION; }
+#ifdef CT_SORT_STAMPS
+// experiments only (tools/dev/build_raster_exp.sh ... -DCT_SORT_STAMPS): the phase stamps of the sorted kernels' first workgroup
+int ct_debug_sorted_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sorted_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? CT_OK : CT_ELAUNCH;
+}
+#endif
 
 const char* ct_strerror(int status) {
   switch (status) {

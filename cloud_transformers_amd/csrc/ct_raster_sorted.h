@@ -1,0 +1,569 @@
+// Raster backward passes on a plane's points SORTED BY BASE CELL (2D grids, corners from keys, N <= 4096, N % 4 == 0).
+// Included by ct_raster.hip inside its anonymous namespace, after ct_raster_hot.h (uses its helpers).
+//
+// The scatter form of Slice backward (ct_raster_hot.h: slice_bwd_fused_kernel) issues, per point and four channels, 8 random
+// 64-bit LDS atomics and 4 random 16-byte LDS reads: 0.65 of its LDS cycles are bank conflicts, and ~100 vector instructions per
+// point and group go into rounding, pair packing and a corner set-up recomputed per group (0.46 of the roofline).
+// Here the plane's points are counting-sorted by base cell ONCE per workgroup (stable: per-wave histograms, returning LDS
+// atomics), the sorted list is cut into ITEMS — runs of at most four entries of ONE base cell — and a thread owns at most
+// two items for the whole kernel:
+//   * per-entry state (the two fractional weights; w0 = 1 - w1 holds bit for bit) and the g_keys sums live in registers;
+//   * g_out of a four-channel group is read coalesced in point order and staged into LDS in SORTED order as one 16-byte word
+//     per entry, so an item reads its entries' channels with one ds_read_b128 each;
+//   * the conv tile is read once per item (lanes = consecutive cells: conflict-free), not once per point;
+//   * an item sums its <= 4 products per (corner, channel) in float registers and rounds the SUM once to the channel's
+//     fixed-point quantum: 16 integer LDS adds per item — four times fewer than one set per point, issued by lanes on
+//     consecutive cells (no bank conflicts but for a cell's own extra items) — integer adds commute and the items are a
+//     deterministic function of the keys, so g_grid stays bitwise reproducible;
+//   * the next group's g_out rows and conv cells are requested before the current group is processed (registers), so HBM
+//     keeps streaming through the LDS phase.
+// One 1024-thread workgroup per (b, h) plane and CU (LDS: 16 G + 16 G + 16 (N + 1) + 8 N + 4 G + 8 KiB ~ 140 KiB at 32^2, N 4096).
+#pragma once
+
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kItemLen = 4;
+constexpr int kMaxItems = 2 * kSortThreads;
+
+// CT_SORT_STAMPS (experiments): workgroup (0,0,0)'s thread 0 leaves s_memtime at the phase boundaries in g_sorted_stamps
+// (read by ct_debug_sorted_stamps; tools/dev/sorted_check.py --stamps)
+#ifdef CT_SORT_STAMPS
+__device__ unsigned long long g_sorted_stamps[64];
+#define CT_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) g_sorted_stamps[i] = clock64();   \
+  } while (0)
+#else
+#define CT_STAMP(i) ((void)0)
+#endif
+
+// inclusive wave64 scans over DPP (the reduction sequence of wave_sum_i32 IS a scan: every lane ends with its prefix)
+__device__ __forceinline__ unsigned wave_scan_add_u32(unsigned v) {
+#define CT_UADD(a, b) ((a) + (b))
+  CT_DPP_STEP(v, CT_UADD, 0x111, 0xf);
+  CT_DPP_STEP(v, CT_UADD, 0x112, 0xf);
+  CT_DPP_STEP(v, CT_UADD, 0x114, 0xf);
+  CT_DPP_STEP(v, CT_UADD, 0x118, 0xf);
+  CT_DPP_STEP(v, CT_UADD, 0x142, 0xa);
+  CT_DPP_STEP(v, CT_UADD, 0x143, 0xc);
+#undef CT_UADD
+  return v;
+}
+__device__ __forceinline__ unsigned wave_scan_max_u32(unsigned v) {
+#define CT_UMAX(a, b) max((a), (b))
+  CT_DPP_STEP(v, CT_UMAX, 0x111, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x112, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x114, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x118, 0xf);
+  CT_DPP_STEP(v, CT_UMAX, 0x142, 0xa);
+  CT_DPP_STEP(v, CT_UMAX, 0x143, 0xc);
+#undef CT_UMAX
+  return v;
+}
+
+// LDS carve-up shared by the sorted kernels (bytes from the start of dynamic LDS)
+struct SortLds {
+  size_t tile;     // float4[G]: the group's conv cells, channel-interleaved (Slice bwd) / first staged tile
+  size_t acc;      // int[4][G]: fixed-point accumulators of the group (Slice bwd) / second staged tile
+  size_t stage;    // float4[N + 1]: the group's point values in sorted order (+ one zero entry); set-up: per-wave histograms
+  size_t ab;       // float2[N + 1]: the entries' fractional weights (w1x, w1y) in sorted order (+ one zero entry)
+  size_t tot;      // unsigned[G]: points per base cell
+  size_t stp;      // unsigned[G]: {first sorted position | first item << 16} of the cell
+  size_t mark;     // unsigned[kMaxItems]: first-item marks of the non-empty cells
+  size_t misc;     // unsigned[C] channel maxima | K | scan scratch [64]
+  size_t total;
+};
+__host__ __device__ inline SortLds sort_lds(int G, int N, int C) {
+  SortLds L;
+  size_t o = 0;
+  L.tile = o;  o += (size_t)16 * G;
+  L.acc = o;   o += (size_t)16 * G;
+  L.stage = o;
+  {
+    const size_t st = (size_t)16 * (N + 1), hist = (size_t)kSortWaves * G * 4;
+    o += ((st > hist ? st : hist) + 15) & ~(size_t)15;
+  }
+  L.ab = o;    o += (size_t)8 * (N + 1);
+  L.tot = o;   o += (size_t)4 * G;
+  L.stp = o;   o += (size_t)4 * G;
+  L.mark = o;  o += (size_t)4 * kMaxItems;
+  L.misc = o;  o += (size_t)4 * (C + 1 + 64 + 3);
+  L.total = (o + 15) & ~(size_t)15;
+  return L;
+}
+
+// What a thread keeps of the sorted plane: the sorted positions of the four points it LOADS (packed 16 bits each), and its
+// (at most) two ITEMS: base cell and, per slot, the entry's sorted position (N — the zero entries of the stage and weight
+// areas — for a slot beyond the item's entries).  The entries' weights stay in LDS (SortLds::ab): 16 registers less.
+struct SortedPlane {
+  unsigned rk01, rk23;            // ranks of points 4 tid .. 4 tid + 3
+  int cell[2];                    // -1: no item
+  unsigned ent8[2][kItemLen / 2]; // 8 x the sorted position of two entries, 16 bits each: the byte offset of the entry's weights
+                                  // (its stage word: twice that)
+};
+
+// Sorts the plane's points by base cell and deals the items.  All kSortThreads threads call it; the block's LDS must hold the
+// SortLds carve-up; K (max contributions to a cell) is left in misc[C].  On return the stage area is free (hist is dead).
+struct PlaneKeys {
+  int base[4];
+  float fa[4], fb[4];      // w1x, w1y
+};
+// the thread's four points: base cells and fractional weights (issued FIRST: the sort waits for nothing else)
+__device__ __forceinline__ void load_plane_keys(const RasterArgs& a, const GridW<2>& g, int W1, size_t bh, PlaneKeys& K) {
+  const int tid = threadIdx.x, N = a.N;
+  const bool has = (tid << 2) < N;
+  const int n0 = has ? (tid << 2) : 0;
+  const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0);
+  const float4 ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+  const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    Pt2 p;
+    pt2_from_keys(kx[i], ky[i], g, W1, p);
+    K.base[i] = p.base; K.fa[i] = p.w1x; K.fb[i] = p.w1y;
+  }
+}
+
+__device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys& PK, int G, int W1, unsigned char* lds,
+                                           const SortLds& L, SortedPlane& S) {
+  const int tid = threadIdx.x, N = a.N, wave = tid >> 6;
+  unsigned* hist = (unsigned*)(lds + L.stage);
+  float2* AB = (float2*)(lds + L.ab);
+  unsigned* cnt = (unsigned*)(lds + L.tot);
+  unsigned* stp = (unsigned*)(lds + L.stp);
+  unsigned* mark = (unsigned*)(lds + L.mark);
+  unsigned* s_k = (unsigned*)(lds + L.misc) + a.C;
+  unsigned* scr = s_k + 1;            // [0..15] wave sums, [16..47] wave maxima of the item marks, [48] items in all
+  const bool has = (tid << 2) < N;
+  CT_STAMP(0);
+  for (int i = tid; i < (kSortWaves * G) >> 2; i += kSortThreads) ((uint4*)hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < kMaxItems; i += kSortThreads) mark[i] = 0u;
+  if (tid < a.C + 1) ((unsigned*)(lds + L.misc))[tid] = 0u;          // channel maxima, K
+  __syncthreads();
+  // rank inside (wave, cell): the value the returning add hands back — the points of a thread in index order, the lanes of one
+  // instruction in the order the LDS serves them (a fixed function of the addresses: the same on every run)
+  CT_STAMP(1);
+  unsigned r[4] = {0u, 0u, 0u, 0u};
+  if (has) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = atomicAdd(&hist[wave * G + PK.base[i]], 1u);
+  }
+  __syncthreads();
+  CT_STAMP(2);
+  // per cell: the waves' counts -> their exclusive prefix (in place) and the cell's total; then the exclusive scan over the
+  // cells of {points, items} packed into one word (points <= 4096, items <= 2048: no carry between the halves)
+  unsigned carry = 0u;
+  for (int Y0 = 0; Y0 < G; Y0 += kSortThreads) {
+    const int Y = Y0 + tid;
+    unsigned t = 0u;
+    if (Y < G) {
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) {
+        const unsigned c = hist[w * G + Y];
+        hist[w * G + Y] = t;
+        t += c;
+      }
+      cnt[Y] = t;
+    }
+    const unsigned v = t | (((t + kItemLen - 1) / kItemLen) << 16);
+    const unsigned inc = wave_scan_add_u32(v);
+    if ((tid & 63) == 63) scr[wave] = inc;
+    __syncthreads();
+    CT_STAMP(3);
+    unsigned pre = carry, all = 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      const unsigned sw = scr[w];
+      pre += w < wave ? sw : 0u;
+      all += sw;
+    }
+    const unsigned ex = pre + inc - v;
+    if (Y < G) {
+      stp[Y] = ex;
+      if (t) mark[ex >> 16] = (unsigned)Y + 1u;      // the cell's first item
+    }
+    carry += all;
+    if (Y0 + kSortThreads >= G) {      // last round: every cell's count is in place
+      // K: contributions per cell = points based at the cell and at its three lower neighbours (cells of the last row /
+      // column are never a base, so the wrapped neighbours of column 0 read zeros)
+      unsigned kloc = 0u;
+      for (int X = tid; X < G; X += kSortThreads) {
+        unsigned c = cnt[X];
+        if (X >= 1) c += cnt[X - 1];
+        if (X >= W1) c += cnt[X - W1];
+        if (X >= W1 + 1) c += cnt[X - W1 - 1];
+        kloc = max(kloc, c);
+      }
+      kloc = wave_max_u32(kloc);
+      if ((tid & 63) == 0) atomicMax(s_k, kloc);
+      if (tid == 0) scr[48] = carry >> 16;
+    }
+    __syncthreads();                                  // (scr is reused by the next round)
+  }
+  CT_STAMP(4);
+  // points: sorted position = cell start + the earlier waves' points of the cell + rank inside the wave
+  unsigned rk[4] = {0u, 0u, 0u, 0u};
+  if (has) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rk[i] = (stp[PK.base[i]] & 0xffffu) + hist[wave * G + PK.base[i]] + r[i];
+      AB[rk[i]] = make_float2(PK.fa[i], PK.fb[i]);
+    }
+  }
+  if (tid == 0) AB[N] = make_float2(0.0f, 0.0f);
+  S.rk01 = rk[0] | (rk[1] << 16);
+  S.rk23 = rk[2] | (rk[3] << 16);
+  // items: item k belongs to the last cell marked at or before k (inclusive max-scan of the marks)
+  unsigned mk[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    mk[u] = wave_scan_max_u32(mark[tid + u * kSortThreads]);
+    if ((tid & 63) == 63) scr[16 + u * kSortWaves + wave] = mk[u];
+  }
+  __syncthreads();          // hist (the stage area) is dead from here on
+  CT_STAMP(5);
+  const int nitems = (int)scr[48];
+  // the waves' maxima ahead of this wave (and, for the second slot, the whole first slot): lanes 0..31 hold one each
+  const unsigned wm = (tid & 63) < 2 * kSortWaves ? scr[16 + (tid & 63)] : 0u;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const unsigned m = max(mk[u], wave_max_u32((int)(tid & 63) < u * kSortWaves + wave ? wm : 0u));
+    const int k = tid + u * kSortThreads;
+    const bool valid = k < nitems;
+    const int Y = valid ? (int)m - 1 : 0;
+    const unsigned sp = stp[Y];
+    const int first = (int)(sp & 0xffffu) + (k - (int)(sp >> 16)) * kItemLen;
+    const int end = (int)(sp & 0xffffu) + (int)cnt[Y];
+    S.cell[u] = valid ? Y : -1;
+#pragma unroll
+    for (int j = 0; j < kItemLen; j += 2) {
+      const unsigned e0 = (valid && first + j < end) ? first + j : N, e1 = (valid && first + j + 1 < end) ? first + j + 1 : N;
+      S.ent8[u][j >> 1] = (e0 << 3) | (e1 << 19);
+    }
+  }
+  // (no barrier: the weights written above are read behind the first group's staging barrier)
+  CT_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
+// KF': Slice backward on the sorted plane.  grid = (1, H, B), kSortThreads threads.
+// CT_SORT_ABL (experiments, tools/dev/build_raster_exp.sh): 1 = the sort and the epilogue only, 2 = + staging, barriers and
+// write-out (no items), 3 = items without their LDS adds, 4 = items without the gather side.  Results are wrong then: timing only.
+// ---------------------------------------------------------------------------
+#ifndef CT_SORT_ABL
+#define CT_SORT_ABL 0
+#endif
+#ifndef CT_SORT_BODY
+#define CT_SORT_BODY 1      // 1: one loop per item, the next entry's reads in flight; 0: a scatter loop, then a gather loop
+#endif
+// byte offset of slot j's weights (8 x its sorted position); its stage word is at twice that
+#define CT_E8(S, u, j) (((j) & 1) ? ((S).ent8[u][(j) >> 1] >> 16) : ((S).ent8[u][(j) >> 1] & 0xffffu))
+#ifndef CT_SORT_PF
+#define CT_SORT_PF 1        // (body 1) the next entry's LDS reads are issued before this entry's arithmetic
+#endif
+#ifndef CT_SB
+#define CT_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+template <bool HAS_PAD, int WT>
+__global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
+  const SortLds L = sort_lds(G, N, C);
+  float4* T4 = (float4*)(lds_raw + L.tile);
+  int* acc = (int*)(lds_raw + L.acc);
+  float4* Sg = (float4*)(lds_raw + L.stage);
+  const float2* AB = (const float2*)(lds_raw + L.ab);
+  unsigned* s_max = (unsigned*)(lds_raw + L.misc);
+  unsigned* s_k = s_max + C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t bh = (size_t)b * a.H + h;
+  const int tid = threadIdx.x;
+  const int off[4] = {0, W1, 1, W1 + 1};
+  const bool has = (tid << 2) < N;
+  const int n0 = has ? (tid << 2) : 0;
+  const int ngroups = C >> 2;
+
+  // the first group's rows are requested before the sort: they land while it runs
+  float gq[4][4];           // [channel][point] of the thread's quad
+  float cvq[4];             // conv cell `tid` of the group's four channels (cells beyond blockDim: loaded in the loop)
+  const float* const src0 = a.src + bh * C * (size_t)N;               // wave-uniform bases, 32-bit lane offsets
+  const float* const cnv0 = a.tile_in + bh * C * (size_t)G;
+  const unsigned ln0 = (unsigned)n0, lc0 = (unsigned)(tid < G ? tid : 0);
+  auto request = [&](int grp) {
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const float4 t = ld_stream4(src0 + (size_t)(grp * 4 + cj) * N + ln0);
+      gq[cj][0] = t.x; gq[cj][1] = t.y; gq[cj][2] = t.z; gq[cj][3] = t.w;
+      cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
+    }
+  };
+#ifdef CT_SORT_STAGGER
+  if ((blockIdx.y + blockIdx.z) & 1) {      // experiment: odd planes start late, so that sort and streaming phases of different CUs interleave
+    const long long t0 = clock64();
+    while (clock64() - t0 < (long long)a.cnt_mask) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+  PlaneKeys PK;
+  load_plane_keys(a, g, W1, bh, PK);
+  request(0);
+  float pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
+
+  SortedPlane S;
+  sort_plane(a, PK, G, W1, lds_raw, L, S);
+  for (int i = tid; i < G; i += kSortThreads) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
+  if (tid == 0) Sg[N] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // what the slots beyond an item's entries read
+  const float Kf = (float)(*s_k);
+
+  float gsx[2][kItemLen], gsy[2][kItemLen];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < kItemLen; ++j) gsx[u][j] = gsy[u][j] = 0.0f;
+
+#if CT_SORT_ABL != 1
+  // one four-channel group; `more`: another group follows — its rows are requested as soon as this one's are staged (a
+  // compile-time flag: a conditional request would make the compiler copy, and so wait for, the loaded registers at once)
+  auto group = [&](const int grp, auto more) {
+    const int ch0 = grp * 4;
+    if (grp == 1) CT_STAMP(16);
+    // per-channel max |g_out * pad| of the plane (the fixed-point quantum), and the group into LDS in sorted order
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      float m = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = HAS_PAD ? gq[cj][i] * pv[i] : gq[cj][i];
+        x = has ? x : 0.0f;
+        gq[cj][i] = x;
+        x = fabsf(x);
+        m = fmaxf(m, (x < __builtin_inff()) ? x : __builtin_inff());     // inf / NaN -> inf
+      }
+      const unsigned mb = wave_max_u32(__float_as_uint(m));
+      if ((tid & 63) == 0) atomicMax(&s_max[ch0 + cj], mb);
+    }
+    if (grp == 1) CT_STAMP(17);
+    if (has) {
+      const unsigned rk[4] = {S.rk01 & 0xffffu, S.rk01 >> 16, S.rk23 & 0xffffu, S.rk23 >> 16};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Sg[rk[i]] = make_float4(gq[0][i], gq[1][i], gq[2][i], gq[3][i]);
+    }
+    if (tid < G) T4[tid] = make_float4(cvq[0], cvq[1], cvq[2], cvq[3]);
+    for (int cell = tid + kSortThreads; cell < G; cell += kSortThreads) {       // grids of more than blockDim cells
+      const float* p = a.tile_in + (bh * C + ch0) * (size_t)G + cell;
+      T4[cell] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
+    }
+    if (grp == 1) CT_STAMP(18);
+    __syncthreads();
+    if (grp == 1) CT_STAMP(19);
+    if constexpr (decltype(more)::value) request(grp + 1);
+    if (grp == 1) CT_STAMP(20);
+
+    float iq[4];
+    bool any_float = false;
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      float q;
+      bool fixed;
+      fx_quantum(__uint_as_float(s_max[ch0 + cj]) * Kf, q, iq[cj], fixed);
+      if (!fixed) {
+        iq[cj] = 0.0f;         // the channel's sums are rounded to 0 here (0 * x is 0 or NaN) and added by the float pass below
+        any_float = true;
+      }
+      iq[cj] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(iq[cj])));      // wave-uniform: a scalar register
+    }
+#if CT_SORT_ABL != 2
+#if CT_SORT_BODY == 1
+    // One loop per item: an entry's channels and weights are read once and feed both sides; the next entry's reads are issued
+    // before this entry's arithmetic (a wave that runs its second item alone on its SIMD would otherwise sit out every LDS
+    // round trip), the conv corners before anything else.
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (S.cell[u] >= 0) {
+        const int Y = S.cell[u];
+        // (opaque per group: the compiler would otherwise unpack the eight offsets once, outside the group loop — eight more
+        //  live registers, spilled)
+        asm volatile("" : "+v"(S.ent8[u][0]), "+v"(S.ent8[u][1]));
+        float4 cv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
+#if CT_SORT_PF
+        float4 xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, 0));
+        float2 wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, 0));
+#endif
+        ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < kItemLen; ++j) {
+#if CT_SORT_PF
+          const float4 x = xn;
+          const float2 wf = wn;
+          if (j + 1 < kItemLen) {
+            xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j + 1));
+            wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j + 1));
+          }
+#else
+          const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
+          const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
+#endif
+          const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+          const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+          const float cw[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};
+          float gw[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const ct_f2 cwv = {cw[v], cw[v]};
+            s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
+            s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
+            const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
+            const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
+            gw[v] = pr.x + pr.y;
+          }
+          gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
+          gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
+          asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+          CT_SB;
+        }
+        const ct_f2 iq01 = {iq[0], iq[1]}, iq23 = {iq[2], iq[3]};
+        int* Tc = acc + Y;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const ct_f2 a01 = s01[v] * iq01, a23 = s23[v] * iq23;
+          atomicAdd(Tc + off[v], cvt_rpi(a01.x));
+          atomicAdd(Tc + G + off[v], cvt_rpi(a01.y));
+          atomicAdd(Tc + 2 * G + off[v], cvt_rpi(a23.x));
+          atomicAdd(Tc + 3 * G + off[v], cvt_rpi(a23.y));
+        }
+        CT_SB;
+      }
+    }
+#else
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (S.cell[u] >= 0) {
+        const int Y = S.cell[u];
+        // ---- scatter: the item's products, summed per (corner, channel), rounded once, 16 integer adds ----
+        // (packed fp32: v_pk_fma_f32 / v_pk_mul_f32 on channel pairs; the item phase is bound by vector-instruction issue)
+        {
+          ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < kItemLen; ++j) {
+            const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
+            const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
+            const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+            const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+            const float cw[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const ct_f2 cwv = {cw[v], cw[v]};
+              s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
+              s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
+            }
+            CT_SB;       // one entry at a time: the later entries' reads are not hoisted over this one's sums
+          }
+          const ct_f2 iq01 = {iq[0], iq[1]}, iq23 = {iq[2], iq[3]};
+#if CT_SORT_ABL != 3
+          int* Tc = acc + Y;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const ct_f2 a01 = s01[v] * iq01, a23 = s23[v] * iq23;
+            atomicAdd(Tc + off[v], cvt_rpi(a01.x));
+            atomicAdd(Tc + G + off[v], cvt_rpi(a01.y));
+            atomicAdd(Tc + 2 * G + off[v], cvt_rpi(a23.x));
+            atomicAdd(Tc + 3 * G + off[v], cvt_rpi(a23.y));
+          }
+#else
+          float t = 0.0f;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const ct_f2 a01 = s01[v] * iq01, a23 = s23[v] * iq23;
+            t += (float)(cvt_rpi(a01.x) + cvt_rpi(a01.y) + cvt_rpi(a23.x) + cvt_rpi(a23.y));
+          }
+          gsx[u][0] += t * 1e-30f;
+#endif
+          CT_SB;
+        }
+#if CT_SORT_ABL != 4
+        // ---- gather: conv at the cell's corners (read once per item) x g_out -> the entries' key cotangents ----
+        {
+          float4 cv[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
+#pragma unroll
+          for (int j = 0; j < kItemLen; ++j) {
+            const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
+            const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
+            const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+            float gw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              // (c0 x0 + c2 x2) + (c1 x1 + c3 x3): two packed instructions and one add per corner
+              const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
+              const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
+              gw[v] = pr.x + pr.y;
+            }
+            const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+            gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
+            gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
+            asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+            CT_SB;
+          }
+        }
+#endif
+      }
+    }
+#endif
+#endif
+    if (grp == 1) CT_STAMP(21);
+    if (any_float) {           // block-uniform, rare: IEEE float atomics for a channel with inf / NaN (or beyond the fixed-point bound)
+#pragma unroll 1
+      for (int cj = 0; cj < 4; ++cj)
+        if (iq[cj] == 0.0f) scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(acc + cj * G), 1, 0);
+    }
+    __syncthreads();
+    if (grp == 1) CT_STAMP(22);
+    // the group's g_grid rows out, the accumulators cleared for the next group (the next barrier orders both)
+    float* gout = a.tile_out + (bh * C + ch0) * (size_t)G;
+    for (int t = tid; t < G; t += kSortThreads) {          // G int4 = 4 channels x G cells
+      const int ch = (t << 2) / G;
+      float q, iqd;
+      bool fixed;
+      fx_quantum(__uint_as_float(s_max[ch0 + ch]) * Kf, q, iqd, fixed);
+      const int4 rr = ((const int4*)acc)[t];
+      float4 o;
+      if (fixed) o = make_float4((float)rr.x * q, (float)rr.y * q, (float)rr.z * q, (float)rr.w * q);
+      else o = make_float4(__int_as_float(rr.x), __int_as_float(rr.y), __int_as_float(rr.z), __int_as_float(rr.w));
+      st_stream4(gout + ((size_t)t << 2), o);
+      ((int4*)acc)[t] = make_int4(0, 0, 0, 0);
+    }
+    if (grp == 1) CT_STAMP(23);
+  };
+  CT_STAMP(8);
+  for (int grp = 0; grp + 1 < ngroups; ++grp) group(grp, std::true_type{});
+  group(ngroups - 1, std::false_type{});
+  CT_STAMP(9);
+#endif
+  // g_keys: from the item owners (sorted order) back to the point owners through LDS (the stage area is free: the last
+  // group's readers are behind the barrier above)
+  float2* Gs = (float2*)Sg;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < kItemLen; ++j)
+      *(float2*)((unsigned char*)Gs + CT_E8(S, u, j)) = make_float2(gsx[u][j], gsy[u][j]);       // (slots beyond an item's entries: word N, nobody's)
+  __syncthreads();
+  if (has) {
+    const unsigned rk[4] = {S.rk01 & 0xffffu, S.rk01 >> 16, S.rk23 & 0xffffu, S.rk23 >> 16};
+    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0), ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
+    const float2 g0 = Gs[rk[0]], g1 = Gs[rk[1]], g2 = Gs[rk[2]], g3 = Gs[rk[3]];
+    const float4 ox = make_float4(g0.x * ct_key_mask(tx.x), g1.x * ct_key_mask(tx.y), g2.x * ct_key_mask(tx.z), g3.x * ct_key_mask(tx.w));
+    const float4 oy = make_float4(g0.y * ct_key_mask(ty.x), g1.y * ct_key_mask(ty.y), g2.y * ct_key_mask(ty.z), g3.y * ct_key_mask(ty.w));
+    st_stream4(a.g_pos + (bh * 2 + 0) * N + n0, ox);
+    st_stream4(a.g_pos + (bh * 2 + 1) * N + n0, oy);
+  }
+  CT_STAMP(10);
+}
