@@ -221,6 +221,9 @@ SIGNATURES = {
     "ct_tickets_init": (_i, [_vp, _vp]),
     "ct_splat_bwd_tk_segments": (_i, [_i, _i, _i, _i, _i, _ip]),
     "ct_slice_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
+    "ct_plane_sort_bytes": (_sz, [_i, _i, _i, _i, _ip]),
+    "ct_plane_sort": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _ip, _vp]),
+    "ct_slice_bwd_ps": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_splat_bwd_tk": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _ip, _i, _vp]),
     "ct_slice_bwd_grid": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_bwd_keys": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),

@@ -72,6 +72,9 @@ struct RasterArgs {
   // split writes its own pair per channel here ([nsplit][B*H*C][2] words, plain stores) and the scatter kernel combines them
   // (max of the maxima, sum of the per-split K) — instead of atomics on slots that a zero_slots launch had to clear first
   unsigned* stats;
+  // sorted planes (ct_raster_sorted.h): the records ct_plane_sort wrote for these keys (null: the kernels sort themselves)
+  const unsigned char* sorted;
+  size_t sorted_stride;
 };
 
 // (M, K) of channel `ch` of plane bh as the scatter kernels need them: from the partial statistics (a.stats) or from the
@@ -1685,6 +1688,12 @@ bool sorted_plane_ok(const RasterArgs& a, int G) {
   return (long long)a.B * a.H >= 256;
 }
 
+// can ct_plane_sort take this layout?  (the consumers add their own conditions: channels, planes)
+bool plane_sort_ok(int N, int dim, int G) {
+  return dim == 2 && N <= 4096 && (N & 3) == 0 && (G & 3) == 0 && N / 4 + (3 * G) / 4 <= kMaxItems && G <= 65535 &&
+         sort_lds(G, N, 64).total <= (size_t)kBigLdsBytes;
+}
+
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<2>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out | (uintptr_t)grid | (uintptr_t)g_pos |
                          (uintptr_t)ws;
@@ -1702,9 +1711,15 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
     { const char* e = getenv("CLOUDCT_SORT_STAGGER"); a.cnt_mask = e ? atoi(e) : 0; }
 #endif
     dim3 wgrid(1, a.H, a.B);
-#define CT_MK_SLICE_BWD_SORTED(PADV, WTV) CT_HOT_KERNEL0(slice_bwd_sorted_kernel, PADV, WTV)
-    CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g);
-    note("slice_bwd_sorted");
+#define CT_MK_SLICE_BWD_SORTED(PADV, WTV, PSV) slice_bwd_sorted_kernel<PADV, WTV, PSV>
+    if (a.sorted != nullptr) {
+      a.sorted_stride = sort_record_bytes(a.N);
+      CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, true);
+      note("slice_bwd_presorted");
+    } else {
+      CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, false);
+      note("slice_bwd_sorted");
+    }
     return CT_OK;
   }
   HotPlan hp;
@@ -2469,12 +2484,13 @@ int slice_fwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
 template <bool FROM_KEYS>
 int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype, const float* g_out,
                    float* g_grid, float* g_pos, int B, int H, int C, int N, int dim, const int* W, hipStream_t st,
-                   void* ws = nullptr, size_t ws_bytes = 0, void* tickets = nullptr) {
+                   void* ws = nullptr, size_t ws_bytes = 0, void* tickets = nullptr, const void* sorted = nullptr) {
   if (!valid_common(B, H, C, N, dim, W) || !grid || !g_out || !g_grid || !g_pos || !valid_pad(pad, pad_dtype)) return CT_EINVAL;
   note_reset();
   RasterArgs a = base_args(B, H, C, N, pad, pad_dtype);
   a.pos = pos; a.src = g_out; a.tile_out = g_grid;
   a.tickets = (unsigned*)tickets;          // only the hot kernels (run_slice_bwd_hot) fold; every other path ignores them
+  a.sorted = (const unsigned char*)sorted; // only the sorted-plane kernels read it
   // (A single fused kernel — grid tile + accumulator tile of a whole (b,h) plane in LDS, one
   //  1024-thread workgroup per CU — was built twice and measured SLOWER than the pair below
   //  (105-124 us vs 92-99 us on the headline shape): the pass is co-bound by LDS atomics/reads
@@ -2662,6 +2678,40 @@ int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int p
   PosSrc pos = {keys, nullptr, nullptr};
   return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes,
                               tickets);
+}
+
+size_t ct_plane_sort_bytes(int B, int H, int N, int dim, const int* W) {
+  if (B <= 0 || H <= 0 || N <= 0 || !W || dim != 2 || W[0] < 2 || W[1] < 2) return 0;
+  const long long G = (long long)W[0] * W[1];
+  if (G > 65535 || !plane_sort_ok(N, dim, (int)G)) return 0;
+  return (size_t)B * H * sort_record_bytes(N);
+}
+
+int ct_plane_sort(const float* keys, void* sorted, size_t sorted_bytes, int B, int H, int N, int dim, const int* W, ct_stream_t s) {
+  const size_t need = ct_plane_sort_bytes(B, H, N, dim, W);
+  if (!keys || !sorted || need == 0 || sorted_bytes < need || (((uintptr_t)keys | (uintptr_t)sorted) & 15)) return CT_EINVAL;
+  note_reset();
+  const GridW<2> g = make_grid<2>(W);
+  RasterArgs a = base_args(B, H, 4, N, nullptr, CT_PAD_NONE);
+  a.pos = {keys, nullptr, nullptr};
+  const SortLds L = sort_lds(g.G, N, 0);
+  dim3 wgrid(1, H, B);
+  if (g.W[0] == 32 && g.W[1] == 32)
+    CT_LAUNCH((plane_sort_kernel<32>), wgrid, kSortThreads, L.total, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
+  else
+    CT_LAUNCH((plane_sort_kernel<0>), wgrid, kSortThreads, L.total, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
+  note("plane_sort");
+  return CT_OK;
+}
+
+int ct_slice_bwd_ps(const float* keys, const float* grid, const void* pad, int pad_dtype, const float* g_out,
+                    float* g_grid, float* g_keys, void* ws, size_t ws_bytes, void* tickets, const void* sorted, int B, int H, int C,
+                    int N, int dim, const int* W, ct_stream_t s) {
+  if (!keys) return CT_EINVAL;
+  if (sorted != nullptr && (ct_plane_sort_bytes(B, H, N, dim, W) == 0 || ((uintptr_t)sorted & 15))) return CT_EINVAL;
+  PosSrc pos = {keys, nullptr, nullptr};
+  return slice_bwd_impl<true>(pos, grid, pad, pad_dtype, g_out, g_grid, g_keys, B, H, C, N, dim, W, (hipStream_t)s, ws, ws_bytes,
+                              tickets, sorted);
 }
 
 int ct_splat_bwd_tk(const float* keys, const float* feat, const void* pad, int pad_dtype, const float* grid,

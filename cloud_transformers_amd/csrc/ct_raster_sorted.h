@@ -29,12 +29,17 @@ constexpr int kMaxItems = 2 * kSortThreads;
 // (read by ct_debug_sorted_stamps; tools/dev/sorted_check.py --stamps)
 #ifdef CT_SORT_STAMPS
 __device__ unsigned long long g_sorted_stamps[64];
+#define CT_WSTAMP(i)                                                                                               \
+  do {                                                                                                              \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) g_sorted_stamps[i] = clock64();        \
+  } while (0)
 #define CT_STAMP(i)                                                                                      \
   do {                                                                                                   \
     if (threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) g_sorted_stamps[i] = clock64();   \
   } while (0)
 #else
 #define CT_STAMP(i) ((void)0)
+#define CT_WSTAMP(i) ((void)0)
 #endif
 
 // inclusive wave64 scans over DPP (the reduction sequence of wave_sum_i32 IS a scan: every lane ends with its prefix)
@@ -95,18 +100,40 @@ __host__ __device__ inline SortLds sort_lds(int G, int N, int C) {
 // What a thread keeps of the sorted plane: the sorted positions of the four points it LOADS (packed 16 bits each), and its
 // (at most) two ITEMS: base cell and, per slot, the entry's sorted position (N — the zero entries of the stage and weight
 // areas — for a slot beyond the item's entries).  The entries' weights stay in LDS (SortLds::ab): 16 registers less.
+constexpr unsigned kRankMask = 0x1fffu, kInsideX = 0x4000u, kInsideY = 0x8000u;
 struct SortedPlane {
-  unsigned rk01, rk23;            // ranks of points 4 tid .. 4 tid + 3
+  unsigned rk01, rk23;            // sorted positions of points 4 tid .. 4 tid + 3, 16 bits each: position | kInsideX | kInsideY
   int cell[2];                    // -1: no item
   unsigned ent8[2][kItemLen / 2]; // 8 x the sorted position of two entries, 16 bits each: the byte offset of the entry's weights
                                   // (its stage word: twice that)
 };
+
+// item u of the thread: `n` entries of cell Y from sorted position `first` (valid = false: none)
+__device__ __forceinline__ void set_item(SortedPlane& S, int u, bool valid, int Y, int first, int n, int N) {
+  S.cell[u] = valid ? Y : -1;
+#pragma unroll
+  for (int j = 0; j < kItemLen; j += 2) {
+    const unsigned e0 = (valid && j < n) ? first + j : N, e1 = (valid && j + 1 < n) ? first + j + 1 : N;
+    S.ent8[u][j >> 1] = (e0 << 3) | (e1 << 19);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The sorted plane as a RECORD in global memory (ct_plane_sort): sorted once per key tensor, read by every raster pass that
+// takes those keys — and by SEVERAL workgroups of a plane where there are fewer planes than CUs.  Per (b, h) plane:
+//   +0            unsigned nitems, K (max contributions to a cell), 2 x reserved
+//   +16           float2 ab[N]            fractional weights (w1x, w1y) in sorted order
+//   +16 + 8 N     uint16 rk[N]            sorted position of point p | kInsideX | kInsideY
+//   +16 + 10 N    unsigned item[kMaxItems]  first | (n - 1) << 13 | cell << 16
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t sort_record_bytes(int N) { return ((size_t)16 + (size_t)10 * N + (size_t)4 * kMaxItems + 255) & ~(size_t)255; }
 
 // Sorts the plane's points by base cell and deals the items.  All kSortThreads threads call it; the block's LDS must hold the
 // SortLds carve-up; K (max contributions to a cell) is left in misc[C].  On return the stage area is free (hist is dead).
 struct PlaneKeys {
   int base[4];
   float fa[4], fb[4];      // w1x, w1y
+  unsigned inside;         // bits 2i, 2i + 1: key x / y of point i lies inside the clamp range (its cotangent passes)
 };
 // the thread's four points: base cells and fractional weights (issued FIRST: the sort waits for nothing else)
 __device__ __forceinline__ void load_plane_keys(const RasterArgs& a, const GridW<2>& g, int W1, size_t bh, PlaneKeys& K) {
@@ -122,10 +149,15 @@ __device__ __forceinline__ void load_plane_keys(const RasterArgs& a, const GridW
     pt2_from_keys(kx[i], ky[i], g, W1, p);
     K.base[i] = p.base; K.fa[i] = p.w1x; K.fb[i] = p.w1y;
   }
+  K.inside = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    K.inside |= (ct_key_mask(kx[i]) != 0.0f ? 1u : 0u) << (2 * i) | (ct_key_mask(ky[i]) != 0.0f ? 2u : 0u) << (2 * i);
 }
 
+// record != null: the items, ranks and header are also written there (the weights: by the caller, from LDS, behind a barrier)
 __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys& PK, int G, int W1, unsigned char* lds,
-                                           const SortLds& L, SortedPlane& S) {
+                                           const SortLds& L, SortedPlane& S, unsigned char* record = nullptr) {
   const int tid = threadIdx.x, N = a.N, wave = tid >> 6;
   unsigned* hist = (unsigned*)(lds + L.stage);
   float2* AB = (float2*)(lds + L.ab);
@@ -211,6 +243,8 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
     }
   }
   if (tid == 0) AB[N] = make_float2(0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rk[i] |= ((PK.inside >> (2 * i)) & 1u ? kInsideX : 0u) | ((PK.inside >> (2 * i)) & 2u ? kInsideY : 0u);
   S.rk01 = rk[0] | (rk[1] << 16);
   S.rk23 = rk[2] | (rk[3] << 16);
   // items: item k belongs to the last cell marked at or before k (inclusive max-scan of the marks)
@@ -234,37 +268,87 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
     const unsigned sp = stp[Y];
     const int first = (int)(sp & 0xffffu) + (k - (int)(sp >> 16)) * kItemLen;
     const int end = (int)(sp & 0xffffu) + (int)cnt[Y];
-    S.cell[u] = valid ? Y : -1;
-#pragma unroll
-    for (int j = 0; j < kItemLen; j += 2) {
-      const unsigned e0 = (valid && first + j < end) ? first + j : N, e1 = (valid && first + j + 1 < end) ? first + j + 1 : N;
-      S.ent8[u][j >> 1] = (e0 << 3) | (e1 << 19);
+    const int n = min(kItemLen, end - first);
+    set_item(S, u, valid, Y, first, n, N);
+    if (record != nullptr && valid)
+      ((unsigned*)(record + 16 + (size_t)10 * N))[k] = (unsigned)first | (unsigned)(n - 1) << 13 | (unsigned)Y << 16;
+  }
+  if (record != nullptr) {
+    if (tid == 0) {
+      ((unsigned*)record)[0] = (unsigned)nitems;
+      ((unsigned*)record)[1] = *s_k;
     }
+    if (has) *(uint2*)(record + 16 + (size_t)8 * N + (size_t)8 * tid) = make_uint2(S.rk01, S.rk23);
   }
   // (no barrier: the weights written above are read behind the first group's staging barrier)
   CT_STAMP(6);
 }
 
+// The record of a plane -> what sort_plane leaves behind: the weights into LDS (visible after the caller's next barrier), ranks
+// and items into registers, K into misc[C].  One memory round trip instead of the sort.
+__device__ __forceinline__ void load_sorted_plane(const RasterArgs& a, const unsigned char* record, unsigned char* lds,
+                                                  const SortLds& L, SortedPlane& S) {
+  const int tid = threadIdx.x, N = a.N;
+  float4* AB4 = (float4*)(lds + L.ab);
+  unsigned* misc = (unsigned*)(lds + L.misc);
+  const bool has = (tid << 2) < N;
+  const unsigned nitems = ((const unsigned*)record)[0];
+  const uint2 rk = has ? *(const uint2*)(record + 16 + (size_t)8 * N + (size_t)8 * tid) : make_uint2(0u, 0u);
+  unsigned desc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const unsigned k = (unsigned)tid + (unsigned)u * kSortThreads;
+    desc[u] = k < nitems ? ((const unsigned*)(record + 16 + (size_t)10 * N))[k] : 0xffffffffu;
+  }
+  for (int i = tid; i < (N >> 1); i += kSortThreads) AB4[i] = ((const float4*)(record + 16))[i];
+  if (tid < a.C) misc[tid] = 0u;                                  // channel maxima
+  if (tid == 0) {
+    misc[a.C] = ((const unsigned*)record)[1];                     // K
+    ((float2*)(lds + L.ab))[N] = make_float2(0.0f, 0.0f);
+  }
+  S.rk01 = rk.x; S.rk23 = rk.y;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const bool valid = desc[u] != 0xffffffffu;
+    set_item(S, u, valid, (int)(desc[u] >> 16), (int)(desc[u] & 0x1fffu), (int)((desc[u] >> 13) & 3u) + 1, N);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KP: the plane sort alone (ct_plane_sort): one workgroup per (b, h) plane writes the plane's record.  grid = (1, H, B)
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void __launch_bounds__(kSortThreads) plane_sort_kernel(RasterArgs a, GridW<2> g, unsigned char* records, size_t stride) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
+  const SortLds L = sort_lds(G, N, 0);
+  const size_t bh = (size_t)blockIdx.z * a.H + blockIdx.y;
+  unsigned char* rec = records + bh * stride;
+  a.C = 0;
+  PlaneKeys PK;
+  load_plane_keys(a, g, W1, bh, PK);
+  SortedPlane S;
+  sort_plane(a, PK, G, W1, lds_raw, L, S, rec);
+  __syncthreads();                 // the weights are in LDS (sorted order): out as they lie
+  const float4* AB4 = (const float4*)(lds_raw + L.ab);
+  for (int i = threadIdx.x; i < (N >> 1); i += kSortThreads) ((float4*)(rec + 16))[i] = AB4[i];
+}
+
 // ---------------------------------------------------------------------------
 // KF': Slice backward on the sorted plane.  grid = (1, H, B), kSortThreads threads.
 // CT_SORT_ABL (experiments, tools/dev/build_raster_exp.sh): 1 = the sort and the epilogue only, 2 = + staging, barriers and
-// write-out (no items), 3 = items without their LDS adds, 4 = items without the gather side.  Results are wrong then: timing only.
+// write-out (no items).  Results are wrong then: timing only.
 // ---------------------------------------------------------------------------
 #ifndef CT_SORT_ABL
 #define CT_SORT_ABL 0
 #endif
-#ifndef CT_SORT_BODY
-#define CT_SORT_BODY 1      // 1: one loop per item, the next entry's reads in flight; 0: a scatter loop, then a gather loop
-#endif
 // byte offset of slot j's weights (8 x its sorted position); its stage word is at twice that
 #define CT_E8(S, u, j) (((j) & 1) ? ((S).ent8[u][(j) >> 1] >> 16) : ((S).ent8[u][(j) >> 1] & 0xffffu))
-#ifndef CT_SORT_PF
-#define CT_SORT_PF 1        // (body 1) the next entry's LDS reads are issued before this entry's arithmetic
-#endif
 #ifndef CT_SB
 #define CT_SB __builtin_amdgcn_sched_barrier(0)
 #endif
-template <bool HAS_PAD, int WT>
+// PRESORTED: the plane's record (a.sorted, ct_plane_sort) is loaded instead of sorting here.
+template <bool HAS_PAD, int WT, bool PRESORTED>
 __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
@@ -289,13 +373,14 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   const float* const src0 = a.src + bh * C * (size_t)N;               // wave-uniform bases, 32-bit lane offsets
   const float* const cnv0 = a.tile_in + bh * C * (size_t)G;
   const unsigned ln0 = (unsigned)n0, lc0 = (unsigned)(tid < G ? tid : 0);
+  auto request1 = [&](int grp, int cj) {          // one channel of group grp: the quad's g_out and the thread's conv cell
+    const float4 t = ld_stream4(src0 + (size_t)(grp * 4 + cj) * N + ln0);
+    gq[cj][0] = t.x; gq[cj][1] = t.y; gq[cj][2] = t.z; gq[cj][3] = t.w;
+    cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
+  };
   auto request = [&](int grp) {
 #pragma unroll
-    for (int cj = 0; cj < 4; ++cj) {
-      const float4 t = ld_stream4(src0 + (size_t)(grp * 4 + cj) * N + ln0);
-      gq[cj][0] = t.x; gq[cj][1] = t.y; gq[cj][2] = t.z; gq[cj][3] = t.w;
-      cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
-    }
+    for (int cj = 0; cj < 4; ++cj) request1(grp, cj);
   };
 #ifdef CT_SORT_STAGGER
   if ((blockIdx.y + blockIdx.z) & 1) {      // experiment: odd planes start late, so that sort and streaming phases of different CUs interleave
@@ -304,14 +389,16 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   }
 #endif
   PlaneKeys PK;
-  load_plane_keys(a, g, W1, bh, PK);
+  if constexpr (!PRESORTED) load_plane_keys(a, g, W1, bh, PK);
+  SortedPlane S;
+  if constexpr (PRESORTED) load_sorted_plane(a, a.sorted + bh * a.sorted_stride, lds_raw, L, S);
   request(0);
   float pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
 
-  SortedPlane S;
-  sort_plane(a, PK, G, W1, lds_raw, L, S);
+  if constexpr (!PRESORTED) sort_plane(a, PK, G, W1, lds_raw, L, S);
+  else __syncthreads();            // K (and the cleared channel maxima) for everybody
   for (int i = tid; i < G; i += kSortThreads) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
   if (tid == 0) Sg[N] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // what the slots beyond an item's entries read
   const float Kf = (float)(*s_k);
@@ -345,7 +432,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
     }
     if (grp == 1) CT_STAMP(17);
     if (has) {
-      const unsigned rk[4] = {S.rk01 & 0xffffu, S.rk01 >> 16, S.rk23 & 0xffffu, S.rk23 >> 16};
+      const unsigned rk[4] = {S.rk01 & kRankMask, (S.rk01 >> 16) & kRankMask, S.rk23 & kRankMask, (S.rk23 >> 16) & kRankMask};
 #pragma unroll
       for (int i = 0; i < 4; ++i) Sg[rk[i]] = make_float4(gq[0][i], gq[1][i], gq[2][i], gq[3][i]);
     }
@@ -357,8 +444,8 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
     if (grp == 1) CT_STAMP(18);
     __syncthreads();
     if (grp == 1) CT_STAMP(19);
-    if constexpr (decltype(more)::value) request(grp + 1);
     if (grp == 1) CT_STAMP(20);
+    if (grp == 1) CT_WSTAMP(24 + (threadIdx.x >> 6));
 
     float iq[4];
     bool any_float = false;
@@ -374,58 +461,54 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       iq[cj] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(iq[cj])));      // wave-uniform: a scalar register
     }
 #if CT_SORT_ABL != 2
-#if CT_SORT_BODY == 1
     // One loop per item: an entry's channels and weights are read once and feed both sides; the next entry's reads are issued
-    // before this entry's arithmetic (a wave that runs its second item alone on its SIMD would otherwise sit out every LDS
-    // round trip), the conv corners before anything else.
+    // before this entry's arithmetic, the conv corners before anything else.  The NEXT group's eight global loads are issued
+    // one channel per entry of the first item: a CU's vector-memory path takes ~3 k cycles to issue the 80 KiB of a group, and
+    // issued as one block behind the barrier they held the last waves' items back by that long (profiles/r5_sorted_stamps.txt).
+    auto item = [&](auto U) {
+      constexpr int u = decltype(U)::value;
+      constexpr bool spread = u == 0 && decltype(more)::value;
+      const int Y = S.cell[u] < 0 ? 0 : S.cell[u];       // (a lane without an item reads the zero entries and adds nothing)
+      // (opaque per group: the compiler would otherwise unpack the eight offsets once, outside the group loop — eight more
+      //  live registers, spilled)
+      asm volatile("" : "+v"(S.ent8[u][0]), "+v"(S.ent8[u][1]));
+      float4 cv[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (S.cell[u] >= 0) {
-        const int Y = S.cell[u];
-        // (opaque per group: the compiler would otherwise unpack the eight offsets once, outside the group loop — eight more
-        //  live registers, spilled)
-        asm volatile("" : "+v"(S.ent8[u][0]), "+v"(S.ent8[u][1]));
-        float4 cv[4];
+      for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
+      float4 xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, 0));
+      float2 wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, 0));
+      ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
-#if CT_SORT_PF
-        float4 xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, 0));
-        float2 wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, 0));
-#endif
-        ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
+      for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < kItemLen; ++j) {
-#if CT_SORT_PF
-          const float4 x = xn;
-          const float2 wf = wn;
-          if (j + 1 < kItemLen) {
-            xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j + 1));
-            wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j + 1));
-          }
-#else
-          const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
-          const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
-#endif
-          const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-          const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
-          const float cw[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};
-          float gw[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const ct_f2 cwv = {cw[v], cw[v]};
-            s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
-            s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
-            const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
-            const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
-            gw[v] = pr.x + pr.y;
-          }
-          gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
-          gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
-          asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
-          CT_SB;
+      for (int j = 0; j < kItemLen; ++j) {
+        if constexpr (spread) request1(grp + 1, j);
+        const float4 x = xn;
+        const float2 wf = wn;
+        if (j + 1 < kItemLen) {
+          xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j + 1));
+          wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j + 1));
         }
+        const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+        const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+        const float cw[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};
+        float gw[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const ct_f2 cwv = {cw[v], cw[v]};
+          s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
+          s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
+          // (c0 x0 + c2 x2) + (c1 x1 + c3 x3): two packed instructions and one add per corner
+          const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
+          const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
+          gw[v] = pr.x + pr.y;
+        }
+        gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
+        gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
+        asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+        CT_SB;
+      }
+      if (S.cell[u] >= 0) {
         const ct_f2 iq01 = {iq[0], iq[1]}, iq23 = {iq[2], iq[3]};
         int* Tc = acc + Y;
 #pragma unroll
@@ -436,89 +519,16 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
           atomicAdd(Tc + 2 * G + off[v], cvt_rpi(a23.x));
           atomicAdd(Tc + 3 * G + off[v], cvt_rpi(a23.y));
         }
-        CT_SB;
       }
-    }
+      CT_SB;
+    };
+    item(std::integral_constant<int, 0>{});              // always: it carries the next group's loads
+    if (S.cell[1] >= 0) item(std::integral_constant<int, 1>{});
 #else
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (S.cell[u] >= 0) {
-        const int Y = S.cell[u];
-        // ---- scatter: the item's products, summed per (corner, channel), rounded once, 16 integer adds ----
-        // (packed fp32: v_pk_fma_f32 / v_pk_mul_f32 on channel pairs; the item phase is bound by vector-instruction issue)
-        {
-          ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
-#pragma unroll
-          for (int j = 0; j < kItemLen; ++j) {
-            const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
-            const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
-            const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-            const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
-            const float cw[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const ct_f2 cwv = {cw[v], cw[v]};
-              s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
-              s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
-            }
-            CT_SB;       // one entry at a time: the later entries' reads are not hoisted over this one's sums
-          }
-          const ct_f2 iq01 = {iq[0], iq[1]}, iq23 = {iq[2], iq[3]};
-#if CT_SORT_ABL != 3
-          int* Tc = acc + Y;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const ct_f2 a01 = s01[v] * iq01, a23 = s23[v] * iq23;
-            atomicAdd(Tc + off[v], cvt_rpi(a01.x));
-            atomicAdd(Tc + G + off[v], cvt_rpi(a01.y));
-            atomicAdd(Tc + 2 * G + off[v], cvt_rpi(a23.x));
-            atomicAdd(Tc + 3 * G + off[v], cvt_rpi(a23.y));
-          }
-#else
-          float t = 0.0f;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const ct_f2 a01 = s01[v] * iq01, a23 = s23[v] * iq23;
-            t += (float)(cvt_rpi(a01.x) + cvt_rpi(a01.y) + cvt_rpi(a23.x) + cvt_rpi(a23.y));
-          }
-          gsx[u][0] += t * 1e-30f;
-#endif
-          CT_SB;
-        }
-#if CT_SORT_ABL != 4
-        // ---- gather: conv at the cell's corners (read once per item) x g_out -> the entries' key cotangents ----
-        {
-          float4 cv[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
-#pragma unroll
-          for (int j = 0; j < kItemLen; ++j) {
-            const float4 x = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, j));
-            const float2 wf = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, j));
-            const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-            float gw[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              // (c0 x0 + c2 x2) + (c1 x1 + c3 x3): two packed instructions and one add per corner
-              const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
-              const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
-              gw[v] = pr.x + pr.y;
-            }
-            const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
-            gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
-            gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
-            asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
-            CT_SB;
-          }
-        }
-#endif
-      }
-    }
-#endif
+    if constexpr (decltype(more)::value) request(grp + 1);
 #endif
     if (grp == 1) CT_STAMP(21);
+    if (grp == 1) CT_WSTAMP(40 + (threadIdx.x >> 6));
     if (any_float) {           // block-uniform, rare: IEEE float atomics for a channel with inf / NaN (or beyond the fixed-point bound)
 #pragma unroll 1
       for (int cj = 0; cj < 4; ++cj)
@@ -557,13 +567,16 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       *(float2*)((unsigned char*)Gs + CT_E8(S, u, j)) = make_float2(gsx[u][j], gsy[u][j]);       // (slots beyond an item's entries: word N, nobody's)
   __syncthreads();
   if (has) {
-    const unsigned rk[4] = {S.rk01 & 0xffffu, S.rk01 >> 16, S.rk23 & 0xffffu, S.rk23 >> 16};
-    const float4 tx = *(const float4*)(a.pos.keys + (bh * 2 + 0) * N + n0), ty = *(const float4*)(a.pos.keys + (bh * 2 + 1) * N + n0);
-    const float2 g0 = Gs[rk[0]], g1 = Gs[rk[1]], g2 = Gs[rk[2]], g3 = Gs[rk[3]];
-    const float4 ox = make_float4(g0.x * ct_key_mask(tx.x), g1.x * ct_key_mask(tx.y), g2.x * ct_key_mask(tx.z), g3.x * ct_key_mask(tx.w));
-    const float4 oy = make_float4(g0.y * ct_key_mask(ty.x), g1.y * ct_key_mask(ty.y), g2.y * ct_key_mask(ty.z), g3.y * ct_key_mask(ty.w));
-    st_stream4(a.g_pos + (bh * 2 + 0) * N + n0, ox);
-    st_stream4(a.g_pos + (bh * 2 + 1) * N + n0, oy);
+    const unsigned rw[4] = {S.rk01 & 0xffffu, S.rk01 >> 16, S.rk23 & 0xffffu, S.rk23 >> 16};
+    float2 gk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gk[i] = Gs[rw[i] & kRankMask];
+      gk[i].x *= (rw[i] & kInsideX) ? 1.0f : 0.0f;       // torch.clamp passes the cotangent only inside [lo, hi]
+      gk[i].y *= (rw[i] & kInsideY) ? 1.0f : 0.0f;
+    }
+    st_stream4(a.g_pos + (bh * 2 + 0) * N + n0, make_float4(gk[0].x, gk[1].x, gk[2].x, gk[3].x));
+    st_stream4(a.g_pos + (bh * 2 + 1) * N + n0, make_float4(gk[0].y, gk[1].y, gk[2].y, gk[3].y));
   }
   CT_STAMP(10);
 }

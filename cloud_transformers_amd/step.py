@@ -20,7 +20,7 @@ class SplatSliceStep:
     second backward adds the first one's result inside its own store.
     """
 
-    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True):
+    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True, plane_sort=True):
         assert keys.is_cuda and feat.is_cuda and cot.is_cuda
         self.W = sizes_of(tensor_size, dim)
         self.H, self.dim, self.reduce = heads, dim, reduce
@@ -47,10 +47,19 @@ class SplatSliceStep:
         # arrival tickets (ct_tickets_init contract: zero once, the kernels leave them zero): the sums over a plane's
         # workgroups happen inside the backward kernels — one launch per pass on the few-plane shapes too
         self.tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device=dev, dtype=torch.int32) if tickets else None
+        # sorted planes (ct_plane_sort): one record per key tensor, read by the backward passes (None: no sorted form here)
+        nps = self.lib.ct_plane_sort_bytes(self.B, self.H, self.N, dim, self.Wa) if plane_sort else 0
+        self.sorted = torch.empty(nps, device=dev, dtype=torch.uint8) if nps else None
+        self.nps = nps
         if tickets and reduce == "max" and self.lib.ct_splat_bwd_tk_segments(self.B, self.H, self.C, self.N, dim, self.Wa) > 1:
             self.g_keys_out = torch.empty_like(self.keys)    # ... or into a second tensor where point segments pay (ct_splat_bwd_tk)
 
     # the four passes, individually callable (bench.py times them one by one)
+    def plane_sort(self):
+        if self.sorted is not None:
+            _lib.check(self.lib.ct_plane_sort(_ptr(self.keys), _ptr(self.sorted), self.nps, self.B, self.H, self.N, self.dim,
+                                              self.Wa, _stream()), "ct_plane_sort")
+
     def splat_fwd(self):
         _lib.check(self.lib.ct_splat_fwd(_ptr(self.keys), _ptr(self.feat), None, 0, _ptr(self.z),
                                          self.B, self.H, self.C, self.N, self.dim, self.Wa, self.red, _stream()),
@@ -73,10 +82,10 @@ class SplatSliceStep:
                    "ct_slice_bwd_keys")
 
     def slice_bwd(self):
-        _lib.check(self.lib.ct_slice_bwd_tk(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
+        _lib.check(self.lib.ct_slice_bwd_ps(_ptr(self.keys), _ptr(self.z), None, 0, _ptr(self.cot),
                                             _ptr(self.g_z), _ptr(self.g_keys_buf), _ptr(self.ws2), self.nws2, _ptr(self.tickets),
-                                            self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
-                   "ct_slice_bwd_tk")
+                                            _ptr(self.sorted), self.B, self.H, self.C, self.N, self.dim, self.Wa, _stream()),
+                   "ct_slice_bwd_ps")
 
     def splat_bwd(self):
         """g_keys_out = g_keys_buf (Slice's key cotangent: call after slice_bwd) + Splat's"""
@@ -111,6 +120,7 @@ class SplatSliceStep:
         return tags
 
     def run(self):
+        self.plane_sort()
         self.splat_fwd()
         self.slice_fwd()
         self.slice_bwd()

@@ -144,6 +144,19 @@ int ct_tickets_init(void* tickets, ct_stream_t s);
 int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int pad_dtype,
                     const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
                     void* tickets, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
+/* Sorted planes (csrc/ct_raster_sorted.h; no counterpart in the reference, whose Splat / Slice re-derive everything from
+ * local_coordinate / flattened_index per call, layers/cloud_transform.py:72-124).  One diff_poss(lattice) feeds the Splat and
+ * the Slice of a block (layers/multihead_ct.py:99-107), so the four raster passes of a step see the SAME keys: ct_plane_sort
+ * counting-sorts every (b, h) plane's points by base cell once (stable: the record is a function of the keys alone) and leaves
+ * per plane the sorted positions, the fractional corner weights in sorted order and the plane's work items in `sorted`
+ * (ct_plane_sort_bytes; 0: this layout has no sorted form — dim 3, N > 4096 ...).  The *_ps entry points take the record of
+ * THEIR keys (NULL: they behave as the *_tk entry points and sort inside where they use the sorted form); a record made from
+ * other keys gives wrong results, not an error. */
+size_t ct_plane_sort_bytes(int B, int H, int N, int dim, const int* W);
+int ct_plane_sort(const float* keys, void* sorted, size_t sorted_bytes, int B, int H, int N, int dim, const int* W, ct_stream_t s);
+int ct_slice_bwd_ps(const float* keys, const float* grid, const void* pad, int pad_dtype,
+                    const float* g_out, float* g_grid, float* g_keys, void* workspace, size_t workspace_bytes,
+                    void* tickets, const void* sorted, int B, int H, int C, int N, int dim, const int* W, ct_stream_t s);
 /* ct_splat_bwd_tk: g_keys = g_keys_add + (key cotangent of this Splat); g_keys_add NULL: g_keys = the cotangent;
  * g_keys_add == g_keys: in place, as CT_BWD_ACCUMULATE_KEYS.  With tickets AND a g_keys_add that is not g_keys (or NULL) a
  * plane's POINTS may be dealt to several workgroups (point segments: no partial sums at all, every workgroup walks all

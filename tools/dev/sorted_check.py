@@ -51,8 +51,13 @@ def headline(args):
         step = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
         step.splat_fwd(); step.slice_fwd()
         res = {}
-        for name, fl in (("scatter", _lib.DEBUG_NO_SORTED), ("sorted", _lib.DEBUG_FORCE_SORTED)):
+        srec = step.sorted
+        step.plane_sort(); torch.cuda.synchronize()
+        if args.time and srec is not None:
+            print("seed %d plane_sort %.1f us" % (seed, time_pass(step.plane_sort)), flush=True)
+        for name, fl in (("scatter", _lib.DEBUG_NO_SORTED), ("sorted", _lib.DEBUG_FORCE_SORTED), ("presorted", _lib.DEBUG_FORCE_SORTED)):
             lib.ct_debug_set_flags(fl)
+            step.sorted = srec if name == "presorted" else None
             step.g_z.zero_(); step.g_keys_buf.zero_()
             step.slice_bwd()
             torch.cuda.synchronize()
@@ -74,8 +79,14 @@ def headline(args):
                 g = [buf[i] for i in range(16, 24)]
                 gn = ["wait+max", "stage", "barrier1", "request", "items", "barrier2", "writeout"]
                 print("  group 1:", " ".join("%s:%d" % (gn[i], g[i + 1] - g[i]) for i in range(7)), flush=True)
+                t0 = min(buf[24 + w] for w in range(16))
+                print("  group 1 items per wave (start-t0 .. end-t0):", " ".join(
+                    "w%d:%d..%d" % (w, buf[24 + w] - t0, buf[40 + w] - t0) for w in range(16)), flush=True)
             print("seed %d %-8s tag=%s reproducible=%s  %.1f us" % (seed, name, tag, same, t), flush=True)
         lib.ct_debug_set_flags(0)
+        step.sorted = srec
+        print("  presorted == sorted bit for bit:", torch.equal(res["sorted"][0], res["presorted"][0]) and
+              torch.equal(res["sorted"][1], res["presorted"][1]), flush=True)
         print("  sorted vs scatter: g_z per-channel %.2e  g_keys %.2e" % (
             per_channel_err(res["sorted"][0], res["scatter"][0], H, C), relerr(res["sorted"][1], res["scatter"][1])), flush=True)
         # oracle on a few planes
