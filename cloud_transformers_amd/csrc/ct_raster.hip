@@ -2244,6 +2244,12 @@ int run_splat_max_bwd(RasterArgs a, const int* W, void* ws, size_t ws_bytes, hip
     bool single = false;
     int ncg = 1, nseg = 1;
     if (splat_bwd_hot_plan<DIM>(a, g, hp, ncg, nseg, single)) {
+      // In-place accumulation (gpos_add == g_pos) by ONE group whose g_keys sums go through memory (2D beyond the register
+      // form, every 3D call): the optimistic pass leaves incoming + its result in g_pos chunk by chunk, and a plane with exact
+      // ties would start its single-winner redo from THAT (incoming + optimistic + claims).  Not eligible: the
+      // caller computes the plain cotangent into its scratch (this very kernel, not accumulating) and adds it.
+      const bool reg_form = DIM == 2 && (a.N >> 2) <= 2 * kHotThreads;
+      if (a.gpos_add != nullptr && a.gpos_add == a.g_pos && ncg == 1 && nseg == 1 && !reg_form) return CT_EINVAL;
       const size_t need = ncg > 1 ? (size_t)ncg * a.B * a.H * DIM * a.N * 4 : 0;
       // several groups: the partial sums go through the workspace and the final sum adds the incoming cotangent; one
       // group (or point segments): the kernel adds it in its own store — every thread owns its rows
@@ -2694,12 +2700,12 @@ int ct_plane_sort(const float* keys, void* sorted, size_t sorted_bytes, int B, i
   const GridW<2> g = make_grid<2>(W);
   RasterArgs a = base_args(B, H, 4, N, nullptr, CT_PAD_NONE);
   a.pos = {keys, nullptr, nullptr};
-  const SortLds L = sort_lds(g.G, N, 0);
+  const size_t lds = plane_sort_lds(g.G, N);
   dim3 wgrid(1, H, B);
   if (g.W[0] == 32 && g.W[1] == 32)
-    CT_LAUNCH((plane_sort_kernel<32>), wgrid, kSortThreads, L.total, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
+    CT_LAUNCH((plane_sort_kernel<32>), wgrid, kSortThreads, lds, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
   else
-    CT_LAUNCH((plane_sort_kernel<0>), wgrid, kSortThreads, L.total, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
+    CT_LAUNCH((plane_sort_kernel<0>), wgrid, kSortThreads, lds, (hipStream_t)s, a, g, (unsigned char*)sorted, sort_record_bytes(N));
   note("plane_sort");
   return CT_OK;
 }

@@ -4,8 +4,8 @@
 // The scatter form of Slice backward (ct_raster_hot.h: slice_bwd_fused_kernel) issues, per point and four channels, 8 random
 // 64-bit LDS atomics and 4 random 16-byte LDS reads: 0.65 of its LDS cycles are bank conflicts, and ~100 vector instructions per
 // point and group go into rounding, pair packing and a corner set-up recomputed per group (0.46 of the roofline).
-// Here the plane's points are counting-sorted by base cell ONCE per workgroup (stable: per-wave histograms, returning LDS
-// atomics), the sorted list is cut into ITEMS — runs of at most four entries of ONE base cell — and a thread owns at most
+// Here the plane's points are counting-sorted by base cell ONCE per workgroup (deterministic: per-wave histograms, returning
+// LDS atomics — a function of the keys alone), the sorted list is cut into ITEMS — runs of at most four entries of ONE base cell — and a thread owns at most
 // two items for the whole kernel:
 //   * per-entry state (the two fractional weights; w0 = 1 - w1 holds bit for bit) and the g_keys sums live in registers;
 //   * g_out of a four-channel group is read coalesced in point order and staged into LDS in SORTED order as one 16-byte word
@@ -155,22 +155,46 @@ __device__ __forceinline__ void load_plane_keys(const RasterArgs& a, const GridW
     K.inside |= (ct_key_mask(kx[i]) != 0.0f ? 1u : 0u) << (2 * i) | (ct_key_mask(ky[i]) != 0.0f ? 2u : 0u) << (2 * i);
 }
 
-// record != null: the items, ranks and header are also written there (the weights: by the caller, from LDS, behind a barrier)
-__device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys& PK, int G, int W1, unsigned char* lds,
-                                           const SortLds& L, SortedPlane& S, unsigned char* record = nullptr) {
+// LDS of the sort itself
+struct SortPtrs {
+  unsigned* hist;     // [kSortWaves][G / 2]: per-wave counts, two cells (16 bits each) per word
+  float2* ab;         // [N + 1] weights in sorted order, or null (AB_GLOBAL: they go to the record)
+  unsigned* cnt;      // [G]
+  unsigned* stp;      // [G]
+  unsigned* mark;     // [kMaxItems]
+  unsigned* s_k;      // K; channel maxima in the nC words before it
+  unsigned* scr;      // [64]
+};
+__device__ __forceinline__ SortPtrs sort_ptrs(unsigned char* lds, const SortLds& L, int C) {
+  SortPtrs P;
+  P.hist = (unsigned*)(lds + L.stage);
+  P.ab = (float2*)(lds + L.ab);
+  P.cnt = (unsigned*)(lds + L.tot);
+  P.stp = (unsigned*)(lds + L.stp);
+  P.mark = (unsigned*)(lds + L.mark);
+  P.s_k = (unsigned*)(lds + L.misc) + C;
+  P.scr = P.s_k + 1;
+  return P;
+}
+
+// record != null: the items, ranks and header are also written there (the weights: by the caller).  P.ab null: the weights are
+// not placed (the caller does it, e.g. into the histograms' space once they are dead: on return).  nC: channel-maximum words in front of K that are cleared here.
+__device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys& PK, int G, int W1, const SortPtrs& P, int nC,
+                                           SortedPlane& S, unsigned char* record = nullptr) {
   const int tid = threadIdx.x, N = a.N, wave = tid >> 6;
-  unsigned* hist = (unsigned*)(lds + L.stage);
-  float2* AB = (float2*)(lds + L.ab);
-  unsigned* cnt = (unsigned*)(lds + L.tot);
-  unsigned* stp = (unsigned*)(lds + L.stp);
-  unsigned* mark = (unsigned*)(lds + L.mark);
-  unsigned* s_k = (unsigned*)(lds + L.misc) + a.C;
-  unsigned* scr = s_k + 1;            // [0..15] wave sums, [16..47] wave maxima of the item marks, [48] items in all
+  unsigned* const hist = P.hist;
+  float2* const AB = P.ab;
+  unsigned* const cnt = P.cnt;
+  unsigned* const stp = P.stp;
+  unsigned* const mark = P.mark;
+  unsigned* const s_k = P.s_k;
+  unsigned* const scr = P.scr;            // [0..15] wave sums, [16..47] wave maxima of the item marks, [48] items in all
+  const int G2 = G >> 1;
   const bool has = (tid << 2) < N;
   CT_STAMP(0);
-  for (int i = tid; i < (kSortWaves * G) >> 2; i += kSortThreads) ((uint4*)hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < (kSortWaves * G2) >> 2; i += kSortThreads) ((uint4*)hist)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < kMaxItems; i += kSortThreads) mark[i] = 0u;
-  if (tid < a.C + 1) ((unsigned*)(lds + L.misc))[tid] = 0u;          // channel maxima, K
+  if (tid < nC + 1) (s_k - nC)[tid] = 0u;          // channel maxima, K
   __syncthreads();
   // rank inside (wave, cell): the value the returning add hands back — the points of a thread in index order, the lanes of one
   // instruction in the order the LDS serves them (a fixed function of the addresses: the same on every run)
@@ -178,27 +202,32 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
   unsigned r[4] = {0u, 0u, 0u, 0u};
   if (has) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = atomicAdd(&hist[wave * G + PK.base[i]], 1u);
+    for (int i = 0; i < 4; ++i) {
+      const unsigned sh = (unsigned)(PK.base[i] & 1) << 4;        // a wave holds 256 points: its counts fit 16 bits
+      r[i] = (atomicAdd(&hist[wave * G2 + (PK.base[i] >> 1)], 1u << sh) >> sh) & 0xffffu;
+    }
   }
   __syncthreads();
   CT_STAMP(2);
-  // per cell: the waves' counts -> their exclusive prefix (in place) and the cell's total; then the exclusive scan over the
-  // cells of {points, items} packed into one word (points <= 4096, items <= 2048: no carry between the halves)
+  // per PAIR of cells (one histogram word): the waves' counts -> their exclusive prefix (in place) and the cells' totals; then the
+  // exclusive scan over the cells of {points, items} packed into one word (points <= 4096, items <= 2048: no carry between the
+  // halves; a pair's two words are scanned as their sum)
   unsigned carry = 0u;
-  for (int Y0 = 0; Y0 < G; Y0 += kSortThreads) {
-    const int Y = Y0 + tid;
+  for (int Y0 = 0; Y0 < G2; Y0 += kSortThreads) {
+    const int Wd = Y0 + tid;
     unsigned t = 0u;
-    if (Y < G) {
-#pragma unroll
+    if (Wd < G2) {
+#pragma unroll 8
       for (int w = 0; w < kSortWaves; ++w) {
-        const unsigned c = hist[w * G + Y];
-        hist[w * G + Y] = t;
-        t += c;
+        const unsigned c = hist[w * G2 + Wd];
+        hist[w * G2 + Wd] = t;
+        t += c;                                        // (both halves at once: a cell holds at most 4096 points)
       }
-      cnt[Y] = t;
+      *(uint2*)(cnt + 2 * Wd) = make_uint2(t & 0xffffu, t >> 16);
     }
-    const unsigned v = t | (((t + kItemLen - 1) / kItemLen) << 16);
-    const unsigned inc = wave_scan_add_u32(v);
+    const unsigned t0 = t & 0xffffu, t1 = t >> 16;
+    const unsigned v0 = t0 | (((t0 + kItemLen - 1) / kItemLen) << 16), v1 = t1 | (((t1 + kItemLen - 1) / kItemLen) << 16);
+    const unsigned inc = wave_scan_add_u32(v0 + v1);
     if ((tid & 63) == 63) scr[wave] = inc;
     __syncthreads();
     CT_STAMP(3);
@@ -209,13 +238,14 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
       pre += w < wave ? sw : 0u;
       all += sw;
     }
-    const unsigned ex = pre + inc - v;
-    if (Y < G) {
-      stp[Y] = ex;
-      if (t) mark[ex >> 16] = (unsigned)Y + 1u;      // the cell's first item
+    const unsigned ex0 = pre + inc - (v0 + v1), ex1 = ex0 + v0;
+    if (Wd < G2) {
+      *(uint2*)(stp + 2 * Wd) = make_uint2(ex0, ex1);
+      if (t0) mark[ex0 >> 16] = (unsigned)(2 * Wd) + 1u;      // the cell's first item
+      if (t1) mark[ex1 >> 16] = (unsigned)(2 * Wd) + 2u;
     }
     carry += all;
-    if (Y0 + kSortThreads >= G) {      // last round: every cell's count is in place
+    if (Y0 + kSortThreads >= G2) {      // last round: every cell's count is in place
       // K: contributions per cell = points based at the cell and at its three lower neighbours (cells of the last row /
       // column are never a base, so the wrapped neighbours of column 0 read zeros)
       unsigned kloc = 0u;
@@ -238,11 +268,12 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
   if (has) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      rk[i] = (stp[PK.base[i]] & 0xffffu) + hist[wave * G + PK.base[i]] + r[i];
-      AB[rk[i]] = make_float2(PK.fa[i], PK.fb[i]);
+      const unsigned sh = (unsigned)(PK.base[i] & 1) << 4;
+      rk[i] = (stp[PK.base[i]] & 0xffffu) + ((hist[wave * G2 + (PK.base[i] >> 1)] >> sh) & 0xffffu) + r[i];
+      if (AB != nullptr) AB[rk[i]] = make_float2(PK.fa[i], PK.fb[i]);
     }
   }
-  if (tid == 0) AB[N] = make_float2(0.0f, 0.0f);
+  if (AB != nullptr && tid == 0) AB[N] = make_float2(0.0f, 0.0f);
 #pragma unroll
   for (int i = 0; i < 4; ++i) rk[i] |= ((PK.inside >> (2 * i)) & 1u ? kInsideX : 0u) | ((PK.inside >> (2 * i)) & 2u ? kInsideY : 0u);
   S.rk01 = rk[0] | (rk[1] << 16);
@@ -317,21 +348,42 @@ __device__ __forceinline__ void load_sorted_plane(const RasterArgs& a, const uns
 // ---------------------------------------------------------------------------
 // KP: the plane sort alone (ct_plane_sort): one workgroup per (b, h) plane writes the plane's record.  grid = (1, H, B)
 // ---------------------------------------------------------------------------
+// LDS of the sort alone: packed histograms 32 G | cnt 4 G | stp 4 G | marks | K + scratch  (48.5 KiB at 32^2: two workgroups per
+// CU, whose latency-bound phases overlap)
+__host__ __device__ inline size_t plane_sort_hist_bytes(int G, int N) {
+  const size_t h = (size_t)kSortWaves * (G >> 1) * 4, w = (size_t)8 * N;       // (the weights pass through the histograms' space)
+  return ((h > w ? h : w) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t plane_sort_lds(int G, int N) { return plane_sort_hist_bytes(G, N) + (size_t)8 * G + (size_t)4 * kMaxItems + 4 * 68; }
+
 template <int WT>
-__global__ void __launch_bounds__(kSortThreads) plane_sort_kernel(RasterArgs a, GridW<2> g, unsigned char* records, size_t stride) {
+__global__ void __launch_bounds__(kSortThreads, 8) plane_sort_kernel(RasterArgs a, GridW<2> g, unsigned char* records, size_t stride) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
-  const SortLds L = sort_lds(G, N, 0);
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const size_t bh = (size_t)blockIdx.z * a.H + blockIdx.y;
-  unsigned char* rec = records + bh * stride;
-  a.C = 0;
+  SortPtrs P;
+  P.hist = (unsigned*)lds_raw;
+  P.ab = nullptr;
+  P.cnt = (unsigned*)(lds_raw + plane_sort_hist_bytes(G, a.N));
+  P.stp = P.cnt + G;
+  P.mark = P.stp + G;
+  P.s_k = P.mark + kMaxItems;
+  P.scr = P.s_k + 1;
   PlaneKeys PK;
   load_plane_keys(a, g, W1, bh, PK);
   SortedPlane S;
-  sort_plane(a, PK, G, W1, lds_raw, L, S, rec);
-  __syncthreads();                 // the weights are in LDS (sorted order): out as they lie
-  const float4* AB4 = (const float4*)(lds_raw + L.ab);
-  for (int i = threadIdx.x; i < (N >> 1); i += kSortThreads) ((float4*)(rec + 16))[i] = AB4[i];
+  unsigned char* rec = records + bh * stride;
+  sort_plane(a, PK, G, W1, P, 0, S, rec);
+  // the weights: into sorted order through the (now dead) histograms, out in 16-byte rows (8-byte stores scattered over the
+  // record were measured: the whole kernel 14 -> 24 us)
+  float2* ABl = (float2*)P.hist;
+  if ((threadIdx.x << 2) < a.N) {
+    const unsigned rk[4] = {S.rk01 & kRankMask, (S.rk01 >> 16) & kRankMask, S.rk23 & kRankMask, (S.rk23 >> 16) & kRankMask};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ABl[rk[i]] = make_float2(PK.fa[i], PK.fb[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (a.N >> 1); i += kSortThreads) ((float4*)(rec + 16))[i] = ((const float4*)ABl)[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -397,7 +449,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
 
-  if constexpr (!PRESORTED) sort_plane(a, PK, G, W1, lds_raw, L, S);
+  if constexpr (!PRESORTED) sort_plane(a, PK, G, W1, sort_ptrs(lds_raw, L, C), C, S);
   else __syncthreads();            // K (and the cleared channel maxima) for everybody
   for (int i = tid; i < G; i += kSortThreads) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
   if (tid == 0) Sg[N] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // what the slots beyond an item's entries read

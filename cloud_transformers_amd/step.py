@@ -20,7 +20,7 @@ class SplatSliceStep:
     second backward adds the first one's result inside its own store.
     """
 
-    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True, plane_sort=True):
+    def __init__(self, keys, feat, cot, tensor_size, heads, dim, reduce="max", tickets=True, plane_sort=False):
         assert keys.is_cuda and feat.is_cuda and cot.is_cuda
         self.W = sizes_of(tensor_size, dim)
         self.H, self.dim, self.reduce = heads, dim, reduce
@@ -47,7 +47,9 @@ class SplatSliceStep:
         # arrival tickets (ct_tickets_init contract: zero once, the kernels leave them zero): the sums over a plane's
         # workgroups happen inside the backward kernels — one launch per pass on the few-plane shapes too
         self.tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device=dev, dtype=torch.int32) if tickets else None
-        # sorted planes (ct_plane_sort): one record per key tensor, read by the backward passes (None: no sorted form here)
+        # sorted planes (ct_plane_sort): one record per key tensor, read by the backward passes (None: the kernels that use the
+        # sorted form sort inside — measured faster where a plane is ONE workgroup: 190.7 vs 200.9 us per headline step,
+        # profiles/r5_step_overlap.txt; the record pays where several workgroups share a plane)
         nps = self.lib.ct_plane_sort_bytes(self.B, self.H, self.N, dim, self.Wa) if plane_sort else 0
         self.sorted = torch.empty(nps, device=dev, dtype=torch.uint8) if nps else None
         self.nps = nps
@@ -107,6 +109,8 @@ class SplatSliceStep:
         "gather_ci": "gather_ci_kernel",
         "gather_quad": "quad_kernel<2, 0,",
         "slice_bwd_fused": "slice_bwd_fused_kernel",
+        "slice_bwd_sorted": "slice_bwd_sorted_kernel",
+        "slice_bwd_presorted": "slice_bwd_sorted_kernel",
         "splat_max_bwd_hot": "splat_max_bwd_hot_kernel",
         "splat_max_bwd_whole_head": "quad_kernel<2, 2, 4, 1024,",
     }

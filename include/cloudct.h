@@ -147,7 +147,7 @@ int ct_slice_bwd_tk(const float* keys, const float* grid, const void* pad, int p
 /* Sorted planes (csrc/ct_raster_sorted.h; no counterpart in the reference, whose Splat / Slice re-derive everything from
  * local_coordinate / flattened_index per call, layers/cloud_transform.py:72-124).  One diff_poss(lattice) feeds the Splat and
  * the Slice of a block (layers/multihead_ct.py:99-107), so the four raster passes of a step see the SAME keys: ct_plane_sort
- * counting-sorts every (b, h) plane's points by base cell once (stable: the record is a function of the keys alone) and leaves
+ * counting-sorts every (b, h) plane's points by base cell once (the record is a function of the keys alone) and leaves
  * per plane the sorted positions, the fractional corner weights in sorted order and the plane's work items in `sorted`
  * (ct_plane_sort_bytes; 0: this layout has no sorted form — dim 3, N > 4096 ...).  The *_ps entry points take the record of
  * THEIR keys (NULL: they behave as the *_tk entry points and sort inside where they use the sorted form); a record made from

@@ -48,7 +48,7 @@ def headline(args):
         keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
         feat = torch.randn(B, H * C, N, device="cuda")
         cot = torch.randn(B, H * C, N, device="cuda")
-        step = SplatSliceStep(keys, feat, cot, W, H, dim, "max")
+        step = SplatSliceStep(keys, feat, cot, W, H, dim, "max", plane_sort=True)
         step.splat_fwd(); step.slice_fwd()
         res = {}
         srec = step.sorted

@@ -37,7 +37,7 @@ def pmc_avg(path, counter):
 
 def main():
     stats, fetch, write, prefix = sys.argv[1:5]
-    ours = ("scatter_", "quad_kernel", "gather_", "splat_max_bwd", "slice_bwd_fused", "positions_", "nn_kernel", "emd_", "occupancy")
+    ours = ("scatter_", "quad_kernel", "gather_", "splat_max_bwd", "slice_bwd_fused", "slice_bwd_sorted", "plane_sort", "positions_", "nn_kernel", "emd_", "occupancy")
     rows = []
     with open(stats) as f:
         for row in csv.DictReader(f):
