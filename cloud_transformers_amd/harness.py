@@ -322,7 +322,9 @@ class Trainer:
             parallel.barrier(self.dist)
             parallel.quiesce()                                       # the process group's watchdog drops the warm-up's work items
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=self._stream, capture_error_mode="thread_local"):
+        # (captured on the stream the warm-up ran on — under DDP the wrapper's, else `side`: the per-stream workspaces and
+        #  tickets of the raster ops were created by the warm-up, outside the capture and outside the graph's private pool)
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             static_loss = self._loss(static)
             static_loss.backward()
         return graph, static, static_loss, [p.grad for p in params]
@@ -335,7 +337,16 @@ class Trainer:
         key = tuple(tuple(t.shape) for t in batch)
         rec = self._graphs.get(key)
         if rec is None:
-            rec = self._graphs[key] = self._capture(batch)
+            try:
+                rec = self._capture(batch)
+            except RuntimeError as ex:       # capture refused (e.g. the process group's watchdog touched an event): eager steps
+                if self.rank == 0:
+                    print("harness: HIP-graph capture failed (%s); continuing with eager steps" % (ex,), flush=True)
+                self._graphs[key] = rec = False
+            else:
+                self._graphs[key] = rec
+        if rec is False:
+            return self._eager_step(batch)
         graph, static, static_loss, grads = rec
         for dst, src in zip(static, batch):
             dst.copy_(src, non_blocking=True)
@@ -350,7 +361,9 @@ class Trainer:
 
         `hip_graph` (default: `train.hip_graph` of the config, else False): replay forward + loss + backward as one HIP graph
         (under DistributedDataParallel too: the gradient all-reduce and the norms' statistics exchanges are captured with
-        the kernels, after DDP's warm-up iterations).  Losses stay on the
+        the kernels, after DDP's warm-up iterations; the process group must have been created with
+        TORCH_NCCL_ASYNC_ERROR_HANDLING=0 in the environment — launch.rank_env sets it, torchrun users set it themselves —
+        and a capture that fails falls back to eager steps).  Losses stay on the
         device and are read back every `log_each` steps (default `train.log_each`, else 10) in ONE transfer — no host
         synchronisation per step (the reference reads the loss every step: train_segmentation.py:180-186)."""
         tr = self.cfg["train"]

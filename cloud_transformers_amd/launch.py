@@ -58,6 +58,9 @@ def rank_env(rank, world, port, base=None):
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this driver
+    # torch's recipe for capturing collectives into a graph (notes/cuda.rst): without it the process group's watchdog queries
+    # events of the capturing stream and takes the process down (harness.fit(hip_graph=True), bench.py --mode ddp-step)
+    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     return env
 
 

@@ -97,42 +97,52 @@ class ChamferDistance(torch.nn.Module):
 
 
 class AverageMeter(object):
-    """Last value / running mean of one scalar or of a named list (grdnet_utils.py:26-65)."""
+    """Running mean of one scalar, or of a row of named scalars (the interface the completion eval loop uses:
+    `AverageMeter(names)`, `.update(value | [values])`, `.val()/.count()/.avg()` with an optional column index —
+    grdnet_utils.py:26-65).  Kept as one running record per column."""
+
+    class _Column(object):
+        __slots__ = ("last", "total", "n")
+
+        def __init__(self):
+            self.last, self.total, self.n = 0, 0, 0
+
+        def push(self, v):
+            self.last = v
+            self.total += v
+            self.n += 1
+
+        def mean(self):
+            return self.total / self.n if self.n else 0.0
 
     def __init__(self, items=None):
         self.items = items
-        self.n_items = 1 if items is None else len(items)
+        self.n_items = len(items) if items is not None else 1
         self.reset()
 
     def reset(self):
-        self._val = [0] * self.n_items
-        self._sum = [0] * self.n_items
-        self._count = [0] * self.n_items
+        self._cols = [AverageMeter._Column() for _ in range(self.n_items)]
 
     def update(self, values):
-        if isinstance(values, list):
-            for i, v in enumerate(values):
-                self._val[i] = v
-                self._sum[i] += v
-                self._count[i] += 1
-        else:
-            self._val[0] = values
-            self._sum[0] += values
-            self._count[0] += 1
+        row = values if isinstance(values, list) else [values]
+        for col, v in zip(self._cols, row):
+            col.push(v)
 
-    def _pick(self, seq, idx):
+    def _read(self, field, idx):
         if idx is not None:
-            return seq[idx]
-        return seq[0] if self.items is None else list(seq)
+            return field(self._cols[idx])
+        if self.items is None:
+            return field(self._cols[0])
+        return [field(c) for c in self._cols]
 
     def val(self, idx=None):
-        return self._pick(self._val, idx)
+        return self._read(lambda c: c.last, idx)
 
     def count(self, idx=None):
-        return self._pick(self._count, idx)
+        return self._read(lambda c: c.n, idx)
 
     def avg(self, idx=None):
-        return self._pick([s / c if c else 0.0 for s, c in zip(self._sum, self._count)], idx)
+        return self._read(lambda c: c.mean(), idx)
 
 
 class Metrics(object):
