@@ -1674,7 +1674,8 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
 
 // Sorted-plane kernels (ct_raster_sorted.h): one 1024-thread workgroup per (b, h) plane; every thread owns at most two items
 // (N / 4 + 3 G / 4 <= 2048), positions and counts fit 16 bits, the carve-up fits a CU's LDS.  Worth it only where there is a
-// plane per CU at least (the kernel does not split a plane).  CLOUDCT_SORTED=0/1 overrides the default.
+// plane per CU at least (the kernel does not split a plane) and three channel groups to spread the sort over.  CLOUDCT_SORTED=0
+// turns the form off (A/B runs).
 bool sorted_plane_ok(const RasterArgs& a, int G) {
   static const int env = [] {
     const char* e = getenv("CLOUDCT_SORTED");
@@ -1685,7 +1686,9 @@ bool sorted_plane_ok(const RasterArgs& a, int G) {
   if (a.N > 4096 || (a.N & 3) || (a.C & 3) || (G & 3) || a.N / 4 + (3 * G) / 4 > kMaxItems) return false;
   if (sort_lds(G, a.N, a.C).total > (size_t)kBigLdsBytes) return false;
   if (f & CT_DEBUG_FORCE_SORTED) return true;
-  return (long long)a.B * a.H >= 256;
+  // the sort is paid once per plane and workgroup, the gain per four-channel group: B8 H64 N4096 32^2, sorted | scatter form
+  // C4 27.8 | 23.1 us, C8 38.7 | 38.3, C12 51.3 | 57.6, C16 60.3 | 69.5, C32 99.9 | 138.9 (profiles/r5_sorted_channels.txt)
+  return (long long)a.B * a.H >= 256 && a.C >= 12;
 }
 
 // can ct_plane_sort take this layout?  (the consumers add their own conditions: channels, planes)

@@ -17,6 +17,7 @@ bench)   # the bench.py lines (default workload, C4, sum, the DDP step graphed /
   bash tools/profile_round.sh > $O/ev_profile_round.log 2>&1
   bash tools/pmc_sq.sh > $O/ev_pmc_sq.log 2>&1
   python3 tools/pmc_sq.py > $O/ev_bench_sq_counters.txt 2>&1
+  bash tools/dev/bench_seeds.sh > $O/ev_bench_seeds.txt 2>&1
   ;;
 zoo)     # the zoo head shapes: HIP-event sweep, rocprofv3 counters, the Splat(max) backward's point segments
   python tools/zoo_sweep.py > $O/ev_zoo_sweep.txt 2>&1
