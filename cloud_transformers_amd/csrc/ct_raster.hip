@@ -1778,6 +1778,15 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
 int run_scatter_add_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
+  if (sorted_plane_ok(a, g.G)) {       // the sorted-plane kernel without its gather side (ct_raster_sorted.h)
+    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = 1; a.nseg = 1; a.Nrow = 0; a.tickets = nullptr; a.tile_in = nullptr; a.sorted = nullptr;
+    const SortLds L = sort_lds(g.G, a.N, a.C);
+    dim3 wgrid(1, a.H, a.B);
+#define CT_MK_SCATTER_ADD_SORTED(PADV, WTV) slice_bwd_sorted_kernel<PADV, WTV, false, false>
+    CT_LAUNCH_HOT_(CT_MK_SCATTER_ADD_SORTED, wgrid, kSortThreads, L.total, st, a, g);
+    note("scatter_add_sorted");
+    return CT_OK;
+  }
   HotPlan hp;
   if (!hot_chunks(a.C, (size_t)g.G * 4, (size_t)(g.G + a.C + 2) * 4, hp)) return CT_EINVAL;
   int ncg = 1;

@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(kSortThreads, 8) plane_sort_kernel(RasterArgs 
 #define CT_SB __builtin_amdgcn_sched_barrier(0)
 #endif
 // PRESORTED: the plane's record (a.sorted, ct_plane_sort) is loaded instead of sorting here.
-template <bool HAS_PAD, int WT, bool PRESORTED>
+// GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
+template <bool HAS_PAD, int WT, bool PRESORTED, bool GATHER = true>
 __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   auto request1 = [&](int grp, int cj) {          // one channel of group grp: the quad's g_out and the thread's conv cell
     const float4 t = ld_stream4(src0 + (size_t)(grp * 4 + cj) * N + ln0);
     gq[cj][0] = t.x; gq[cj][1] = t.y; gq[cj][2] = t.z; gq[cj][3] = t.w;
-    cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
+    if constexpr (GATHER) cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
   };
   auto request = [&](int grp) {
 #pragma unroll
@@ -488,8 +489,8 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
 #pragma unroll
       for (int i = 0; i < 4; ++i) Sg[rk[i]] = make_float4(gq[0][i], gq[1][i], gq[2][i], gq[3][i]);
     }
-    if (tid < G) T4[tid] = make_float4(cvq[0], cvq[1], cvq[2], cvq[3]);
-    for (int cell = tid + kSortThreads; cell < G; cell += kSortThreads) {       // grids of more than blockDim cells
+    if (GATHER && tid < G) T4[tid] = make_float4(cvq[0], cvq[1], cvq[2], cvq[3]);
+    for (int cell = tid + kSortThreads; GATHER && cell < G; cell += kSortThreads) {       // grids of more than blockDim cells
       const float* p = a.tile_in + (bh * C + ch0) * (size_t)G + cell;
       T4[cell] = make_float4(ld_stream(p), ld_stream(p + G), ld_stream(p + 2 * (size_t)G), ld_stream(p + 3 * (size_t)G));
     }
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       asm volatile("" : "+v"(S.ent8[u][0]), "+v"(S.ent8[u][1]));
       float4 cv[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) cv[v] = T4[Y + off[v]];
+      for (int v = 0; v < 4; ++v) cv[v] = GATHER ? T4[Y + off[v]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       float4 xn = *(const float4*)((const unsigned char*)Sg + 2u * CT_E8(S, u, 0));
       float2 wn = *(const float2*)((const unsigned char*)AB + CT_E8(S, u, 0));
       ct_f2 s01[4], s23[4];      // [corner] x channels (0,1) / (2,3)
@@ -550,14 +551,18 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
           const ct_f2 cwv = {cw[v], cw[v]};
           s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
           s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
-          // (c0 x0 + c2 x2) + (c1 x1 + c3 x3): two packed instructions and one add per corner
-          const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
-          const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
-          gw[v] = pr.x + pr.y;
+          if constexpr (GATHER) {
+            // (c0 x0 + c2 x2) + (c1 x1 + c3 x3): two packed instructions and one add per corner
+            const ct_f2 c01 = {cv[v].x, cv[v].y}, c23 = {cv[v].z, cv[v].w};
+            const ct_f2 pr = __builtin_elementwise_fma(c23, x23, c01 * x01);
+            gw[v] = pr.x + pr.y;
+          }
         }
-        gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
-        gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
-        asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+        if constexpr (GATHER) {
+          gsx[u][j] = __builtin_fmaf(gw[3] - gw[2], w1y, __builtin_fmaf(gw[1] - gw[0], w0y, gsx[u][j]));
+          gsy[u][j] = __builtin_fmaf(gw[3] - gw[1], w1x, __builtin_fmaf(gw[2] - gw[0], w0x, gsy[u][j]));
+          asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+        }
         CT_SB;
       }
       if (S.cell[u] >= 0) {
@@ -609,6 +614,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   group(ngroups - 1, std::false_type{});
   CT_STAMP(9);
 #endif
+  if constexpr (!GATHER) return;
   // g_keys: from the item owners (sorted order) back to the point owners through LDS (the stage area is free: the last
   // group's readers are behind the barrier above)
   float2* Gs = (float2*)Sg;

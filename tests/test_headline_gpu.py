@@ -85,7 +85,7 @@ def test_headline_shape_fwd_bwd_against_oracle_planes(C, reduce, flags):
     # (512 planes and >= 3 channel groups: the sorted-plane form, csrc/ct_raster_sorted.h — tests/test_sorted_gpu.py compares
     #  it with the scatter form; C4: the scatter form)
     assert tags["slice_bwd"] == ("slice_bwd_sorted" if C >= 12 else "slice_bwd_fused"), tags
-    assert tags["splat_fwd"] == ("scatter_quad_max" if reduce == "max" else "scatter_add_fused"), tags
+    assert tags["splat_fwd"] == ("scatter_quad_max" if reduce == "max" else "scatter_add_sorted" if C >= 12 else "scatter_add_fused"), tags
     assert tags["splat_bwd"] == ("splat_max_bwd_hot" if reduce == "max" else "splat_sum_bwd_hot"), tags
     step.run()                                    # (launch_tags re-ran the passes: g_keys was accumulated twice)
     torch.cuda.synchronize()

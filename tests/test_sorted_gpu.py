@@ -184,6 +184,36 @@ def test_sorted_slice_backward_against_the_oracle(cfg, record, flags):
     assert relerr(outs[0][1], k.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("cfg", SMALL, ids=str)
+def test_sorted_splat_sum_forward_against_the_oracle(cfg, flags):
+    """Splat(reduce=sum) forward = the scatter-add side of the sorted kernel alone (no conv tile, no key cotangent):
+    layers/cloud_transform.py:164-173 with scatter_add_."""
+    from cloud_transformers_amd import ops
+    mod, lib = _lib()
+    B, H, C, N, W, pad, dup = cfg
+    dim = 2
+    torch.manual_seed(9)
+    keys = torch.tanh(torch.randn(B, H * dim, N) * (0.3 if dup else 1.0))
+    if dup:
+        keys[:, :, N // 2:] = keys[:, :, :N // 2]
+    if W == (4, 4):
+        keys = keys * 0.2
+    feat = torch.randn(B, H * C, N)
+    p = (torch.rand(B, N) > 0.2).float() if pad else None
+    lc, idx = R.positions(keys, list(W), H, dim)
+    ref = R.splat(lc, idx, feat, p, list(W), H, dim, "sum")
+    outs = []
+    for _ in range(2):
+        flags(mod.DEBUG_FORCE_SORTED | mod.DEBUG_FORCE_HOT)
+        z = ops.splat_keys(keys.cuda(), feat.cuda(), p.cuda() if pad else None, list(W), H, dim, "sum")
+        tag = lib.ct_debug_last_launch().decode()
+        flags(0)
+        assert tag == "scatter_add_sorted", tag
+        outs.append(z)
+    assert torch.equal(outs[0], outs[1]), "not bitwise reproducible"
+    assert per_channel_err(outs[0], ref, H * C) <= 1e-4
+
+
 def test_record_and_inside_sort_agree_bit_for_bit_and_with_the_scatter_form(flags):
     """B4 H64 (256 planes: the sorted form is the default) N4096 C16 32^2: the three forms of Slice backward on one input."""
     from cloud_transformers_amd.ops import _ptr, _stream
