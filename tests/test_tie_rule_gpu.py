@@ -1,0 +1,81 @@
+"""Exact ties in Splat(max) backward: ONE winner per (cell, channel) in every kernel family — never a split award.
+
+torch_scatter.scatter_max's backward (layers/cloud_transform.py:164-173 through torch_scatter) gives the cotangent of a cell to the
+single arg-max element it recorded; which of several bit-equal contributions that is differs between its CPU and CUDA kernels.
+The rule here, per family: the hot, generic and quad kernels award the contribution whose compare-and-swap
+reaches the cell's word first (one winner, identity unspecified); the banded kernels award the lowest point index.
+
+Construction: two identical points alone in their neighbourhood, one cotangent value per corner cell.  The four corner cells see
+exactly the two tied contributions each, so the pair's gradients must be a PARTITION of the four corner terms g_z * weight."""
+import itertools
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from cloud_transformers_amd import _lib
+    return _lib, _lib.load()
+
+
+CASES = [
+    # name, debug flags, dim, W, C, N, lowest index must win
+    ("hot_2d_register_form", "FORCE_HOT", 2, 32, 8, 1024, False),
+    ("hot_2d_through_memory", "FORCE_HOT", 2, 32, 8, 8192, False),
+    ("hot_3d", "FORCE_HOT", 3, 8, 8, 1024, False),
+    ("generic_2d", "NO_HOT", 2, 32, 8, 1024, False),
+    ("generic_3d", "NO_HOT", 3, 8, 8, 1000, False),
+    ("banded_2d", "FORCE_BAND", 2, 32, 4, 1024, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_one_winner_per_cell_and_channel(case):
+    from cloud_transformers_amd import ops
+    mod, lib = _lib()
+    name, flag, dim, W, C, N, lowest = case
+    B, H = 2, 16
+    g = torch.Generator().manual_seed(41)
+    Ws = [W] * dim
+    # the cloud sits in the lower half of the grid; the tied pair alone near the upper corner
+    keys = torch.rand(B, H * dim, N, generator=g) * 0.8 - 0.9
+    p0, p1 = 5, N - 7
+    spot = torch.rand(B, H * dim, generator=g) * 0.1 + 0.7
+    keys[:, :, p0] = spot
+    keys[:, :, p1] = spot
+    feat = torch.rand(B, H * C, N, generator=g) + 0.5
+    feat[:, :, p1] = feat[:, :, p0]
+    gz = torch.randn(B, H * C, *Ws, generator=g)
+    lc, idx = R.positions(keys, Ws, H, dim)                          # (B, H, V, N): corner weights / cells
+    V = 1 << dim
+    kd, fd = keys.cuda().requires_grad_(True), feat.cuda().requires_grad_(True)
+    lib.ct_debug_set_flags(getattr(mod, "DEBUG_" + flag))
+    try:
+        z = ops.splat_keys(kd, fd, None, Ws, H, dim, "max")
+        z.backward(gz.cuda())
+        tag = lib.ct_debug_last_launch().decode()
+    finally:
+        lib.ct_debug_set_flags(0)
+    want = {"FORCE_HOT": ("hot",), "NO_HOT": ("generic", "quad", "whole"), "FORCE_BAND": ("band",)}[flag]
+    assert any(w in tag for w in want) and ("hot" in tag) == (flag == "FORCE_HOT"), (name, tag)
+    gf = fd.grad.cpu()
+    G = W ** dim
+    for b in range(B):
+        for h in range(H):
+            w = lc[b, h, :, p0]                                      # the pair's corner weights (identical for both)
+            cells = idx[b, h, :, p0]
+            for c in range(C):
+                terms = gz[b, h * C + c].reshape(G)[cells] * w       # g_z * weight per corner
+                a, bb = float(gf[b, h * C + c, p0]), float(gf[b, h * C + c, p1])
+                scale = float(terms.abs().sum()) + 1e-12
+                sums = {S: float(sum(terms[v] for v in S)) for k in range(V + 1) for S in itertools.combinations(range(V), k)}
+                full = sums[tuple(range(V))]
+                assert abs(a + bb - full) <= 1e-5 * scale, (name, tag, b, h, c)
+                assert any(abs(a - s) <= 1e-5 * scale for s in sums.values()), \
+                    "%s (%s): plane (%d,%d) channel %d: the pair's award %.6g / %.6g splits a corner term" % (name, tag, b, h, c, a, bb)
+                if lowest:
+                    assert abs(a - full) <= 1e-5 * scale and abs(bb) <= 1e-5 * scale, (name, tag, "the lower point index wins every corner")
