@@ -192,10 +192,15 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
   const int G2 = G >> 1;
   const bool has = (tid << 2) < N;
   CT_STAMP(0);
-  for (int i = tid; i < (kSortWaves * G2) >> 2; i += kSortThreads) ((uint4*)hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // every wave clears ITS OWN histogram (a wave's LDS operations complete in order: no barrier before it counts into it); the
+  // marks, maxima and K are first touched behind later barriers
+  if ((G2 & 3) == 0) {
+    for (int i = (tid & 63); i < (G2 >> 2); i += 64) ((uint4*)(hist + wave * G2))[i] = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (int i = (tid & 63); i < G2; i += 64) hist[wave * G2 + i] = 0u;
+  }
   for (int i = tid; i < kMaxItems; i += kSortThreads) mark[i] = 0u;
   if (tid < nC + 1) (s_k - nC)[tid] = 0u;          // channel maxima, K
-  __syncthreads();
   // rank inside (wave, cell): the value the returning add hands back — the points of a thread in index order, the lanes of one
   // instruction in the order the LDS serves them (a fixed function of the addresses: the same on every run)
   CT_STAMP(1);
