@@ -1619,6 +1619,19 @@ bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
       CT_LAUNCH((MK(false, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);          \
   } while (0)
 
+// the sorted-plane kernels (ct_raster_sorted.h) also know the 16 x 16 grid of the H16 blocks at compile time
+#define CT_LAUNCH_SORTED_(MK, GRID, NT, LDS, STREAM, ARGS, GW, ...)                       \
+  do {                                                                                   \
+    if ((ARGS).pad_dtype != CT_PAD_NONE)                                                  \
+      CT_LAUNCH((MK(true, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);           \
+    else if ((GW).W[0] == 32 && (GW).W[1] == 32)                                          \
+      CT_LAUNCH((MK(false, 32, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
+    else if ((GW).W[0] == 16 && (GW).W[1] == 16)                                          \
+      CT_LAUNCH((MK(false, 16, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
+    else                                                                                  \
+      CT_LAUNCH((MK(false, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);          \
+  } while (0)
+
 int hot_threads(int nq) {
   const int t = round_threads(nq);
   return t > kHotThreads ? kHotThreads : t;
@@ -1663,13 +1676,23 @@ int slice_bwd_segments(int B, int H, int C, int N, int G, int dim) {
 
 // Slice backward, fused.  CT_EINVAL: not eligible.  ws: scratch for the chunk groups' partial g_keys (may be null: then
 // only shapes that need a single group per plane qualify).
+// channel-group workgroups per plane of the sorted kernels: enough workgroups for the CUs, at least two groups each
+int sorted_groups(long long planes, int C) {
+  int ncg = 1;
+  while (planes * ncg < 256 && (C >> 2) / (2 * ncg) >= 2) ncg *= 2;
+  return ncg;
+}
+
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   HotPlan hp;
   int ncg = 1;
   const int nseg = slice_bwd_segments(B, H, C, N, g.G, 2);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
-  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
-  return (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
+  size_t sorted_need = 0;       // the sorted kernel's channel-group workgroups (few planes): partial g_keys
+  if (nseg == 1 && N <= 4096 && sorted_groups((long long)B * H, C) > 1) sorted_need = (size_t)sorted_groups((long long)B * H, C) * B * H * 2 * N * 4;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return sorted_need;
+  const size_t fused_need = (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
+  return fused_need > sorted_need ? fused_need : sorted_need;
 }
 
 // Sorted-plane kernels (ct_raster_sorted.h): one 1024-thread workgroup per (b, h) plane; every thread owns at most two items
@@ -1687,8 +1710,13 @@ bool sorted_plane_ok(const RasterArgs& a, int G) {
   if (sort_lds(G, a.N, a.C).total > (size_t)kBigLdsBytes) return false;
   if (f & CT_DEBUG_FORCE_SORTED) return true;
   // the sort is paid once per plane and workgroup, the gain per four-channel group: B8 H64 N4096 32^2, sorted | scatter form
-  // C4 27.8 | 23.1 us, C8 38.7 | 38.3, C12 51.3 | 57.6, C16 60.3 | 69.5, C32 99.9 | 138.9 (profiles/r5_sorted_channels.txt)
-  return (long long)a.B * a.H >= 256 && a.C >= 12;
+  // C4 27.8 | 23.1 us, C8 38.7 | 38.3, C12 51.3 | 57.6, C16 60.3 | 69.5, C32 99.9 | 138.9 (profiles/r5_sorted_channels.txt);
+  // with fewer planes than CUs the scatter form is further from its best and two groups per workgroup already pay
+  // (profiles/r5_sorted_h16.txt)
+  const long long planes = (long long)a.B * a.H;
+  const int ncg = sorted_groups(planes, a.C);
+  if (planes * ncg < 256) return false;
+  return ncg > 1 ? true : a.C >= 12;
 }
 
 // can ct_plane_sort take this layout?  (the consumers add their own conditions: channels, planes)
@@ -1707,21 +1735,38 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
   if (nseg == 1 && sorted_plane_ok(a, g.G)) {
     // the plane's points sorted by base cell, items of <= 4 entries per thread (ct_raster_sorted.h)
-    a.tile_in = grid; a.g_pos = g_pos;
-    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = 1; a.nseg = 1; a.Nrow = 0; a.tickets = nullptr;
+    int sg = (t_dbg_flags & CT_DEBUG_FORCE_SORTED) && (long long)a.B * a.H * sorted_groups((long long)a.B * a.H, a.C) < 256
+                 ? ((a.C >> 2) >= 2 ? 2 : 1)          // tests: the group split on small shapes too
+                 : sorted_groups((long long)a.B * a.H, a.C);
+    const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
+    if (sg > 1 && (!ws || ws_bytes < (size_t)sg * gpos_n * 4)) sg = 1;       // no scratch for the partial key cotangents
+    a.tile_in = grid;
+    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = sg; a.nseg = 1; a.Nrow = 0;
+    a.g_pos = sg > 1 ? (float*)ws : g_pos;
+    a.gpos_stride = sg > 1 ? gpos_n : 0;
+    a.fold_gpos = g_pos;
+    const bool fold = sg > 1 && tickets_cover(a.tickets, (long long)a.B * a.H, sg, 1) && fold_pays((size_t)sg * 2 * a.N * 4);
+    if (!fold) a.tickets = nullptr;
     const SortLds L = sort_lds(g.G, a.N, a.C);
 #ifdef CT_SORT_STAGGER
     { const char* e = getenv("CLOUDCT_SORT_STAGGER"); a.cnt_mask = e ? atoi(e) : 0; }
 #endif
-    dim3 wgrid(1, a.H, a.B);
+    dim3 wgrid(sg, a.H, a.B);
 #define CT_MK_SLICE_BWD_SORTED(PADV, WTV, PSV) slice_bwd_sorted_kernel<PADV, WTV, PSV>
     if (a.sorted != nullptr) {
       a.sorted_stride = sort_record_bytes(a.N);
-      CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, true);
-      note("slice_bwd_presorted");
+      CT_LAUNCH_SORTED_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, true);
+      note(sg > 1 ? "slice_bwd_presorted_groups" : "slice_bwd_presorted");
     } else {
-      CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, false);
-      note("slice_bwd_sorted");
+      CT_LAUNCH_SORTED_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, false);
+      note(sg > 1 ? "slice_bwd_sorted_groups" : "slice_bwd_sorted");
+    }
+    if (fold) {
+      note("folded");
+    } else if (sg > 1) {
+      CT_CLEAR_ERROR();
+      if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, sg, nullptr, st) != CT_OK) return CT_ELAUNCH;
+      CT_CHECK_LAUNCH();
     }
     return CT_OK;
   }
@@ -1779,11 +1824,12 @@ int run_scatter_add_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
   if (!hot_shape_ok(a, g.G, bits) || a.N > 8 * kHotThreads) return CT_EINVAL;
   if (sorted_plane_ok(a, g.G)) {       // the sorted-plane kernel without its gather side (ct_raster_sorted.h)
-    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = 1; a.nseg = 1; a.Nrow = 0; a.tickets = nullptr; a.tile_in = nullptr; a.sorted = nullptr;
+    const int sg = sorted_groups((long long)a.B * a.H, a.C);      // (no g_keys here: the groups share nothing)
+    a.CC = 4; a.nchunks = a.C >> 2; a.ncg = sg; a.nseg = 1; a.Nrow = 0; a.tickets = nullptr; a.tile_in = nullptr; a.sorted = nullptr;
     const SortLds L = sort_lds(g.G, a.N, a.C);
-    dim3 wgrid(1, a.H, a.B);
+    dim3 wgrid(sg, a.H, a.B);
 #define CT_MK_SCATTER_ADD_SORTED(PADV, WTV) slice_bwd_sorted_kernel<PADV, WTV, false, false>
-    CT_LAUNCH_HOT_(CT_MK_SCATTER_ADD_SORTED, wgrid, kSortThreads, L.total, st, a, g);
+    CT_LAUNCH_SORTED_(CT_MK_SCATTER_ADD_SORTED, wgrid, kSortThreads, L.total, st, a, g);
     note("scatter_add_sorted");
     return CT_OK;
   }

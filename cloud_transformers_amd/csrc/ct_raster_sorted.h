@@ -417,13 +417,18 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   const float2* AB = (const float2*)(lds_raw + L.ab);
   unsigned* s_max = (unsigned*)(lds_raw + L.misc);
   unsigned* s_k = s_max + C;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const size_t bh = (size_t)b * a.H + h;
+  // Few planes (the H16 blocks: B8 x H16 = 128): the plane's channel groups are dealt to a.ncg workgroups (grid.x), every one
+  // sorting the plane for itself (or reading its record) and writing its partial g_keys to its slice of the workspace; the
+  // plane's last workgroup adds them (arrival tickets) or a sum_parts launch does — as in slice_bwd_fused_kernel
+  const WgCoord wg = wg_coord(a.ncg, 1, a.H, a.B);
+  const int b = wg.b, cgi = wg.cgi, ncg = a.ncg;
+  const size_t bh = (size_t)b * a.H + wg.h;
   const int tid = threadIdx.x;
   const int off[4] = {0, W1, 1, W1 + 1};
   const bool has = (tid << 2) < N;
   const int n0 = has ? (tid << 2) : 0;
   const int ngroups = C >> 2;
+  const bool fold_keys = GATHER && a.tickets != nullptr && ncg > 1;
 
   // the first group's rows are requested before the sort: they land while it runs
   float gq[4][4];           // [channel][point] of the thread's quad
@@ -450,7 +455,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   if constexpr (!PRESORTED) load_plane_keys(a, g, W1, bh, PK);
   SortedPlane S;
   if constexpr (PRESORTED) load_sorted_plane(a, a.sorted + bh * a.sorted_stride, lds_raw, L, S);
-  request(0);
+  request(cgi);
   float pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
@@ -540,7 +545,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < kItemLen; ++j) {
-        if constexpr (spread) request1(grp + 1, j);
+        if constexpr (spread) request1(grp + ncg, j);
         const float4 x = xn;
         const float2 wf = wn;
         if (j + 1 < kItemLen) {
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
     item(std::integral_constant<int, 0>{});              // always: it carries the next group's loads
     if (S.cell[1] >= 0) item(std::integral_constant<int, 1>{});
 #else
-    if constexpr (decltype(more)::value) request(grp + 1);
+    if constexpr (decltype(more)::value) request(grp + ncg);
 #endif
     if (grp == 1) CT_STAMP(21);
     if (grp == 1) CT_WSTAMP(40 + (threadIdx.x >> 6));
@@ -615,8 +620,9 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
     if (grp == 1) CT_STAMP(23);
   };
   CT_STAMP(8);
-  for (int grp = 0; grp + 1 < ngroups; ++grp) group(grp, std::true_type{});
-  group(ngroups - 1, std::false_type{});
+  int grp = cgi;
+  for (; grp + ncg < ngroups; grp += ncg) group(grp, std::true_type{});
+  group(grp, std::false_type{});
   CT_STAMP(9);
 #endif
   if constexpr (!GATHER) return;
@@ -638,8 +644,16 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       gk[i].x *= (rw[i] & kInsideX) ? 1.0f : 0.0f;       // torch.clamp passes the cotangent only inside [lo, hi]
       gk[i].y *= (rw[i] & kInsideY) ? 1.0f : 0.0f;
     }
-    st_stream4(a.g_pos + (bh * 2 + 0) * N + n0, make_float4(gk[0].x, gk[1].x, gk[2].x, gk[3].x));
-    st_stream4(a.g_pos + (bh * 2 + 1) * N + n0, make_float4(gk[0].y, gk[1].y, gk[2].y, gk[3].y));
+    float* gp = a.g_pos + (size_t)cgi * a.gpos_stride;
+    st_part4(gp + (bh * 2 + 0) * N + n0, make_float4(gk[0].x, gk[1].x, gk[2].x, gk[3].x), fold_keys);
+    st_part4(gp + (bh * 2 + 1) * N + n0, make_float4(gk[0].y, gk[1].y, gk[2].y, gk[3].y), fold_keys);
+  }
+  if (fold_keys) {       // kernel-uniform
+    if (arrive_last(a.tickets + bh, (unsigned)ncg, nullptr, 0u, s_k + 1) & 1u) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fold_rows(a.g_pos + (bh * 2 + j) * N, a.gpos_stride, ncg, a.fold_gpos + (bh * 2 + j) * N, N >> 2, nullptr);
+    }
   }
   CT_STAMP(10);
 }

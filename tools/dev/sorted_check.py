@@ -42,7 +42,7 @@ def time_pass(fn, iters=50):
 
 def headline(args):
     lib = _lib.load()
-    B, N, H, W, dim, C = 8, 4096, 64, 32, 2, args.C
+    B, N, H, W, dim, C = args.B, 4096, args.H, args.W, 2, args.C
     for seed in args.seeds:
         torch.manual_seed(seed)
         keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
@@ -90,7 +90,7 @@ def headline(args):
         print("  sorted vs scatter: g_z per-channel %.2e  g_keys %.2e" % (
             per_channel_err(res["sorted"][0], res["scatter"][0], H, C), relerr(res["sorted"][1], res["scatter"][1])), flush=True)
         # oracle on a few planes
-        for (b, h) in ((0, 0), (3, 17), (7, 63)):
+        for (b, h) in ((0, 0), (B // 2, H // 3), (B - 1, H - 1)):
             k = keys[b:b + 1, h * 2:(h + 1) * 2].cpu().clone().requires_grad_(True)
             z = step.z[b:b + 1, h * C:(h + 1) * C].cpu().clone().requires_grad_(True)
             lc, idx = R.positions(k, [W, W], 1, dim)
@@ -171,6 +171,9 @@ if __name__ == "__main__":
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--C", type=int, default=16)
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--H", type=int, default=64)
+    ap.add_argument("--W", type=int, default=32)
     ap.add_argument("--seeds", type=int, nargs="*", default=[1234])
     args = ap.parse_args()
     if args.small:
