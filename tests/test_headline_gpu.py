@@ -317,6 +317,11 @@ ZOO_SHAPES = [
     # shapes of the completion model (B2 N16384, model_zoo/completion/inpainter.py:135-155)
     (4, 128, 2, 8, 4096), (4, 32, 3, 8, 4096), (16, 64, 2, 8, 4096), (16, 16, 3, 8, 4096), (16, 16, 2, 8, 4096),
     (32, 8, 3, 8, 4096), (16, 64, 2, 2, 16384), (32, 8, 3, 2, 16384), (16, 16, 2, 2, 16384), (16, 16, 3, 2, 16384),
+    # round 5: the shapes that used to run only in tools/zoo_sweep.py — the ScanObjectNN batch
+    # (BASELINE configs[1]: B8 N2048, model_zoo/scanobject/classifier.py:46-92) on all six head shapes, the What3D batch
+    # (configs[4]: B4 N8192) on the decoder's widest head, and the two four-channel decoder heads at B2 N16384
+    (4, 128, 2, 8, 2048), (4, 32, 3, 8, 2048), (16, 64, 2, 8, 2048), (16, 16, 3, 8, 2048), (16, 16, 2, 8, 2048),
+    (32, 8, 3, 8, 2048), (16, 64, 2, 4, 8192), (4, 128, 2, 2, 16384), (4, 32, 3, 2, 16384),
 ]
 
 
@@ -344,7 +349,17 @@ def test_zoo_head_shapes_at_full_size_against_oracle_planes(cfg, flags):
         mine = (got[0][b:b + 1, sl], got[1][b:b + 1, sl], got[2][b:b + 1, sl], got[3][b:b + 1, sl],
                 got[4][b:b + 1, h * dim:(h + 1) * dim])
         assert torch.equal(mine[0].cpu(), ref[0]), "z plane (%d,%d)" % (b, h)
+        # A point that lies EXACTLY on a cell boundary has corner weights of exactly 0: its product into the far cell is
+        # +-0.0, and where that cell stays at the zero floor the three implementations disagree on purpose — torch_scatter
+        # routes the cell's cotangent to the zero-valued candidate, torch's amax (the oracle) splits it with the floor, the
+        # kernels here route nothing.  Only that point's key cotangent can differ (0 * x carries no
+        # feature gradient): such points (a few per million) are left out of the g_keys comparison.
+        lc_ref, _ = R.positions(keys[b:b + 1, h * dim:(h + 1) * dim].cpu(), W, 1, dim)
+        on_edge = (lc_ref[0, 0] == 0).any(dim=0)                       # (N,)
+        assert int(on_edge.sum()) <= max(2, N // 2000), int(on_edge.sum())
         for name, a, r in zip(NAMES, mine, ref):
+            if name == "g_keys":
+                a, r = a.cpu()[..., ~on_edge], r[..., ~on_edge]
             assert relerr(a, r) <= 1e-4, "%s plane (%d,%d): %.2e" % (name, b, h, relerr(a, r))
     # the other kernel family on the full tensors (module path: separate g_keys of Splat and Slice summed by autograd)
     flags(mod.DEBUG_NO_HOT)
