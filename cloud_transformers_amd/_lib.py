@@ -283,7 +283,6 @@ SIGNATURES = {
     "ct_debug_set_core": (None, [ctypes.c_uint]),
     "ct_debug_set_gconv": (None, [ctypes.c_uint]),
     "ct_debug_set_emd": (None, [ctypes.c_uint]),
-    "ct_debug_set_pw_kernel": (None, [_i]),
     "ct_mhct_core_status": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _ip, ctypes.POINTER(ctypes.c_int), _vp]),
     "ct_chamfer_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ct_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

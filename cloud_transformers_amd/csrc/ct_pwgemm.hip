@@ -260,9 +260,11 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   // over the threads,
   // folded through the (still unused) LDS
   unsigned ma = 0u, mb = 0u;
-  if (a.amax_a)
+  // (an operand with per-row scales never uses its tensor-wide maximum: its up to 32768 partial maxima — 128 KiB per
+  //  workgroup — are not folded)
+  if (a.amax_a && a.rows_a <= 0)
     for (int i = t; i < a.n_amax_a; i += kPwThreads) ma = max(ma, __float_as_uint(a.amax_a[i]) & 0x7fffffffu);
-  if (a.amax_b)
+  if (a.amax_b && !(B_KMAJOR && a.rows_b > 0))
     for (int i = t; i < a.n_amax_b; i += kPwThreads) mb = max(mb, __float_as_uint(a.amax_b[i]) & 0x7fffffffu);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -455,8 +457,6 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
 #endif
     }
 }
-
-#include "ct_pwgemm2.h"
 
 // out[i] = sum_z slabs[z][i] in a fixed order: 32 float4 outputs x 8 z-groups per block, each group summed z ascending
 // (four loads in flight), the groups added in order through LDS
@@ -674,87 +674,9 @@ static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
   return true;
 }
 
-// The second kernel's plan (ct_pwgemm2.h): 128 x 256 tiles walked by one persistent workgroup per CU.  Weight gradient: the
-// number of k chunks per cloud that minimises rounds x (steps per chunk + what an item costs besides its steps) plus the
-// slabs' round trip.
-static int pw_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ? prop.multiProcessorCount : 256;
-  }
-  return n;
-}
-// Which kernel: 0 = default, 1 = the first kernel only, 2 = the second wherever it applies; env CLOUDCT_PW_KERNEL read once,
-// ct_debug_set_pw_kernel overrides.  Stand-alone (profiles/r4_pw_gemm_bench.txt) the persistent 128x256 kernel wins the weight
-// gradients of wide layers (848x512 105.9 vs 118.7 us, 592x512 81.9 vs 92.8, B2 N16384 104.9 vs 130.0) and forward / data
-// gradient at K >= 1024 (117.1 vs 123.1, 130.0 vs 138.0) and loses on thin shapes (K or M <= 128: 32.8 vs 24.7 us).  Inside the
-// training steps it wins nothing: a layer's data and weight gradients run on two streams and fill each other's partial rounds
-// of workgroup slots (ops.pw_backward), which a kernel that owns every CU with 147 KiB of LDS cannot — graphed steps with the
-// shape rule above / first kernel only / second everywhere, one box: segmenter 17.2 / 17.2 / 17.3 ms, classifier 15.2 / 15.1 /
-// 15.3, inpainter 32.6 / 31.6 / 32.5 (profiles/r4_model_steps.txt).  So the default is the first kernel; the second stays
-// built, tested (tests/test_pw_gemm_gpu.py runs every case on both) and selectable.
-static int g_pw_kernel = -1;
-static int pw_kernel_choice() {
-  if (g_pw_kernel < 0) {
-    const char* e = getenv("CLOUDCT_PW_KERNEL");
-    const int v = e ? atoi(e) : 0;
-    g_pw_kernel = (v == 1 || v == 2) ? v : 0;
-  }
-  return g_pw_kernel;
-}
-static bool pw2_wanted(int mode, int Co, int Ci) {
-  (void)mode; (void)Co; (void)Ci;
-  return pw_kernel_choice() == 2;
-}
-static bool pw2_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
-  if (!pw_plan(mode, B, Co, Ci, N, p) || !pw2_wanted(mode, Co, Ci)) return false;
-  if (p.M + (mode == CT_PW_WGRAD ? p.N : 1) > k2TabMax) return false;
-  p.tilesM = (p.M + k2TM - 1) / k2TM;
-  p.tilesN = (p.N + k2TN - 1) / k2TN;
-  p.ksplit = 1;
-  p.Kc = (p.K + k2BK - 1) / k2BK * k2BK;
-  p.ws = 0;
-  const int ncu = pw_cu_count();
-  if (mode == CT_PW_WGRAD) {
-    const long long tiles = (long long)p.tilesM * p.tilesN * B;
-    double best = 1e30;
-    int best_ks = 1;
-    for (int ks = 1; ks <= 32; ++ks) {
-      const int kc = ((p.K + ks - 1) / ks + k2BK - 1) / k2BK * k2BK;
-      if (ks > 1 && kc < 8 * k2BK) break;
-      const int real = (p.K + kc - 1) / kc;
-      const long long items = tiles * real;
-      const double rounds = (double)((items + ncu - 1) / ncu);
-      const double z = (double)B * real;
-      const double cost = rounds * (kc / k2BK + 4) * 0.4 + (z > 1 ? z * Co * Ci * 8.0 / 4.0e6 : 0.0);      // us
-      if (cost < best) { best = cost; best_ks = real; p.Kc = kc; }
-    }
-    p.ksplit = best_ks;
-    if ((long long)B * p.ksplit > 1) p.ws = (size_t)B * p.ksplit * Co * Ci * sizeof(float);
-  }
-  if (mode == CT_PW_DGRAD) p.ws = (size_t)Co * Ci * sizeof(float);
-  p.Z = B * p.ksplit;
-  return (long long)p.tilesM * p.tilesN * p.Z <= 0x7fffffffLL;
-}
-
-template <bool BKM>
-static int pw2_launch(const PwArgs& a, hipStream_t st) {
-  auto k = pw2_gemm_kernel<BKM>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, k2LdsBytes) != hipSuccess) return CT_ELAUNCH;
-    attr = true;
-  }
-  const long long items = (long long)a.tilesM * a.tilesN * a.Z;
-  const int ncu = pw_cu_count();
-  const int blocks = items >= ncu ? ncu : (int)((items + 7) / 8 * 8);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(k2Threads), k2LdsBytes, st, a);
-  return CT_OK;
-}
-
+// (A second, persistent 128 x 256 kernel lived here through round 4: faster stand-alone on wide weight gradients and at K >= 1024,
+// nothing inside the training steps — 17.2 / 15.2 / 32.6 vs 17.2 / 15.1 / 31.6 ms, profiles/r4_model_steps.txt — and dispatched
+// nowhere by default.  Out of the build since round 5: tools/dev/experiments/ct_pwgemm2.h.)
 template <bool AK, bool BK>
 static int pw_launch(const PwArgs& a, int blocks, hipStream_t st) {
   auto k = pw_gemm_kernel<AK, BK>;
@@ -804,12 +726,8 @@ int ct_pw_prep_weight(const float* w, float* wt, float* amax, int Co, int Ci, ct
 
 size_t ct_pw_gemm_workspace_bytes(int mode, int B, int Co, int Ci, int N) {
   PwPlan p;
-  if (pw2_plan(mode, B, Co, Ci, N, p)) return p.ws;
   return pw_plan(mode, B, Co, Ci, N, p) ? p.ws : 0;
 }
-
-// test hook: 0 = by measurement, 1 = the first kernel (pw_gemm_kernel) only, 2 = the second (pw2_gemm_kernel) wherever it applies
-void ct_debug_set_pw_kernel(int which) { g_pw_kernel = (which == 1 || which == 2) ? which : 0; }
 
 // per-row / per-column maxima of W [Co][Ci] for ct_pw_gemm_rs: rowmax f32[ceil(Ci/32)][Co], colmax f32[ceil(Co/32)][Ci];
 // wt f32[Ci][Co] = W^T or NULL
@@ -841,8 +759,7 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
                   int N, ct_stream_t s) {
   PwPlan p;
   if (!a || !b || !out) return CT_EINVAL;
-  const bool v2 = pw2_plan(mode, B, Co, Ci, N, p);
-  if (!v2 && !pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
+  if (!pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
   if ((amax_a && (n_amax_a < 1 || n_amax_a > kPwAmaxMax)) || (amax_b && (n_amax_b < 1 || n_amax_b > kPwAmaxMax))) return CT_EINVAL;
   // per-row maxima: of the A operand's rows in the arrangement the kernel reads it in (W: Co rows; W^T: Ci; g_y: Co) and, for
   // the weight gradient, of x's Ci rows; anything else about rows_* is an error, 0 = the maxima are partials of ONE maximum
@@ -869,21 +786,21 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
   int rc;
   if (mode == CT_PW_FWD) {            // A = W [Co][Ci] (k contiguous), B = x[b] [Ci][N] (columns contiguous)
     g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Ci * N; g.C = out; g.ldc = N; g.c_zs = (long long)Co * N;
-    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
+    rc = pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD) {   // A = W^T [Ci][Co] written to the workspace (k = co contiguous), B = g_y[b] [Co][N]
     hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, st, a, (float*)workspace, Co, Ci);
     CT_CHECK_LAUNCH();
     g.A = (const float*)workspace;
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
+    rc = pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD_T) {  // a IS W^T [Ci][Co] (ct_pw_prep_weight wrote it in the layer's forward)
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = v2 ? pw2_launch<false>(g, st) : pw_launch<true, false>(g, blocks, st);
+    rc = pw_launch<true, false>(g, blocks, st);
   } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous
     g.lda = N; g.a_bs = (long long)Co * N; g.ldb = N; g.b_bs = (long long)Ci * N; g.ldc = Ci;
     g.C = p.ws ? (float*)workspace : out;
     g.c_zs = (long long)Co * Ci;
-    rc = v2 ? pw2_launch<true>(g, st) : pw_launch<true, true>(g, blocks, st);
+    rc = pw_launch<true, true>(g, blocks, st);
   }
   if (rc != CT_OK) return rc;
   CT_CHECK_LAUNCH();

@@ -492,11 +492,6 @@ void ct_debug_set_gconv(unsigned flags);
 /* Test hook of the EMD auction: bit 0 = the per-batch update (GetMax, Assign, next list) on one workgroup per batch in every
  * iteration (default: several workgroups per batch while the batch has more than 1024 unassigned points). */
 void ct_debug_set_emd(unsigned flags);
-/* Test hook of the pointwise GEMMs: 0 / 1 = the first kernel (128x128 tiles, one tile per workgroup: the default — inside the
- * training steps nothing is gained by the other, csrc/ct_pwgemm.hip), 2 = the persistent 128x256 kernel wherever it applies
- * (faster stand-alone on wide weight gradients and at K >= 1024); env CLOUDCT_PW_KERNEL is read once for the initial value.
- * ct_pw_gemm_workspace_bytes follows the selection: set it before sizing a workspace. */
-void ct_debug_set_pw_kernel(int which);
 int ct_mhct_core_status(const void* workspace, size_t workspace_bytes, int B, int H, int C, int N, int dim, const int* W,
                         int* host_status, ct_stream_t s);
 

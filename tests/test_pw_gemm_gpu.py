@@ -8,17 +8,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["tile_per_workgroup", "persistent"])
-def _both_kernels(request):
-    """every test on both GEMM kernels (csrc/ct_pwgemm.hip: 128x128 tile per workgroup; csrc/ct_pwgemm2.h: persistent 128x256):
-    the library picks between them by shape, the hook forces one"""
-    from cloud_transformers_amd import _lib
-    lib = _lib.load()
-    lib.ct_debug_set_pw_kernel(request.param)
-    yield
-    lib.ct_debug_set_pw_kernel(0)
-
-
 def _needs_split16():
     from cloud_transformers_amd import ops
     if ops.PW_GEMM != "split16":
