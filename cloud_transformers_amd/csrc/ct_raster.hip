@@ -1739,7 +1739,14 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
                  ? ((a.C >> 2) >= 2 ? 2 : 1)          // tests: the group split on small shapes too
                  : sorted_groups((long long)a.B * a.H, a.C);
     const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
-    if (sg > 1 && (!ws || ws_bytes < (size_t)sg * gpos_n * 4)) sg = 1;       // no scratch for the partial key cotangents
+    // no scratch for the partial key cotangents: one workgroup per plane — which only fills the chip where there is a plane
+    // per CU (else the scatter form below, unless a test forces the sorted one)
+    bool sorted_here = true;
+    if (sg > 1 && (!ws || ws_bytes < (size_t)sg * gpos_n * 4)) {
+      sg = 1;
+      sorted_here = (long long)a.B * a.H >= 256 || (t_dbg_flags & CT_DEBUG_FORCE_SORTED);
+    }
+    if (sorted_here) {
     a.tile_in = grid;
     a.CC = 4; a.nchunks = a.C >> 2; a.ncg = sg; a.nseg = 1; a.Nrow = 0;
     a.g_pos = sg > 1 ? (float*)ws : g_pos;
@@ -1769,6 +1776,7 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
       CT_CHECK_LAUNCH();
     }
     return CT_OK;
+    }
   }
   HotPlan hp;
   int ncg = 1;

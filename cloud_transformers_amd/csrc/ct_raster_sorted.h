@@ -439,7 +439,11 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   auto request1 = [&](int grp, int cj) {          // one channel of group grp: the quad's g_out and the thread's conv cell
     const float4 t = ld_stream4(src0 + (size_t)(grp * 4 + cj) * N + ln0);
     gq[cj][0] = t.x; gq[cj][1] = t.y; gq[cj][2] = t.z; gq[cj][3] = t.w;
+#if CT_SORT_ABL == 5        // experiment: no conv loads (wrong g_keys): what do the 64 one-dword load instructions per group cost?
+    cvq[cj] = 1.0f;
+#else
     if constexpr (GATHER) cvq[cj] = ld_stream(cnv0 + (size_t)(grp * 4 + cj) * G + lc0);
+#endif
   };
   auto request = [&](int grp) {
 #pragma unroll
