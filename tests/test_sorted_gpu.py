@@ -242,8 +242,7 @@ def test_record_and_inside_sort_agree_bit_for_bit_and_with_the_scatter_form(flag
 
 
 @pytest.mark.parametrize("cfg", [(8, 16, 16, 4096, (16, 16)), (2, 16, 32, 2048, (32, 32)), (1, 3, 12, 1024, (16, 24))], ids=str)
-@pytest.mark.parametrize("tickets", [False, True], ids=["sum_parts", "folded"])
-def test_channel_groups_of_a_plane_on_several_workgroups(cfg, tickets, flags):
+def test_channel_groups_of_a_plane_on_several_workgroups(cfg, flags):
     """Few planes (the H16 blocks): a plane's channel groups are dealt to 2+ workgroups, each with its own sort, the partial
     g_keys added by the plane's last workgroup (tickets) or by a sum_parts launch — against the oracle, and bit for bit the
     same with and without the tickets (the partials are added in ascending order either way)."""
@@ -263,23 +262,22 @@ def test_channel_groups_of_a_plane_on_several_workgroups(cfg, tickets, flags):
     Wa = mod.int_array(list(W))
     nws = max(lib.ct_slice_bwd_workspace_bytes(B, H, C, N, dim, Wa), 2 * keys.numel() * 4)
     ws = torch.empty(nws, device="cuda", dtype=torch.uint8)
-    tk = torch.zeros(mod.TICKETS_BYTES // 4, device="cuda", dtype=torch.int32) if tickets else None
-    g_z, g_k = torch.full_like(zd, float("nan")), torch.full_like(kd, float("nan"))
-    flags(mod.DEBUG_FORCE_SORTED | mod.DEBUG_FORCE_HOT)
-    mod.check(lib.ct_slice_bwd_ps(_ptr(kd), _ptr(zd), None, 0, _ptr(cd), _ptr(g_z), _ptr(g_k), _ptr(ws), nws, _ptr(tk), None,
-                                  B, H, C, N, dim, Wa, _stream()), "ct_slice_bwd_ps")
-    tag = lib.ct_debug_last_launch().decode()
-    flags(0)
-    assert tag == ("slice_bwd_sorted_groups+folded" if tickets else "slice_bwd_sorted_groups"), tag
-    if tickets:
-        assert int(tk.abs().sum()) == 0, "the tickets were not handed back as zeros"
-    assert per_channel_err(g_z, zz.grad, H * C) <= 1e-4
-    assert relerr(g_k, k.grad) <= 1e-4
-    test_channel_groups_of_a_plane_on_several_workgroups.seen = getattr(test_channel_groups_of_a_plane_on_several_workgroups, "seen", {})
-    other = test_channel_groups_of_a_plane_on_several_workgroups.seen.get(cfg)
-    if other is not None:
-        assert torch.equal(other[0], g_z) and torch.equal(other[1], g_k), "tickets / sum_parts differ"
-    test_channel_groups_of_a_plane_on_several_workgroups.seen[cfg] = (g_z, g_k)
+    outs = {}
+    for tickets in (False, True):
+        tk = torch.zeros(mod.TICKETS_BYTES // 4, device="cuda", dtype=torch.int32) if tickets else None
+        g_z, g_k = torch.full_like(zd, float("nan")), torch.full_like(kd, float("nan"))
+        flags(mod.DEBUG_FORCE_SORTED | mod.DEBUG_FORCE_HOT)
+        mod.check(lib.ct_slice_bwd_ps(_ptr(kd), _ptr(zd), None, 0, _ptr(cd), _ptr(g_z), _ptr(g_k), _ptr(ws), nws, _ptr(tk), None,
+                                      B, H, C, N, dim, Wa, _stream()), "ct_slice_bwd_ps")
+        tag = lib.ct_debug_last_launch().decode()
+        flags(0)
+        assert tag == ("slice_bwd_sorted_groups+folded" if tickets else "slice_bwd_sorted_groups"), tag
+        if tickets:
+            assert int(tk.abs().sum()) == 0, "the tickets were not handed back as zeros"
+        assert per_channel_err(g_z, zz.grad, H * C) <= 1e-4
+        assert relerr(g_k, k.grad) <= 1e-4
+        outs[tickets] = (g_z, g_k)
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]), "tickets / sum_parts differ"
 
 
 def test_sorted_slice_backward_with_non_finite_channels(flags):
