@@ -299,6 +299,13 @@ def run_op(args):
     torch.cuda.synchronize()
     barrier(dist)
     dt = time.perf_counter() - t0
+    # every rank's own time beside the maximum the value is made of: a rank whose clouds hold an exact tie runs its
+    # Splat(max) backward 8-15 us longer (profiles/r5_bench_seeds.txt), and the slowest rank sets the step
+    rank_ms = [dt / args.steps * 1e3]
+    if dist is not None:
+        gathered = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([rank_ms[0]], device="cuda", dtype=torch.float64))
+        rank_ms = [float(g.item()) for g in gathered]
     dt = max_over_ranks(dist, dt)
     ms = dt / args.steps * 1e3
 
@@ -353,6 +360,7 @@ def run_op(args):
             # exact ties of the Splat(max) maxima in the clouds of ALL ranks (each costs its plane's workgroup a redo: the
             # step of a rank with ties runs a few per cent longer, and the value is the max over ranks)
             "ties_seen": ties,
+            "rank_ms_per_step": rank_ms,
             "kernels": {p: step.KERNEL_OF.get(t, t) for p, t in tags.items()},
             "step_roofline": {"algorithmic_bytes_per_step": alg["total"],
                               "achieved_GBs": alg["total"] / (ms * 1e-3) / 1e9,
