@@ -179,8 +179,14 @@ __device__ __forceinline__ SortPtrs sort_ptrs(unsigned char* lds, const SortLds&
 
 // record != null: the items, ranks and header are also written there (the weights: by the caller).  P.ab null: the weights are
 // not placed (the caller does it, e.g. into the histograms' space once they are dead: on return).  nC: channel-maximum words in front of K that are cleared here.
+struct SortNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_count: called once the keys have been used (the counting adds are issued) — where a caller puts its first bulk loads,
+// so that they do not compete with the keys the whole sort waits for
+template <typename F = SortNoHook>
 __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys& PK, int G, int W1, const SortPtrs& P, int nC,
-                                           SortedPlane& S, unsigned char* record = nullptr) {
+                                           SortedPlane& S, unsigned char* record = nullptr, F after_count = F()) {
   const int tid = threadIdx.x, N = a.N, wave = tid >> 6;
   unsigned* const hist = P.hist;
   float2* const AB = P.ab;
@@ -212,6 +218,8 @@ __device__ __forceinline__ void sort_plane(const RasterArgs& a, const PlaneKeys&
       r[i] = (atomicAdd(&hist[wave * G2 + (PK.base[i] >> 1)], 1u << sh) >> sh) & 0xffffu;
     }
   }
+  asm volatile("" ::: "memory");
+  after_count();
   __syncthreads();
   CT_STAMP(2);
   // per PAIR of cells (one histogram word): the waves' counts -> their exclusive prefix (in place) and the cells' totals; then the
@@ -459,12 +467,20 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   if constexpr (!PRESORTED) load_plane_keys(a, g, W1, bh, PK);
   SortedPlane S;
   if constexpr (PRESORTED) load_sorted_plane(a, a.sorted + bh * a.sorted_stride, lds_raw, L, S);
-  request(cgi);
+#ifndef CT_SORT_LATE_REQUEST
+#define CT_SORT_LATE_REQUEST 1
+#endif
+  if (PRESORTED || !CT_SORT_LATE_REQUEST) request(cgi);
   float pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * N + n0 + i) : 1.0f;
 
-  if constexpr (!PRESORTED) sort_plane(a, PK, G, W1, sort_ptrs(lds_raw, L, C), C, S);
+  // (the first group's rows are requested behind the keys' use: 28 MB asked for at once by all CUs made every plane wait ~2 k
+  //  cycles longer for its 32 KiB of keys)
+  if constexpr (!PRESORTED) {
+    if (CT_SORT_LATE_REQUEST) sort_plane(a, PK, G, W1, sort_ptrs(lds_raw, L, C), C, S, nullptr, [&]() { request(cgi); });
+    else sort_plane(a, PK, G, W1, sort_ptrs(lds_raw, L, C), C, S);
+  }
   else __syncthreads();            // K (and the cleared channel maxima) for everybody
   for (int i = tid; i < G; i += kSortThreads) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
   if (tid == 0) Sg[N] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // what the slots beyond an item's entries read
