@@ -565,7 +565,13 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
       for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < kItemLen; ++j) {
-        if constexpr (spread) request1(grp + ncg, j);
+#ifndef CT_SORT_SPREAD
+#define CT_SORT_SPREAD 1      // channels of the next group requested per entry of the first item (2: two per entry, over the first two)
+#endif
+        if constexpr (spread) {
+          if (CT_SORT_SPREAD == 1) request1(grp + ncg, j);
+          else if (j < 2) { request1(grp + ncg, 2 * j); request1(grp + ncg, 2 * j + 1); }
+        }
         const float4 x = xn;
         const float2 wf = wn;
         if (j + 1 < kItemLen) {
