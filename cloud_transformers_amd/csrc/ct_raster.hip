@@ -1546,8 +1546,8 @@ struct HotPlan {
 
 // channels per chunk: a multiple of 4 such that `fixed + CC * per_ch` bytes fit half a CU's LDS (else a whole CU's)
 // LDS of the Splat(max) backward kernels behind their tiles: four counters and, per four-channel group of the plane (<= 64), its
-// non-zero cells and its matches (ct_raster_hot.h: kTieGroups)
-constexpr size_t kSplatBwdFixed = 16 + 2 * 64 * 4;
+// non-zero cells, its matches and the xor of their cells (ct_raster_hot.h: kTieGroups), and the words of the single-tie repair
+constexpr size_t kSplatBwdFixed = 16 + 3 * 64 * 4 + 32;
 
 bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budget = kHalfCuLdsBytes) {
   if ((C & 3) != 0) return false;

@@ -593,6 +593,16 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 // never NaN (a NaN product does not beat the zero floor in the forward), and a product equals this pattern only if
 // a feature is that very NaN.
 constexpr unsigned kNoMatch = 0x7FFFFFFFu;
+#ifndef CT_SPLAT_ZG_TUPLES
+#define CT_SPLAT_ZG_TUPLES 0      // measured: the reads issued together and pinned as tuples are SLOWER (profiles/r5_splat_bwd_loop.txt)
+#endif
+#ifndef CT_TIE_FIX
+// 1: the optimistic pass also sums the cells of its matches, and a group with ONE surplus match is repaired at that cell alone
+// (splat_bwd_fix_one_tie) instead of being redone.  Measured on the headline (profiles/r5_splat_bwd_loop.txt): tied workloads
+// 83 -> 78 us, tie-free ones 68.5 -> 72.5: the five multiply-adds per (point, channel pair) cost more than the redo they save
+// on one workload in three.  Off in the product; tests/test_tie_rule_gpu.py passes in both builds.
+#define CT_TIE_FIX 0
+#endif
 
 // rows of the point-sized tensors as one workgroup sees them: Nr floats long, the workgroup's points start at `so`
 // (point segments: RasterArgs::nseg; Nr = N, so = 0 without them)
@@ -605,6 +615,30 @@ struct PtRows {
 // groups of four channels a plane's tie test distinguishes (s_cnt[4 + i]: non-zero cells of group i, s_cnt[4 + kTieGroups + i]:
 // its matches): a plane with C > 4 * kTieGroups channels only has the plane-wide test
 constexpr int kTieGroups = 64;
+constexpr int kTieFixWords = 8;      // behind the 3 * kTieGroups words: splat_bwd_fix_one_tie's winners and counts
+
+// s_cnt[4 + 2 * kTieGroups + i]: the sum of `cell` over the group's matches MINUS the sum over its non-zero (cell, channel) pairs,
+// modulo 2^13.  Every non-zero pair has at least one match, so with exactly one surplus match the word IS the tied cell, and
+// the plane's workgroup repairs that cell alone (splat_bwd_fix_one_tie).  Per thread the sums travel as four 16-bit fields
+// (the groups of a chunk), each term reduced to 13 bits before it is added: no carry crosses a field.
+// a * b + c in ONE instruction (24-bit signed factors; what the compiler makes of __mul24 and an add is a shift-and-extend
+// sequence with temporaries, which this kernel has no registers for)
+__device__ __forceinline__ int mad24_acc(int a, int b, int c) {
+  asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(c) : "v"(a), "s"(b));
+  return c;
+}
+__device__ __forceinline__ int mad24_acc_v(int a, int b, int c) {
+  asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+constexpr unsigned kTieCellMask = 0x1fffu;
+constexpr unsigned long long kTieCellFields = 0x1fff1fff1fff1fffull;
+__device__ __forceinline__ void plane_sum_cells(int* words, unsigned long long packed, int ngroups, int sign) {
+  for (int f = 0; f < ngroups; ++f) {
+    const int v = wave_sum_i32((int)((packed >> (16 * f)) & 0xffffu));
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(words + f, sign * v);
+  }
+}
 
 // DELTA (with CLAIMS): the redo of ONE four-channel group after an optimistic pass — its g_feat rows are rewritten with the
 // single-winner award, and gs receives only the difference to what the optimistic pass had added for these channels (the
@@ -612,7 +646,8 @@ constexpr int kTieGroups = 64;
 template <bool HAS_PAD, bool CLAIMS, int WT, bool DELTA = false>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
                                                int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
-                                               float (&gs)[4][2], int& nm, unsigned* nmp = nullptr) {
+                                               float (&gs)[4][2], int& nm, unsigned* nmp = nullptr,
+                                               unsigned long long* xsp = nullptr) {
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
@@ -622,6 +657,7 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
   // (Requesting the next step's rows before this step is processed was measured: the 16 extra registers spill, 73 -> 102 us.)
   for (int cg0 = 0; cg0 < cc; cg0 += 4) {
     const int nm_before = nm;
+    int xs = 0;              // sum of the cells of this group's matches (see plane_sum_cells)
     float fv[4][4];          // [channel][point]
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
@@ -640,14 +676,20 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
         float4* Zp = Zc + (size_t)pr * G + p.base;
         const float xa = HAS_PAD ? fv[2 * pr][i] * pv[i] : fv[2 * pr][i];
         const float xb = HAS_PAD ? fv[2 * pr + 1][i] * pv[i] : fv[2 * pr + 1][i];
-        float4 zg[4];
+        ct_f4 zg[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          zg[v] = Zp[off[v]];
-          // (whole 16-byte reads: keeps the compiler from splitting them into a narrow read plus conditional ones)
-          asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
-        }
+        for (int v = 0; v < 4; ++v) zg[v] = *(const ct_f4*)(Zp + off[v]);
+        // Whole 16-byte reads, pinned as register tuples and all four at once: left alone the compiler splits them into a narrow
+        // read plus conditional ones; pinned per component (rounds 2-4) it waited for every read by itself and moved three of
+        // the four words to other registers behind it — a tenth of the instructions of a loop that is bound by their issue.
+#if CT_SPLAT_ZG_TUPLES
+        asm volatile("" : "+v"(zg[0]), "+v"(zg[1]), "+v"(zg[2]), "+v"(zg[3]));
+#else
+#pragma unroll
+        for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
+#endif
         float gfa = 0.0f, gfb = 0.0f;
+        int cm = 0;              // (CT_TIE_FIX) matches of this point in this pair of channels
         if (!CLAIMS) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -655,14 +697,28 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
             // staged as kNoMatch, so bit-equality alone is the winner test.
             const unsigned ba = __float_as_uint(xa * p.cw[v]), bb = __float_as_uint(xb * p.cw[v]);
             const bool ma = ba == __float_as_uint(zg[v].x), mb = bb == __float_as_uint(zg[v].y);
+#if CT_TIE_FIX
+            cm += (int)ma;
+            cm += (int)mb;
+            asm volatile("" : "+v"(cm));
+            // The sum over the matches of their cell = base + off[v] comes from the running count of this (point, pair) alone —
+            // no mask is kept, nothing is selected: sum_v off[v] * (c_(v+1) - c_v) telescopes to c_(v+1) * (off[v] - off[v+1])
+            // [+ c_4 * off[3]], one multiply-add each; the base term follows behind the corners.
+            xs = mad24_acc(cm, v < 3 ? off[v] - off[v + 1] : off[3], xs);
+#else
             nm += (int)ma;       // (add-with-carry of the compare mask: one instruction each ...
             nm += (int)mb;
             asm volatile("" : "+v"(nm));      //  ... issued here: otherwise all 32 masks of a point are kept for a final sum)
+#endif
             const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
             gfa = __builtin_fmaf(ga, p.cw[v], gfa);
             gfb = __builtin_fmaf(gb, p.cw[v], gfb);
             gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
           }
+#if CT_TIE_FIX
+          nm += cm;
+          xs = mad24_acc_v(cm, p.base, xs);
+#endif
         } else {
           // claims: a cell's z word is won by the first matching contribution that flips its sign bit (z > 0 in every non-empty
           // cell: the zero floor of the forward), so a later contribution still sees WHAT the maximum was and knows that it
@@ -716,8 +772,129 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
       st_part4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]), R.wt);
     // this group's matches into the thread's packed per-chunk counter (8 bits per four-channel group of the chunk: <= 4 groups,
     // <= 2 quads x 64 products per thread and group); LDS adds per (quad, group) — even one per wave — cost 3.5 us of 68 on the headline
-    if (!CLAIMS && nmp != nullptr) *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
+    if (!CLAIMS && nmp != nullptr) {
+      *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
+      if (CT_TIE_FIX) *xsp += (unsigned long long)((unsigned)xs & kTieCellMask) << (16 * ((cg0 >> 2) & 3));
+    }
   }
+}
+
+// The repair of ONE exact tie (one surplus match in the four-channel group at `cabs`, all of it in cell `t`: see plane_sum_cells)
+// behind an optimistic pass, by the plane's workgroup with its points in registers (QPT > 0).  Only the points with a corner
+// in `t` do anything: they test their four products against the cell's maxima; per channel the lowest point index keeps the
+// award, every other match gives it back — its g_feat element recomputed without that corner, its key cotangent corrected by
+// the negated award exactly as splat_bwd_quad<.., DELTA> would.  Two dependent trips to memory for a handful of lanes, where the
+// redo of the group walks every point of the plane again (headline: +10..14 us -> see DESIGN 4.1).  Returns false (block-uniform,
+// nothing written) if the cell does not hold what the counters promised; the caller then redoes the group.
+template <bool HAS_PAD, int WT, int QPT>
+__device__ __forceinline__ bool splat_bwd_fix_one_tie(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int cabs, int t,
+                                                      const PtRows& R, float (&gs)[QPT ? QPT : 1][4][2], int* s_fix) {
+  const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
+  const int off[4] = {0, W1, 1, W1 + 1};
+  const int tid = threadIdx.x, nq = a.N >> 2;
+  __syncthreads();
+  if (tid < kTieFixWords) s_fix[tid] = tid < 4 ? 0x7fffffff : 0;
+  __syncthreads();
+  const float* zrow = a.tile_in + (bh * a.C + cabs) * (size_t)G;
+  const float* grow = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
+  unsigned zt[4];
+  int expect = 1;
+#pragma unroll
+  for (int cj = 0; cj < 4; ++cj) {
+    zt[cj] = __float_as_uint(zrow[(size_t)cj * G + t]);
+    expect += zt[cj] != 0u;
+  }
+  const float* keyx = a.pos.keys + (bh * 2 + 0) * R.Nr + R.so;
+  const float* keyy = a.pos.keys + (bh * 2 + 1) * R.Nr + R.so;
+  unsigned hit = 0u;          // per point slot (u, i): 4 bits, the channels of the group whose maximum this point's product equals
+#pragma unroll
+  for (int u = 0; u < (QPT ? QPT : 1); ++u) {
+    const int q = tid + u * (int)blockDim.x;
+    if (q >= nq) continue;
+    const int n0 = q << 2;
+    const float4 tx = *(const float4*)(keyx + n0);
+    const float4 ty = *(const float4*)(keyy + n0);
+    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pt2 p;
+      pt2_from_keys(kx[i], ky[i], g, W1, p);
+      const int d = t - p.base;
+      const int v = d == 0 ? 0 : d == W1 ? 1 : d == 1 ? 2 : d == W1 + 1 ? 3 : -1;
+      if (v < 0) continue;
+      const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
+      const float w = v == 0 ? p.cw[0] : v == 1 ? p.cw[1] : v == 2 ? p.cw[2] : p.cw[3];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i];
+        const float x = HAS_PAD ? f * pv : f;
+        if (zt[cj] != 0u && __float_as_uint(x * w) == zt[cj]) {
+          hit |= 1u << (4 * (4 * u + i) + cj);
+          atomicMin(&s_fix[cj], n0 + i);
+          atomicAdd(&s_fix[4], 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (s_fix[4] != expect) return false;          // block-uniform
+  if (hit != 0u) {
+#pragma unroll
+    for (int u = 0; u < (QPT ? QPT : 1); ++u) {
+      if (((hit >> (16 * u)) & 0xffffu) == 0u) continue;
+      const int n0 = (tid + u * (int)blockDim.x) << 2;
+      const float4 tx = *(const float4*)(keyx + n0);
+      const float4 ty = *(const float4*)(keyy + n0);
+      const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned m = (hit >> (4 * (4 * u + i))) & 0xfu;
+        unsigned lost = 0u;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+          if (((m >> cj) & 1u) && s_fix[cj] != n0 + i) lost |= 1u << cj;
+        if (lost == 0u) continue;
+        Pt2 p;
+        pt2_from_keys(kx[i], ky[i], g, W1, p);
+        const int vt = t - p.base == 0 ? 0 : t - p.base == W1 ? 1 : t - p.base == 1 ? 2 : 3;
+        const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
+        float x[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i];
+          x[cj] = HAS_PAD ? f * pv : f;
+        }
+        // the key cotangent: the lost awards, negated, through the corner-weight gradient (the arithmetic of DELTA)
+        float gwt = 0.0f;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const float da = ((lost >> (2 * pr)) & 1u) ? -grow[(size_t)(2 * pr) * G + t] : 0.0f;
+          const float db = ((lost >> (2 * pr + 1)) & 1u) ? -grow[(size_t)(2 * pr + 1) * G + t] : 0.0f;
+          gwt = __builtin_fmaf(db, x[2 * pr + 1], __builtin_fmaf(da, x[2 * pr], gwt));
+        }
+        float gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gw[v] = v == vt ? gwt : 0.0f;
+        gs[u][i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[u][i][0]));
+        gs[u][i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[u][i][1]));
+        // g_feat of the lost channels: the point's other corners keep what they matched
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          if (!((lost >> cj) & 1u)) continue;
+          float gf = 0.0f;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const unsigned zc = __float_as_uint(zrow[(size_t)cj * G + p.base + off[v]]);
+            const float gc = grow[(size_t)cj * G + p.base + off[v]];
+            const bool won = v != vt && zc != 0u && __float_as_uint(x[cj] * p.cw[v]) == zc;
+            gf = __builtin_fmaf(won ? gc : 0.0f, p.cw[v], gf);
+          }
+          a.dst[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i] = HAS_PAD ? gf * pv : gf;
+        }
+      }
+    }
+  }
+  return true;
 }
 
 // one pass over the workgroup's points (N of them, rows R) and its chunks; cgi: chunk group (see slice_bwd_fused_kernel)
@@ -738,7 +915,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
     const float* gin = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
     __syncthreads();                              // readers of the previous chunk (or pass) are done
-    unsigned long long nzp = 0ull;
+    unsigned long long nzp = 0ull, xzp = 0ull;
     for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
       const int cp = t / G, cell = t - cp * G;
       const size_t o = (size_t)(cp * 2) * G + cell;
@@ -751,6 +928,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int nzt = (z0 != 0u) + (z1 != 0u);
         nz += nzt;
         nzp += (unsigned long long)(unsigned)nzt << (16 * ((cp >> 1) & 3));      // per four-channel group of the chunk (packed: see nmp)
+        if (CT_TIE_FIX) xzp = (xzp + ((unsigned long long)(unsigned)(nzt * cell) << (16 * ((cp >> 1) & 3)))) & kTieCellFields;
       }
     }
     if (!CLAIMS && grp != nullptr) {
@@ -759,9 +937,11 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nzp >> (16 * f)) & 0xffffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + (c0 >> 2) + f, v);
       }
+      if (CT_TIE_FIX) plane_sum_cells(grp + 2 * kTieGroups + (c0 >> 2), xzp, cc >> 2, -1);
     }
     __syncthreads();
     unsigned nmp = 0u;
+    unsigned long long xmp = 0ull;
     unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
     if constexpr (QPT > 0) {
 #pragma unroll
@@ -772,7 +952,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float4 tx = *(const float4*)(keyx + n0);
           const float4 ty = *(const float4*)(keyy + n0);
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
-          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm);
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm, &xmp);
         }
       }
     } else {
@@ -784,7 +964,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         float gs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
-        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm);
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm, &xmp);
         // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns these
         // addresses); the first chunk starts from the incoming cotangent where there is one (a.gpos_add)
         float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
@@ -817,6 +997,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nmp >> (8 * f)) & 0xffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
+      if (CT_TIE_FIX) plane_sum_cells(grp + 2 * kTieGroups + (c0 >> 2), xmp, cc >> 2, 1);
     }
   }
   if (!CLAIMS) {
@@ -869,7 +1050,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
   // corrected by the difference.
   int* const grp = (QPT > 0 && QPT <= 2 && nsg == 1 && a.C <= 4 * kTieGroups && a.CC <= 16) ? s_cnt + 4 : nullptr;
   if (grp != nullptr) {
-    for (int i = threadIdx.x; i < 2 * kTieGroups; i += blockDim.x) grp[i] = 0;
+    for (int i = threadIdx.x; i < 3 * kTieGroups; i += blockDim.x) grp[i] = 0;
   }
 #ifdef CT_EXP_CLAIMS_ONLY       // experiment: no optimistic pass, every plane with single-winner claims (the cost of a tie-proof single pass)
   tie = nsg == 1;
@@ -885,6 +1066,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
         if (grp[gi] == grp[kTieGroups + gi]) continue;           // block-uniform (LDS words, written before the pass's last barrier)
         const int cabs = gi << 2;                                 // the group's first channel
         if ((cabs / a.CC) % a.ncg != wg.cgi) continue;            // (another chunk group's channels)
+        const int tcell = (int)((unsigned)grp[2 * kTieGroups + gi] & kTieCellMask);
+        if (CT_TIE_FIX && grp[kTieGroups + gi] - grp[gi] == 1 && G <= (int)kTieCellMask + 1 && tcell < G &&
+            splat_bwd_fix_one_tie<HAS_PAD, WT, QPT>(a, g, bh, b, cabs, tcell, R, gs, grp + 3 * kTieGroups))
+          continue;
         const float* zin = a.tile_in + (bh * a.C + cabs) * (size_t)G;
         const float* gin = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
         __syncthreads();

@@ -422,12 +422,16 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
         float gfa = 0.0f, gfb = 0.0f;
 #pragma unroll
         for (int hv = 0; hv < 2; ++hv) {
-          float4 zg[4];
+          ct_f4 zg[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            zg[v] = Zp[off[hv * 4 + v]];
-            asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
-          }
+          for (int v = 0; v < 4; ++v) zg[v] = *(const ct_f4*)(Zp + off[hv * 4 + v]);
+          // (whole reads, pinned as tuples and together: see splat_bwd_quad)
+#if CT_SPLAT_ZG_TUPLES
+          asm volatile("" : "+v"(zg[0]), "+v"(zg[1]), "+v"(zg[2]), "+v"(zg[3]));
+#else
+#pragma unroll
+          for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
+#endif
           if (!CLAIMS) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {

@@ -114,3 +114,80 @@ def test_a_zero_valued_candidate_does_not_win_a_cell_at_the_zero_floor(flag):
         lib.ct_debug_set_flags(0)
     assert float((kd.grad.cpu() - k.grad).abs().max()) <= 1e-5 * float(k.grad.abs().max())
     assert float((fd.grad.cpu() - f.grad).abs().max()) <= 1e-5 * float(f.grad.abs().max())
+
+
+def _node_key(W):
+    """a float32 key whose scaled coordinate (key + 1) * ((W - 1) / 2), rounded as ct_axis rounds it, is an exact integer j >= 1:
+    the point then sits on a grid node and three of its four corner weights are exactly 0"""
+    import numpy as np
+    hw = np.float32((W - 1) / 2.0)
+    for j in range(2, W - 2):
+        k = np.float32(2.0 * j / (W - 1) - 1.0)
+        for _ in range(8):
+            s = np.float32(np.float32(k + np.float32(1.0)) * hw)
+            if float(s) == float(j):
+                return float(k), j
+            k = np.nextafter(k, np.float32(1.0 if s < j else -1.0), dtype=np.float32)
+    raise AssertionError("no node key for W = %d" % W)
+
+
+@pytest.mark.parametrize("shape", [(32, 16, 4096, 2), (32, 16, 2048, 1), (16, 16, 4096, 1), (20, 8, 2048, 1)],
+                         ids=["32x32_two_quads", "32x32_one_quad", "16x16", "generic_width"])
+def test_a_single_tie_in_one_group_of_one_plane(shape):
+    """One surplus match in one four-channel group of one plane (what a random B8 H64 workload holds about one time in three).
+    The hot 2D kernel redoes that group alone (splat_bwd_quad<.., DELTA>) or, built with -DCT_TIE_FIX=1, finds the cell from its
+    cell sums and repairs it alone (splat_bwd_fix_one_tie: the lower point index keeps the award).  Two points on the same grid
+    node (one non-zero corner weight), equal and dominant in ONE channel: exactly one tie.  Checked for either build: one of the
+    two keeps the cell's cotangent, the other gets exactly nothing from it (features and keys), and every element outside the
+    pair equals the same launch without the second point's feature (no tie at all)."""
+    from cloud_transformers_amd import ops
+    mod, lib = _lib()
+    W, C, N, _ = shape
+    B, H, dim = 4, 64, 2                     # a plane per workgroup: the register form with the per-group counters
+    g = torch.Generator().manual_seed(7)
+    k_node, j = _node_key(W)
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    feat = torch.randn(B, H * C, N, generator=g)
+    gz = torch.randn(B, H * C, W, W, generator=g)
+    p0, p1 = 37, N - 5                       # different threads, different quads
+    b0, h0, c0 = 1, 3, C - 2                 # (the last four-channel group of its chunk)
+    keys[b0, h0 * dim:(h0 + 1) * dim, p0] = k_node
+    keys[b0, h0 * dim:(h0 + 1) * dim, p1] = k_node
+    feat[b0, h0 * C:(h0 + 1) * C, p1] = -1.0              # never above the zero floor ...
+    feat[b0, h0 * C + c0, p0] = 100.0
+    feat_untied = feat.clone()
+    feat[b0, h0 * C + c0, p1] = 100.0                      # ... except here: bit-equal to p0's product
+    lc, idx = R.positions(keys, [W, W], H, dim)
+    assert sorted(lc[b0, h0, :, p0].tolist())[:3] == [0.0, 0.0, 0.0]
+    cell = int(idx[b0, h0, :, p0][lc[b0, h0, :, p0] > 0][0])
+    assert cell == j * W + j
+
+    def run(f):
+        kd, fd = keys.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
+        lib.ct_debug_set_flags(mod.DEBUG_FORCE_HOT)
+        try:
+            ops.splat_keys(kd, fd, None, [W, W], H, dim, "max").backward(gz.cuda())
+            tag = lib.ct_debug_last_launch().decode()
+        finally:
+            lib.ct_debug_set_flags(0)
+        assert "hot" in tag, tag
+        return kd.grad.cpu(), fd.grad.cpu()
+
+    gk, gf = run(feat)
+    gk0, gf0 = run(feat_untied)
+    award = float(gz[b0, h0 * C + c0].reshape(-1)[cell])
+    a0, a1 = float(gf[b0, h0 * C + c0, p0]), float(gf[b0, h0 * C + c0, p1])
+    assert (a0 == pytest.approx(award, rel=1e-6) and a1 == 0.0) or (a1 == pytest.approx(award, rel=1e-6) and a0 == 0.0), (a0, a1, award)
+    if a1 == 0.0:          # p0 kept it: p1 (whose other features never pass the zero floor) ends with exactly nothing
+        assert float(gf[b0, h0 * C:(h0 + 1) * C, p1].abs().max()) == 0.0
+        assert float(gk[b0, h0 * dim:(h0 + 1) * dim, p1].abs().max()) == 0.0
+        assert torch.equal(gf, gf0)
+        assert torch.equal(gk, gk0)
+    else:                  # p1 kept it: the pair's rows differ from the untied launch, nothing else does
+        keep = torch.ones(N, dtype=torch.bool)
+        keep[p0] = keep[p1] = False
+        assert torch.equal(gf[:, :, keep], gf0[:, :, keep])
+        assert torch.equal(gk[:, :, keep], gk0[:, :, keep])
+        lost = float(gk0[b0, h0 * dim:(h0 + 1) * dim, p0].abs().max())
+        assert float((gk[b0, h0 * dim:(h0 + 1) * dim, p0] + gk[b0, h0 * dim:(h0 + 1) * dim, p1]
+                      - gk0[b0, h0 * dim:(h0 + 1) * dim, p0]).abs().max()) <= 1e-5 * lost
