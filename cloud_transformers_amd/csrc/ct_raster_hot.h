@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 // a feature is that very NaN.
 constexpr unsigned kNoMatch = 0x7FFFFFFFu;
 #ifndef CT_SPLAT_ZG_TUPLES
-#define CT_SPLAT_ZG_TUPLES 0      // measured: the reads issued together and pinned as tuples are SLOWER (profiles/r5_splat_bwd_loop.txt)
+#define CT_SPLAT_ZG_TUPLES 0      // 1: the four reads together, pinned as tuples; 2: tuples, one at a time — both measured SLOWER (profiles/r5_splat_bwd_loop.txt)
 #endif
 #ifndef CT_TIE_FIX
 // 1: the optimistic pass also sums the cells of its matches, and a group with ONE surplus match is repaired at that cell alone
@@ -678,13 +678,18 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
         const float xb = HAS_PAD ? fv[2 * pr + 1][i] * pv[i] : fv[2 * pr + 1][i];
         ct_f4 zg[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) zg[v] = *(const ct_f4*)(Zp + off[v]);
+        for (int v = 0; v < 4; ++v) {
+          zg[v] = *(const ct_f4*)(Zp + off[v]);
+#if CT_SPLAT_ZG_TUPLES == 2
+          asm volatile("" : "+v"(zg[v]));
+#endif
+        }
         // Whole 16-byte reads, pinned as register tuples and all four at once: left alone the compiler splits them into a narrow
         // read plus conditional ones; pinned per component (rounds 2-4) it waited for every read by itself and moved three of
         // the four words to other registers behind it — a tenth of the instructions of a loop that is bound by their issue.
-#if CT_SPLAT_ZG_TUPLES
+#if CT_SPLAT_ZG_TUPLES == 1
         asm volatile("" : "+v"(zg[0]), "+v"(zg[1]), "+v"(zg[2]), "+v"(zg[3]));
-#else
+#elif CT_SPLAT_ZG_TUPLES == 0
 #pragma unroll
         for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
 #endif
