@@ -1546,8 +1546,9 @@ struct HotPlan {
 
 // channels per chunk: a multiple of 4 such that `fixed + CC * per_ch` bytes fit half a CU's LDS (else a whole CU's)
 // LDS of the Splat(max) backward kernels behind their tiles: four counters and, per four-channel group of the plane (<= 64), its
-// non-zero cells, its matches and the xor of their cells (ct_raster_hot.h: kTieGroups), and the words of the single-tie repair
-constexpr size_t kSplatBwdFixed = 16 + 3 * 64 * 4 + 32;
+// non-zero cells and its matches, per chunk the sum of the awarded cotangents' bit patterns (ct_raster_hot.h: kTieGroups), and the
+// words of the single-tie repair and of its search
+constexpr size_t kSplatBwdFixed = 16 + 3 * 64 * 4 + 64 + (CT_SPLAT_PARK ? 7 * 512 * 4 : 0);      // (+ the parking rows of a two-quad thread's sums)
 
 bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budget = kHalfCuLdsBytes) {
   if ((C & 3) != 0) return false;
@@ -2587,6 +2588,14 @@ int slice_bwd_impl(PosSrc pos, const float* grid, const void* pad, int pad_dtype
 extern "C" {
 
 int ct_abi_version(void) { return CT_ABI_VERSION; }
+#ifdef CT_TIE_DEBUG
+// experiments only (-DCT_TIE_DEBUG): what the Splat(max) backward's tie paths did since the last call (read and reset)
+int ct_debug_tie_counters(unsigned* dst) {
+  static const unsigned zero[16] = {};
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tie_dbg), sizeof(zero)) != hipSuccess) return CT_ELAUNCH;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tie_dbg), zero, sizeof(zero)) == hipSuccess ? CT_OK : CT_ELAUNCH;
+}
+#endif
 #ifdef CT_SORT_STAMPS
 // experiments only (tools/dev/build_raster_exp.sh ... -DCT_SORT_STAMPS): the phase stamps of the sorted kernels' first workgroup
 int ct_debug_sorted_stamps(unsigned long long* dst) {

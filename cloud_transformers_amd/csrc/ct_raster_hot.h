@@ -596,12 +596,15 @@ constexpr unsigned kNoMatch = 0x7FFFFFFFu;
 #ifndef CT_SPLAT_ZG_TUPLES
 #define CT_SPLAT_ZG_TUPLES 0      // 1: the four reads together, pinned as tuples; 2: tuples, one at a time — both measured SLOWER (profiles/r5_splat_bwd_loop.txt)
 #endif
+#ifndef CT_SPLAT_PARK
+#define CT_SPLAT_PARK 0      // measured: +1.5 us, and it is not the register count that the loop trips over (profiles/r5_splat_bwd_loop.txt)
+#endif
 #ifndef CT_TIE_FIX
-// 1: the optimistic pass also sums the cells of its matches, and a group with ONE surplus match is repaired at that cell alone
-// (splat_bwd_fix_one_tie) instead of being redone.  Measured on the headline (profiles/r5_splat_bwd_loop.txt): tied workloads
-// 83 -> 78 us, tie-free ones 68.5 -> 72.5: the five multiply-adds per (point, channel pair) cost more than the redo they save
-// on one workload in three.  Off in the product; tests/test_tie_rule_gpu.py passes in both builds.
-#define CT_TIE_FIX 0
+// 1: the optimistic pass also sums the BIT PATTERNS of the cotangents it awards (one three-operand add per corner and channel
+// pair), the staging pass those of the non-zero cells; with ONE surplus match in a chunk the difference is the tied cell's
+// cotangent, the cell is found by value, and that cell alone is repaired (splat_bwd_fix_one_tie) instead of its group being
+// redone.  0: every tied group is redone.  profiles/r5_splat_bwd_loop.txt has both, and the cell-sum form that lost.
+#define CT_TIE_FIX 1
 #endif
 
 // rows of the point-sized tensors as one workgroup sees them: Nr floats long, the workgroup's points start at `so`
@@ -621,23 +624,12 @@ constexpr int kTieFixWords = 8;      // behind the 3 * kTieGroups words: splat_b
 // modulo 2^13.  Every non-zero pair has at least one match, so with exactly one surplus match the word IS the tied cell, and
 // the plane's workgroup repairs that cell alone (splat_bwd_fix_one_tie).  Per thread the sums travel as four 16-bit fields
 // (the groups of a chunk), each term reduced to 13 bits before it is added: no carry crosses a field.
-// a * b + c in ONE instruction (24-bit signed factors; what the compiler makes of __mul24 and an add is a shift-and-extend
-// sequence with temporaries, which this kernel has no registers for)
-__device__ __forceinline__ int mad24_acc(int a, int b, int c) {
-  asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(c) : "v"(a), "s"(b));
-  return c;
-}
-__device__ __forceinline__ int mad24_acc_v(int a, int b, int c) {
-  asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-}
-constexpr unsigned kTieCellMask = 0x1fffu;
-constexpr unsigned long long kTieCellFields = 0x1fff1fff1fff1fffull;
-__device__ __forceinline__ void plane_sum_cells(int* words, unsigned long long packed, int ngroups, int sign) {
-  for (int f = 0; f < ngroups; ++f) {
-    const int v = wave_sum_i32((int)((packed >> (16 * f)) & 0xffffu));
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(words + f, sign * v);
-  }
+// s_cnt[4 + 2 * kTieGroups + chunk]: the sum (mod 2^32) of the bit patterns of g_z over the chunk's matches MINUS the sum over its
+// non-zero (cell, channel) pairs.  Every non-zero pair has at least one match, so with exactly one surplus match in the chunk the
+// word IS the bit pattern of g_z at the tied pair (0: the surplus award was +0, nothing to repair).
+__device__ __forceinline__ void plane_sum_bits(int* word, unsigned v, int sign) {
+  const int t = wave_sum_i32((int)v);
+  if ((threadIdx.x & 63) == 0 && t) atomicAdd(word, sign * t);
 }
 
 // DELTA (with CLAIMS): the redo of ONE four-channel group after an optimistic pass — its g_feat rows are rewritten with the
@@ -647,7 +639,8 @@ template <bool HAS_PAD, bool CLAIMS, int WT, bool DELTA = false>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
                                                int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
                                                float (&gs)[4][2], int& nm, unsigned* nmp = nullptr,
-                                               unsigned long long* xsp = nullptr) {
+                                               unsigned* xsp = nullptr) {
+  unsigned xs = xsp != nullptr ? *xsp : 0u;      // (CT_TIE_FIX) running sum of the bit patterns of the awarded cotangents (see plane_sum_bits)
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
@@ -657,7 +650,6 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
   // (Requesting the next step's rows before this step is processed was measured: the 16 extra registers spill, 73 -> 102 us.)
   for (int cg0 = 0; cg0 < cc; cg0 += 4) {
     const int nm_before = nm;
-    int xs = 0;              // sum of the cells of this group's matches (see plane_sum_cells)
     float fv[4][4];          // [channel][point]
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
@@ -694,7 +686,6 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
         for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
 #endif
         float gfa = 0.0f, gfb = 0.0f;
-        int cm = 0;              // (CT_TIE_FIX) matches of this point in this pair of channels
         if (!CLAIMS) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -702,28 +693,18 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
             // staged as kNoMatch, so bit-equality alone is the winner test.
             const unsigned ba = __float_as_uint(xa * p.cw[v]), bb = __float_as_uint(xb * p.cw[v]);
             const bool ma = ba == __float_as_uint(zg[v].x), mb = bb == __float_as_uint(zg[v].y);
-#if CT_TIE_FIX
-            cm += (int)ma;
-            cm += (int)mb;
-            asm volatile("" : "+v"(cm));
-            // The sum over the matches of their cell = base + off[v] comes from the running count of this (point, pair) alone —
-            // no mask is kept, nothing is selected: sum_v off[v] * (c_(v+1) - c_v) telescopes to c_(v+1) * (off[v] - off[v+1])
-            // [+ c_4 * off[3]], one multiply-add each; the base term follows behind the corners.
-            xs = mad24_acc(cm, v < 3 ? off[v] - off[v + 1] : off[3], xs);
-#else
             nm += (int)ma;       // (add-with-carry of the compare mask: one instruction each ...
             nm += (int)mb;
             asm volatile("" : "+v"(nm));      //  ... issued here: otherwise all 32 masks of a point are kept for a final sum)
-#endif
             const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
+            if (CT_TIE_FIX) {
+              xs += __float_as_uint(ga) + __float_as_uint(gb);
+              asm volatile("" : "+v"(xs));      // (added here and now: see nm)
+            }
             gfa = __builtin_fmaf(ga, p.cw[v], gfa);
             gfb = __builtin_fmaf(gb, p.cw[v], gfb);
             gw[v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[v]));
           }
-#if CT_TIE_FIX
-          nm += cm;
-          xs = mad24_acc_v(cm, p.base, xs);
-#endif
         } else {
           // claims: a cell's z word is won by the first matching contribution that flips its sign bit (z > 0 in every non-empty
           // cell: the zero floor of the forward), so a later contribution still sees WHAT the maximum was and knows that it
@@ -779,12 +760,12 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
     // <= 2 quads x 64 products per thread and group); LDS adds per (quad, group) — even one per wave — cost 3.5 us of 68 on the headline
     if (!CLAIMS && nmp != nullptr) {
       *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
-      if (CT_TIE_FIX) *xsp += (unsigned long long)((unsigned)xs & kTieCellMask) << (16 * ((cg0 >> 2) & 3));
     }
   }
+  if (CT_TIE_FIX && !CLAIMS && nmp != nullptr) *xsp = xs;
 }
 
-// The repair of ONE exact tie (one surplus match in the four-channel group at `cabs`, all of it in cell `t`: see plane_sum_cells)
+// The repair of ONE exact tie (one surplus match in the four-channel group at `cabs`, all of it in cell `t`)
 // behind an optimistic pass, by the plane's workgroup with its points in registers (QPT > 0).  Only the points with a corner
 // in `t` do anything: they test their four products against the cell's maxima; per channel the lowest point index keeps the
 // award, every other match gives it back — its g_feat element recomputed without that corner, its key cotangent corrected by
@@ -793,7 +774,8 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
 // nothing written) if the cell does not hold what the counters promised; the caller then redoes the group.
 template <bool HAS_PAD, int WT, int QPT>
 __device__ __forceinline__ bool splat_bwd_fix_one_tie(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int cabs, int t,
-                                                      const PtRows& R, float (&gs)[QPT ? QPT : 1][4][2], int* s_fix) {
+                                                      const PtRows& R, float (&gs)[QPT ? QPT : 1][4][2], int* s_fix,
+                                                      const float4 (&keysx)[QPT ? QPT : 1], const float4 (&keysy)[QPT ? QPT : 1]) {
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   const int tid = threadIdx.x, nq = a.N >> 2;
@@ -802,6 +784,8 @@ __device__ __forceinline__ bool splat_bwd_fix_one_tie(const RasterArgs& a, const
   __syncthreads();
   const float* zrow = a.tile_in + (bh * a.C + cabs) * (size_t)G;
   const float* grow = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
+  const float* keyx = a.pos.keys + (bh * 2 + 0) * R.Nr + R.so;
+  const float* keyy = a.pos.keys + (bh * 2 + 1) * R.Nr + R.so;
   unsigned zt[4];
   int expect = 1;
 #pragma unroll
@@ -809,97 +793,181 @@ __device__ __forceinline__ bool splat_bwd_fix_one_tie(const RasterArgs& a, const
     zt[cj] = __float_as_uint(zrow[(size_t)cj * G + t]);
     expect += zt[cj] != 0u;
   }
-  const float* keyx = a.pos.keys + (bh * 2 + 0) * R.Nr + R.so;
-  const float* keyy = a.pos.keys + (bh * 2 + 1) * R.Nr + R.so;
-  unsigned hit = 0u;          // per point slot (u, i): 4 bits, the channels of the group whose maximum this point's product equals
+  // which of the thread's points have a corner in `t` (no memory behind this: base cells from the keys in registers); the few
+  // that do are then walked one at a time, so that the code behind exists once and not per point slot
+  unsigned cand = 0u;
 #pragma unroll
   for (int u = 0; u < (QPT ? QPT : 1); ++u) {
-    const int q = tid + u * (int)blockDim.x;
-    if (q >= nq) continue;
-    const int n0 = q << 2;
-    const float4 tx = *(const float4*)(keyx + n0);
-    const float4 ty = *(const float4*)(keyy + n0);
-    const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+    const float kx[4] = {keysx[u].x, keysx[u].y, keysx[u].z, keysx[u].w}, ky[4] = {keysy[u].x, keysy[u].y, keysy[u].z, keysy[u].w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Pt2 p;
-      pt2_from_keys(kx[i], ky[i], g, W1, p);
-      const int d = t - p.base;
-      const int v = d == 0 ? 0 : d == W1 ? 1 : d == 1 ? 2 : d == W1 + 1 ? 3 : -1;
-      if (v < 0) continue;
-      const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
-      const float w = v == 0 ? p.cw[0] : v == 1 ? p.cw[1] : v == 2 ? p.cw[2] : p.cw[3];
+      float w0, w1;
+      int fx, fy;
+      ct_axis(kx[i], g.hw[0], g.W[0], w0, w1, fx);
+      ct_axis(ky[i], g.hw[1], g.W[1], w0, w1, fy);
+      const int d = t - (fx * W1 + fy);
+      if ((d == 0 || d == W1 || d == 1 || d == W1 + 1) && tid + u * (int)blockDim.x < nq) cand |= 1u << (4 * u + i);
+    }
+  }
+  unsigned hit = 0u;          // per point slot (u, i): 4 bits, the channels of the group whose maximum this point's product equals
+#pragma unroll 1
+  for (unsigned m = cand; m != 0u; m &= m - 1u) {
+    const int slot = __builtin_ctz(m);
+    const int n = ((tid + (slot >> 2) * (int)blockDim.x) << 2) + (slot & 3);
+    Pt2 p;
+    pt2_from_keys(keyx[n], keyy[n], g, W1, p);
+    const int d = t - p.base;
+    const float w = d == 0 ? p.cw[0] : d == W1 ? p.cw[1] : d == 1 ? p.cw[2] : p.cw[3];
+    const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n) : 1.0f;
 #pragma unroll
-      for (int cj = 0; cj < 4; ++cj) {
-        const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i];
-        const float x = HAS_PAD ? f * pv : f;
-        if (zt[cj] != 0u && __float_as_uint(x * w) == zt[cj]) {
-          hit |= 1u << (4 * (4 * u + i) + cj);
-          atomicMin(&s_fix[cj], n0 + i);
-          atomicAdd(&s_fix[4], 1);
-        }
+    for (int cj = 0; cj < 4; ++cj) {
+      const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n];
+      const float x = HAS_PAD ? f * pv : f;
+      if (zt[cj] != 0u && __float_as_uint(x * w) == zt[cj]) {
+        hit |= 1u << (4 * slot + cj);
+        atomicMin(&s_fix[cj], n);
+        atomicAdd(&s_fix[4], 1);
       }
     }
   }
   __syncthreads();
   if (s_fix[4] != expect) return false;          // block-uniform
-  if (hit != 0u) {
+#pragma unroll 1
+  for (unsigned m = cand; m != 0u; m &= m - 1u) {
+    const int slot = __builtin_ctz(m);
+    const unsigned mine = (hit >> (4 * slot)) & 0xfu;
+    const int n = ((tid + (slot >> 2) * (int)blockDim.x) << 2) + (slot & 3);
+    unsigned lost = 0u;
 #pragma unroll
-    for (int u = 0; u < (QPT ? QPT : 1); ++u) {
-      if (((hit >> (16 * u)) & 0xffffu) == 0u) continue;
-      const int n0 = (tid + u * (int)blockDim.x) << 2;
-      const float4 tx = *(const float4*)(keyx + n0);
-      const float4 ty = *(const float4*)(keyy + n0);
-      const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
+    for (int cj = 0; cj < 4; ++cj)
+      if (((mine >> cj) & 1u) && s_fix[cj] != n) lost |= 1u << cj;
+    if (lost == 0u) continue;
+    Pt2 p;
+    pt2_from_keys(keyx[n], keyy[n], g, W1, p);
+    const int vt = t - p.base == 0 ? 0 : t - p.base == W1 ? 1 : t - p.base == 1 ? 2 : 3;
+    const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n) : 1.0f;
+    float x[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned m = (hit >> (4 * (4 * u + i))) & 0xfu;
-        unsigned lost = 0u;
+    for (int cj = 0; cj < 4; ++cj) {
+      const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n];
+      x[cj] = HAS_PAD ? f * pv : f;
+    }
+    // the key cotangent: the lost awards, negated, through the corner-weight gradient (the arithmetic of DELTA)
+    float gwt = 0.0f;
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-          if (((m >> cj) & 1u) && s_fix[cj] != n0 + i) lost |= 1u << cj;
-        if (lost == 0u) continue;
-        Pt2 p;
-        pt2_from_keys(kx[i], ky[i], g, W1, p);
-        const int vt = t - p.base == 0 ? 0 : t - p.base == W1 ? 1 : t - p.base == 1 ? 2 : 3;
-        const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * R.Nr + R.so + n0 + i) : 1.0f;
-        float x[4];
+    for (int pr = 0; pr < 2; ++pr) {
+      const float da = ((lost >> (2 * pr)) & 1u) ? -grow[(size_t)(2 * pr) * G + t] : 0.0f;
+      const float db = ((lost >> (2 * pr + 1)) & 1u) ? -grow[(size_t)(2 * pr + 1) * G + t] : 0.0f;
+      gwt = __builtin_fmaf(db, x[2 * pr + 1], __builtin_fmaf(da, x[2 * pr], gwt));
+    }
+    float gw[4];
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-          const float f = a.src[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i];
-          x[cj] = HAS_PAD ? f * pv : f;
+    for (int v = 0; v < 4; ++v) gw[v] = v == vt ? gwt : 0.0f;
+    const float d0 = __builtin_fmaf(gw[3] - gw[2], p.w1y, (gw[1] - gw[0]) * p.w0y);
+    const float d1 = __builtin_fmaf(gw[3] - gw[1], p.w1x, (gw[2] - gw[0]) * p.w0x);
+    // (the slot is a run-time value here: the sums are addressed by selects, not by index)
+#pragma unroll
+    for (int u = 0; u < (QPT ? QPT : 1); ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (slot == 4 * u + i) {
+          gs[u][i][0] += d0;
+          gs[u][i][1] += d1;
         }
-        // the key cotangent: the lost awards, negated, through the corner-weight gradient (the arithmetic of DELTA)
-        float gwt = 0.0f;
+    // g_feat of the lost channels: the point's other corners keep what they matched
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const float da = ((lost >> (2 * pr)) & 1u) ? -grow[(size_t)(2 * pr) * G + t] : 0.0f;
-          const float db = ((lost >> (2 * pr + 1)) & 1u) ? -grow[(size_t)(2 * pr + 1) * G + t] : 0.0f;
-          gwt = __builtin_fmaf(db, x[2 * pr + 1], __builtin_fmaf(da, x[2 * pr], gwt));
-        }
-        float gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cj = 0; cj < 4; ++cj) {
+      if (!((lost >> cj) & 1u)) continue;
+      float gf = 0.0f;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) gw[v] = v == vt ? gwt : 0.0f;
-        gs[u][i][0] = __builtin_fmaf(gw[3] - gw[2], p.w1y, __builtin_fmaf(gw[1] - gw[0], p.w0y, gs[u][i][0]));
-        gs[u][i][1] = __builtin_fmaf(gw[3] - gw[1], p.w1x, __builtin_fmaf(gw[2] - gw[0], p.w0x, gs[u][i][1]));
-        // g_feat of the lost channels: the point's other corners keep what they matched
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-          if (!((lost >> cj) & 1u)) continue;
-          float gf = 0.0f;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const unsigned zc = __float_as_uint(zrow[(size_t)cj * G + p.base + off[v]]);
-            const float gc = grow[(size_t)cj * G + p.base + off[v]];
-            const bool won = v != vt && zc != 0u && __float_as_uint(x[cj] * p.cw[v]) == zc;
-            gf = __builtin_fmaf(won ? gc : 0.0f, p.cw[v], gf);
-          }
-          a.dst[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n0 + i] = HAS_PAD ? gf * pv : gf;
-        }
+      for (int v = 0; v < 4; ++v) {
+        const unsigned zc = __float_as_uint(zrow[(size_t)cj * G + p.base + off[v]]);
+        const float gc = grow[(size_t)cj * G + p.base + off[v]];
+        const bool won = v != vt && zc != 0u && __float_as_uint(x[cj] * p.cw[v]) == zc;
+        gf = __builtin_fmaf(won ? gc : 0.0f, p.cw[v], gf);
       }
+      a.dst[(bh * a.C + cabs + cj) * (size_t)R.Nr + R.so + n] = HAS_PAD ? gf * pv : gf;
     }
   }
   return true;
+}
+
+// The tied cell found by the VALUE of its cotangent (plane_sum_bits): the cells of the group's four rows whose g_z has these bits
+// (and whose z is not empty) are tried one after the other — a cell that is not the tied one fails the repair's own count and is
+// left untouched.  False (block-uniform) if none fits or there are more than kTieTry of them (a constant g_z: redo the group).
+constexpr int kTieTry = 7;
+#ifdef CT_TIE_DEBUG
+__device__ unsigned g_tie_dbg[16];
+#define CT_TIE_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_tie_dbg[i], (unsigned)(v)); } while (0)
+#else
+#define CT_TIE_COUNT(i, v) do { } while (0)
+#endif
+template <bool HAS_PAD, int WT, int QPT>
+__device__ __forceinline__ bool splat_bwd_fix_by_value(const RasterArgs& a, const GridW<2>& g, size_t bh, int b, int cabs, unsigned gbits,
+                                                       const PtRows& R, float (&gs)[QPT ? QPT : 1][4][2], int* s_fix, int* s_list,
+                                                       const float4* resident) {
+  const int G = WT ? WT * WT : g.G;
+  const int tid = threadIdx.x, nq = a.N >> 2;
+  const float* zrow = a.tile_in + (bh * a.C + cabs) * (size_t)G;
+  const float* grow = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
+  // the thread's keys travel with the search's loads (one trip to memory less in front of the repair)
+  float4 keysx[QPT ? QPT : 1], keysy[QPT ? QPT : 1];
+#pragma unroll
+  for (int u = 0; u < (QPT ? QPT : 1); ++u) {
+    const int q = min(tid + u * (int)blockDim.x, nq - 1);
+    keysx[u] = *(const float4*)(a.pos.keys + (bh * 2 + 0) * R.Nr + R.so + (q << 2));
+    keysy[u] = *(const float4*)(a.pos.keys + (bh * 2 + 1) * R.Nr + R.so + (q << 2));
+  }
+  __syncthreads();
+  if (tid == 0) s_list[0] = 0;
+  __syncthreads();
+  if (resident != nullptr) {      // the group's pairs are still staged: {z(c), z(c+1), g_z(c), g_z(c+1)} per cell, empty cells as kNoMatch
+    for (int i = tid; i < 2 * G; i += blockDim.x) {
+      const float4 e = resident[i];
+      const bool h0 = __float_as_uint(e.z) == gbits && __float_as_uint(e.x) != kNoMatch;
+      const bool h1 = __float_as_uint(e.w) == gbits && __float_as_uint(e.y) != kNoMatch;
+      if (h0 | h1) {
+        const int k = atomicAdd(&s_list[0], 1);
+        if (k < kTieTry) s_list[1 + k] = i % G;
+      }
+    }
+  } else {
+    for (int i = tid; i < 4 * G; i += blockDim.x) {
+      if (__float_as_uint(grow[i]) == gbits && __float_as_uint(zrow[i]) != 0u) {
+        const int k = atomicAdd(&s_list[0], 1);
+        if (k < kTieTry) s_list[1 + k] = i % G;
+      }
+    }
+  }
+  __syncthreads();
+  const int n = s_list[0];
+  CT_TIE_COUNT(0, 1); CT_TIE_COUNT(1, n); CT_TIE_COUNT(2, resident != nullptr);
+  if (n > kTieTry) return false;
+  int cells[kTieTry];
+#pragma unroll
+  for (int k = 0; k < kTieTry; ++k) cells[k] = k < n ? s_list[1 + k] : -1;
+#pragma unroll 1
+  for (int k = 0; k < n; ++k) {
+    int t = cells[0];
+#pragma unroll
+    for (int j = 1; j < kTieTry; ++j) t = k == j ? cells[j] : t;
+    if (splat_bwd_fix_one_tie<HAS_PAD, WT, QPT>(a, g, bh, b, cabs, t, R, gs, s_fix, keysx, keysy)) { CT_TIE_COUNT(3, 1); return true; }
+    CT_TIE_COUNT(4, 1);
+  }
+  return false;
+}
+
+// seven of a quad's eight sums to / from the workgroup's parking rows ([7][kHotThreads] floats behind the tie words; lane-
+// contiguous: conflict-free).  The memory clobbers keep the compiler from forwarding the stored values in registers.
+template <bool STORE>
+__device__ __forceinline__ void gs_park(float* park, float (&gs)[4][2]) {
+  if (!STORE) asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    if (STORE) park[j * kHotThreads] = gs[j >> 1][j & 1];
+    else gs[j >> 1][j & 1] = park[j * kHotThreads];
+  }
+  if (STORE) asm volatile("" ::: "memory");
 }
 
 // one pass over the workgroup's points (N of them, rows R) and its chunks; cgi: chunk group (see slice_bwd_fused_kernel)
@@ -920,20 +988,21 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     const float* zin = a.tile_in + (bh * a.C + c0) * (size_t)G;
     const float* gin = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
     __syncthreads();                              // readers of the previous chunk (or pass) are done
-    unsigned long long nzp = 0ull, xzp = 0ull;
+    unsigned long long nzp = 0ull;
+    unsigned xzp = 0u;
     for (int t = tid; t < (cc >> 1) * G; t += blockDim.x) {
       const int cp = t / G, cell = t - cp * G;
       const size_t o = (size_t)(cp * 2) * G + cell;
       // an empty cell (z = 0: nothing beat the zero floor) is staged as kNoMatch, a bit pattern no product of finite
       // inputs has, so that the winner test in the loop is one compare
       const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
-      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
-                          ld_stream(gin + o + G));
+      const float g0 = ld_stream(gin + o), g1 = ld_stream(gin + o + G);
+      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), g0, g1);
       if (!CLAIMS) {
         const int nzt = (z0 != 0u) + (z1 != 0u);
         nz += nzt;
         nzp += (unsigned long long)(unsigned)nzt << (16 * ((cp >> 1) & 3));      // per four-channel group of the chunk (packed: see nmp)
-        if (CT_TIE_FIX) xzp = (xzp + ((unsigned long long)(unsigned)(nzt * cell) << (16 * ((cp >> 1) & 3)))) & kTieCellFields;
+        if (CT_TIE_FIX) xzp += (z0 ? __float_as_uint(g0) : 0u) + (z1 ? __float_as_uint(g1) : 0u);
       }
     }
     if (!CLAIMS && grp != nullptr) {
@@ -942,15 +1011,20 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nzp >> (16 * f)) & 0xffffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + (c0 >> 2) + f, v);
       }
-      if (CT_TIE_FIX) plane_sum_cells(grp + 2 * kTieGroups + (c0 >> 2), xzp, cc >> 2, -1);
+      if (CT_TIE_FIX) plane_sum_bits(grp + 2 * kTieGroups + chunk, xzp, -1);
     }
     __syncthreads();
     unsigned nmp = 0u;
-    unsigned long long xmp = 0ull;
+    unsigned xmp = 0u;
     unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
     if constexpr (QPT > 0) {
+      // Two quads per thread: while one is walked the other's eight key-cotangent sums are dead weight in a loop that has no
+      // register to spare — seven of them wait in LDS meanwhile (what fits beside the tile; gs_park).
+      constexpr bool PARK = QPT == 2 && CT_SPLAT_PARK != 0;
+      float* const park = (float*)(s_cnt + 4 + 3 * kTieGroups + 2 * kTieFixWords) + tid;
 #pragma unroll
       for (int u = 0; u < QPT; ++u) {
+        if (PARK) gs_park<true>(park, gs_reg[1 - u]);
         const int q = tid + u * (int)blockDim.x;
         if (q < nq) {
           const int n0 = q << 2;
@@ -959,6 +1033,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
           splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm, &xmp);
         }
+        if (PARK) gs_park<false>(park, gs_reg[1 - u]);
       }
     } else {
       for (int q = tid; q < nq; q += blockDim.x) {
@@ -1002,7 +1077,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nmp >> (8 * f)) & 0xffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
-      if (CT_TIE_FIX) plane_sum_cells(grp + 2 * kTieGroups + (c0 >> 2), xmp, cc >> 2, 1);
+      if (CT_TIE_FIX) plane_sum_bits(grp + 2 * kTieGroups + chunk, xmp, 1);
     }
   }
   if (!CLAIMS) {
@@ -1067,16 +1142,32 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
     if (tie && grp != nullptr) {    // block-uniform
       const int G = WT ? WT * WT : g.G;
       const int tid = threadIdx.x, nq = N >> 2;
+      bool staged = true;
       for (int gi = 0; gi < (a.C >> 2); ++gi) {
         if (grp[gi] == grp[kTieGroups + gi]) continue;           // block-uniform (LDS words, written before the pass's last barrier)
         const int cabs = gi << 2;                                 // the group's first channel
         if ((cabs / a.CC) % a.ncg != wg.cgi) continue;            // (another chunk group's channels)
-        const int tcell = (int)((unsigned)grp[2 * kTieGroups + gi] & kTieCellMask);
-        if (CT_TIE_FIX && grp[kTieGroups + gi] - grp[gi] == 1 && G <= (int)kTieCellMask + 1 && tcell < G &&
-            splat_bwd_fix_one_tie<HAS_PAD, WT, QPT>(a, g, bh, b, cabs, tcell, R, gs, grp + 3 * kTieGroups))
-          continue;
+        if (CT_TIE_FIX) {
+          // one surplus match in the whole chunk: its cotangent's bit pattern is what the chunk's word holds
+          const int chunk = cabs / a.CC;
+          int extra = 0;
+          for (int g2 = (chunk * a.CC) >> 2; g2 < (min(chunk * a.CC + a.CC, a.C) >> 2); ++g2) extra += grp[kTieGroups + g2] - grp[g2];
+          const unsigned gbits = (unsigned)grp[2 * kTieGroups + chunk];
+          CT_TIE_COUNT(7, 1); CT_TIE_COUNT(8, extra);
+          if (extra == 1) {
+            if (gbits == 0u) continue;      // the surplus award was +0: nothing went anywhere
+            // (the pass's last chunk is still staged unless a redo below has overwritten it)
+            const int last_chunk = wg.cgi + ((a.nchunks - 1 - wg.cgi) / a.ncg) * a.ncg;
+            const float4* res = (staged && chunk == last_chunk) ? ZG + (size_t)((cabs - chunk * a.CC) >> 1) * G : nullptr;
+            if (splat_bwd_fix_by_value<HAS_PAD, WT, QPT>(a, g, bh, b, cabs, gbits, R, gs, grp + 3 * kTieGroups,
+                                                         grp + 3 * kTieGroups + kTieFixWords, res))
+              continue;
+          }
+        }
         const float* zin = a.tile_in + (bh * a.C + cabs) * (size_t)G;
         const float* gin = a.tile_in2 + (bh * a.C + cabs) * (size_t)G;
+        staged = false;
+        CT_TIE_COUNT(5, 1);
         __syncthreads();
         for (int t = tid; t < 2 * G; t += blockDim.x) {
           const int cp = t / G, cell = t - cp * G;
@@ -1106,6 +1197,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
   }
 #endif
   if (tie && nsg == 1) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
+    CT_TIE_COUNT(6, 1);
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
 #pragma unroll
