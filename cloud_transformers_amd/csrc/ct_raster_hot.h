@@ -640,7 +640,7 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
                                                int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
                                                float (&gs)[4][2], int& nm, unsigned* nmp = nullptr,
                                                unsigned* xsp = nullptr) {
-  unsigned xs = xsp != nullptr ? *xsp : 0u;      // (CT_TIE_FIX) running sum of the bit patterns of the awarded cotangents (see plane_sum_bits)
+  unsigned xs = (CT_TIE_FIX && xsp != nullptr) ? *xsp : 0u;      // (CT_TIE_FIX) running sum of the bit patterns of the awarded cotangents (see plane_sum_bits)
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
@@ -762,7 +762,7 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
       *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
     }
   }
-  if (CT_TIE_FIX && !CLAIMS && nmp != nullptr) *xsp = xs;
+  if (CT_TIE_FIX && !CLAIMS && xsp != nullptr) *xsp = xs;
 }
 
 // The repair of ONE exact tie (one surplus match in the four-channel group at `cabs`, all of it in cell `t`)
@@ -1017,6 +1017,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     unsigned nmp = 0u;
     unsigned xmp = 0u;
     unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
+    unsigned* const pxs = (CT_TIE_FIX && !CLAIMS && grp != nullptr) ? &xmp : nullptr;
     if constexpr (QPT > 0) {
       // Two quads per thread: while one is walked the other's eight key-cotangent sums are dead weight in a loop that has no
       // register to spare — seven of them wait in LDS meanwhile (what fits beside the tile; gs_park).
@@ -1031,7 +1032,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float4 tx = *(const float4*)(keyx + n0);
           const float4 ty = *(const float4*)(keyy + n0);
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
-          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm, &xmp);
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm, pxs);
         }
         if (PARK) gs_park<false>(park, gs_reg[1 - u]);
       }
@@ -1044,7 +1045,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         float gs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
-        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm, &xmp);
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm, pxs);
         // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns these
         // addresses); the first chunk starts from the incoming cotangent where there is one (a.gpos_add)
         float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
@@ -1077,8 +1078,8 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nmp >> (8 * f)) & 0xffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
-      if (CT_TIE_FIX) plane_sum_bits(grp + 2 * kTieGroups + chunk, xmp, 1);
     }
+    if (pxs != nullptr) plane_sum_bits(grp + 2 * kTieGroups + chunk, xmp, 1);
   }
   if (!CLAIMS) {
     nz = wave_sum_i32(nz);
