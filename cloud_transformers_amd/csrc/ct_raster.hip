@@ -1912,7 +1912,8 @@ bool splat_bwd_hot_plan(const RasterArgs& a, const GridW<DIM>& g, HotPlan& hp, i
   nseg = 1;
   if (!hot_shape_ok(a, g.G, bits)) return false;
   // segments first: every workgroup stages every chunk, so the chunks are as fat as LDS allows (no chunk groups)
-  if (a.tickets != nullptr && tickets_cover(a.tickets, (long long)a.B * a.H, 1, 1) && (a.gpos_add == nullptr || a.gpos_add != a.g_pos)) {
+  if (a.tickets != nullptr && tickets_cover(a.tickets, (long long)a.B * a.H, 1, 1) && (long long)a.B * a.H <= kTicketHalf / 2 &&
+      ((uintptr_t)a.tickets & 7) == 0 && (a.gpos_add == nullptr || a.gpos_add != a.g_pos)) {
     HotPlan sp;
     if (hot_chunks(a.C, (size_t)g.G * 8, kSplatBwdFixed, sp)) {
       const int ns = splat_bwd_segments(a.B, a.H, a.C, a.N, g.G, DIM, sp.lds);

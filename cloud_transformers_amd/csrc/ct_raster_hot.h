@@ -618,6 +618,9 @@ struct PtRows {
 // groups of four channels a plane's tie test distinguishes (s_cnt[4 + i]: non-zero cells of group i, s_cnt[4 + kTieGroups + i]:
 // its matches): a plane with C > 4 * kTieGroups channels only has the plane-wide test
 constexpr int kTieGroups = 64;
+// forms without per-group counters (3D, point segments, N beyond the register forms): the whole pass's two bit-pattern sums
+// (plane_sum_bits) sit in the first words of the group area, the repair's words behind them
+constexpr int kTieSumPos = 4, kTieSumNeg = 5, kTieMemFix = 8, kTieMemList = 16;      // indices into s_cnt
 constexpr int kTieFixWords = 8;      // behind the 3 * kTieGroups words: splat_bwd_fix_one_tie's winners and counts
 
 // s_cnt[4 + 2 * kTieGroups + i]: the sum of `cell` over the group's matches MINUS the sum over its non-zero (cell, channel) pairs,
@@ -1011,13 +1014,14 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         const int v = wave_sum_i32((int)((nzp >> (16 * f)) & 0xffffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + (c0 >> 2) + f, v);
       }
-      if (CT_TIE_FIX) plane_sum_bits(grp + 2 * kTieGroups + chunk, xzp, -1);
     }
+    // (forms without the per-group words — point segments, N beyond the register forms — keep the pass's two sums apart)
+    if (CT_TIE_FIX && !CLAIMS) plane_sum_bits(grp != nullptr ? grp + 2 * kTieGroups + chunk : s_cnt + kTieSumNeg, xzp, grp != nullptr ? -1 : 1);
     __syncthreads();
     unsigned nmp = 0u;
     unsigned xmp = 0u;
     unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
-    unsigned* const pxs = (CT_TIE_FIX && !CLAIMS && grp != nullptr) ? &xmp : nullptr;
+    unsigned* const pxs = (CT_TIE_FIX && !CLAIMS) ? &xmp : nullptr;
     if constexpr (QPT > 0) {
       // Two quads per thread: while one is walked the other's eight key-cotangent sums are dead weight in a loop that has no
       // register to spare — seven of them wait in LDS meanwhile (what fits beside the tile; gs_park).
@@ -1079,7 +1083,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
     }
-    if (pxs != nullptr) plane_sum_bits(grp + 2 * kTieGroups + chunk, xmp, 1);
+    if (pxs != nullptr) plane_sum_bits(grp != nullptr ? grp + 2 * kTieGroups + chunk : s_cnt + kTieSumPos, xmp, 1);
   }
   if (!CLAIMS) {
     nz = wave_sum_i32(nz);
@@ -1092,6 +1096,11 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     tie = s_cnt[0] != s_cnt[1];
   }
 }
+
+// (ct_raster_hot3d.h: the repair of one tie through memory, 2D and 3D)
+template <int DIM, bool HAS_PAD>
+__device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi, unsigned gbits, int Nr, size_t gpos_off, bool wt,
+                                                       int* s_cnt);
 
 // Point segments (a.nseg > 1): the plane's points are dealt to nseg workgroups, each walking ALL chunks for its own points —
 // no partial g_keys, nothing to fold, nseg times the workgroups (the decoders' 32 planes fill the chip; the zoo's 128 planes
@@ -1132,6 +1141,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
   int* const grp = (QPT > 0 && QPT <= 2 && nsg == 1 && a.C <= 4 * kTieGroups && a.CC <= 16) ? s_cnt + 4 : nullptr;
   if (grp != nullptr) {
     for (int i = threadIdx.x; i < 3 * kTieGroups; i += blockDim.x) grp[i] = 0;
+  } else if (threadIdx.x < 20) {
+    s_cnt[kTieSumPos + threadIdx.x] = 0;       // the pass's bit sums, the words of splat_bwd_fix_mem
   }
 #ifdef CT_EXP_CLAIMS_ONLY       // experiment: no optimistic pass, every plane with single-winner claims (the cost of a tie-proof single pass)
   tie = nsg == 1;
@@ -1197,6 +1208,13 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
     }
   }
 #endif
+  if constexpr (QPT == 0) {       // the through-memory form: the key cotangents are in their rows, one surplus match is repaired there
+    if (CT_TIE_FIX && tie && nsg == 1 && s_cnt[1] - s_cnt[0] == 1) {
+      const unsigned gbits = (unsigned)(s_cnt[kTieSumPos] - s_cnt[kTieSumNeg]);
+      if (gbits == 0u || splat_bwd_fix_mem_cold<2, HAS_PAD>(bh, b, wg.cgi, gbits, R.Nr, (size_t)wg.cgi * a.gpos_stride, fold_keys, s_cnt))
+        tie = false;
+    }
+  }
   if (tie && nsg == 1) {          // block-uniform: exact ties in this plane — redo it with single-winner claims
     CT_TIE_COUNT(6, 1);
 #pragma unroll
@@ -1243,17 +1261,29 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
     }
   }
   if (nsg > 1) {         // kernel-uniform: the plane's tie test across its segments
-    unsigned* matches = a.tickets + kTicketHalf + bh;
+    // the plane's matches (low word) and the bit sum of their cotangents (high word: plane_sum_bits) in ONE 64-bit word of the
+    // ticket buffer's second half (splat_bwd_hot_plan: planes <= kTicketHalf / 2)
+    unsigned long long* matches = (unsigned long long*)(a.tickets + kTicketHalf) + bh;
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(matches, (unsigned)s_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(matches, ((unsigned long long)(unsigned)s_cnt[kTieSumPos] << 32) | (unsigned)s_cnt[1], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counted before the ticket is taken
     }
     const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
     if (last) {          // block-uniform
       // (read and reset in ONE atomic: a load could be served from a line an earlier launch left in this XCD's L2)
-      if (threadIdx.x == 0) s_cnt[3] = (int)__hip_atomic_exchange(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {
+        const unsigned long long m = __hip_atomic_exchange(matches, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cnt[3] = (int)(unsigned)m;
+        s_cnt[2] = (int)(unsigned)(m >> 32);      // (the low word never carries into it: the matches of a plane are < 2^32)
+      }
       __syncthreads();
-      if (s_cnt[3] != s_cnt[0]) {       // the plane has exact ties: all of it again, with claims, by this workgroup
+      bool redo = s_cnt[3] != s_cnt[0];
+      if (CT_TIE_FIX && s_cnt[3] - s_cnt[0] == 1) {      // ONE surplus match in the plane: repaired in the segments' rows
+        const unsigned gbits = (unsigned)(s_cnt[2] - s_cnt[kTieSumNeg]);
+        if (gbits == 0u || splat_bwd_fix_mem_cold<2, HAS_PAD>(bh, b, 0, gbits, R.Nr, 0, false, s_cnt)) redo = false;
+      }
+      if (redo) {       // the plane has exact ties: all of it again, with claims, by this workgroup
         PtRows Rall;
         Rall.Nr = R.Nr; Rall.so = 0; Rall.wt = false;
         float gs0[1][4][2];

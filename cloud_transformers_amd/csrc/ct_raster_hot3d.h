@@ -386,12 +386,188 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 }
 
 // ---------------------------------------------------------------------------
+// The repair of ONE exact tie through memory, for the forms whose key cotangents are already in their rows when the tie is known
+// (3D; point segments; N beyond the register forms) — see splat_bwd_fix_one_tie / plane_sum_bits in ct_raster_hot.h.  `gbits`:
+// the bit pattern of g_z at the tied (cell, channel), from the pass's bit sums.  The (cell, channel) pairs of the caller's chunks
+// whose g_z has these bits are tried in turn: every point with a corner in the cell tests its product against the cell's
+// maximum; exactly two must match (else the pair is not the tied one and nothing is written), the lower point index keeps the
+// award, the other gives it back — its g_feat element recomputed without that corner, its g_keys elements corrected in place
+// by the negated award.  Any thread handles any point: the caller guarantees that every workgroup that wrote these rows is done
+// (its own pass, or the plane's segments behind their last ticket).  False (block-uniform): redo.
+//   rows: Nr floats per row (the whole plane); gpos: the g_keys rows to correct; wt: written through (another workgroup reads them)
+// ---------------------------------------------------------------------------
+template <int DIM>
+__device__ __forceinline__ int tie_corner(int d, const int (&off)[1 << DIM]) {
+  int v = -1;
+#pragma unroll
+  for (int c = 0; c < (1 << DIM); ++c) v = d == off[c] ? c : v;
+  return v;
+}
+
+template <int DIM, bool HAS_PAD>
+__device__ __forceinline__ bool splat_bwd_fix_mem_cell(const RasterArgs& a, const GridW<DIM>& g, size_t bh, int b, int ch, int t, int Nr,
+                                                       float* gpos, bool wt, int* s_fix) {
+  constexpr int V = 1 << DIM;
+  const int G = g.G, tid = threadIdx.x, nq = Nr >> 2;
+  int off[V];
+  if constexpr (DIM == 2) {
+    off[0] = 0; off[1] = g.W[1]; off[2] = 1; off[3] = g.W[1] + 1;
+  } else {
+    corner_offsets3(g, off);
+  }
+  const float* zrow = a.tile_in + (bh * a.C + ch) * (size_t)G;
+  const float* grow = a.tile_in2 + (bh * a.C + ch) * (size_t)G;
+  const float* srow = a.src + (bh * a.C + ch) * (size_t)Nr;
+  const unsigned zt = __float_as_uint(zrow[t]);
+  const float gt = grow[t];
+  __syncthreads();
+  if (tid < 2) s_fix[tid] = tid == 0 ? 0x7fffffff : 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int winner = pass ? s_fix[0] : 0;
+#pragma unroll 1
+    for (int q = tid; q < nq; q += blockDim.x) {
+      float k[DIM][4];
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) {
+        const float4 kv = *(const float4*)(a.pos.keys + (bh * DIM + j) * Nr + (q << 2));
+        k[j][0] = kv.x; k[j][1] = kv.y; k[j][2] = kv.z; k[j][3] = kv.w;
+      }
+      unsigned cand = 0u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          float w0, w1;
+          int f;
+          ct_axis(k[j][i], g.hw[j], g.W[j], w0, w1, f);
+          base = base * g.W[j] + f;
+        }
+        if (tie_corner<DIM>(t - base, off) >= 0) cand |= 1u << i;
+      }
+#pragma unroll 1
+      for (unsigned m = cand; m != 0u; m &= m - 1u) {          // rare: the points with a corner in `t`, one at a time
+        const int i = __builtin_ctz(m), n = (q << 2) + i;
+        float kp[DIM], w0[DIM], w1[DIM], cw[V];
+        int base;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) kp[j] = i == 0 ? k[j][0] : i == 1 ? k[j][1] : i == 2 ? k[j][2] : k[j][3];
+        if constexpr (DIM == 2) {
+          Pt2 p;
+          pt2_from_keys(kp[0], kp[1], g, g.W[1], p);
+          w0[0] = p.w0x; w1[0] = p.w1x; w0[1] = p.w0y; w1[1] = p.w1y;
+#pragma unroll
+          for (int v = 0; v < V; ++v) cw[v] = p.cw[v];
+          base = p.base;
+        } else {
+          Pt3 p;
+          pt3_from_keys(kp[0], kp[1], kp[2], g, p);
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) { w0[j] = p.w0[j]; w1[j] = p.w1[j]; }
+#pragma unroll
+          for (int v = 0; v < V; ++v) cw[v] = p.cw[v];
+          base = p.base;
+        }
+        const int vt = tie_corner<DIM>(t - base, off);
+        float wt_c = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) wt_c = v == vt ? cw[v] : wt_c;
+        const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + n) : 1.0f;
+        const float f = srow[n];
+        const float x = HAS_PAD ? f * pv : f;
+        if (__float_as_uint(x * wt_c) != zt) continue;
+        if (pass == 0) {
+          atomicMin(&s_fix[0], n);
+          atomicAdd(&s_fix[1], 1);
+          continue;
+        }
+        if (n == winner) continue;
+        // the loser: the award it was given, taken back through the corner-weight gradient ...
+        float gw[V], gd[DIM];
+#pragma unroll
+        for (int v = 0; v < V; ++v) gw[v] = v == vt ? -(gt * x) : 0.0f;
+        ct_corner_grad<DIM>(w0, w1, gw, gd);
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          float* pk = gpos + (bh * DIM + j) * Nr + n;
+          const float nv = *pk + gd[j] * ct_key_mask(kp[j]);
+          if (wt) __hip_atomic_store(pk, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *pk = nv;
+        }
+        // ... and its g_feat element without that corner (the other corners keep what they matched), in the pass's order
+        float gf = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const unsigned zc = __float_as_uint(zrow[base + off[v]]);
+          const float gc = grow[base + off[v]];
+          const bool won = v != vt && zc != 0u && __float_as_uint(x * cw[v]) == zc;
+          gf = __builtin_fmaf(won ? gc : 0.0f, cw[v], gf);
+        }
+        a.dst[(bh * a.C + ch) * (size_t)Nr + n] = HAS_PAD ? gf * pv : gf;
+      }
+    }
+    __syncthreads();
+    if (pass == 0 && s_fix[1] != 2) return false;          // block-uniform: not the tied pair
+  }
+  return true;
+}
+
+template <int DIM, bool HAS_PAD>
+__device__ __forceinline__ bool splat_bwd_fix_mem(const RasterArgs& a, const GridW<DIM>& g, size_t bh, int b, int cgi, unsigned gbits,
+                                                  int Nr, float* gpos, bool wt, int* s_cnt) {
+  const int G = g.G, tid = threadIdx.x;
+  int* s_fix = s_cnt + kTieMemFix;
+  int* s_list = s_cnt + kTieMemList;
+  if (G > 0xffff) return false;
+  __syncthreads();
+  if (tid == 0) s_list[0] = 0;
+  __syncthreads();
+  for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
+    const int c0 = chunk * a.CC, cc = min(a.CC, a.C - c0);
+    const float* zrow = a.tile_in + (bh * a.C + c0) * (size_t)G;
+    const float* grow = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
+    for (int i = tid; i < cc * G; i += blockDim.x) {
+      if (__float_as_uint(grow[i]) == gbits && __float_as_uint(zrow[i]) != 0u) {
+        const int k = atomicAdd(&s_list[0], 1);
+        if (k < kTieTry) s_list[1 + k] = ((c0 + i / G) << 16) | (i % G);
+      }
+    }
+  }
+  __syncthreads();
+  const int n = s_list[0];
+  if (n == 0 || n > kTieTry) return false;
+#pragma unroll 1
+  for (int k = 0; k < n; ++k) {
+    const int e = s_list[1 + k];
+    if (splat_bwd_fix_mem_cell<DIM, HAS_PAD>(a, g, bh, b, e >> 16, e & 0xffff, Nr, gpos, wt, s_fix)) { CT_TIE_COUNT(9, 1); return true; }
+  }
+  CT_TIE_COUNT(10, 1);
+  return false;
+}
+
+// The caller's arguments, read again from the kernel's argument segment: the repair is a cold path at the end of kernels whose
+// loops have no register to spare, and holding the arguments for it across those loops costs them dearly (3D: +8..14 us per
+// launch when the repair used the kernel's own copies).  Valid in kernels whose parameters are (RasterArgs, GridW<DIM>).
+template <int DIM, bool HAS_PAD>
+__device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi, unsigned gbits, int Nr, size_t gpos_off, bool wt,
+                                                       int* s_cnt) {
+  const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  const RasterArgs& a = *(const RasterArgs*)kp;
+  constexpr size_t goff = (sizeof(RasterArgs) + alignof(GridW<DIM>) - 1) / alignof(GridW<DIM>) * alignof(GridW<DIM>);
+  const GridW<DIM>& g = *(const GridW<DIM>*)(kp + goff);
+  return splat_bwd_fix_mem<DIM, HAS_PAD>(a, g, bh, b, cgi, gbits, Nr, a.g_pos + gpos_off, wt, s_cnt);
+}
+
+// ---------------------------------------------------------------------------
 // KB3: Splat(max0) backward (see splat_max_bwd_hot_kernel).  grid = (ncg, H, B)
 // ---------------------------------------------------------------------------
 template <bool HAS_PAD, bool CLAIMS>
 __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW<3>& g, float4* ZG, size_t bh, int b, int c0,
                                                 int cc, int n0, const PtRows& R, const float (&k)[3][4], const int (&off)[8],
-                                                float (&gs)[4][3], int& nm) {
+                                                float (&gs)[4][3], int& nm, unsigned& xs) {
   const int G = g.G;
   float pv[4];
 #pragma unroll
@@ -447,6 +623,10 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
               nm += (int)mb;
               asm volatile("" : "+v"(nm));
               const float ga = ma ? zg[v].z : 0.0f, gb = mb ? zg[v].w : 0.0f;
+              if (CT_TIE_FIX) {      // the bit patterns of the awarded cotangents, summed (ct_raster_hot.h: plane_sum_bits)
+                xs += __float_as_uint(ga) + __float_as_uint(gb);
+                asm volatile("" : "+v"(xs));
+              }
               gfa = __builtin_fmaf(ga, w, gfa);
               gfb = __builtin_fmaf(gb, w, gfb);
               gw[hv * 4 + v] = __builtin_fmaf(gb, xb, __builtin_fmaf(ga, xa, gw[hv * 4 + v]));
@@ -505,6 +685,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
   const int tid = threadIdx.x;
   const int nq = N >> 2;
   int nz = 0, nm = 0;
+  unsigned xm = 0u, xz = 0u;      // (CT_TIE_FIX) bit-pattern sums of the awarded cotangents / of those of the non-zero cells
   float* gpos = a.g_pos + (size_t)cgi * a.gpos_stride;
   for (int chunk = cgi; chunk < a.nchunks; chunk += a.ncg) {
     const int c0 = chunk * CC;
@@ -516,9 +697,12 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
       const int cp = t / G, cell = t - cp * G;
       const size_t o = (size_t)(cp * 2) * G + cell;
       const unsigned z0 = __float_as_uint(ld_stream(zin + o)), z1 = __float_as_uint(ld_stream(zin + o + G));
-      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), ld_stream(gin + o),
-                          ld_stream(gin + o + G));
-      if (!CLAIMS) nz += (z0 != 0u) + (z1 != 0u);
+      const float g0 = ld_stream(gin + o), g1 = ld_stream(gin + o + G);
+      ZG[t] = make_float4(__uint_as_float(z0 ? z0 : kNoMatch), __uint_as_float(z1 ? z1 : kNoMatch), g0, g1);
+      if (!CLAIMS) {
+        nz += (z0 != 0u) + (z1 != 0u);
+        if (CT_TIE_FIX) xz += (z0 ? __float_as_uint(g0) : 0u) + (z1 ? __float_as_uint(g1) : 0u);
+      }
     }
     __syncthreads();
     if constexpr (QPT > 0) {
@@ -528,7 +712,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
         if (q < nq) {
           float k[3][4];
           load_keys3(a.pos.keys, bh, R.Nr, (int)R.so + (q << 2), k);
-          splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs_reg[u], nm);
+          splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs_reg[u], nm, xm);
         }
       }
     } else {
@@ -538,7 +722,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
         float gs[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-        splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs, nm);
+        splat_bwd_quad3<HAS_PAD, CLAIMS>(a, g, ZG, bh, b, c0, cc, q << 2, R, k, off, gs, nm, xm);
         // a chunk adds to the workgroup's own rows; the first starts from the incoming cotangent where there is one
         // (a.gpos_add); the finished rows go out write-through where another workgroup reads or overwrites them
         store_gkeys3(gpos, bh, R.Nr, (int)R.so + (q << 2), gs, k, chunk > cgi || a.gpos_add != nullptr,
@@ -553,6 +737,10 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
     if ((tid & 63) == 0) {
       atomicAdd(&s_cnt[0], nz);
       atomicAdd(&s_cnt[1], nm);
+    }
+    if (CT_TIE_FIX) {
+      plane_sum_bits(s_cnt + kTieSumPos, xm, 1);
+      plane_sum_bits(s_cnt + kTieSumNeg, xz, 1);
     }
     __syncthreads();
     tie = s_cnt[0] != s_cnt[1];
@@ -577,6 +765,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
   int off[8];
   corner_offsets3(g, off);
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4 + kTieFixWords + kTieFixWords) s_cnt[kTieSumPos + threadIdx.x] = 0;
   float gs[QPT ? QPT : 1][4][3];
 #pragma unroll
   for (int u = 0; u < (QPT ? QPT : 1); ++u)
@@ -584,6 +773,12 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
     for (int i = 0; i < 4; ++i) gs[u][i][0] = gs[u][i][1] = gs[u][i][2] = 0.0f;
   bool tie = false;
   splat_bwd_plane_pass3<HAS_PAD, false, QPT>(a, g, ZG, s_cnt, bh, b, wg.cgi, N, R, off, gs, tie);
+  if (CT_TIE_FIX && QPT == 0 && tie && nsg == 1 && s_cnt[1] - s_cnt[0] == 1) {      // block-uniform: ONE surplus match in this pass
+    const unsigned gbits = (unsigned)(s_cnt[kTieSumPos] - s_cnt[kTieSumNeg]);
+    // (+0: the surplus award added nothing anywhere)
+    if (gbits == 0u || splat_bwd_fix_mem_cold<3, HAS_PAD>(bh, b, wg.cgi, gbits, R.Nr, (size_t)wg.cgi * a.gpos_stride, fold_keys, s_cnt))
+      tie = false;
+  }
   if (tie && nsg == 1) {
 #pragma unroll
     for (int u = 0; u < (QPT ? QPT : 1); ++u)
@@ -612,16 +807,29 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
     }
   }
   if (nsg > 1) {         // kernel-uniform: the plane's tie test across its segments
-    unsigned* matches = a.tickets + kTicketHalf + bh;
+    // the plane's matches (low word) and the bit sum of their cotangents (high word: plane_sum_bits) in ONE 64-bit word of the
+    // ticket buffer's second half (splat_bwd_hot_plan: planes <= kTicketHalf / 2)
+    unsigned long long* matches = (unsigned long long*)(a.tickets + kTicketHalf) + bh;
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(matches, (unsigned)s_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(matches, ((unsigned long long)(unsigned)s_cnt[kTieSumPos] << 32) | (unsigned)s_cnt[1], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counted before the ticket is taken
     }
     const bool last = (arrive_last(a.tickets + bh, (unsigned)nsg, nullptr, 0u, (unsigned*)(s_cnt + 2)) & 1u) != 0;
-    if (last) {
-      if (threadIdx.x == 0) s_cnt[3] = (int)__hip_atomic_exchange(matches, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {          // block-uniform
+      // (read and reset in ONE atomic: a load could be served from a line an earlier launch left in this XCD's L2)
+      if (threadIdx.x == 0) {
+        const unsigned long long m = __hip_atomic_exchange(matches, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cnt[3] = (int)(unsigned)m;
+        s_cnt[2] = (int)(unsigned)(m >> 32);      // (the low word never carries into it: the matches of a plane are < 2^32)
+      }
       __syncthreads();
-      if (s_cnt[3] != s_cnt[0]) {
+      bool redo = s_cnt[3] != s_cnt[0];
+      if (CT_TIE_FIX && s_cnt[3] - s_cnt[0] == 1) {      // ONE surplus match in the plane: s_cnt[2] = the segments' bit sums
+        const unsigned gbits = (unsigned)(s_cnt[2] - s_cnt[kTieSumNeg]);
+        if (gbits == 0u || splat_bwd_fix_mem_cold<3, HAS_PAD>(bh, b, 0, gbits, R.Nr, 0, false, s_cnt)) redo = false;
+      }
+      if (redo) {       // the plane has exact ties: all of it again, with claims, by this workgroup
         PtRows Rall;
         Rall.Nr = R.Nr; Rall.so = 0; Rall.wt = false;
         float gs0[1][4][3];

@@ -191,3 +191,80 @@ def test_a_single_tie_in_one_group_of_one_plane(shape):
         lost = float(gk0[b0, h0 * dim:(h0 + 1) * dim, p0].abs().max())
         assert float((gk[b0, h0 * dim:(h0 + 1) * dim, p0] + gk[b0, h0 * dim:(h0 + 1) * dim, p1]
                       - gk0[b0, h0 * dim:(h0 + 1) * dim, p0]).abs().max()) <= 1e-5 * lost
+
+
+MEM_FORMS = [
+    # name, dim, W, C, N, B, H, forced segments, tickets
+    ("segments_2d", 2, 16, 16, 4096, 2, 4, 4, True),
+    ("segments_3d", 3, 8, 32, 4096, 2, 4, 4, True),
+    ("chunk_groups_3d_folded", 3, 8, 32, 4096, 8, 16, 0, True),
+    ("chunk_groups_3d_two_launches", 3, 8, 32, 4096, 8, 16, 0, False),
+    ("planes_3d", 3, 8, 16, 2048, 4, 64, 0, False),
+    ("through_memory_2d", 2, 32, 8, 16384, 2, 128, 0, False),
+]
+
+
+@pytest.mark.parametrize("form", MEM_FORMS, ids=[f[0] for f in MEM_FORMS])
+def test_a_single_tie_is_repaired_in_the_rows_it_touched(form):
+    """The forms of the hot Splat(max) backward whose key cotangents are in memory when a tie is known (3D, point segments, N
+    beyond the register forms) used to redo the whole pass of the workgroup — or the whole plane by its last workgroup — with
+    claims: twice the time for one tie.  One surplus match is now repaired through memory (ct_raster_hot3d.h: splat_bwd_fix_mem):
+    the lower point index keeps the award.  Same construction as the register form's test; the launch with the second point's
+    feature removed (no tie) is the expected result: g_feat bit for bit, g_keys to rounding (the award is taken back by
+    subtraction from the stored sum)."""
+    from cloud_transformers_amd import _lib
+    from cloud_transformers_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    name, dim, W, C, N, B, H, nseg, use_tickets = form
+    Wl = [W] * dim
+    g = torch.Generator().manual_seed(13)
+    k_node, j = _node_key(W)
+    keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
+    feat = torch.randn(B, H * C, N, generator=g)
+    cot = torch.randn(B, H * C, *Wl, generator=g)
+    add = torch.randn(B, H * dim, N, generator=g)
+    p0, p1 = 37, N - 5                      # (different segments)
+    b0, h0, c0 = B - 1, H // 2, C - 3
+    keys[b0, h0 * dim:(h0 + 1) * dim, p0] = k_node
+    keys[b0, h0 * dim:(h0 + 1) * dim, p1] = k_node
+    feat[b0, h0 * C:(h0 + 1) * C, p1] = -1.0
+    feat[b0, h0 * C + c0, p0] = 100.0
+    feat_untied = feat.clone()
+    feat[b0, h0 * C + c0, p1] = 100.0
+    kd, cd, addd = keys.cuda(), cot.cuda(), add.cuda()
+    Wa = _lib.int_array(Wl)
+    nws = lib.ct_splat_bwd_ex_workspace_bytes(B, H, C, N, dim, Wa, 0, 1)
+    ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
+    tickets = torch.zeros(_lib.TICKETS_BYTES // 4, device="cuda", dtype=torch.int32) if use_tickets else None
+
+    def run(f):
+        fd = f.cuda()
+        z = torch.empty(B, H * C, *Wl, device="cuda")
+        _lib.check(lib.ct_splat_fwd(_ptr(kd), _ptr(fd), None, 0, _ptr(z), B, H, C, N, dim, Wa, 0, _stream()), "fwd")
+        g_feat = torch.full_like(fd, float("nan"))
+        g_keys = torch.full_like(kd, float("nan"))
+        lib.ct_debug_set_flags(_lib.DEBUG_FORCE_HOT)
+        lib.ct_debug_set_nseg(nseg)
+        try:
+            _lib.check(lib.ct_splat_bwd_tk(_ptr(kd), _ptr(fd), None, 0, _ptr(z), _ptr(cd), _ptr(g_feat), _ptr(addd), _ptr(g_keys),
+                                           _ptr(ws), nws, _ptr(tickets), B, H, C, N, dim, Wa, 0, _stream()), "bwd")
+            torch.cuda.synchronize()
+            tag = lib.ct_debug_last_launch().decode()
+        finally:
+            lib.ct_debug_set_flags(0)
+            lib.ct_debug_set_nseg(0)
+        return g_feat.cpu(), g_keys.cpu(), tag, z.cpu()
+
+    gf, gk, tag, z = run(feat)
+    gf0, gk0, tag0, z0 = run(feat_untied)
+    assert "hot" in tag and tag == tag0, (tag, tag0)
+    assert ("segments" in tag) == (nseg > 0), tag
+    if use_tickets:
+        assert int(tickets.abs().sum()) == 0
+    assert torch.equal(z, z0)
+    cell = j * sum(W ** e for e in range(dim))
+    award = float(cot[b0, h0 * C + c0].reshape(-1)[cell])
+    assert float(gf[b0, h0 * C + c0, p0]) == pytest.approx(award, rel=1e-6), (name, tag)
+    assert float(gf[b0, h0 * C + c0, p1]) == 0.0, (name, tag)
+    assert torch.equal(gf, gf0), (name, tag)
+    assert float((gk - gk0).abs().max()) <= 1e-5 * float(gk0.abs().max()), (name, tag)

@@ -18,5 +18,6 @@ st.run(); torch.cuda.synchronize()
 fn(buf)
 st.run(); torch.cuda.synchronize()
 fn(buf)
-names = ["searches", "candidates", "resident", "repaired", "failed tries", "group redos", "plane redos", "tied groups", "surplus"]
+names = ["searches", "candidates", "resident", "repaired", "failed tries", "group redos", "plane redos", "tied groups", "surplus",
+         "repaired through memory", "memory repairs failed"]
 print("seed", seed, {n: buf[i] for i, n in enumerate(names)})
