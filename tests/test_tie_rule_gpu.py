@@ -2,8 +2,9 @@
 
 torch_scatter.scatter_max's backward (layers/cloud_transform.py:164-173 through torch_scatter) gives the cotangent of a cell to the
 single arg-max element it recorded; which of several bit-equal contributions that is differs between its CPU and CUDA kernels.
-The rule here, per family: the hot, generic and quad kernels award the contribution whose compare-and-swap
-reaches the cell's word first (one winner, identity unspecified); the banded kernels award the lowest point index.
+The rule here, per family: the hot kernels repair a single chance tie in favour of the lowest point index and
+redo anything beyond it with claims; there, and in the generic and quad kernels, the contribution whose compare-and-swap reaches
+the cell's word first wins (one winner, identity unspecified); the banded kernels award the lowest point index.
 
 Construction: two identical points alone in their neighbourhood, one cotangent value per corner cell.  The four corner cells see
 exactly the two tied contributions each, so the pair's gradients must be a PARTITION of the four corner terms g_z * weight."""
