@@ -935,10 +935,19 @@ __device__ __forceinline__ bool splat_bwd_fix_by_value(const RasterArgs& a, cons
       }
     }
   } else {
-    for (int i = tid; i < 4 * G; i += blockDim.x) {
-      if (__float_as_uint(grow[i]) == gbits && __float_as_uint(zrow[i]) != 0u) {
-        const int k = atomicAdd(&s_list[0], 1);
-        if (k < kTieTry) s_list[1 + k] = i % G;
+    // (eight loads per thread in flight, the tests behind them: one trip to memory, not one per element)
+    const int n = 4 * G, step = (int)blockDim.x;
+    for (int i0 = tid; i0 < n; i0 += 8 * step) {
+      unsigned gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gv[u] = __float_as_uint(grow[min(i0 + u * step, n - 1)]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * step;
+        if (i < n && gv[u] == gbits && __float_as_uint(zrow[i]) != 0u) {
+          const int k = atomicAdd(&s_list[0], 1);
+          if (k < kTieTry) s_list[1 + k] = i % G;
+        }
       }
     }
   }

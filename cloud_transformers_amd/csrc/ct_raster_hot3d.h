@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(Raster
 // the bit pattern of g_z at the tied (cell, channel), from the pass's bit sums.  The (cell, channel) pairs of the caller's chunks
 // whose g_z has these bits are tried in turn: every point with a corner in the cell tests its product against the cell's
 // maximum; exactly two must match (else the pair is not the tied one and nothing is written), the lower point index keeps the
-// award, the other gives it back — its g_feat element recomputed without that corner, its g_keys elements corrected in place
+// award, the other gives it back (one lane does that) — its g_feat element recomputed without that corner, its g_keys elements corrected in place
 // by the negated award.  Any thread handles any point: the caller guarantees that every workgroup that wrote these rows is done
 // (its own pass, or the plane's segments behind their last ticket).  False (block-uniform): redo.
 //   rows: Nr floats per row (the whole plane); gpos: the g_keys rows to correct; wt: written through (another workgroup reads them)
@@ -402,6 +402,32 @@ __device__ __forceinline__ int tie_corner(int d, const int (&off)[1 << DIM]) {
 #pragma unroll
   for (int c = 0; c < (1 << DIM); ++c) v = d == off[c] ? c : v;
   return v;
+}
+
+// one point's corner weights, base cell and per-axis terms from its keys (both dimensions behind one interface)
+template <int DIM>
+struct TiePoint {
+  float w0[DIM], w1[DIM], cw[1 << DIM];
+  int base;
+};
+template <int DIM>
+__device__ __forceinline__ void tie_point(const float (&kp)[DIM], const GridW<DIM>& g, TiePoint<DIM>& tp) {
+  if constexpr (DIM == 2) {
+    Pt2 p;
+    pt2_from_keys(kp[0], kp[1], g, g.W[1], p);
+    tp.w0[0] = p.w0x; tp.w1[0] = p.w1x; tp.w0[1] = p.w0y; tp.w1[1] = p.w1y;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tp.cw[v] = p.cw[v];
+    tp.base = p.base;
+  } else {
+    Pt3 p;
+    pt3_from_keys(kp[0], kp[1], kp[2], g, p);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { tp.w0[j] = p.w0[j]; tp.w1[j] = p.w1[j]; }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) tp.cw[v] = p.cw[v];
+    tp.base = p.base;
+  }
 }
 
 template <int DIM, bool HAS_PAD>
@@ -419,98 +445,89 @@ __device__ __forceinline__ bool splat_bwd_fix_mem_cell(const RasterArgs& a, cons
   const float* grow = a.tile_in2 + (bh * a.C + ch) * (size_t)G;
   const float* srow = a.src + (bh * a.C + ch) * (size_t)Nr;
   const unsigned zt = __float_as_uint(zrow[t]);
-  const float gt = grow[t];
   __syncthreads();
-  if (tid < 2) s_fix[tid] = tid == 0 ? 0x7fffffff : 0;
+  if (tid < 4) s_fix[tid] = tid == 0 ? 0x7fffffff : 0;      // [0] lowest matching point, [1] matches, [2], [3] the first two of them
   __syncthreads();
+  // every point of the plane: a corner in `t`?  (nothing is written in this loop: the key loads of several quads travel together)
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int winner = pass ? s_fix[0] : 0;
-#pragma unroll 1
-    for (int q = tid; q < nq; q += blockDim.x) {
-      float k[DIM][4];
+  for (int q = tid; q < nq; q += blockDim.x) {
+    float k[DIM][4];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      const float4 kv = *(const float4*)(a.pos.keys + (bh * DIM + j) * Nr + (q << 2));
+      k[j][0] = kv.x; k[j][1] = kv.y; k[j][2] = kv.z; k[j][3] = kv.w;
+    }
+    unsigned cand = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int base = 0;
 #pragma unroll
       for (int j = 0; j < DIM; ++j) {
-        const float4 kv = *(const float4*)(a.pos.keys + (bh * DIM + j) * Nr + (q << 2));
-        k[j][0] = kv.x; k[j][1] = kv.y; k[j][2] = kv.z; k[j][3] = kv.w;
+        float w0, w1;
+        int f;
+        ct_axis(k[j][i], g.hw[j], g.W[j], w0, w1, f);
+        base = base * g.W[j] + f;
       }
-      unsigned cand = 0u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int base = 0;
-#pragma unroll
-        for (int j = 0; j < DIM; ++j) {
-          float w0, w1;
-          int f;
-          ct_axis(k[j][i], g.hw[j], g.W[j], w0, w1, f);
-          base = base * g.W[j] + f;
-        }
-        if (tie_corner<DIM>(t - base, off) >= 0) cand |= 1u << i;
-      }
+      if (tie_corner<DIM>(t - base, off) >= 0) cand |= 1u << i;
+    }
 #pragma unroll 1
-      for (unsigned m = cand; m != 0u; m &= m - 1u) {          // rare: the points with a corner in `t`, one at a time
-        const int i = __builtin_ctz(m), n = (q << 2) + i;
-        float kp[DIM], w0[DIM], w1[DIM], cw[V];
-        int base;
+    for (unsigned m = cand; m != 0u; m &= m - 1u) {          // rare
+      const int i = __builtin_ctz(m), n = (q << 2) + i;
+      float kp[DIM];
 #pragma unroll
-        for (int j = 0; j < DIM; ++j) kp[j] = i == 0 ? k[j][0] : i == 1 ? k[j][1] : i == 2 ? k[j][2] : k[j][3];
-        if constexpr (DIM == 2) {
-          Pt2 p;
-          pt2_from_keys(kp[0], kp[1], g, g.W[1], p);
-          w0[0] = p.w0x; w1[0] = p.w1x; w0[1] = p.w0y; w1[1] = p.w1y;
+      for (int j = 0; j < DIM; ++j) kp[j] = i == 0 ? k[j][0] : i == 1 ? k[j][1] : i == 2 ? k[j][2] : k[j][3];
+      TiePoint<DIM> tp;
+      tie_point<DIM>(kp, g, tp);
+      const int vt = tie_corner<DIM>(t - tp.base, off);
+      float wc = 0.0f;
 #pragma unroll
-          for (int v = 0; v < V; ++v) cw[v] = p.cw[v];
-          base = p.base;
-        } else {
-          Pt3 p;
-          pt3_from_keys(kp[0], kp[1], kp[2], g, p);
-#pragma unroll
-          for (int j = 0; j < DIM; ++j) { w0[j] = p.w0[j]; w1[j] = p.w1[j]; }
-#pragma unroll
-          for (int v = 0; v < V; ++v) cw[v] = p.cw[v];
-          base = p.base;
-        }
-        const int vt = tie_corner<DIM>(t - base, off);
-        float wt_c = 0.0f;
-#pragma unroll
-        for (int v = 0; v < V; ++v) wt_c = v == vt ? cw[v] : wt_c;
-        const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + n) : 1.0f;
-        const float f = srow[n];
-        const float x = HAS_PAD ? f * pv : f;
-        if (__float_as_uint(x * wt_c) != zt) continue;
-        if (pass == 0) {
-          atomicMin(&s_fix[0], n);
-          atomicAdd(&s_fix[1], 1);
-          continue;
-        }
-        if (n == winner) continue;
-        // the loser: the award it was given, taken back through the corner-weight gradient ...
-        float gw[V], gd[DIM];
-#pragma unroll
-        for (int v = 0; v < V; ++v) gw[v] = v == vt ? -(gt * x) : 0.0f;
-        ct_corner_grad<DIM>(w0, w1, gw, gd);
-#pragma unroll
-        for (int j = 0; j < DIM; ++j) {
-          float* pk = gpos + (bh * DIM + j) * Nr + n;
-          const float nv = *pk + gd[j] * ct_key_mask(kp[j]);
-          if (wt) __hip_atomic_store(pk, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *pk = nv;
-        }
-        // ... and its g_feat element without that corner (the other corners keep what they matched), in the pass's order
-        float gf = 0.0f;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const unsigned zc = __float_as_uint(zrow[base + off[v]]);
-          const float gc = grow[base + off[v]];
-          const bool won = v != vt && zc != 0u && __float_as_uint(x * cw[v]) == zc;
-          gf = __builtin_fmaf(won ? gc : 0.0f, cw[v], gf);
-        }
-        a.dst[(bh * a.C + ch) * (size_t)Nr + n] = HAS_PAD ? gf * pv : gf;
+      for (int v = 0; v < V; ++v) wc = v == vt ? tp.cw[v] : wc;
+      const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + n) : 1.0f;
+      const float x = HAS_PAD ? srow[n] * pv : srow[n];
+      if (__float_as_uint(x * wc) == zt) {
+        const int c = atomicAdd(&s_fix[1], 1);
+        if (c < 2) s_fix[2 + c] = n;
+        atomicMin(&s_fix[0], n);
       }
     }
-    __syncthreads();
-    if (pass == 0 && s_fix[1] != 2) return false;          // block-uniform: not the tied pair
   }
+  __syncthreads();
+  if (s_fix[1] != 2) return false;          // block-uniform: not the tied pair, nothing written
+  if (tid == 0) {
+    // the loser (the higher of the two point indices): the award it was given, taken back through the corner-weight gradient,
+    // and its g_feat element without that corner — the other corners keep what they matched, in the pass's order
+    const int n = s_fix[2] == s_fix[0] ? s_fix[3] : s_fix[2];
+    float kp[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) kp[j] = a.pos.keys[(bh * DIM + j) * Nr + n];
+    TiePoint<DIM> tp;
+    tie_point<DIM>(kp, g, tp);
+    const int vt = tie_corner<DIM>(t - tp.base, off);
+    const float pv = HAS_PAD ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + n) : 1.0f;
+    const float x = HAS_PAD ? srow[n] * pv : srow[n];
+    const float gt = grow[t];
+    float gw[V], gd[DIM];
+#pragma unroll
+    for (int v = 0; v < V; ++v) gw[v] = v == vt ? -(gt * x) : 0.0f;
+    ct_corner_grad<DIM>(tp.w0, tp.w1, gw, gd);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      float* pk = gpos + (bh * DIM + j) * Nr + n;
+      const float nv = *pk + gd[j] * ct_key_mask(kp[j]);
+      if (wt) __hip_atomic_store(pk, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *pk = nv;
+    }
+    float gf = 0.0f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const unsigned zc = __float_as_uint(zrow[tp.base + off[v]]);
+      const float gc = grow[tp.base + off[v]];
+      const bool won = v != vt && zc != 0u && __float_as_uint(x * tp.cw[v]) == zc;
+      gf = __builtin_fmaf(won ? gc : 0.0f, tp.cw[v], gf);
+    }
+    a.dst[(bh * a.C + ch) * (size_t)Nr + n] = HAS_PAD ? gf * pv : gf;
+  }
+  __syncthreads();
   return true;
 }
 
@@ -528,7 +545,7 @@ __device__ __forceinline__ bool splat_bwd_fix_mem(const RasterArgs& a, const Gri
     const int c0 = chunk * a.CC, cc = min(a.CC, a.C - c0);
     const float* zrow = a.tile_in + (bh * a.C + c0) * (size_t)G;
     const float* grow = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
-    for (int i = tid; i < cc * G; i += blockDim.x) {
+    for (int i = tid; i < cc * G; i += blockDim.x) {      // (batching these loads, as the register form's search does, puts 11 scratch accesses into the 3D LOOP)
       if (__float_as_uint(grow[i]) == gbits && __float_as_uint(zrow[i]) != 0u) {
         const int k = atomicAdd(&s_list[0], 1);
         if (k < kTieTry) s_list[1 + k] = ((c0 + i / G) << 16) | (i % G);
