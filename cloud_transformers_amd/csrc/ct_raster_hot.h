@@ -641,9 +641,10 @@ __device__ __forceinline__ void plane_sum_bits(int* word, unsigned v, int sign) 
 template <bool HAS_PAD, bool CLAIMS, int WT, bool DELTA = false>
 __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<2>& g, float4* ZG, size_t bh, int b,
                                                int c0, int cc, int n0, const PtRows& R, const float (&kx)[4], const float (&ky)[4],
-                                               float (&gs)[4][2], int& nm, unsigned* nmp = nullptr,
-                                               unsigned* xsp = nullptr) {
-  unsigned xs = (CT_TIE_FIX && xsp != nullptr) ? *xsp : 0u;      // (CT_TIE_FIX) running sum of the bit patterns of the awarded cotangents (see plane_sum_bits)
+                                               float (&gs)[4][2], int& nm, unsigned& nmp, unsigned& xs, bool per_group) {
+  // nmp: the per-group match counts of this chunk (per_group), xs: the running sum of the bit patterns of the awarded cotangents
+  // (CT_TIE_FIX; plane_sum_bits).  REFERENCES to the caller's registers: through a pointer that may be null (rounds 4 and 5 until
+  // here) the compiler kept both in scratch, and the read-modify-write behind every group waited for the group's stores.
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1];
   const int off[4] = {0, W1, 1, W1 + 1};
   float pv[4];
@@ -761,11 +762,8 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
       st_part4(a.dst + (bh * a.C + c0 + cg0 + cj) * (size_t)R.Nr + R.so + n0, make_float4(fv[cj][0], fv[cj][1], fv[cj][2], fv[cj][3]), R.wt);
     // this group's matches into the thread's packed per-chunk counter (8 bits per four-channel group of the chunk: <= 4 groups,
     // <= 2 quads x 64 products per thread and group); LDS adds per (quad, group) — even one per wave — cost 3.5 us of 68 on the headline
-    if (!CLAIMS && nmp != nullptr) {
-      *nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
-    }
+    if (!CLAIMS && per_group) nmp += (unsigned)(nm - nm_before) << (8 * ((cg0 >> 2) & 3));
   }
-  if (CT_TIE_FIX && !CLAIMS && xsp != nullptr) *xsp = xs;
 }
 
 // The repair of ONE exact tie (one surplus match in the four-channel group at `cabs`, all of it in cell `t`)
@@ -1029,8 +1027,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     __syncthreads();
     unsigned nmp = 0u;
     unsigned xmp = 0u;
-    unsigned* const pnm = (!CLAIMS && grp != nullptr) ? &nmp : nullptr;
-    unsigned* const pxs = (CT_TIE_FIX && !CLAIMS) ? &xmp : nullptr;
+    const bool per_group = !CLAIMS && grp != nullptr;
     if constexpr (QPT > 0) {
       // Two quads per thread: while one is walked the other's eight key-cotangent sums are dead weight in a loop that has no
       // register to spare — seven of them wait in LDS meanwhile (what fits beside the tile; gs_park).
@@ -1045,7 +1042,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float4 tx = *(const float4*)(keyx + n0);
           const float4 ty = *(const float4*)(keyy + n0);
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
-          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, pnm, pxs);
+          splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, nmp, xmp, per_group);
         }
         if (PARK) gs_park<false>(park, gs_reg[1 - u]);
       }
@@ -1058,7 +1055,7 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         float gs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i][0] = gs[i][1] = 0.0f;
-        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, pnm, pxs);
+        splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs, nm, nmp, xmp, per_group);
         // the partial g_keys sums of the chunks go through memory (plain read-modify-write: the thread owns these
         // addresses); the first chunk starts from the incoming cotangent where there is one (a.gpos_add)
         float4 ox = make_float4(gs[0][0] * ct_key_mask(kx[0]), gs[1][0] * ct_key_mask(kx[1]),
@@ -1085,14 +1082,14 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
         }
       }
     }
-    if (pnm != nullptr) {                         // (all lanes are back here: threads without a quad add zeros)
+    if (per_group) {                              // (all lanes are back here: threads without a quad add zeros)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const int v = wave_sum_i32((int)((nmp >> (8 * f)) & 0xffu));
         if ((tid & 63) == 0 && v) atomicAdd(grp + kTieGroups + (c0 >> 2) + f, v);
       }
     }
-    if (pxs != nullptr) plane_sum_bits(grp != nullptr ? grp + 2 * kTieGroups + chunk : s_cnt + kTieSumPos, xmp, 1);
+    if (CT_TIE_FIX && !CLAIMS) plane_sum_bits(grp != nullptr ? grp + 2 * kTieGroups + chunk : s_cnt + kTieSumPos, xmp, 1);
   }
   if (!CLAIMS) {
     nz = wave_sum_i32(nz);
@@ -1209,7 +1206,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
             const float4 ty = *(const float4*)(keyy + n0);
             const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
             int nm_unused = 0;
-            splat_bwd_quad<HAS_PAD, true, WT, true>(a, g, ZG, bh, b, cabs, 4, n0, R, kx, ky, gs[u], nm_unused);
+            unsigned u0 = 0u, u1 = 0u;
+            splat_bwd_quad<HAS_PAD, true, WT, true>(a, g, ZG, bh, b, cabs, 4, n0, R, kx, ky, gs[u], nm_unused, u0, u1, false);
           }
         }
       }
