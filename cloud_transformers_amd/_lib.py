@@ -254,6 +254,7 @@ SIGNATURES = {
     "ct_bn_group_stats_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ct_bn_group_apply_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ct_bn_group_reduce_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ct_bn_group_reduce_bwd_copy": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "ct_bn_group_apply_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "ct_bn_relu_fwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "ct_bn_relu_bwd_amax": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

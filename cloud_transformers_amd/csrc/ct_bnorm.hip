@@ -214,6 +214,10 @@ struct BnBwdArgs {
   const float* sum1;
   const float* count;
   float* amax_out;   // nullable: amax_out[c] = max |gx| of channel c (see BnArgs::amax_out)
+  // mode 1, nullable: a second copy of the two sums (the collective overwrites the first in place; this one stays this rank's
+  // g_bias / g_weight — without it the caller clones the buffer: one more launch in every norm group's backward chain)
+  float* g_bias2;
+  float* g_weight2;
 };
 
 // the ReLU mask is recomputed with EXACTLY the forward's expression ((x - mean) * (weight * rstd) + bias, same operation
@@ -255,6 +259,10 @@ __device__ __forceinline__ void bn_bwd_reg_body(const BnBwdArgs& a, const int c)
     if (threadIdx.x == 0) {
       a.g_bias[c] = s[0];
       a.g_weight[c] = s[1];
+      if (a.g_bias2 != nullptr) {
+        a.g_bias2[c] = s[0];
+        a.g_weight2[c] = s[1];
+      }
     }
     if (a.mode == 1) return;      // this rank's sums for the exchange
   } else {
@@ -402,6 +410,10 @@ __device__ __forceinline__ void bn_bwd_loop_body(const BnBwdArgs& a, const int c
     if (threadIdx.x == 0) {
       a.g_bias[c] = s[0];
       a.g_weight[c] = s[1];
+      if (a.g_bias2 != nullptr) {
+        a.g_bias2[c] = s[0];
+        a.g_weight2[c] = s[1];
+      }
     }
     if (a.mode == 1) return;      // this rank's sums for the exchange
   } else {
@@ -706,7 +718,7 @@ extern "C" int ct_bn_group_apply_fwd(const ct_bn_fwd_item* items, int n, int B, 
 }
 
 static int bn_group_bwd_table(const ct_bn_bwd_item* items, int n, int B, int N, int mode, float* sums, const float* count,
-                              BnBwdTable& t, bool& vec_all) {
+                              BnBwdTable& t, bool& vec_all, float* sums_copy = nullptr) {
   if (!items || n < 1 || n > kBnMaxItems || !sums) return CT_EINVAL;
   int Ct = 0;
   for (int i = 0; i < n; ++i) Ct += items[i].C;
@@ -721,7 +733,8 @@ static int bn_group_bwd_table(const ct_bn_bwd_item* items, int n, int B, int N, 
     int rc;
     if (mode == 1) {          // this rank's two sums per channel (g_bias = sum g' -> sums[c], g_weight = sum g' xhat -> sums[Ct + c])
       a = BnBwdArgs{it.x, it.weight, it.bias, it.save_mean, it.save_rstd, it.gy, const_cast<float*>(it.x), sums + Ct + c0, sums + c0,
-                    B, it.C, N, it.relu, 0, 0, 0, 1, nullptr, nullptr, nullptr, nullptr};
+                    B, it.C, N, it.relu, 0, 0, 0, 1, nullptr, nullptr, nullptr, nullptr,
+                    sums_copy ? sums_copy + c0 : nullptr, sums_copy ? sums_copy + Ct + c0 : nullptr};
       rc = bn_bwd_prepare(a, it.x_batch_stride, it.gy_batch_stride, it.x_batch_stride, vec);
     } else {
       if (!it.gx || !count) return CT_EINVAL;
@@ -743,6 +756,15 @@ extern "C" int ct_bn_group_reduce_bwd(const ct_bn_bwd_item* items, int n, int B,
   BnBwdTable t{};
   bool vec;
   const int rc = bn_group_bwd_table(items, n, B, N, 1, sums, nullptr, t, vec);
+  return rc != CT_OK ? rc : bn_bwd_launch_table(t, vec, (hipStream_t)s);
+}
+
+extern "C" int ct_bn_group_reduce_bwd_copy(const ct_bn_bwd_item* items, int n, int B, int N, float* sums, float* sums_copy,
+                                           ct_stream_t s) {
+  if (!sums_copy) return CT_EINVAL;
+  BnBwdTable t{};
+  bool vec;
+  const int rc = bn_group_bwd_table(items, n, B, N, 1, sums, nullptr, t, vec, sums_copy);
   return rc != CT_OK ? rc : bn_bwd_launch_table(t, vec, (hipStream_t)s);
 }
 

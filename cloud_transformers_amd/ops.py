@@ -1114,8 +1114,9 @@ def _bn_group_bwd(items, B, N, device, group, count):
             e.save_mean, e.save_rstd, e.gy, e.gy_batch_stride = _ptr(it["mean"]), _ptr(it["rstd"]), it["gy"], it["gybs"]
             e.gx, e.gx_batch_stride, e.g_weight, e.g_bias, e.amax_out = it["gx"], it["gxbs"], None, None, it.get("amax")
             e.C, e.relu = it["C"], int(it["relu"])
-        _lib.check(lib.ct_bn_group_reduce_bwd(ctypes.addressof(arr), len(items), B, N, _ptr(sums), _stream()), "ct_bn_group_reduce_bwd")
-        local = sums.clone()                                              # this rank's g_bias / g_weight
+        local = torch.empty_like(sums)                                    # this rank's g_bias / g_weight: written by the same launch
+        _lib.check(lib.ct_bn_group_reduce_bwd_copy(ctypes.addressof(arr), len(items), B, N, _ptr(sums), _ptr(local), _stream()),
+                   "ct_bn_group_reduce_bwd_copy")
         work = dist.all_reduce(sums, group=group, async_op=True)
         _sync_stats_collectives += 1
         work.wait()

@@ -309,6 +309,10 @@ int ct_bn_group_stats_fwd(const ct_bn_fwd_item* items, int n, int B, int N, floa
 int ct_bn_group_apply_fwd(const ct_bn_fwd_item* items, int n, int B, int N, const float* gathered, int world,
                           float* count_total, ct_stream_t s);
 int ct_bn_group_reduce_bwd(const ct_bn_bwd_item* items, int n, int B, int N, float* sums, ct_stream_t s);
+/* the same, leaving a second copy of the sums in sums_copy f32[2 Ct] (same layout): the all_reduce runs in place on `sums`, the copy
+ * stays this rank's g_bias / g_weight (torch: grad of the SyncBatchNorm's affine parameters is local, DDP averages it) — one launch
+ * less per norm group than cloning the buffer */
+int ct_bn_group_reduce_bwd_copy(const ct_bn_bwd_item* items, int n, int B, int N, float* sums, float* sums_copy, ct_stream_t s);
 int ct_bn_group_apply_bwd(const ct_bn_bwd_item* items, int n, int B, int N, const float* sums, const float* count,
                           ct_stream_t s);
 /* The same two with amax_out f32[C] (nullable): max |y| (after ReLU and skip) / max |g_x| per channel, a by-product of the
