@@ -545,10 +545,21 @@ __device__ __forceinline__ bool splat_bwd_fix_mem(const RasterArgs& a, const Gri
     const int c0 = chunk * a.CC, cc = min(a.CC, a.C - c0);
     const float* zrow = a.tile_in + (bh * a.C + c0) * (size_t)G;
     const float* grow = a.tile_in2 + (bh * a.C + c0) * (size_t)G;
-    for (int i = tid; i < cc * G; i += blockDim.x) {      // (batching these loads, as the register form's search does, puts 11 scratch accesses into the 3D LOOP)
-      if (__float_as_uint(grow[i]) == gbits && __float_as_uint(zrow[i]) != 0u) {
-        const int k = atomicAdd(&s_list[0], 1);
-        if (k < kTieTry) s_list[1 + k] = ((c0 + i / G) << 16) | (i % G);
+    // 2D: four loads in flight, the tests behind them (64^2 C16 B2 N16384: a workgroup walks 16 k words).  3D: one at a time — ANY
+    // batching here puts 10+ scratch accesses into the 3D kernel's LOOP (the register allocator's doing, measured: +8 us per launch)
+    const int nn = cc * G, step = (int)blockDim.x;
+    constexpr int UB = DIM == 2 ? 4 : 1;
+    for (int i0 = tid; i0 < nn; i0 += UB * step) {
+      unsigned gv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) gv[u] = __float_as_uint(grow[min(i0 + u * step, nn - 1)]);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = i0 + u * step;
+        if (i < nn && gv[u] == gbits && __float_as_uint(zrow[i]) != 0u) {
+          const int k = atomicAdd(&s_list[0], 1);
+          if (k < kTieTry) s_list[1 + k] = ((c0 + i / G) << 16) | (i % G);
+        }
       }
     }
   }
