@@ -74,8 +74,10 @@ int ct_positions_bwd(const float* keys, const float* g_local_coord, float* g_key
  *   grid f32[B,H*C,G] (fully overwritten)
  * Splat backward (torch_scatter.scatter_max backward: the single arg-max
  *   contribution of a cell receives the cotangent; on EXACT ties exactly one of
- *   the tied contributions receives it, which one is unspecified — as in
- *   torch_scatter's CUDA path)
+ *   the tied contributions receives it — as in torch_scatter, whose CPU and CUDA
+ *   paths differ in WHICH one.  Here: a single chance tie in a plane is awarded
+ *   to the lowest point index; with more ties (duplicated points) the winner is
+ *   unspecified.  DESIGN.md section 2 has the rule per kernel family.)
  *   needs `grid` = the forward output, g_grid f32[B,H*C,G];
  *   writes g_feat f32[B,H*C,N] and g_keys f32[B,H*dim,N] (both overwritten).
  * workspace: scratch of ct_splat_bwd_workspace_bytes(...) bytes (may be 0).
@@ -160,8 +162,9 @@ int ct_slice_bwd_ps(const float* keys, const float* grid, const void* pad, int p
 /* ct_splat_bwd_tk: g_keys = g_keys_add + (key cotangent of this Splat); g_keys_add NULL: g_keys = the cotangent;
  * g_keys_add == g_keys: in place, as CT_BWD_ACCUMULATE_KEYS.  With tickets AND a g_keys_add that is not g_keys (or NULL) a
  * plane's POINTS may be dealt to several workgroups (point segments: no partial sums at all, every workgroup walks all
- * channel chunks for its points); the plane's exact-tie test then runs across them through the tickets, and a plane
- * that has ties is redone by its last workgroup from g_keys_add — which is why it must not alias the output.
+ * channel chunks for its points); the plane's exact-tie test then runs across them through the tickets (a 64-bit word per
+ * plane in the buffer's second half: the buffer must be 8-byte aligned for this form), and a plane with more than one tie
+ * is redone by its last workgroup from g_keys_add — which is why it must not alias the output.
  * workspace: ct_splat_bwd_ex_workspace_bytes(..., CT_BWD_ACCUMULATE_KEYS if g_keys_add else 0). */
 /* > 1: with tickets and a g_keys_add that is not g_keys, ct_splat_bwd_tk(reduce = max) deals the points of a plane of this
  * shape to that many workgroups — worth a second key-cotangent tensor; 1: it would not (adding in place is as good). */
