@@ -286,11 +286,6 @@ def run_op(args):
     # W = 200 (a 20-step burst after idle runs at 0.24 ms per step, tools/dev/lat_probe.py; sustained load: 0.195).  The
     # line says so (`config.order`).
     passes = time_passes(step)
-    ties = count_ties(step)
-    if dist is not None:
-        t = torch.tensor([ties], device="cuda", dtype=torch.int64)
-        dist.all_reduce(t)
-        ties = int(t.item())
     run_steps(args.warmup)
     barrier(dist)
     torch.cuda.synchronize()
@@ -308,6 +303,13 @@ def run_op(args):
         rank_ms = [float(g.item()) for g in gathered]
     dt = max_over_ranks(dist, dt)
     ms = dt / args.steps * 1e3
+    # (counted BEHIND the timed steps: its host synchronisations between the per-pass timings and a short timed region let the
+    #  clocks fall again — the driver's `--steps 20 --warmup 5` read 163 M points/s with it in front, 176 M with it here)
+    ties = count_ties(step)
+    if dist is not None:
+        t = torch.tensor([ties], device="cuda", dtype=torch.int64)
+        dist.all_reduce(t)
+        ties = int(t.item())
 
     if rank == 0:
         alg = step.algorithmic_bytes()
