@@ -147,6 +147,12 @@ class FakeLib:
             c0 += it.C
         return 0
 
+    def ct_bn_group_reduce_bwd_copy(self, items, n, B, N, sums, sums_copy, stream):
+        # (the same sums twice: one buffer for the in-place collective, one stays this rank's parameter gradients)
+        rc = self.ct_bn_group_reduce_bwd(items, n, B, N, sums, stream)
+        rc2 = self.ct_bn_group_reduce_bwd(items, n, B, N, sums_copy, stream)
+        return rc or rc2
+
     def ct_bn_group_apply_bwd(self, items, n, B, N, sums, count, stream):
         from cloud_transformers_amd._lib import BnBwdItem
         arr = self._items(items, n, BnBwdItem)
