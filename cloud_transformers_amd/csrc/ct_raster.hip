@@ -1992,6 +1992,21 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
     if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((KPAD), GRID, NT, LDS, STREAM, ARGS, GW); \
     else CT_LAUNCH((KNOPAD), GRID, NT, LDS, STREAM, ARGS, GW);                             \
   } while (0)
+// the same for kernels instantiated for the zoo's cubic grids (8^3, 16^3: the extent a template constant) beside the general form
+#ifndef CT_HOT3_CUBES
+#define CT_HOT3_CUBES 1
+#endif
+inline int cube_of(const GridW<3>& g) {
+  if (!CT_HOT3_CUBES || g.W[0] != g.W[1] || g.W[1] != g.W[2]) return 0;
+  return g.W[0] == 8 ? 8 : g.W[0] == 16 ? 16 : 0;
+}
+#define CT_LAUNCH_HOT3W_(KERNEL, QPTV, GRID, NT, LDS, STREAM, ARGS, GW)                                              \
+  do {                                                                                                               \
+    const int cube_ = cube_of(GW);                                                                                   \
+    if (cube_ == 8) CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 8>), (KERNEL<false, QPTV, 8>), GRID, NT, LDS, STREAM, ARGS, GW);       \
+    else if (cube_ == 16) CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 16>), (KERNEL<false, QPTV, 16>), GRID, NT, LDS, STREAM, ARGS, GW); \
+    else CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 0>), (KERNEL<false, QPTV, 0>), GRID, NT, LDS, STREAM, ARGS, GW);                    \
+  } while (0)
 
 int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.dst | (uintptr_t)a.tile_in;
@@ -2008,7 +2023,12 @@ int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
   a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N);
   const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
   dim3 grid(hp.nchunks * a.nsplit, a.H, a.B);
-  CT_LAUNCH_HOT3_((gather_ci3_kernel<true>), (gather_ci3_kernel<false>), grid, hot_threads(nq), hp.lds, st, a, g);
+  {
+    const int cube = cube_of(g);
+    if (cube == 8) CT_LAUNCH_HOT3_((gather_ci3_kernel<true, 8>), (gather_ci3_kernel<false, 8>), grid, hot_threads(nq), hp.lds, st, a, g);
+    else if (cube == 16) CT_LAUNCH_HOT3_((gather_ci3_kernel<true, 16>), (gather_ci3_kernel<false, 16>), grid, hot_threads(nq), hp.lds, st, a, g);
+    else CT_LAUNCH_HOT3_((gather_ci3_kernel<true, 0>), (gather_ci3_kernel<false, 0>), grid, hot_threads(nq), hp.lds, st, a, g);
+  }
   note("gather_ci3");
   return CT_OK;
 }
@@ -2057,9 +2077,9 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
   if (nq <= kHotThreads)
-    CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 1>), (slice_bwd_fused3_kernel<false, 1>), wgrid, hot_threads(nq), hp.lds, st, a, g);
+    CT_LAUNCH_HOT3W_(slice_bwd_fused3_kernel, 1, wgrid, hot_threads(nq), hp.lds, st, a, g);
   else
-    CT_LAUNCH_HOT3_((slice_bwd_fused3_kernel<true, 2>), (slice_bwd_fused3_kernel<false, 2>), wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
+    CT_LAUNCH_HOT3W_(slice_bwd_fused3_kernel, 2, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
   note(nseg > 1 ? "slice_bwd_fused3_segments" : ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
   if (fold) {
     note("folded");
@@ -2098,7 +2118,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   if (nseg > 1) {       // point segments (see the 2D form)
     a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
     dim3 wgrid(1, a.H, a.B * nseg);
-    CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, hot_threads(a.N >> 2), hp.lds, st, a, g);
+    CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(a.N >> 2), hp.lds, st, a, g);
     note("splat_max_bwd_hot3_segments");
     return CT_OK;
   }
@@ -2114,7 +2134,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   const int nq = a.N >> 2;
   // always the loop form (g_keys partials stored per chunk): keeping a quad's 12 g_keys values in registers across the
   // chunks makes the 3D kernel spill
-  CT_LAUNCH_HOT3_((splat_max_bwd_hot3_kernel<true, 0>), (splat_max_bwd_hot3_kernel<false, 0>), wgrid, hot_threads(nq), hp.lds, st, a, g);
+  CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(nq), hp.lds, st, a, g);
   note(ncg > 1 ? "splat_max_bwd_hot3_groups" : "splat_max_bwd_hot3");
   if (fold) {
     note("folded");
