@@ -1607,7 +1607,11 @@ bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
          ((long long)a.B * a.H >= 32 || (t_dbg_flags & CT_DEBUG_FORCE_HOT));
 }
 
-// kernels are instantiated for the 32 x 32 grid of the headline shape (immediate corner offsets) and for any grid
+// kernels are instantiated for the 32 x 32 grid of the headline shape, the zoo's 64 x 64 and 16 x 16 (extent a template constant:
+// immediate corner offsets, half-widths, cell count) and for any grid
+#ifndef CT_HOT2_SQUARES
+#define CT_HOT2_SQUARES 1
+#endif
 #define CT_HOT_KERNEL0(KERNEL, PADV, WTV) KERNEL<PADV, WTV>
 #define CT_HOT_KERNEL1(KERNEL, PADV, WTV, QPTV) KERNEL<PADV, WTV, QPTV>
 #define CT_LAUNCH_HOT_(MK, GRID, NT, LDS, STREAM, ARGS, GW, ...)                          \
@@ -1616,6 +1620,10 @@ bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
       CT_LAUNCH((MK(true, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);           \
     else if ((GW).W[0] == 32 && (GW).W[1] == 32)                                          \
       CT_LAUNCH((MK(false, 32, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
+    else if (CT_HOT2_SQUARES && (GW).W[0] == 64 && (GW).W[1] == 64)                       \
+      CT_LAUNCH((MK(false, 64, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
+    else if (CT_HOT2_SQUARES && (GW).W[0] == 16 && (GW).W[1] == 16)                       \
+      CT_LAUNCH((MK(false, 16, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);         \
     else                                                                                  \
       CT_LAUNCH((MK(false, 0, ##__VA_ARGS__)), GRID, NT, LDS, STREAM, ARGS, GW);          \
   } while (0)

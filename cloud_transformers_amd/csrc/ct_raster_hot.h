@@ -167,6 +167,21 @@ __device__ __forceinline__ WgCoord wg_coord(int ncg, int nseg, int H, int B) {
 }
 
 
+// A square grid whose extent is a template constant (WT > 0: the headline's 32 x 32, the zoo's 64 x 64 and 16 x 16): extents,
+// half-widths and cell count as immediates (see grid3_of in ct_raster_hot3d.h); WT = 0: the caller's grid.
+template <int WT>
+__device__ __forceinline__ GridW<2> grid2_of(const GridW<2>& g) {
+  if constexpr (WT == 0) {
+    return g;
+  } else {
+    GridW<2> c;
+    c.W[0] = c.W[1] = WT;
+    c.hw[0] = c.hw[1] = (float)(WT - 1) * 0.5f;
+    c.G = WT * WT;
+    return c;
+  }
+}
+
 // per-axis terms and corner weights of one 2D point
 struct Pt2 {
   float w0x, w1x, w0y, w1y;
@@ -237,7 +252,8 @@ __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const
 
 // GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
 template <bool HAS_PAD, int WT, int QPT, bool GATHER>
-__global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g_arg) {
+  const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   // WT > 0: square WT x WT grid known at compile time (corner offsets become instruction immediates)
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], CC = a.CC, N = a.N;
@@ -1116,7 +1132,8 @@ __device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi
 // single-winner claims, overwriting what the segments wrote — which is why their results went out write-through and
 // why the incoming key cotangent (a.gpos_add) must not alias the output then.
 template <bool HAS_PAD, int WT, int QPT>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g_arg) {
+  const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);
@@ -1305,7 +1322,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
 //   one ds_read_b128 per (point, corner, 4 channels).   grid = (nchunks * nsplit, H, B)
 // ---------------------------------------------------------------------------
 template <bool HAS_PAD, int WT>
-__global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a, GridW<2> g_arg) {
+  const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
   float4* T4 = (float4*)lds;
@@ -1381,7 +1399,8 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
 //   grid = (nsplit, H, B)
 // ---------------------------------------------------------------------------
 template <bool HAS_PAD, int WT>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_sum_bwd_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kHotThreads, 4) splat_sum_bwd_kernel(RasterArgs a, GridW<2> g_arg) {
+  const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
   float4* T4 = (float4*)lds;

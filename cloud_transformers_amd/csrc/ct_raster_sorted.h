@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(kSortThreads, 8) plane_sort_kernel(RasterArgs 
 // PRESORTED: the plane's record (a.sorted, ct_plane_sort) is loaded instead of sorting here.
 // GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
 template <bool HAS_PAD, int WT, bool PRESORTED, bool GATHER = true>
-__global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g) {
+__global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g_arg) {
+  const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
   const SortLds L = sort_lds(G, N, C);
