@@ -19,6 +19,21 @@ struct GridW {
   int G;           // cells
 };
 
+// A square grid whose extent is a template constant (WT > 0: the headline's 32 x 32, the zoo's 64 x 64 and 16 x 16): extents,
+// half-widths and cell count as immediates (see grid3_of in ct_raster_hot3d.h); WT = 0: the caller's grid.
+template <int WT>
+__device__ __forceinline__ GridW<2> grid2_of(const GridW<2>& g) {
+  if constexpr (WT == 0) {
+    return g;
+  } else {
+    GridW<2> c;
+    c.W[0] = c.W[1] = WT;
+    c.hw[0] = c.hw[1] = (float)(WT - 1) * 0.5f;
+    c.G = WT * WT;
+    return c;
+  }
+}
+
 // Per-axis terms of one key (layers/cloud_transform.py:91-94,
 // layers/utils.py:122,168): clamp, (k+1)*((W-1)/2) in that rounding order,
 // floor, low/high weights.

@@ -167,21 +167,6 @@ __device__ __forceinline__ WgCoord wg_coord(int ncg, int nseg, int H, int B) {
 }
 
 
-// A square grid whose extent is a template constant (WT > 0: the headline's 32 x 32, the zoo's 64 x 64 and 16 x 16): extents,
-// half-widths and cell count as immediates (see grid3_of in ct_raster_hot3d.h); WT = 0: the caller's grid.
-template <int WT>
-__device__ __forceinline__ GridW<2> grid2_of(const GridW<2>& g) {
-  if constexpr (WT == 0) {
-    return g;
-  } else {
-    GridW<2> c;
-    c.W[0] = c.W[1] = WT;
-    c.hw[0] = c.hw[1] = (float)(WT - 1) * 0.5f;
-    c.G = WT * WT;
-    return c;
-  }
-}
-
 // per-axis terms and corner weights of one 2D point
 struct Pt2 {
   float w0x, w1x, w0y, w1y;

@@ -102,7 +102,7 @@ class SplatSliceStep:
 
     # kernel-family tag (ct_debug_last_launch) -> kernel name as rocprofv3 prints it (substring)
     KERNEL_OF = {
-        "scatter_quad_max": "scatter_quad_kernel<2, false, false>",
+        "scatter_quad_max": "scatter_quad_kernel<2, false, false, 32>",
         "scatter_add_fx_reg": "scatter_add_fx_reg_kernel",
         "scatter_add_fused": "slice_bwd_fused_kernel<false, 32, 2, false>",
         "scatter_add_sorted": "slice_bwd_sorted_kernel<false, 32, false, false>",
