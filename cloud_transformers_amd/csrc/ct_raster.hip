@@ -1615,6 +1615,12 @@ bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
 #ifndef CT_HOT2_SQUARES
 #define CT_HOT2_SQUARES 1
 #endif
+#ifndef CT_SPLAT_BWD_HEADLINE
+#define CT_SPLAT_BWD_HEADLINE 0    // the hot Splat(max) backward with the headline's counts as constants: measured SLOWER (75 vs 69 us: profiles/r5_hot2_squares.txt)
+#endif
+#ifndef CT_SORTED_HEADLINE
+#define CT_SORTED_HEADLINE 1      // the sorted Slice backward with the headline's point and channel counts as constants too
+#endif
 #define CT_HOT_KERNEL0(KERNEL, PADV, WTV) KERNEL<PADV, WTV>
 #define CT_HOT_KERNEL1(KERNEL, PADV, WTV, QPTV) KERNEL<PADV, WTV, QPTV>
 #define CT_LAUNCH_HOT_(MK, GRID, NT, LDS, STREAM, ARGS, GW, ...)                          \
@@ -1777,7 +1783,10 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
       CT_LAUNCH_SORTED_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, true);
       note(sg > 1 ? "slice_bwd_presorted_groups" : "slice_bwd_presorted");
     } else {
-      CT_LAUNCH_SORTED_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, false);
+      if (CT_SORTED_HEADLINE && a.pad_dtype == CT_PAD_NONE && g.W[0] == 32 && g.W[1] == 32 && a.N == 4096 && a.C == 16 && a.ncg == 1)
+        CT_LAUNCH((slice_bwd_sorted_kernel<false, 32, false, true, 4096, 16>), wgrid, kSortThreads, L.total, st, a, g);
+      else
+        CT_LAUNCH_SORTED_(CT_MK_SLICE_BWD_SORTED, wgrid, kSortThreads, L.total, st, a, g, false);
       note(sg > 1 ? "slice_bwd_sorted_groups" : "slice_bwd_sorted");
     }
     if (fold) {
@@ -1980,7 +1989,10 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
-  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  if (CT_SPLAT_BWD_HEADLINE && a.pad_dtype == CT_PAD_NONE && g.W[0] == 32 && g.W[1] == 32 && a.N == 4096 && a.C == 16 && a.CC == 8 &&
+      a.nchunks == 2 && ncg == 1 && a.Nrow == 0 && kHotThreads == 512)
+    CT_LAUNCH((splat_max_bwd_hot_kernel<false, 32, 2, true>), wgrid, 512, hp.lds, st, a, g);
+  else if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
   note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");

@@ -1116,9 +1116,14 @@ __device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi
 // ticket, and the holder of the last ticket compares; on a tie (duplicated points: rare) it redoes the whole plane with
 // single-winner claims, overwriting what the segments wrote — which is why their results went out write-through and
 // why the incoming key cotangent (a.gpos_add) must not alias the output then.
-template <bool HAS_PAD, int WT, int QPT>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g_arg) {
+// HL: the headline's launch (N 4096, C 16 in two chunks of 8, one workgroup per plane, no segments): its counts as constants too
+template <bool HAS_PAD, int WT, int QPT, bool HL = false>
+__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a_arg, GridW<2> g_arg) {
   const GridW<2> g = grid2_of<WT>(g_arg);
+  RasterArgs a = a_arg;
+  if constexpr (HL) {
+    a.N = 4096; a.C = 16; a.CC = 8; a.nchunks = 2; a.ncg = 1; a.nseg = 0; a.Nrow = 0;
+  }
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);

@@ -414,9 +414,13 @@ __global__ void __launch_bounds__(kSortThreads, 8) plane_sort_kernel(RasterArgs 
 #endif
 // PRESORTED: the plane's record (a.sorted, ct_plane_sort) is loaded instead of sorting here.
 // GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
-template <bool HAS_PAD, int WT, bool PRESORTED, bool GATHER = true>
-__global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a, GridW<2> g_arg) {
+// NT, CT > 0: the point and channel counts as template constants too (the headline's 4096 x 16 on one workgroup per plane: a.ncg = 1)
+template <bool HAS_PAD, int WT, bool PRESORTED, bool GATHER = true, int NT = 0, int CT = 0>
+__global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterArgs a_arg, GridW<2> g_arg) {
   const GridW<2> g = grid2_of<WT>(g_arg);
+  RasterArgs a = a_arg;
+  if constexpr (NT > 0) { a.N = NT; a.ncg = 1; }
+  if constexpr (CT > 0) a.C = CT;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N, C = a.C;
   const SortLds L = sort_lds(G, N, C);

@@ -105,13 +105,13 @@ class SplatSliceStep:
         "scatter_quad_max": "scatter_quad_kernel<2, false, false, 32>",
         "scatter_add_fx_reg": "scatter_add_fx_reg_kernel",
         "scatter_add_fused": "slice_bwd_fused_kernel<false, 32, 2, false>",
-        "scatter_add_sorted": "slice_bwd_sorted_kernel<false, 32, false, false>",
+        "scatter_add_sorted": "slice_bwd_sorted_kernel<false, 32, false, false",
         "splat_sum_bwd_hot": "splat_sum_bwd_kernel",
         "gather_ci": "gather_ci_kernel",
         "gather_quad": "quad_kernel<2, 0,",
         "slice_bwd_fused": "slice_bwd_fused_kernel",
-        "slice_bwd_sorted": "slice_bwd_sorted_kernel<false, 32, false, true>",
-        "slice_bwd_presorted": "slice_bwd_sorted_kernel<false, 32, true, true>",
+        "slice_bwd_sorted": "slice_bwd_sorted_kernel<false, 32, false, true",
+        "slice_bwd_presorted": "slice_bwd_sorted_kernel<false, 32, true, true",
         "splat_max_bwd_hot": "splat_max_bwd_hot_kernel",
         "splat_max_bwd_whole_head": "quad_kernel<2, 2, 4, 1024,",
     }
