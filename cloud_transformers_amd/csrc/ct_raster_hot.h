@@ -1122,7 +1122,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(Raste
   const GridW<2> g = grid2_of<WT>(g_arg);
   RasterArgs a = a_arg;
   if constexpr (HL) {
-    a.N = 4096; a.C = 16; a.CC = 8; a.nchunks = 2; a.ncg = 1; a.nseg = 0; a.Nrow = 0;
+    // (the chunk and group counts stay opaque: as constants they unroll those loops, and the unrolled body spills inside the loop)
+    int cc8 = 8, nch2 = 2;
+    asm volatile("" : "+s"(cc8), "+s"(nch2));
+    a.N = 4096; a.C = 16; a.CC = cc8; a.nchunks = nch2; a.ncg = 1; a.nseg = 0; a.Nrow = 0;
   }
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
