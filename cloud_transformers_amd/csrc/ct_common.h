@@ -34,6 +34,21 @@ __device__ __forceinline__ GridW<2> grid2_of(const GridW<2>& g) {
   }
 }
 
+// The zoo's 3D grids are cubes of 8 and 16 cells (model_zoo: 8^3 C32, 16^3 C16): with the extent a template constant the cell count,
+// the corner offsets and the half-widths are immediates instead of registers in kernels that have none to spare (W3 = 0: any grid).
+template <int W3>
+__device__ __forceinline__ GridW<3> grid3_of(const GridW<3>& g) {
+  if constexpr (W3 == 0) {
+    return g;
+  } else {
+    GridW<3> c;
+    c.W[0] = c.W[1] = c.W[2] = W3;
+    c.hw[0] = c.hw[1] = c.hw[2] = (float)(W3 - 1) * 0.5f;
+    c.G = W3 * W3 * W3;
+    return c;
+  }
+}
+
 // Per-axis terms of one key (layers/cloud_transform.py:91-94,
 // layers/utils.py:122,168): clamp, (k+1)*((W-1)/2) in that rounding order,
 // floor, low/high weights.

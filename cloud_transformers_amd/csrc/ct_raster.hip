@@ -457,10 +457,14 @@ __global__ void __launch_bounds__(1024, DIM == 2 ? 8 : 4) scatter_add_fx_stream_
 //   group's LDS atomics, so a wave keeps CG KiB of HBM reads in flight instead of CG*256 B.
 //   grid = (nchunks, H, B)
 // ---------------------------------------------------------------------------
+#ifndef CT_SCATTER3_CUBES
+#define CT_SCATTER3_CUBES 1      // the 3D Splat forward instantiated for the zoo's 8^3 / 16^3 grids
+#endif
 template <int DIM, bool ADD, bool HAS_PAD, int WT = 0>
 __global__ void __launch_bounds__(DIM == 2 ? 1024 : 512, DIM == 2 ? 8 : 4) scatter_quad_kernel(RasterArgs a, GridW<DIM> g_arg) {
   GridW<DIM> g = g_arg;
   if constexpr (DIM == 2 && WT > 0) g = grid2_of<WT>(g_arg);      // (the headline's 32 x 32: the grid's constants folded)
+  if constexpr (DIM == 3 && WT > 0) g = grid3_of<WT>(g_arg);      // (the zoo's 8^3 and 16^3)
   constexpr int V = 1 << DIM;
   constexpr int CG = DIM == 2 ? 4 : 2;
   extern __shared__ __align__(16) float lds[];
@@ -1465,6 +1469,8 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
         const int qt = scatter_quad_threads(DIM, a.N);
         if (a.pad_dtype != CT_PAD_NONE) CT_LAUNCH((scatter_quad_kernel<DIM, false, true>), grid, qt, p.lds_bytes, st, a, g);
         else if (DIM == 2 && g.W[0] == 32 && g.W[DIM - 1] == 32) CT_LAUNCH((scatter_quad_kernel<DIM, false, false, DIM == 2 ? 32 : 0>), grid, qt, p.lds_bytes, st, a, g);
+        else if (DIM == 3 && CT_SCATTER3_CUBES && g.W[0] == 8 && g.W[1] == 8 && g.W[DIM - 1] == 8) CT_LAUNCH((scatter_quad_kernel<DIM, false, false, DIM == 3 ? 8 : 0>), grid, qt, p.lds_bytes, st, a, g);
+        else if (DIM == 3 && CT_SCATTER3_CUBES && g.W[0] == 16 && g.W[1] == 16 && g.W[DIM - 1] == 16) CT_LAUNCH((scatter_quad_kernel<DIM, false, false, DIM == 3 ? 16 : 0>), grid, qt, p.lds_bytes, st, a, g);
         else CT_LAUNCH((scatter_quad_kernel<DIM, false, false>), grid, qt, p.lds_bytes, st, a, g);
         note("scatter_quad_max");
       } else {

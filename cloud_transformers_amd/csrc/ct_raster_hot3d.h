@@ -22,21 +22,6 @@ __device__ __forceinline__ void pt3_from_keys(float kx, float ky, float kz, cons
   p.cw[4] = xy00 * p.w1[2]; p.cw[5] = xy10 * p.w1[2]; p.cw[6] = xy01 * p.w1[2]; p.cw[7] = xy11 * p.w1[2];
 }
 
-// The zoo's 3D grids are cubes of 8 and 16 cells (model_zoo: 8^3 C32, 16^3 C16): with the extent a template constant the cell count,
-// the corner offsets and the half-widths are immediates instead of registers in kernels that have none to spare (W3 = 0: any grid).
-template <int W3>
-__device__ __forceinline__ GridW<3> grid3_of(const GridW<3>& g) {
-  if constexpr (W3 == 0) {
-    return g;
-  } else {
-    GridW<3> c;
-    c.W[0] = c.W[1] = c.W[2] = W3;
-    c.hw[0] = c.hw[1] = c.hw[2] = (float)(W3 - 1) * 0.5f;
-    c.G = W3 * W3 * W3;
-    return c;
-  }
-}
-
 // cell offsets of the 8 corners relative to the base cell
 __device__ __forceinline__ void corner_offsets3(const GridW<3>& g, int (&off)[8]) {
   const int sx = g.W[1] * g.W[2], sy = g.W[2];
