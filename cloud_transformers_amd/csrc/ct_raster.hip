@@ -1557,7 +1557,7 @@ struct HotPlan {
 // LDS of the Splat(max) backward kernels behind their tiles: four counters and, per four-channel group of the plane (<= 64), its
 // non-zero cells and its matches, per chunk the sum of the awarded cotangents' bit patterns (ct_raster_hot.h: kTieGroups), and the
 // words of the single-tie repair and of its search
-constexpr size_t kSplatBwdFixed = 16 + 3 * 64 * 4 + 64 + (CT_SPLAT_PARK ? 7 * 512 * 4 : 0);      // (+ the parking rows of a two-quad thread's sums)
+constexpr size_t kSplatBwdFixed = 16 + 3 * 64 * 4 + 64;
 
 bool hot_chunks(int C, size_t per_ch, size_t fixed, HotPlan& hp, long long budget = kHalfCuLdsBytes) {
   if ((C & 3) != 0) return false;
@@ -1620,9 +1620,6 @@ bool hot_shape_ok(const RasterArgs& a, int G, uintptr_t ptr_bits) {
 // immediate corner offsets, half-widths, cell count) and for any grid
 #ifndef CT_HOT2_SQUARES
 #define CT_HOT2_SQUARES 1
-#endif
-#ifndef CT_SPLAT_BWD_HEADLINE
-#define CT_SPLAT_BWD_HEADLINE 0    // the hot Splat(max) backward with the headline's counts as constants: measured SLOWER (75 vs 69 us: profiles/r5_hot2_squares.txt)
 #endif
 #ifndef CT_SORTED_HEADLINE
 #define CT_SORTED_HEADLINE 1      // the sorted Slice backward with the headline's point and channel counts as constants too
@@ -1995,10 +1992,7 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
-  if (CT_SPLAT_BWD_HEADLINE && a.pad_dtype == CT_PAD_NONE && g.W[0] == 32 && g.W[1] == 32 && a.N == 4096 && a.C == 16 && a.CC == 8 &&
-      a.nchunks == 2 && ncg == 1 && a.Nrow == 0 && kHotThreads == 512)
-    CT_LAUNCH((splat_max_bwd_hot_kernel<false, 32, 2, true>), wgrid, 512, hp.lds, st, a, g);
-  else if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
   note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");

@@ -594,12 +594,6 @@ __global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_k
 // never NaN (a NaN product does not beat the zero floor in the forward), and a product equals this pattern only if
 // a feature is that very NaN.
 constexpr unsigned kNoMatch = 0x7FFFFFFFu;
-#ifndef CT_SPLAT_ZG_TUPLES
-#define CT_SPLAT_ZG_TUPLES 0      // 1: the four reads together, pinned as tuples; 2: tuples, one at a time — both measured SLOWER (profiles/r5_splat_bwd_loop.txt)
-#endif
-#ifndef CT_SPLAT_PARK
-#define CT_SPLAT_PARK 0      // measured: +1.5 us, and it is not the register count that the loop trips over (profiles/r5_splat_bwd_loop.txt)
-#endif
 #ifndef CT_TIE_FIX
 // 1: the optimistic pass also sums the BIT PATTERNS of the cotangents it awards (one three-operand add per corner and channel
 // pair), the staging pass those of the non-zero cells; with ONE surplus match in a chunk the difference is the tied cell's
@@ -675,21 +669,12 @@ __device__ __forceinline__ void splat_bwd_quad(const RasterArgs& a, const GridW<
         const float xb = HAS_PAD ? fv[2 * pr + 1][i] * pv[i] : fv[2 * pr + 1][i];
         ct_f4 zg[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          zg[v] = *(const ct_f4*)(Zp + off[v]);
-#if CT_SPLAT_ZG_TUPLES == 2
-          asm volatile("" : "+v"(zg[v]));
-#endif
-        }
-        // Whole 16-byte reads, pinned as register tuples and all four at once: left alone the compiler splits them into a narrow
-        // read plus conditional ones; pinned per component (rounds 2-4) it waited for every read by itself and moved three of
-        // the four words to other registers behind it — a tenth of the instructions of a loop that is bound by their issue.
-#if CT_SPLAT_ZG_TUPLES == 1
-        asm volatile("" : "+v"(zg[0]), "+v"(zg[1]), "+v"(zg[2]), "+v"(zg[3]));
-#elif CT_SPLAT_ZG_TUPLES == 0
+        for (int v = 0; v < 4; ++v) zg[v] = *(const ct_f4*)(Zp + off[v]);
+        // Whole 16-byte reads, pinned per component: left alone the compiler splits them into a narrow read plus conditional ones.
+        // (Pinned as register tuples — together or one at a time — the loop has 15 % fewer instructions and is SLOWER, in 3D by
+        // 15 %: profiles/r5_splat_bwd_loop.txt.)
 #pragma unroll
         for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
-#endif
         float gfa = 0.0f, gfb = 0.0f;
         if (!CLAIMS) {
 #pragma unroll
@@ -968,19 +953,6 @@ __device__ __forceinline__ bool splat_bwd_fix_by_value(const RasterArgs& a, cons
   return false;
 }
 
-// seven of a quad's eight sums to / from the workgroup's parking rows ([7][kHotThreads] floats behind the tie words; lane-
-// contiguous: conflict-free).  The memory clobbers keep the compiler from forwarding the stored values in registers.
-template <bool STORE>
-__device__ __forceinline__ void gs_park(float* park, float (&gs)[4][2]) {
-  if (!STORE) asm volatile("" ::: "memory");
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    if (STORE) park[j * kHotThreads] = gs[j >> 1][j & 1];
-    else gs[j >> 1][j & 1] = park[j * kHotThreads];
-  }
-  if (STORE) asm volatile("" ::: "memory");
-}
-
 // one pass over the workgroup's points (N of them, rows R) and its chunks; cgi: chunk group (see slice_bwd_fused_kernel)
 template <bool HAS_PAD, bool CLAIMS, int WT, int QPT>
 __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const GridW<2>& g, float4* ZG, int* s_cnt,
@@ -1030,13 +1002,8 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
     unsigned xmp = 0u;
     const bool per_group = !CLAIMS && grp != nullptr;
     if constexpr (QPT > 0) {
-      // Two quads per thread: while one is walked the other's eight key-cotangent sums are dead weight in a loop that has no
-      // register to spare — seven of them wait in LDS meanwhile (what fits beside the tile; gs_park).
-      constexpr bool PARK = QPT == 2 && CT_SPLAT_PARK != 0;
-      float* const park = (float*)(s_cnt + 4 + 3 * kTieGroups + 2 * kTieFixWords) + tid;
 #pragma unroll
       for (int u = 0; u < QPT; ++u) {
-        if (PARK) gs_park<true>(park, gs_reg[1 - u]);
         const int q = tid + u * (int)blockDim.x;
         if (q < nq) {
           const int n0 = q << 2;
@@ -1045,7 +1012,6 @@ __device__ __forceinline__ void splat_bwd_plane_pass(const RasterArgs& a, const 
           const float kx[4] = {tx.x, tx.y, tx.z, tx.w}, ky[4] = {ty.x, ty.y, ty.z, ty.w};
           splat_bwd_quad<HAS_PAD, CLAIMS, WT>(a, g, ZG, bh, b, c0, cc, n0, R, kx, ky, gs_reg[u], nm, nmp, xmp, per_group);
         }
-        if (PARK) gs_park<false>(park, gs_reg[1 - u]);
       }
     } else {
       for (int q = tid; q < nq; q += blockDim.x) {
@@ -1116,17 +1082,9 @@ __device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi
 // ticket, and the holder of the last ticket compares; on a tie (duplicated points: rare) it redoes the whole plane with
 // single-winner claims, overwriting what the segments wrote — which is why their results went out write-through and
 // why the incoming key cotangent (a.gpos_add) must not alias the output then.
-// HL: the headline's launch (N 4096, C 16 in two chunks of 8, one workgroup per plane, no segments): its counts as constants too
-template <bool HAS_PAD, int WT, int QPT, bool HL = false>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a_arg, GridW<2> g_arg) {
+template <bool HAS_PAD, int WT, int QPT>
+__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g_arg) {
   const GridW<2> g = grid2_of<WT>(g_arg);
-  RasterArgs a = a_arg;
-  if constexpr (HL) {
-    // (the chunk and group counts stay opaque: as constants they unroll those loops, and the unrolled body spills inside the loop)
-    int cc8 = 8, nch2 = 2;
-    asm volatile("" : "+s"(cc8), "+s"(nch2));
-    a.N = 4096; a.C = 16; a.CC = cc8; a.nchunks = nch2; a.ncg = 1; a.nseg = 0; a.Nrow = 0;
-  }
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
   int* s_cnt = (int*)(lds + (size_t)a.CC * g.G * 2);

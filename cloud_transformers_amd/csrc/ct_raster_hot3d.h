@@ -629,19 +629,10 @@ __device__ __forceinline__ void splat_bwd_quad3(const RasterArgs& a, const GridW
         for (int hv = 0; hv < 2; ++hv) {
           ct_f4 zg[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            zg[v] = *(const ct_f4*)(Zp + off[hv * 4 + v]);
-#if CT_SPLAT_ZG_TUPLES == 2
-            asm volatile("" : "+v"(zg[v]));
-#endif
-          }
-          // (whole reads, pinned as tuples and together: see splat_bwd_quad)
-#if CT_SPLAT_ZG_TUPLES == 1
-          asm volatile("" : "+v"(zg[0]), "+v"(zg[1]), "+v"(zg[2]), "+v"(zg[3]));
-#elif CT_SPLAT_ZG_TUPLES == 0
+          for (int v = 0; v < 4; ++v) zg[v] = *(const ct_f4*)(Zp + off[hv * 4 + v]);
+          // (whole reads, pinned per component: see splat_bwd_quad)
 #pragma unroll
           for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(zg[v].x), "+v"(zg[v].y), "+v"(zg[v].z), "+v"(zg[v].w));
-#endif
           if (!CLAIMS) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {

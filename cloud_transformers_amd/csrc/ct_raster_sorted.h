@@ -475,9 +475,6 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
 #ifndef CT_SORT_LATE_REQUEST
 #define CT_SORT_LATE_REQUEST 1
 #endif
-#ifndef CT_SORT_PREFETCH
-#define CT_SORT_PREFETCH 0         // 256: touch the keys of the plane this XCD gets next round — measured: no gain (profiles/r5_sorted_stamps.txt)
-#endif
   if (PRESORTED || !CT_SORT_LATE_REQUEST) request(cgi);
   float pv[4];
 #pragma unroll
@@ -656,15 +653,6 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
   CT_STAMP(8);
   int grp = cgi;
   for (; grp + ncg < ngroups; grp += ncg) group(grp, std::true_type{});
-#if CT_SORT_PREFETCH
-  // One workgroup per CU and one plane per workgroup: the workgroup that takes this CU next waits ~2.3 us for its plane's keys
-  // with nothing else in flight.  Consecutive workgroups go to the XCDs in turn, so plane p + 256 (the next round: 256 CUs) runs on
-  // THIS XCD — one dword per 32 bytes of its keys, asked for before this plane's last group, brings them into this XCD's L2.  The
-  // value is consumed behind the kernel's last store (a test that never holds), so nothing waits for it before then.
-  float pf = 0.0f;
-  if (ncg == 1 && bh + CT_SORT_PREFETCH < (size_t)a.B * a.H)
-    pf = a.pos.keys[(bh + CT_SORT_PREFETCH) * 2 * (size_t)N + ((size_t)tid << 3) % (2 * (size_t)N)];
-#endif
   group(grp, std::false_type{});
   CT_STAMP(9);
 #endif
@@ -698,8 +686,5 @@ __global__ void __launch_bounds__(kSortThreads) slice_bwd_sorted_kernel(RasterAr
         fold_rows(a.g_pos + (bh * 2 + j) * N, a.gpos_stride, ncg, a.fold_gpos + (bh * 2 + j) * N, N >> 2, nullptr);
     }
   }
-#if CT_SORT_PREFETCH && CT_SORT_ABL != 1
-  if (__float_as_uint(pf) == 0x7fc12345u) a.g_pos[0] = pf;        // (never: keys are finite)
-#endif
   CT_STAMP(10);
 }
