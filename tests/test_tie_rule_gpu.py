@@ -132,8 +132,8 @@ def _node_key(W):
     raise AssertionError("no node key for W = %d" % W)
 
 
-@pytest.mark.parametrize("shape", [(32, 16, 4096, 2), (32, 16, 2048, 1), (16, 16, 4096, 1), (20, 8, 2048, 1)],
-                         ids=["32x32_two_quads", "32x32_one_quad", "16x16", "generic_width"])
+@pytest.mark.parametrize("shape", [(32, 16, 4096, 2), (32, 16, 2048, 1), (16, 16, 4096, 1), (20, 8, 2048, 1), (32, 16, 4096, -2)],
+                         ids=["32x32_two_quads", "32x32_one_quad", "16x16", "generic_width", "32x32_padding_mask"])
 def test_a_single_tie_in_one_group_of_one_plane(shape):
     """One surplus match in one four-channel group of one plane (what a random B8 H64 workload holds about one time in three).
     The hot 2D kernel redoes that group alone (splat_bwd_quad<.., DELTA>) or, built with -DCT_TIE_FIX=1, finds the cell from its
@@ -143,8 +143,13 @@ def test_a_single_tie_in_one_group_of_one_plane(shape):
     pair equals the same launch without the second point's feature (no tie at all)."""
     from cloud_transformers_amd import ops
     mod, lib = _lib()
-    W, C, N, _ = shape
+    W, C, N, quads = shape
     B, H, dim = 4, 64, 2                     # a plane per workgroup: the register form with the per-group counters
+    pad = None
+    if quads < 0:                            # with a padding mask (float32 0 / 1 per point: the kernels' HAS_PAD instantiations)
+        pad = (torch.rand(B, N, generator=torch.Generator().manual_seed(3)) > 0.1).float()
+        pad[:, 37] = 1.0
+        pad[:, N - 5] = 1.0
     g = torch.Generator().manual_seed(7)
     k_node, j = _node_key(W)
     keys = torch.tanh(torch.randn(B, H * dim, N, generator=g))
@@ -167,7 +172,7 @@ def test_a_single_tie_in_one_group_of_one_plane(shape):
         kd, fd = keys.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
         lib.ct_debug_set_flags(mod.DEBUG_FORCE_HOT)
         try:
-            ops.splat_keys(kd, fd, None, [W, W], H, dim, "max").backward(gz.cuda())
+            ops.splat_keys(kd, fd, None if pad is None else pad.cuda(), [W, W], H, dim, "max").backward(gz.cuda())
             tag = lib.ct_debug_last_launch().decode()
         finally:
             lib.ct_debug_set_flags(0)
@@ -202,6 +207,8 @@ MEM_FORMS = [
     ("chunk_groups_3d_two_launches", 3, 8, 32, 4096, 8, 16, 0, False),
     ("planes_3d", 3, 8, 16, 2048, 4, 64, 0, False),
     ("through_memory_2d", 2, 32, 8, 16384, 2, 128, 0, False),
+    ("segments_2d_padding_mask", 2, 16, 16, 4096, 2, 4, 4, True),
+    ("planes_3d_padding_mask", 3, 8, 16, 2048, 4, 64, 0, False),
 ]
 
 
@@ -233,6 +240,12 @@ def test_a_single_tie_is_repaired_in_the_rows_it_touched(form):
     feat_untied = feat.clone()
     feat[b0, h0 * C + c0, p1] = 100.0
     kd, cd, addd = keys.cuda(), cot.cuda(), add.cuda()
+    padd, pad_code = None, 0
+    if name.endswith("padding_mask"):        # (float32 0 / 1 per point: the kernels' HAS_PAD instantiations)
+        pad = (torch.rand(B, N, generator=g) > 0.1).float()
+        pad[:, p0] = 1.0
+        pad[:, p1] = 1.0
+        padd, pad_code = pad.cuda(), _lib.PAD_F32
     Wa = _lib.int_array(Wl)
     nws = lib.ct_splat_bwd_ex_workspace_bytes(B, H, C, N, dim, Wa, 0, 1)
     ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
@@ -241,13 +254,13 @@ def test_a_single_tie_is_repaired_in_the_rows_it_touched(form):
     def run(f):
         fd = f.cuda()
         z = torch.empty(B, H * C, *Wl, device="cuda")
-        _lib.check(lib.ct_splat_fwd(_ptr(kd), _ptr(fd), None, 0, _ptr(z), B, H, C, N, dim, Wa, 0, _stream()), "fwd")
+        _lib.check(lib.ct_splat_fwd(_ptr(kd), _ptr(fd), _ptr(padd), pad_code, _ptr(z), B, H, C, N, dim, Wa, 0, _stream()), "fwd")
         g_feat = torch.full_like(fd, float("nan"))
         g_keys = torch.full_like(kd, float("nan"))
         lib.ct_debug_set_flags(_lib.DEBUG_FORCE_HOT)
         lib.ct_debug_set_nseg(nseg)
         try:
-            _lib.check(lib.ct_splat_bwd_tk(_ptr(kd), _ptr(fd), None, 0, _ptr(z), _ptr(cd), _ptr(g_feat), _ptr(addd), _ptr(g_keys),
+            _lib.check(lib.ct_splat_bwd_tk(_ptr(kd), _ptr(fd), _ptr(padd), pad_code, _ptr(z), _ptr(cd), _ptr(g_feat), _ptr(addd), _ptr(g_keys),
                                            _ptr(ws), nws, _ptr(tickets), B, H, C, N, dim, Wa, 0, _stream()), "bwd")
             torch.cuda.synchronize()
             tag = lib.ct_debug_last_launch().decode()
