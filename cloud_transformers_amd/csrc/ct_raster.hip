@@ -1502,10 +1502,14 @@ int quad_threads(int N, int nsplit) {
   return t > CT_QUAD_THREADS ? CT_QUAD_THREADS : t;
 }
 
-int pick_nsplit(int B, int H, int nchunks, int N) {
+// dim: 2 / 3 for the Slice-forward gathers, 0 for the other callers.  Measured over the zoo rows (profiles/r5_nsplit_want.txt): the 2D
+// gathers and the short 3D clouds are fastest at ONE workgroup per CU (every split stages the tile again and a 128-thread workgroup
+// is mostly latency), the long 3D clouds (N = 16384, eight corners of work per point) at two.
+int pick_nsplit(int B, int H, int nchunks, int N, int dim = 0) {
   // pure gather kernels may split N freely (the tile is re-staged per split)
+  const long long want = (dim == 2 || (dim == 3 && N <= 2048)) ? 256 : 512;
   int ns = 1;
-  while ((long long)B * H * nchunks * ns < 512 && N / (ns * 2) >= 256) ns *= 2;
+  while ((long long)B * H * nchunks * ns < want && N / (ns * 2) >= 256) ns *= 2;
   return ns;
 }
 
@@ -1665,7 +1669,7 @@ int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   HotPlan hp;
   if (!hot_chunks(a.C, (size_t)g.G * 4, 0, hp)) return CT_EINVAL;
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = hp.nchunks;
-  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N);
+  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N, 2);
   const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
   dim3 grid(hp.nchunks * a.nsplit, a.H, a.B);
 #define CT_MK_GATHER(PADV, WTV) CT_HOT_KERNEL0(gather_ci_kernel, PADV, WTV)
@@ -2043,7 +2047,7 @@ int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
     hp.lds = (size_t)hp.CC * g.G * 4;
   }
   a.CC = hp.CC; a.nchunks = hp.nchunks; a.ncg = hp.nchunks;
-  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N);
+  a.nsplit = pick_nsplit(a.B, a.H, hp.nchunks, a.N, 3);
   const int nq = ((a.N >> 2) + a.nsplit - 1) / a.nsplit;
   dim3 grid(hp.nchunks * a.nsplit, a.H, a.B);
   {
@@ -2242,7 +2246,7 @@ int run_gather(RasterArgs a, const int* W, hipStream_t st) {
   Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
   a.CC = p.CC;
   a.nchunks = p.nchunks;
-  a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N);
+  a.nsplit = pick_nsplit(a.B, a.H, p.nchunks, a.N, DIM);
   int threads = round_threads((a.N + a.nsplit - 1) / a.nsplit);
   dim3 grid(p.nchunks * a.nsplit, a.H, a.B);
   if constexpr (FROM_KEYS) {
