@@ -1435,11 +1435,14 @@ int scatter_quad_threads(int dim, int N) {
   return t > cap ? cap : t;
 }
 
+#ifndef CT_SCATTER_WANT
+#define CT_SCATTER_WANT 256      // workgroups the forward scatter's channel chunks aim for
+#endif
 // scatter: Splat fwd (max/sum) and Slice bwd g_grid
 template <int DIM, bool FROM_KEYS>
 int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
   GridW<DIM> g = make_grid<DIM>(W);
-  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1);
+  Plan p = make_plan(a.B, a.H, a.C, a.N, g.G, 1, CT_SCATTER_WANT);
   a.CC = p.CC;
   a.nchunks = p.nchunks;
   dim3 grid(p.nchunks, a.H, a.B);
