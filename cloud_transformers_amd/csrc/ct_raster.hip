@@ -1435,8 +1435,10 @@ int scatter_quad_threads(int dim, int N) {
   return t > cap ? cap : t;
 }
 
+// workgroups the forward scatter's channel chunks aim for: one per CU in 2D, two in 3D (eight corners of atomics per point: measured
+// over the zoo rows, profiles/r5_nsplit_want.txt)
 #ifndef CT_SCATTER_WANT
-#define CT_SCATTER_WANT 256      // workgroups the forward scatter's channel chunks aim for
+#define CT_SCATTER_WANT (DIM == 3 ? 512 : 256)
 #endif
 // scatter: Splat fwd (max/sum) and Slice bwd g_grid
 template <int DIM, bool FROM_KEYS>
