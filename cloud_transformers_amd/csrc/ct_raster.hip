@@ -1435,10 +1435,11 @@ int scatter_quad_threads(int dim, int N) {
   return t > cap ? cap : t;
 }
 
-// workgroups the forward scatter's channel chunks aim for: one per CU in 2D, two in 3D (eight corners of atomics per point: measured
-// over the zoo rows, profiles/r5_nsplit_want.txt)
+// workgroups the forward scatter's channel chunks aim for: one per CU in 2D, two in 3D (eight corners of atomics per point); with two
+// or more planes per CU (the headline: 512) a plane's channels still go to TWO workgroups — 1024 thinner workgroups balance the
+// tail better than 512 (measured: profiles/r5_nsplit_want.txt)
 #ifndef CT_SCATTER_WANT
-#define CT_SCATTER_WANT (DIM == 3 ? 512 : 256)
+#define CT_SCATTER_WANT (DIM == 3 ? 512 : ((long long)a.B * a.H >= 512 ? 2ll * a.B * a.H : 256))
 #endif
 // scatter: Splat fwd (max/sum) and Slice bwd g_grid
 template <int DIM, bool FROM_KEYS>
