@@ -57,6 +57,9 @@ def parse():
                    help="steps captured per HIP graph (the K timed steps are replays of it plus single-step replays for the rest)")
     p.add_argument("--seed", type=int, default=1234, help="rank r draws its clouds from seed + r")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-ddp-step", action="store_true", help="N > 1, mode op: do not attach the data-parallel training step")
+    p.add_argument("--ddp-steps", type=int, default=10, help="timed steps of the attached data-parallel training step")
+    p.add_argument("--ddp-timeout", type=int, default=420, help="seconds the attached step may take before the line goes out without it")
     p.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg")
     return p.parse_args()
 
@@ -370,6 +373,20 @@ def run_op(args):
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+    else:
+        out = {}
+    if dist is not None and not args.no_ddp_step:
+        # N > 1 ranks: the op-level numbers above are taken; now the SAME ranks run the data-parallel training step (mode ddp-step's
+        # workload: DDP gradient all-reduce + SyncBatchNorm exchanges on RCCL) and rank 0 attaches it to the ONE line — `value`
+        # stays the op-level throughput, `ddp_step.value` is what BASELINE's ">= 6x DDP throughput at 8 GPUs vs 1" is read from
+        # (the 1-GPU denominator: `bench.py --mode ddp-step`, profiles/*_bench_line_ddp_step.json)
+        del step, keys, feat, cot
+        torch.cuda.empty_cache()
+        guard = ddp_step_deadline(out, rank, args.ddp_timeout)       # a hung collective must not cost the op-level line
+        attach_ddp_step(out, lambda: ddp_step_measure(dist, rank, world, args.ddp_steps, 3, args.batch, args.points, local_rank,
+                                                      no_graph=args.no_graph))
+        guard.cancel()
+    if rank == 0:
         if dist is not None:
             dist.barrier()             # every rank's banners are out (they flush below before this barrier completes)
         emit(json.dumps(out))
@@ -382,134 +399,204 @@ def run_op(args):
         dist.destroy_process_group()
 
 
+def ddp_step_measure(dist, rank, world, steps, warmup, batch, points, device_index, no_graph=False, make=None):
+    """The S3DIS-shaped segmenter training step under DDP + SyncBatchNorm, timed in the calling rank of an initialised process
+    group (train_segmentation.py:128-130: SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel; gradient all-reduce
+    as utils/train_util_distributed.py:12-34 averages them).  Every rank returns the same-shaped dict:
+      ms_per_step, value (world * batch * points / s), collectives_per_step (norm-statistics exchanges), params_equal_across_ranks,
+      param_checksum_spread, step ("graph" | "eager" | "eager (graph capture failed on some rank: ...)"), loss, parameters.
+    Forward + loss + backward run as ONE HIP graph with the RCCL collectives captured; the ranks AGREE on graph-or-eager (an
+    all-reduced flag after the capture: a rank replaying a graph beside ranks stepping eagerly would deadlock in DDP's
+    reducer), and the eager fallback starts from a FRESH DDP wrapper and optimizer (a capture that failed inside backward leaves
+    the old reducer mid-iteration).  `make` (tests: a CPU stand-in under gloo) -> (net, input, labels) on the target device;
+    `device_index` None = CPU (no graphs, no streams)."""
+    import torch
+    from torch import nn
+    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks, quiesce as parallel_quiesce
+    from cloud_transformers_amd import ops
+    on_gpu = device_index is not None
+    B, N = batch, points
+    torch.manual_seed(0)                               # same initial weights on every rank
+    if make is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from segmenter_step_bench import Segmenter
+        net = Segmenter().cuda()
+    prev_stream = work_stream = None
+    if on_gpu:
+        # Everything DDP runs on ONE side stream — its construction (the reducer stashes the parameters' AccumulateGrad nodes,
+        # which remember the stream they were made on: its gradient hooks, and with them the bucketed all-reduce, run THERE),
+        # the warm-up iterations, the capture and the replays: torch's recipe for capturing DDP (notes/cuda.rst).
+        prev_stream = torch.cuda.current_stream()
+        work_stream = torch.cuda.Stream()
+        work_stream.wait_stream(prev_stream)
+        torch.cuda.set_stream(work_stream)
+    try:
+        torch.manual_seed(1234 + rank)                     # its own shard of the batch
+        if make is None:
+            cloud = torch.cat([torch.rand(B, 3, N, device="cuda") * 2 - 1, torch.rand(B, 3, N, device="cuda")], dim=1)
+            labels = torch.randint(13, (B, N), device="cuda")
+        else:
+            torch.manual_seed(0)
+            net, cloud, labels = make(rank)
+        state = {}
+
+        def wrap():
+            state["ddp"] = data_parallel(net, device_index)
+            state["opt"] = torch.optim.SGD(state["ddp"].parameters(), lr=0.01, momentum=0.9)
+
+        wrap()
+        lossf = nn.CrossEntropyLoss()
+
+        def fwd_bwd():
+            loss = lossf(state["ddp"](cloud), labels)
+            loss.backward()                                # bucketed gradient all-reduce overlaps with this
+            return loss
+
+        def one_eager():
+            state["opt"].zero_grad(set_to_none=True)
+            loss = fwd_bwd()
+            state["opt"].step()
+            return loss
+
+        # DDP wants 11 eager iterations before a capture (its reducer rebuilds the buckets after the first and settles)
+        for _ in range(max(11, warmup) if on_gpu else max(2, warmup)):
+            one_eager()
+        graph, graph_error, collectives, static_loss = None, None, None, None
+        if on_gpu and not no_graph:
+            torch.cuda.synchronize()
+            barrier(dist)
+            parallel_quiesce()
+            try:
+                state["opt"].zero_grad(set_to_none=True)
+                c0 = ops.sync_stats_collectives()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=work_stream, capture_error_mode="thread_local"):
+                    static_loss = fwd_bwd()
+                collectives = ops.sync_stats_collectives() - c0        # enqueued once, at capture; replayed every step
+            except Exception as e:      # noqa: BLE001
+                graph, graph_error = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+                torch.cuda.synchronize()
+            ok = torch.tensor([1 if graph is not None else 0], device="cuda", dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if graph is not None:
+                    graph_error = "another rank's capture failed"
+                graph, collectives = None, None
+                torch.cuda.synchronize()
+                wrap()                                     # fresh reducer, fresh optimizer state: the eager step in a clean state
+                for _ in range(3):
+                    one_eager()
+
+        def one():
+            if graph is None:
+                return one_eager()
+            graph.replay()
+            state["opt"].step()
+            return static_loss
+
+        for _ in range(3 if on_gpu else 1):
+            one()
+        coll0 = ops.sync_stats_collectives()
+        barrier(dist)
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = one()
+        if on_gpu:
+            torch.cuda.synchronize()
+        barrier(dist)
+        dt = max_over_ranks(dist, time.perf_counter() - t0)
+        if collectives is None:
+            collectives = (ops.sync_stats_collectives() - coll0) / steps
+        # every rank must hold the same parameters and running statistics after the steps (same initial weights, averaged
+        # gradients, job-wide batch statistics): one float64 checksum per rank, gathered
+        with torch.no_grad():
+            chk = torch.stack([t.double().sum() for t in list(net.parameters()) + [b for b in net.buffers() if b.is_floating_point()]]).sum().reshape(1)
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(chks, chk)
+        else:
+            chks = [chk]
+        spread = float((torch.stack(chks) - chks[0]).abs().max() / chks[0].abs().clamp_min(1e-30))
+        return {
+            "ms_per_step": dt / steps * 1e3, "value": world * B * N / (dt / steps), "unit": "points/s", "steps": steps,
+            "collectives_per_step": collectives, "params_equal_across_ranks": spread <= 1e-9, "param_checksum_spread": spread,
+            "step": "graph" if graph is not None else ("eager" + (" (graph capture failed: %s)" % graph_error if graph_error else "")),
+            "loss": float(loss.detach()), "parameters": sum(p.numel() for p in net.parameters()),
+            "per_gpu_batch": B, "points": N, "world_size_seen": world,
+        }
+    finally:
+        if on_gpu:
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(prev_stream)
+
+
+def ddp_step_deadline(out, rank, seconds):
+    """A timer per rank: if the attached data-parallel step has not come back after `seconds` (a collective that never completes
+    cannot be cancelled from Python), rank 0 prints the op-level line with ddp_step.error set and every rank leaves through
+    os._exit(0) — the line the driver came for is not lost to the attachment."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            out["ddp_step"] = {"error": "no result after %d s (a collective did not complete?); op-level numbers above are unaffected" % seconds}
+            emit(json.dumps(out))
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def attach_ddp_step(out, measure):
+    """out["ddp_step"] = measure(), or {"error": ...}: the op-level line is never lost to a failure of the attached leg (every rank
+    calls this; rank 0's `out` is the one printed, the others pass a scratch dict)."""
+    try:
+        out["ddp_step"] = measure()
+    except Exception as e:      # noqa: BLE001
+        out["ddp_step"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return out
+
+
 def run_ddp_step(args):
     """S3DIS-shaped segmenter training step under DDP + SyncBatchNorm (also at world size 1: the wrap is the same)."""
     import torch
-    from torch import nn
     rank, local_rank, world, dist = init_rank()
     import torch.distributed as tdist
     if world == 1:
         # one rank: keep the norms' statistics exchange ON (a one-rank RCCL group), so that the step enqueues — and this
         # line times — what every rank of an N-GPU step enqueues: 76 collectives + the bucketed gradient all-reduce
         os.environ.setdefault("CLOUDCT_SYNCBN_FORCE", "1")
-    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")       # torch's recipe for capturing collectives (notes/cuda.rst)
     if dist is None:            # DDP needs a process group even for one rank
         from cloud_transformers_amd.launch import free_port
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         dist = tdist
-    from cloud_transformers_amd.parallel import barrier, data_parallel, max_over_ranks, quiesce as parallel_quiesce
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from segmenter_step_bench import Segmenter
-
-    B, N = args.batch, args.points
-    torch.manual_seed(0)                               # same initial weights on every rank
-    net = Segmenter().cuda()
-    # Everything DDP runs on ONE side stream — its construction (the reducer stashes the parameters' AccumulateGrad nodes,
-    # which remember the stream they were made on: its gradient hooks, and with them the bucketed all-reduce, run THERE),
-    # the warm-up iterations, the capture and the replays: torch's recipe for capturing DDP (notes/cuda.rst).  A step
-    # captured on another stream than the hooks' would enqueue the all-reduce outside the capture (and RCCL's watchdog
-    # then dies on "event last recorded in a capturing stream").
-    work_stream = torch.cuda.Stream()
-    work_stream.wait_stream(torch.cuda.current_stream())
-    torch.cuda.set_stream(work_stream)
-    ddp = data_parallel(net, local_rank)
-    opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
-    torch.manual_seed(1234 + rank)                     # its own shard of the batch
-    cloud = torch.cat([torch.rand(B, 3, N, device="cuda") * 2 - 1, torch.rand(B, 3, N, device="cuda")], dim=1)
-    labels = torch.randint(13, (B, N), device="cuda")
-    lossf = nn.CrossEntropyLoss()
-
     from cloud_transformers_amd import ops
-
-    def fwd_bwd():
-        loss = lossf(ddp(cloud), labels)
-        loss.backward()                                # bucketed gradient all-reduce overlaps with this
-        return loss
-
-    def one_eager():
-        opt.zero_grad(set_to_none=True)
-        loss = fwd_bwd()
-        opt.step()
-        return loss
-
-    # forward + loss + backward as ONE HIP graph, DDP's bucketed all-reduce and the norms' statistics exchanges captured
-    # with the kernels (RCCL collectives capture like launches).  DDP wants 11 eager iterations first (its reducer rebuilds
-    # the buckets after the first and settles); they run on a side stream, as torch's capture recipe asks.  The optimizer
-    # steps outside the graph.  --no-graph: the eager step (host-bound: ~3 000 launches through Python / ctypes).
-    graph, graph_error = None, None
-    collectives = None
-    if args.no_graph:
-        for _ in range(max(11, args.warmup)):          # (as many as the graphed form: the two lines are comparable step for step)
-            one_eager()
-    else:
-        for _ in range(max(11, args.warmup)):
-            one_eager()
-        torch.cuda.synchronize()
-        barrier(dist)
-        parallel_quiesce()
-        try:
-            opt.zero_grad(set_to_none=True)
-            c0 = ops.sync_stats_collectives()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=work_stream, capture_error_mode="thread_local"):
-                static_loss = fwd_bwd()
-            collectives = ops.sync_stats_collectives() - c0        # enqueued once, at capture; replayed every step
-        except Exception as e:      # noqa: BLE001  (a failed capture leaves the eager path usable: nothing was launched)
-            graph, graph_error = None, "%s: %s" % (type(e).__name__, e)
-            if rank == 0:
-                print("bench: HIP-graph capture of the DDP step failed (%s); timing the eager step" % graph_error, flush=True)
-            torch.cuda.synchronize()
-
-    def one():
-        if graph is None:
-            return one_eager()
-        graph.replay()
-        opt.step()
-        return static_loss
-
-    for _ in range(3):
-        one()
-    coll0 = ops.sync_stats_collectives()
-    barrier(dist)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one()
-    torch.cuda.synchronize()
-    barrier(dist)
-    dt = max_over_ranks(dist, time.perf_counter() - t0)
-    if collectives is None:
-        collectives = (ops.sync_stats_collectives() - coll0) / args.steps
-    # every rank must hold the same parameters and running statistics after the steps (same initial weights, averaged
-    # gradients, job-wide batch statistics): one float64 checksum per rank, gathered
-    with torch.no_grad():
-        chk = torch.stack([t.double().sum() for t in list(net.parameters()) + [b for b in net.buffers() if b.is_floating_point()]]).sum().reshape(1)
-    chks = [torch.zeros_like(chk) for _ in range(world)]
-    if world > 1:
-        dist.all_gather(chks, chk)
-    else:
-        chks = [chk]
-    spread = float((torch.stack(chks) - chks[0]).abs().max() / chks[0].abs().clamp_min(1e-30))
+    B, N = args.batch, args.points
+    m = ddp_step_measure(dist, rank, world, args.steps, args.warmup, B, N, local_rank, no_graph=args.no_graph)
     if rank == 0:
-        nbytes = sum(p.numel() for p in net.parameters()) * 4
+        nbytes = m["parameters"] * 4
         out = {
-            "metric": METRIC, "value": world * B * N / (dt / args.steps), "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": METRIC, "value": m["value"], "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S3DIS-shaped segmenter training step (stem + 12 MultiHeadUnion + head, %.1f M parameters), "
                                    "B=%d clouds x N=%d pts per GPU, cross-entropy + SGD, DistributedDataParallel + SyncBatchNorm on RCCL"
                                    % (nbytes / 4e6, B, N),
                        "per_gpu_batch": B, "parallelism": "dp%d" % world, "world_size_seen": world,
                        "gradient_allreduce_MB_per_step": nbytes / 1e6,
-                       "norm_statistics_collectives_per_step": collectives,
+                       "norm_statistics_collectives_per_step": m["collectives_per_step"],
                        "norm_statistics_exchange": "forced on at world size 1 (CLOUDCT_SYNCBN_FORCE)" if (world == 1 and ops.SYNC_STATS_FORCE)
                                                    else ("on" if world > 1 else "off (one rank: plain batch norm)"),
-                       "step": "HIP graph (forward + loss + backward, collectives captured) + optimizer" if graph is not None
-                               else ("eager" + (" (graph capture failed: %s)" % graph_error if graph_error else "")),
-                       "params_equal_across_ranks": spread <= 1e-9, "param_checksum_spread": spread,
-                       "loss": float(loss.detach())},
+                       "step": "HIP graph (forward + loss + backward, collectives captured) + optimizer" if m["step"] == "graph"
+                               else m["step"],
+                       "params_equal_across_ranks": m["params_equal_across_ranks"], "param_checksum_spread": m["param_checksum_spread"],
+                       "loss": m["loss"]},
         }
         dist.barrier()
         emit(json.dumps(out))
@@ -532,11 +619,18 @@ def main():
         have = launch.visible_gpus()                   # KFD topology + *_VISIBLE_DEVICES: no HIP runtime in the parent
         if have is not None and have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
-        raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                            capture=not args.no_graph and (args.mode == "ddp-step" or not args.no_ddp_step)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if launch.under_launcher() and world != args.gpus:
         print("bench: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d" % (args.gpus, world, world),
               file=sys.stderr)
+    captures_collectives = not args.no_graph and (args.mode == "ddp-step" or (world > 1 and not args.no_ddp_step))
+    if captures_collectives:
+        # torch's recipe for capturing collectives (notes/cuda.rst): with the process group's watchdog polling events of a
+        # capturing stream the capture dies.  The price — a hung collective is not aborted, the job hangs instead of exiting —
+        # is paid only by runs that capture (launch.rank_env(capture=True) does the same for spawned ranks)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     if args.mode == "ddp-step":
         if args.steps == 200 and args.warmup == 20:      # defaults are the op benchmark's: a training step is ~100x longer
             args.steps, args.warmup = 20, 3

@@ -63,6 +63,7 @@ class AdainBwdItem(ctypes.Structure):
                 ("gamma_beta_batch_stride", ctypes.c_longlong)]
 
 
+ABI_VERSION = 2      # CT_ABI_VERSION of include/cloudct.h
 BN_GROUP_MAX = 8
 CT_OK = 0
 REDUCE = {"max": 0, "sum": 1}
@@ -314,12 +315,19 @@ def load():
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(cloud_transformers_amd has no CPU or PyTorch fallback)")
             lib = ctypes.CDLL(LIB_PATH)
+            lib.ct_abi_version.restype = ctypes.c_int
+            if lib.ct_abi_version() != ABI_VERSION:
+                raise RuntimeError("%s reports ABI version %d, this package binds version %d (include/cloudct.h): rebuild it — "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`, or tools/dev/build_raster_exp.sh for an "
+                                   "experimental library selected by CLOUDCT_LIB" % (LIB_PATH, lib.ct_abi_version(), ABI_VERSION))
+            missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+            if missing:
+                raise RuntimeError("%s lacks %d symbol(s) of include/cloudct.h (%s ...): a stale build — rebuild it"
+                                   % (LIB_PATH, len(missing), ", ".join(missing[:4])))
             for name, (res, args) in SIGNATURES.items():
-                fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+                fn = getattr(lib, name)
                 fn.restype = res
                 fn.argtypes = args
-            if lib.ct_abi_version() != 1:
-                raise RuntimeError("libcloudct.so ABI version mismatch")
             _lib = lib
     return _lib
 

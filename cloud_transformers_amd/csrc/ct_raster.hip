@@ -15,6 +15,7 @@
 // and layers/utils.py:100-186 of the reference).
 #include "ct_common.h"
 #include <string.h>
+#include <type_traits>
 #include <atomic>
 #include <mutex>
 
@@ -30,52 +31,7 @@
 
 namespace {
 
-constexpr int kMaxLdsBytes = 64 * 1024;        // tile budget per workgroup (2 WGs / CU)
-constexpr int kBigLdsBytes = 160 * 1024 - 512; // whole-CU budget for huge single-channel tiles
-
-struct PosSrc {
-  const float* keys;        // (B, H*DIM, N)            when FROM_KEYS
-  const float* lc;          // (B, H, V, N)             otherwise
-  const long long* idx;     // (B, H, V, N) int64
-};
-
-struct RasterArgs {
-  PosSrc pos;
-  const float* src;     // point-sized input  (B, H*C, N): feat or g_out
-  const void* pad;      // (B, N) or null
-  int pad_dtype;
-  float* tile_out;      // grid-sized output  (B, H*C, G)
-  const float* tile_in; // grid-sized input   (B, H*C, G)
-  const float* tile_in2;// second grid-sized input (g_grid for splat-max bwd)
-  float* dst;           // point-sized output (B, H*C, N)
-  float* g_pos;         // g_keys (B,H*DIM,N) or g_lc (B,H,V,N)
-  unsigned* claim;      // global copy of z used for single-winner claims (no-LDS fallback)
-  int B, H, C, N;
-  int CC;               // channels per tile
-  int nchunks;          // ceil(C / CC)
-  int ncg;              // chunk groups (grid.x split of the chunk loop in gather-reduce kernels)
-  int nsplit;           // splits of N for pure gather kernels
-  int atomic_gpos;      // accumulate g_pos with global atomics (ncg > 1)
-  int cnt_mask;         // STATS: contributions are counted in cnt_mask+1 (a power of two) counters indexed by cell & cnt_mask
-  size_t gpos_stride;   // > 0: channel-chunk group cg writes its partial g_pos to g_pos + cg*gpos_stride floats (summed afterwards)
-  int accumulate;       // hot Splat(max) backward: g_pos += result instead of g_pos = result
-  int nseg;             // fused Slice backward: point segments per (b,h) plane (grid.z = B * nseg); a.N = points per segment,
-  int Nrow;             //   Nrow = length of a row of the point-sized tensors (= N when nseg == 1)
-  // in-kernel folds of the partials (ct_raster_hot.h, arrive_last): arrival tickets (null: the partials are added by
-  // sum_parts launches), where the folded g_keys / g_grid go, and whether the g_keys fold adds to what is there
-  unsigned* tickets;
-  float* fold_gpos;
-  float* fold_grid;
-  const float* fold_add;  // the g_keys fold adds these rows (the incoming key cotangent) to the sum, or null
-  const float* gpos_add;  // hot Splat(max) backward: g_pos = gpos_add + result (may alias g_pos: in place), or null
-  // Slice backward's statistics (per-channel max |src*pad|, contributions per cell) when N is split over workgroups: each
-  // split writes its own pair per channel here ([nsplit][B*H*C][2] words, plain stores) and the scatter kernel combines them
-  // (max of the maxima, sum of the per-split K) — instead of atomics on slots that a zero_slots launch had to clear first
-  unsigned* stats;
-  // sorted planes (ct_raster_sorted.h): the records ct_plane_sort wrote for these keys (null: the kernels sort themselves)
-  const unsigned char* sorted;
-  size_t sorted_stride;
-};
+#include "ct_raster_args.h"
 
 // (M, K) of channel `ch` of plane bh as the scatter kernels need them: from the partial statistics (a.stats) or from the
 // two slot words at the head of the channel's output tile
@@ -1209,8 +1165,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : CT_QUAD_WAVES) 
 
 #include "ct_raster_hot.h"
 #include "ct_raster_hot3d.h"
+CT_KERNARG_IS_ARGS_AND_GRID((splat_max_bwd_hot_kernel<false, 32, 2>), 2);      // (defined in ct_raster_hot.h, ahead of the macro)
+CT_KERNARG_IS_ARGS_AND_GRID((splat_max_bwd_hot_kernel<true, 0, 0, kHotWideThreads>), 2);
 #include "ct_raster_band.h"
 #include "ct_raster_sorted.h"
+#include "ct_raster_sorted3d.h"
 
 // ---------------------------------------------------------------------------
 // K0: DifferentiablePositions forward / backward (API path only)
@@ -1668,6 +1627,28 @@ int hot_threads(int nq) {
   return t > kHotThreads ? kHotThreads : t;
 }
 
+// WIDE launches of the backward hot kernels: where a workgroup's tiles take more than half a CU's LDS only ONE 512-thread
+// workgroup runs per CU — 8 waves, which neither hide the kernel's HBM waits nor fill its LDS and vector pipes (64^2 C16 / 16^3 C16
+// at B8 N4096: LDS 28-39 % busy, vector ALU 30-39 %, profiles/r5_zoo_counters.txt).  One 1024-thread workgroup with one quad per
+// thread doubles the waves: 64^2 C16 Slice backward 40.0 -> 34.6 us, Splat(max) backward 45.4 -> 34.7; 16^3 C16 54.0 -> 45.7, 58.5 ->
+// 47.9 (profiles/r6_wide.txt).  Where two workgroups fit a CU (8^3 C32) the same launch LOSES (63 -> 70 us): not taken there.
+// CLOUDCT_WIDE=0 turns it off (A/B runs).
+bool wide_enabled() {
+  static const int env = [] {
+    const char* e = getenv("CLOUDCT_WIDE");
+    return e ? atoi(e) : 1;
+  }();
+  return env != 0 && kHotThreads < kHotWideThreads;
+}
+bool hot_wide(size_t lds, int nq) { return wide_enabled() && lds > (size_t)kHalfCuLdsBytes && nq > kHotThreads; }
+// does even a four-channel chunk of the fused Slice backward (conv tile + accumulators + counters) take more than half a CU's LDS?
+// (then its launches are WIDE and a point segment may hold 8192 points: two quads per thread of a 1024-thread workgroup —
+//  64^2 C16 B2 N16384: 2 segments instead of 4, 47.0 -> 37.7 us; 16^3 C16: 60.7 -> 48.1, profiles/r6_wide.txt)
+bool slice_bwd_wide_shape(int G, int C) {
+  return wide_enabled() && (size_t)(G + C + 2) * 4 + (size_t)4 * G * 8 > (size_t)kHalfCuLdsBytes;
+}
+#define CT_HOT_KERNEL1W(KERNEL, PADV, WTV, QPTV) KERNEL<PADV, WTV, QPTV, kHotWideThreads>
+
 // Slice forward / gather with the channel-interleaved tile.  CT_EINVAL: not eligible.
 int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.dst | (uintptr_t)a.tile_in;
@@ -1691,7 +1672,7 @@ int run_gather_hot(RasterArgs a, const GridW<2>& g, hipStream_t st) {
 // are small where this matters (grids of 16^2 .. 16^3 cells), and the 32 planes of such a batch become 128 workgroups.
 // Returns 0 when N cannot be cut into equal float4-addressable segments.
 int slice_bwd_segments(int B, int H, int C, int N, int G, int dim) {
-  const int cap = 8 * kHotThreads;
+  const int cap = 8 * (slice_bwd_wide_shape(G, C) ? kHotWideThreads : kHotThreads);
   if (N <= cap) return 1;
   int nseg = (N + cap - 1) / cap;
   while (nseg <= 64 && (N % nseg != 0 || ((N / nseg) & 3) != 0)) ++nseg;
@@ -1841,9 +1822,13 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
 #define CT_MK_SLICE_BWD(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true>
-  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+#define CT_MK_SLICE_BWD_WIDE(PADV, WTV, QPTV) slice_bwd_fused_kernel<PADV, WTV, QPTV, true, kHotWideThreads>
+  if (hot_wide(hp.lds, nq) && nq <= kHotWideThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_WIDE, wgrid, round_threads(nq), hp.lds, st, a, g, 1);
+  else if (hot_wide(hp.lds, nq)) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD_WIDE, wgrid, round_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
+  else if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else CT_LAUNCH_HOT_(CT_MK_SLICE_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   note(nseg > 1 ? "slice_bwd_fused_segments" : ncg > 1 ? "slice_bwd_fused_groups" : "slice_bwd_fused");
+  if (hot_wide(hp.lds, nq)) note("wide");
   if (fold) {
     note("folded");
     return CT_OK;
@@ -1982,11 +1967,14 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   const float* const add = a.gpos_add;
   const size_t gpos_n = (size_t)a.B * a.H * 2 * a.N;
 #define CT_MK_SPLAT_BWD(PADV, WTV, QPTV) CT_HOT_KERNEL1(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
+#define CT_MK_SPLAT_BWD_WIDE(PADV, WTV, QPTV) CT_HOT_KERNEL1W(splat_max_bwd_hot_kernel, PADV, WTV, QPTV)
   if (nseg > 1) {       // point segments: ncg == 1, tickets present (splat_bwd_hot_plan)
     a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
     dim3 wgrid(1, a.H, a.B * nseg);
     const int nq = a.N >> 2;
-    if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+    if (hot_wide(hp.lds, nq) && nq <= kHotWideThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD_WIDE, wgrid, round_threads(nq), hp.lds, st, a, g, 1);
+    else if (hot_wide(hp.lds, nq)) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD_WIDE, wgrid, kHotWideThreads, hp.lds, st, a, g, 0);
+    else if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
     else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
     else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
     note("splat_max_bwd_hot_segments");
@@ -2002,10 +1990,13 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<2>& g, const HotPlan& hp, in
   }
   dim3 wgrid(ncg, a.H, a.B);
   const int nq = a.N >> 2;
-  if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
+  if (hot_wide(hp.lds, nq) && nq <= kHotWideThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD_WIDE, wgrid, round_threads(nq), hp.lds, st, a, g, 1);
+  else if (hot_wide(hp.lds, nq)) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD_WIDE, wgrid, kHotWideThreads, hp.lds, st, a, g, 0);
+  else if (nq <= kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads(nq), hp.lds, st, a, g, 1);
   else if (nq <= 2 * kHotThreads) CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g, 2);
   else CT_LAUNCH_HOT_(CT_MK_SPLAT_BWD, wgrid, kHotThreads, hp.lds, st, a, g, 0);
   note(ncg > 1 ? "splat_max_bwd_hot_groups" : "splat_max_bwd_hot");
+  if (hot_wide(hp.lds, nq)) note("wide");
   if (fold) {
     note("folded");
     return CT_OK;
@@ -2040,6 +2031,14 @@ inline int cube_of(const GridW<3>& g) {
     else if (cube_ == 16) CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 16>), (KERNEL<false, QPTV, 16>), GRID, NT, LDS, STREAM, ARGS, GW); \
     else CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 0>), (KERNEL<false, QPTV, 0>), GRID, NT, LDS, STREAM, ARGS, GW);                    \
   } while (0)
+// the WIDE launches (hot_wide): 1024-thread workgroups, for the 16^3 cube and any grid
+#define CT_LAUNCH_HOT3WIDE_(KERNEL, QPTV, GRID, NT, LDS, STREAM, ARGS, GW)                                           \
+  do {                                                                                                               \
+    if (cube_of(GW) == 16)                                                                                           \
+      CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 16, kHotWideThreads>), (KERNEL<false, QPTV, 16, kHotWideThreads>), GRID, NT, LDS, STREAM, ARGS, GW); \
+    else                                                                                                             \
+      CT_LAUNCH_HOT3_((KERNEL<true, QPTV, 0, kHotWideThreads>), (KERNEL<false, QPTV, 0, kHotWideThreads>), GRID, NT, LDS, STREAM, ARGS, GW);   \
+  } while (0)
 
 int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.dst | (uintptr_t)a.tile_in;
@@ -2066,13 +2065,107 @@ int run_gather_hot(RasterArgs a, const GridW<3>& g, hipStream_t st) {
   return CT_OK;
 }
 
+// Sorted-segment kernels for small 3D grids (ct_raster_sorted3d.h): 512-thread workgroups of at most 2048 points (nseg point
+// segments per plane, each with its own partial g_grid tile) and a share of the plane's four-channel groups (ncg workgroups per
+// segment, each with its own partial g_keys); every thread owns at most two items (n / 4 + 3 G / 4 <= 1024).  CLOUDCT_SORTED=0 /
+// CT_DEBUG_NO_SORTED turn the form off, CT_DEBUG_FORCE_SORTED takes it wherever it is legal (tests).
+struct Sorted3Plan {
+  int nseg, ncg, n;
+  size_t lds;
+};
+bool sorted3_plan(int B, int H, int C, int N, const GridW<3>& g, bool gather, Sorted3Plan& p) {
+  static const int env = [] {
+    const char* e = getenv("CLOUDCT_SORTED");
+    return e ? atoi(e) : -1;
+  }();
+  const unsigned f = t_dbg_flags.load(std::memory_order_relaxed);
+  const bool forced = (f & CT_DEBUG_FORCE_SORTED) != 0;
+  if ((f & CT_DEBUG_NO_SORTED) || (env == 0 && !forced)) return false;
+  if ((N & 3) || (C & 3) || (g.G & 3) || g.G > 1024) return false;
+  int nseg = (N + kS3MaxPoints - 1) / kS3MaxPoints;
+  while (nseg <= 64 && (N % nseg != 0 || ((N / nseg) & 3) != 0)) ++nseg;
+  if (nseg > 64) return false;
+  const int n = N / nseg;
+  if (n / 4 + (3 * g.G) / 4 > kS3MaxItems) return false;
+  const size_t lds = sort3_lds(g.G, n, C).total;
+  if (lds > (size_t)kBigLdsBytes) return false;
+  const long long planes = (long long)B * H;
+  const int ngroups = C >> 2;
+  int ncg = 1;
+  // two workgroups per CU, at least two groups per workgroup to spread its sort over (the scatter-add alone has no partial
+  // g_keys: its groups share nothing, one group per workgroup is fine)
+  while (planes * nseg * ncg < 512 && ngroups / (2 * ncg) >= (gather ? 2 : 1)) ncg *= 2;
+  if (forced && ncg == 1 && ngroups >= 2 && planes * nseg < 256) ncg = 2;      // tests: the group split on small shapes too
+  p.nseg = nseg; p.ncg = ncg; p.n = n; p.lds = lds;
+  if (forced) return true;
+  // the sort is paid per workgroup, the gain per group: worth it where the chip fills and there are groups to spread it over
+  return planes * nseg * ncg >= 256 && ngroups / ncg >= 2;
+}
+
+size_t sorted3_workspace(int B, int H, int C, int N, const GridW<3>& g) {
+  Sorted3Plan p;
+  if (!sorted3_plan(B, H, C, N, g, true, p)) return 0;
+  return (p.ncg > 1 ? (size_t)p.ncg * B * H * 3 * N * 4 : 0) + (p.nseg > 1 ? (size_t)p.nseg * B * H * C * g.G * 4 : 0);
+}
+
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
   HotPlan hp;
   int ncg = 1;
+  const size_t sorted_need = sorted3_workspace(B, H, C, N, g);
   const int nseg = slice_bwd_segments(B, H, C, N, g.G, 3);
-  if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
-  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return 0;
-  return (ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
+  if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return sorted_need;
+  if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return sorted_need;
+  const size_t fused_need = (ncg > 1 ? (size_t)ncg * B * H * 3 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
+  return fused_need > sorted_need ? fused_need : sorted_need;
+}
+
+#define CT_LAUNCH_SORTED3_(GATHERV, GRID, LDS, STREAM, ARGS, GW)                                                            \
+  do {                                                                                                                     \
+    if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((slice_bwd_sorted3_kernel<true, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW); \
+    else if (cube_of(GW) == 8) CT_LAUNCH((slice_bwd_sorted3_kernel<false, 8, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);         \
+    else CT_LAUNCH((slice_bwd_sorted3_kernel<false, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);                 \
+  } while (0)
+
+// Slice backward on sorted segments.  CT_EINVAL: not eligible (the scatter form below takes the call).
+int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
+  Sorted3Plan p;
+  if (!sorted3_plan(a.B, a.H, a.C, a.N, g, true, p)) return CT_EINVAL;
+  const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
+  const size_t keys_need = p.ncg > 1 ? (size_t)p.ncg * gpos_n * 4 : 0, need = keys_need + (p.nseg > 1 ? (size_t)p.nseg * grid_n * 4 : 0);
+  if (need > 0 && (!ws || ws_bytes < need)) return CT_EINVAL;
+  a.tile_in = grid;
+  a.CC = 4; a.nchunks = a.C >> 2; a.ncg = p.ncg;
+  a.g_pos = p.ncg > 1 ? (float*)ws : g_pos;
+  a.gpos_stride = p.ncg > 1 ? gpos_n : 0;
+  float* const g_grid = a.tile_out;
+  float* const grid_parts = p.nseg > 1 ? (float*)((char*)ws + keys_need) : nullptr;
+  if (p.nseg > 1) a.tile_out = grid_parts;
+  a.nseg = p.nseg; a.Nrow = a.N; a.N = p.n;
+  const int per_wg = ((a.C >> 2) + p.ncg - 1) / p.ncg;
+  const bool fold = (p.ncg > 1 || p.nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, p.ncg, p.nseg) &&
+                    fold_pays(p.ncg > 1 ? (size_t)p.ncg * 3 * a.N * 4 : 0) &&
+                    fold_pays(p.nseg > 1 ? (size_t)p.nseg * per_wg * 4 * g.G * 4 : 0);
+  if (!fold) a.tickets = nullptr;
+  a.fold_gpos = g_pos; a.fold_grid = g_grid;
+  dim3 wgrid(p.ncg, a.H, a.B * p.nseg);
+  CT_LAUNCH_SORTED3_(true, wgrid, p.lds, st, a, g);
+  note(p.nseg > 1 ? "slice_bwd_sorted3_segments" : p.ncg > 1 ? "slice_bwd_sorted3_groups" : "slice_bwd_sorted3");
+  if (fold) {
+    note("folded");
+    return CT_OK;
+  }
+  if (p.ncg > 1) {
+    CT_CLEAR_ERROR();
+    if (launch_sum_parts((const float*)ws, g_pos, gpos_n, gpos_n, p.ncg, nullptr, st) != CT_OK) return CT_ELAUNCH;
+    CT_CHECK_LAUNCH();
+  }
+  if (p.nseg > 1) {
+    CT_CLEAR_ERROR();
+    if (launch_sum_parts(grid_parts, g_grid, grid_n, grid_n, p.nseg, nullptr, st) != CT_OK) return CT_ELAUNCH;
+    CT_CHECK_LAUNCH();
+  }
+  return CT_OK;
 }
 
 int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2080,6 +2173,10 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
                          (uintptr_t)ws;
   const int nseg = slice_bwd_segments(a.B, a.H, a.C, a.N, g.G, 3);
   if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
+  {
+    const int r = run_slice_bwd_sorted3(a, grid, g_pos, g, ws, ws_bytes, st);      // small grids: sorted segments
+    if (r != CT_EINVAL) return r;
+  }
   // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
   // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
@@ -2109,11 +2206,16 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
   a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(ncg, a.H, a.B * nseg);
   const int nq = a.N >> 2;
-  if (nq <= kHotThreads)
+  if (hot_wide(hp.lds, nq) && nq <= kHotWideThreads)
+    CT_LAUNCH_HOT3WIDE_(slice_bwd_fused3_kernel, 1, wgrid, round_threads(nq), hp.lds, st, a, g);
+  else if (hot_wide(hp.lds, nq))
+    CT_LAUNCH_HOT3WIDE_(slice_bwd_fused3_kernel, 2, wgrid, round_threads((nq + 1) >> 1), hp.lds, st, a, g);
+  else if (nq <= kHotThreads)
     CT_LAUNCH_HOT3W_(slice_bwd_fused3_kernel, 1, wgrid, hot_threads(nq), hp.lds, st, a, g);
   else
     CT_LAUNCH_HOT3W_(slice_bwd_fused3_kernel, 2, wgrid, hot_threads((nq + 1) >> 1), hp.lds, st, a, g);
   note(nseg > 1 ? "slice_bwd_fused3_segments" : ncg > 1 ? "slice_bwd_fused3_groups" : "slice_bwd_fused3");
+  if (hot_wide(hp.lds, nq)) note("wide");
   if (fold) {
     note("folded");
     return CT_OK;
@@ -2151,7 +2253,8 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   if (nseg > 1) {       // point segments (see the 2D form)
     a.nseg = nseg; a.Nrow = a.N; a.N = a.N / nseg;
     dim3 wgrid(1, a.H, a.B * nseg);
-    CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(a.N >> 2), hp.lds, st, a, g);
+    if (hot_wide(hp.lds, a.N >> 2)) CT_LAUNCH_HOT3WIDE_(splat_max_bwd_hot3_kernel, 0, wgrid, round_threads(a.N >> 2), hp.lds, st, a, g);
+    else CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(a.N >> 2), hp.lds, st, a, g);
     note("splat_max_bwd_hot3_segments");
     return CT_OK;
   }
@@ -2167,8 +2270,10 @@ int run_splat_max_bwd_hot(RasterArgs a, const GridW<3>& g, const HotPlan& hp, in
   const int nq = a.N >> 2;
   // always the loop form (g_keys partials stored per chunk): keeping a quad's 12 g_keys values in registers across the
   // chunks makes the 3D kernel spill
-  CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(nq), hp.lds, st, a, g);
+  if (hot_wide(hp.lds, nq)) CT_LAUNCH_HOT3WIDE_(splat_max_bwd_hot3_kernel, 0, wgrid, round_threads(nq), hp.lds, st, a, g);
+  else CT_LAUNCH_HOT3W_(splat_max_bwd_hot3_kernel, 0, wgrid, hot_threads(nq), hp.lds, st, a, g);
   note(ncg > 1 ? "splat_max_bwd_hot3_groups" : "splat_max_bwd_hot3");
+  if (hot_wide(hp.lds, nq)) note("wide");
   if (fold) {
     note("folded");
     return CT_OK;
@@ -2654,6 +2759,10 @@ int ct_debug_tie_counters(unsigned* dst) {
 // experiments only (tools/dev/build_raster_exp.sh ... -DCT_SORT_STAMPS): the phase stamps of the sorted kernels' first workgroup
 int ct_debug_sorted_stamps(unsigned long long* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sorted_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? CT_OK : CT_ELAUNCH;
+}
+// {entry clock, exit clock, HW_ID, XCC_ID} of the first 4096 workgroups of the last stamped launch
+int ct_debug_wg_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? CT_OK : CT_ELAUNCH;
 }
 #endif
 

@@ -199,6 +199,7 @@ __device__ __forceinline__ void pt2_from_keys(float kx, float ky, const GridW<2>
 #define CT_HOT_THREADS 512
 #endif
 constexpr int kHotThreads = CT_HOT_THREADS;
+constexpr int kHotWideThreads = 1024;
 #ifndef CT_FUSED_WAVES
 #define CT_FUSED_WAVES 4
 #endif
@@ -236,8 +237,10 @@ __device__ __forceinline__ void scatter_float_channel(const RasterArgs& a, const
 #endif
 
 // GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
-template <bool HAS_PAD, int WT, int QPT, bool GATHER>
-__global__ void __launch_bounds__(kHotThreads, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g_arg) {
+// NTB: the launch's thread bound — kHotWideThreads for the WIDE launches (one 1024-thread workgroup per CU where the tiles leave no
+// room for a second 512-thread one: 16 waves per CU instead of 8, see hot_wide in ct_raster.hip)
+template <bool HAS_PAD, int WT, int QPT, bool GATHER, int NTB = kHotThreads>
+__global__ void __launch_bounds__(NTB, CT_FUSED_WAVES) slice_bwd_fused_kernel(RasterArgs a, GridW<2> g_arg) {
   const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   // WT > 0: square WT x WT grid known at compile time (corner offsets become instruction immediates)
@@ -1082,8 +1085,8 @@ __device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi
 // ticket, and the holder of the last ticket compares; on a tie (duplicated points: rare) it redoes the whole plane with
 // single-winner claims, overwriting what the segments wrote — which is why their results went out write-through and
 // why the incoming key cotangent (a.gpos_add) must not alias the output then.
-template <bool HAS_PAD, int WT, int QPT>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g_arg) {
+template <bool HAS_PAD, int WT, int QPT, int NTB = kHotThreads>
+__global__ void __launch_bounds__(NTB, 4) splat_max_bwd_hot_kernel(RasterArgs a, GridW<2> g_arg) {
   const GridW<2> g = grid2_of<WT>(g_arg);
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;

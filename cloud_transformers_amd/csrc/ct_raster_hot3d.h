@@ -57,8 +57,8 @@ __device__ __forceinline__ void store_gkeys3(float* gpos, size_t bh, int N, int 
 // ---------------------------------------------------------------------------
 // KF3: Slice backward, fused (see slice_bwd_fused_kernel).  grid = (ncg, H, B)
 // ---------------------------------------------------------------------------
-template <bool HAS_PAD, int QPT, int W3 = 0>
-__global__ void __launch_bounds__(kHotThreads, 4) slice_bwd_fused3_kernel(RasterArgs a, GridW<3> g_arg) {
+template <bool HAS_PAD, int QPT, int W3 = 0, int NTB = kHotThreads>
+__global__ void __launch_bounds__(NTB, 4) slice_bwd_fused3_kernel(RasterArgs a, GridW<3> g_arg) {
   const GridW<3> g = grid3_of<W3>(g_arg);
   extern __shared__ __align__(16) float lds[];
   const int G = g.G, CC = a.CC, N = a.N;
@@ -579,9 +579,20 @@ __device__ __forceinline__ bool splat_bwd_fix_mem(const RasterArgs& a, const Gri
 // The caller's arguments, read again from the kernel's argument segment: the repair is a cold path at the end of kernels whose
 // loops have no register to spare, and holding the arguments for it across those loops costs them dearly (3D: +8..14 us per
 // launch when the repair used the kernel's own copies).  Valid in kernels whose parameters are (RasterArgs, GridW<DIM>).
+// ENFORCED: the kernels that call this (splat_max_bwd_hot_kernel, splat_max_bwd_hot3_kernel) carry a static_assert on
+// their signature right behind their definitions (CT_KERNARG_IS_ARGS_AND_GRID); the argument types must be trivially copyable
+// standard-layout structs (the segment holds their bytes as the host passed them); and those kernels must NOT patch their
+// arguments in place (the sorted kernels do — a.N, a.C — and therefore do not use this): the repair would see the caller's values.
+#define CT_KERNARG_IS_ARGS_AND_GRID(KERNEL_INSTANCE, DIMV)                                                                   \
+  static_assert(std::is_same<decltype(&KERNEL_INSTANCE), void (*)(RasterArgs, GridW<DIMV>)>::value,                          \
+                "splat_bwd_fix_mem_cold reads (RasterArgs, GridW<DIM>) back from the kernarg segment: the kernel's parameter list must be exactly that")
 template <int DIM, bool HAS_PAD>
 __device__ __forceinline__ bool splat_bwd_fix_mem_cold(size_t bh, int b, int cgi, unsigned gbits, int Nr, size_t gpos_off, bool wt,
                                                        int* s_cnt) {
+  static_assert(std::is_trivially_copyable<RasterArgs>::value && std::is_standard_layout<RasterArgs>::value &&
+                    std::is_trivially_copyable<GridW<DIM>>::value && std::is_standard_layout<GridW<DIM>>::value,
+                "kernel arguments are read back as raw bytes");
+  static_assert(alignof(RasterArgs) <= 8 && alignof(GridW<DIM>) <= 8, "the kernarg segment is 8-byte aligned at least: nothing here may want more");
   const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp));
   const RasterArgs& a = *(const RasterArgs*)kp;
@@ -767,8 +778,8 @@ __device__ __forceinline__ void splat_bwd_plane_pass3(const RasterArgs& a, const
   }
 }
 
-template <bool HAS_PAD, int QPT, int W3 = 0>
-__global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(RasterArgs a, GridW<3> g_arg) {
+template <bool HAS_PAD, int QPT, int W3 = 0, int NTB = kHotThreads>
+__global__ void __launch_bounds__(NTB, 4) splat_max_bwd_hot3_kernel(RasterArgs a, GridW<3> g_arg) {
   const GridW<3> g = grid3_of<W3>(g_arg);
   extern __shared__ __align__(16) float lds[];
   float4* ZG = (float4*)lds;
@@ -859,6 +870,9 @@ __global__ void __launch_bounds__(kHotThreads, 4) splat_max_bwd_hot3_kernel(Rast
     }
   }
 }
+
+CT_KERNARG_IS_ARGS_AND_GRID((splat_max_bwd_hot3_kernel<false, 0, 0>), 3);
+CT_KERNARG_IS_ARGS_AND_GRID((splat_max_bwd_hot3_kernel<true, 0, 16, kHotWideThreads>), 3);
 
 // ---------------------------------------------------------------------------
 // KG3: Slice forward / gather with the channel-interleaved tile.  grid = (nchunks * nsplit, H, B)

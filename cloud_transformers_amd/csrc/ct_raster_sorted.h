@@ -37,9 +37,28 @@ __device__ unsigned long long g_sorted_stamps[64];
   do {                                                                                                   \
     if (threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) g_sorted_stamps[i] = clock64();   \
   } while (0)
+// every workgroup's {entry, exit, hardware id, XCC id} (ct_debug_wg_stamps): who ran where, when — concurrency and tails of a launch
+__device__ unsigned long long g_wg_stamps[4096][4];
+#define CT_WG_STAMP(slot)                                                                                            \
+  do {                                                                                                                \
+    if (threadIdx.x == 0) {                                                                                           \
+      const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                            \
+      if (wg_ < 4096u) {                                                                                              \
+        g_wg_stamps[wg_][slot] = clock64();                                                                           \
+        if ((slot) == 0) {                                                                                            \
+          unsigned hw_, xcc_;                                                                                         \
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                           \
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                         \
+          g_wg_stamps[wg_][2] = hw_;                                                                                  \
+          g_wg_stamps[wg_][3] = xcc_;                                                                                 \
+        }                                                                                                             \
+      }                                                                                                               \
+    }                                                                                                                 \
+  } while (0)
 #else
 #define CT_STAMP(i) ((void)0)
 #define CT_WSTAMP(i) ((void)0)
+#define CT_WG_STAMP(slot) ((void)0)
 #endif
 
 // inclusive wave64 scans over DPP (the reduction sequence of wave_sum_i32 IS a scan: every lane ends with its prefix)

@@ -337,14 +337,32 @@ class Trainer:
         key = tuple(tuple(t.shape) for t in batch)
         rec = self._graphs.get(key)
         if rec is None:
+            rec, failure = None, None
             try:
                 rec = self._capture(batch)
-            except RuntimeError as ex:       # capture refused (e.g. the process group's watchdog touched an event): eager steps
+            except RuntimeError as ex:
+                # only what a refused CAPTURE raises (HIP's stream-capture errors, e.g. the process group's watchdog touching an
+                # event of the capturing stream); a genuine error inside the model or the loss is not swallowed as "capture failed"
+                if not _is_capture_error(ex):
+                    raise
+                failure = ex
+                torch.cuda.synchronize(self.device)
+            # every rank takes the SAME path: one replaying a graph beside others stepping eagerly would deadlock in the reducer
+            if parallel._active(self.dist):
+                ok = torch.tensor([0 if failure is not None else 1], device=self.device, dtype=torch.int32)
+                self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and failure is None:
+                    failure, rec = RuntimeError("HIP-graph capture failed on another rank"), None
+                if failure is not None:
+                    # a capture that failed inside backward leaves DistributedDataParallel's reducer mid-iteration ("Expected to have
+                    # finished reduction ..." on the next forward): there is no clean eager state to fall back to under DDP
+                    raise RuntimeError("harness: HIP-graph capture failed under DistributedDataParallel (%s); rerun with "
+                                       "train.hip_graph: false" % (failure,)) from failure
+            if failure is not None:
                 if self.rank == 0:
-                    print("harness: HIP-graph capture failed (%s); continuing with eager steps" % (ex,), flush=True)
-                self._graphs[key] = rec = False
-            else:
-                self._graphs[key] = rec
+                    print("harness: HIP-graph capture failed (%s); continuing with eager steps" % (failure,), flush=True)
+                rec = False
+            self._graphs[key] = rec
         if rec is False:
             return self._eager_step(batch)
         graph, static, static_loss, grads = rec
@@ -362,8 +380,9 @@ class Trainer:
         `hip_graph` (default: `train.hip_graph` of the config, else False): replay forward + loss + backward as one HIP graph
         (under DistributedDataParallel too: the gradient all-reduce and the norms' statistics exchanges are captured with
         the kernels, after DDP's warm-up iterations; the process group must have been created with
-        TORCH_NCCL_ASYNC_ERROR_HANDLING=0 in the environment — launch.rank_env sets it, torchrun users set it themselves —
-        and a capture that fails falls back to eager steps).  Losses stay on the
+        TORCH_NCCL_ASYNC_ERROR_HANDLING=0 in the environment — launch.rank_env(capture=True) / spawn_ranks(capture=True) set it,
+        torchrun users set it themselves; the price is that a hung collective then hangs the job instead of aborting it.  A capture that
+        fails falls back to eager steps on one device and RAISES under DistributedDataParallel — the ranks agree on it first).  Losses stay on the
         device and are read back every `log_each` steps (default `train.log_each`, else 10) in ONE transfer — no host
         synchronisation per step (the reference reads the loss every step: train_segmentation.py:180-186)."""
         tr = self.cfg["train"]
@@ -413,6 +432,13 @@ class Trainer:
                     return history
         flush()
         return history
+
+
+def _is_capture_error(ex):
+    """Is this RuntimeError HIP refusing or invalidating a stream capture (as opposed to an error of the captured code)?"""
+    msg = str(ex).lower()
+    return any(k in msg for k in ("capture", "hipgraph", "cudagraph", "graph", "operation not permitted when stream is capturing",
+                                  "streamcapture"))
 
 
 def load_config(path):

@@ -53,24 +53,27 @@ def under_launcher(env=None):
     return "RANK" in env and "WORLD_SIZE" in env
 
 
-def rank_env(rank, world, port, base=None):
+def rank_env(rank, world, port, base=None, capture=False):
+    """`capture`: the ranks will capture collectives into a HIP graph (harness.fit(hip_graph=True), bench.py's DDP step) — torch's
+    recipe (notes/cuda.rst) then wants TORCH_NCCL_ASYNC_ERROR_HANDLING=0: the process group's watchdog otherwise queries events of
+    the capturing stream and takes the process down.  The trade: with the watchdog's error handling off a hung or failed collective
+    is never aborted — the job hangs instead of exiting non-zero — so eager jobs keep the default."""
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this driver
-    # torch's recipe for capturing collectives into a graph (notes/cuda.rst): without it the process group's watchdog queries
-    # events of the capturing stream and takes the process down (harness.fit(hip_graph=True), bench.py --mode ddp-step)
-    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    if capture:
+        env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     return env
 
 
-def spawn_ranks(script, argv, nproc, timeout=None, python=None):
+def spawn_ranks(script, argv, nproc, timeout=None, python=None, capture=False):
     """Run `python script argv...` as ranks 0..nproc-1 of one job; stdout/stderr are inherited (rank 0 prints the
     result line).  Returns 0 when every rank exited 0, else the first non-zero code (the other ranks are
     terminated: a rank that died would leave them waiting in a collective)."""
     port = free_port()
     cmd = [python or sys.executable, script] + list(argv)
-    procs = [subprocess.Popen(cmd, env=rank_env(r, nproc, port)) for r in range(nproc)]
+    procs = [subprocess.Popen(cmd, env=rank_env(r, nproc, port, capture=capture)) for r in range(nproc)]
     deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0
     try:

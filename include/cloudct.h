@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define CT_ABI_VERSION 1
+/* 2 (round 6): ct_plane_sort / ct_plane_sort_bytes / ct_slice_bwd_ps / ct_bn_group_reduce_bwd_copy added, ct_debug_set_pw_kernel
+ * removed, since version 1 — a stale library selected by CLOUDCT_LIB fails this check instead of failing at symbol binding. */
+#define CT_ABI_VERSION 2
 
 /* status codes */
 #define CT_OK 0
@@ -78,6 +80,12 @@ int ct_positions_bwd(const float* keys, const float* g_local_coord, float* g_key
  *   paths differ in WHICH one.  Here: a single chance tie in a plane is awarded
  *   to the lowest point index; with more ties (duplicated points) the winner is
  *   unspecified.  DESIGN.md section 2 has the rule per kernel family.)
+ *   DEVIATION, deliberate: a candidate whose product is exactly +-0 (a point exactly on a cell boundary: one corner weight is 0;
+ *   or a feature that is exactly 0, e.g. under a padding mask) aimed at a cell whose maximum stays at the zero floor receives
+ *   NOTHING here.  torch_scatter.scatter_max records it as the arg-max (0 == 0) and routes the cell's cotangent to it.  Values
+ *   and every cotangent not itself multiplied by that zero agree; what differs is g_keys of a point exactly on a boundary
+ *   (through d(weight)/d(key): a few elements per million points) and g_feat of an exactly-zero feature.  Pinned by
+ *   tests/test_tie_rule_gpu.py; INTEGRATION.md "Known deviations".
  *   needs `grid` = the forward output, g_grid f32[B,H*C,G];
  *   writes g_feat f32[B,H*C,N] and g_keys f32[B,H*dim,N] (both overwritten).
  * workspace: scratch of ct_splat_bwd_workspace_bytes(...) bytes (may be 0).

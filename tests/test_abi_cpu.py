@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.ct_abi_version() == 1
+    assert lib.ct_abi_version() == 2
     assert lib.ct_strerror(0) == b"ok"
     assert b"invalid" in lib.ct_strerror(-1)
     assert b"workspace" in lib.ct_strerror(-3)

@@ -341,7 +341,10 @@ def test_zoo_head_shapes_at_full_size_against_oracle_planes(cfg, flags):
     step = SplatSliceStep(keys, feat, cot, Wn, H, dim, "max")
     step.run()
     torch.cuda.synchronize()
-    got = (step.z, step.out, step.g_z, step.g_feat, step.g_keys())
+    got = (step.z, step.out, step.g_z, step.g_feat, step.g_keys().clone())
+    step.slice_bwd()                               # (Splat's key cotangent may have been added in place: Slice's alone, again)
+    torch.cuda.synchronize()
+    gk_slice_all = step.g_keys_buf.clone()
     for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, 5)):
         ref = oracle_chain(keys[b:b + 1, h * dim:(h + 1) * dim].cpu(), feat[b:b + 1, h * C:(h + 1) * C].cpu(),
                            cot[b:b + 1, h * C:(h + 1) * C].cpu(), W, 1, dim, "max")
@@ -361,6 +364,13 @@ def test_zoo_head_shapes_at_full_size_against_oracle_planes(cfg, flags):
             if name == "g_keys":
                 a, r = a.cpu()[..., ~on_edge], r[..., ~on_edge]
             assert relerr(a, r) <= 1e-4, "%s plane (%d,%d): %.2e" % (name, b, h, relerr(a, r))
+        # The mask above is for the SPLAT(max) term alone: Slice's key cotangent — what ct_slice_bwd* left in
+        # g_keys_buf before Splat's was added into g_keys_out — has no such deviation and is held to the oracle on EVERY point
+        k2 = keys[b:b + 1, h * dim:(h + 1) * dim].cpu().clone().requires_grad_(True)
+        lc2, idx2 = R.positions(k2, W, 1, dim)
+        R.slice_(lc2, idx2, ref[0], None, W, 1, dim).backward(cot[b:b + 1, h * C:(h + 1) * C].cpu())
+        gk_slice = gk_slice_all[b:b + 1, h * dim:(h + 1) * dim]
+        assert relerr(gk_slice, k2.grad) <= 1e-4, "Slice's g_keys, all points, plane (%d,%d): %.2e" % (b, h, relerr(gk_slice, k2.grad))
     # the other kernel family on the full tensors (module path: separate g_keys of Splat and Slice summed by autograd)
     flags(mod.DEBUG_NO_HOT)
     gen, _ = hip_chain(keys, feat, cot, W, H, dim, "max")
