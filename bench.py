@@ -65,8 +65,31 @@ def parse():
 
 
 def time_passes(step, iters=200):
-    """Average device time (ms) of each of the four ABI passes, measured with HIP
-    events on the stream the kernels are launched on (torch's current stream)."""
+    """Average device time (ms) of each of the four ABI passes, measured with HIP events on the stream the kernels are launched
+    on (torch's current stream) — IN SEQUENCE: `iters` eager steps with an event between consecutive passes, so every kernel runs
+    behind the pass that produced its inputs, as inside the timed (graph-replayed) step.  Timing one pass `iters` times back to back
+    (rounds 1-5) read 3-9 % long: a kernel that follows itself finds its inputs colder than one that follows their producer
+    (profiles/r6_headline_replay_trace.txt: 185.7 us summed that way against 176.7 us inside the replays = the step)."""
+    import torch
+    fns = [getattr(step, name) for name in step.PASSES]
+    for _ in range(3):
+        for fn in fns:
+            fn()
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)] for _ in range(iters)]
+    for it in range(iters):
+        ev[it][0].record()
+        for k, fn in enumerate(fns):
+            fn()
+            ev[it][k + 1].record()
+    torch.cuda.synchronize()
+    return {name: sum(ev[it][k].elapsed_time(ev[it][k + 1]) for it in range(iters)) / iters for k, name in enumerate(step.PASSES)}
+
+
+def time_passes_back_to_back(step, iters=200):
+    """The rounds 1-5 form: each pass `iters` times back to back (one kernel following itself).  Kept for the zoo sweeps
+    (tools/zoo_sweep.py): their 8-20 us kernels would leave the host's launch rate, not the device, in an event-per-pass reading,
+    and their rows stay comparable with profiles/r2..r5_zoo_sweep.txt."""
     import torch
     res = {}
     for name in step.PASSES:
@@ -85,21 +108,20 @@ def time_passes(step, iters=200):
     return res
 
 
-def measured_traffic(tag):
-    """HBM bytes per launch of the kernel behind `tag` from the COMMITTED rocprofv3 PMC passes
-    (profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE runs of this same command, with the gfx950 correction of MI355X_MICROARCH.md:
-    FETCH_SIZE counts half of a wide read).  Not measured in this run."""
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` — its FULL instantiated name as rocprofv3 prints it, template arguments included (a
+    substring match would pair any template variant with whatever bytes were last committed: VERDICT r5 #7) — from the COMMITTED
+    rocprofv3 PMC passes (profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc
+    WRITE_SIZE runs of this same command, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide
+    read).  Not measured in this run; None when the committed record has no kernel of exactly that name."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             table = json.load(f)
     except (OSError, ValueError):
         return None
-    for name, rec in table.get("kernels", {}).items():
-        if tag in name:
-            return rec.get("hbm_bytes_per_launch")
-    return None
+    rec = table.get("kernels", {}).get(kernel)
+    return rec.get("hbm_bytes_per_launch") if rec else None
 
 
 def cpu_model():
@@ -325,13 +347,14 @@ def run_op(args):
         achieved = dom_bytes / (passes[dom] * 1e-3) / 1e9
         # the committed PMC passes were collected on the default workload only
         default_shape = (B, N, H, C, W, dim, args.reduce) == (8, 4096, 64, 16, 32, 2, "max")
-        traffic = measured_traffic(step.KERNEL_OF.get(tags[dom], tags[dom])) if default_shape else None
+        exact = step.HEADLINE_KERNELS if default_shape else {}      # full instantiated names: only the default workload has a PMC record
+        traffic = measured_traffic(exact[dom]) if default_shape else None
         roofline_passes = {}
         for p in step.PASSES:
             gbs = alg[p] / (passes[p] * 1e-3) / 1e9
             kern = step.KERNEL_OF.get(tags[p], tags[p])
             roofline_passes[p] = {"kernel": kern, "bytes": alg[p], "ms": passes[p], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-                                  "traffic": measured_traffic(kern) if default_shape and "+" not in tags[p] else None}
+                                  "traffic": measured_traffic(exact[p]) if default_shape and "+" not in tags[p] else None}
         out = {
             "metric": METRIC,
             "value": world * B * N / (dt / args.steps),
@@ -350,7 +373,8 @@ def run_op(args):
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
                        "world_size_seen": world,
                        "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1,
-                       "order": "per-pass HIP-event timings (203 launches of each pass), then W warm-up steps, then the K timed steps"},
+                       "order": "per-pass HIP-event timings (203 eager steps, an event between consecutive passes), then W warm-up steps, "
+                                "then the K timed steps"},
             "roofline": {"bound": "hbm", "kernel": step.KERNEL_OF.get(tags[dom], tags[dom]),
                          "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -116,6 +116,16 @@ class SplatSliceStep:
         "splat_max_bwd_whole_head": "quad_kernel<2, 2, 4, 1024,",
     }
 
+    # the four kernels of the headline workload (B8 N4096 H64 C16 32^2 max) by their FULL instantiated names, as rocprofv3 prints
+    # them — what bench.py looks up in the committed PMC record (profiles/traffic_latest.json); tests/test_headline_gpu.py holds the
+    # dispatch to the kernel families behind them
+    HEADLINE_KERNELS = {
+        "splat_fwd": "scatter_quad_kernel<2, false, false, 32>",
+        "slice_fwd": "gather_ci_kernel<false, 32>",
+        "slice_bwd": "slice_bwd_sorted_kernel<false, 32, false, true, 4096, 16>",
+        "splat_bwd": "splat_max_bwd_hot_kernel<false, 32, 2, 512>",
+    }
+
     def launch_tags(self):
         """{pass: kernel-family tags of the launches behind it} for this shape (runs every pass once)."""
         tags = {}

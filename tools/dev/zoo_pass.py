@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd.step import SplatSliceStep
-from bench import time_passes
+from bench import time_passes_back_to_back as time_passes
 which = sys.argv[1]
 SHAPES = [(4, 128, 2), (4, 32, 3), (16, 64, 2), (16, 16, 3), (16, 16, 2), (32, 8, 3)]
 out = []

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cloud_transformers_amd.step import SplatSliceStep
-from bench import time_passes
+from bench import time_passes_back_to_back as time_passes
 C, W, dim, B, N = [int(v) for v in sys.argv[1:6]]
 reduce = sys.argv[6] if len(sys.argv) > 6 else "max"
 H = 16
