@@ -208,7 +208,7 @@ def cpu_baseline(args):
 
 def count_ties(step):
     """Exact ties of this rank's workload: (cell, channel) pairs of Splat(max) whose maximum is reached by more than one
-    contribution bit for bit — each makes the Splat(max) backward redo a four-channel group of its plane, so a
+    contribution bit for bit — each makes the Splat(max) backward redo a four-channel group of its plane (HISTORY.md §5b.1b), so a
     step with ties runs longer than one without.  Counted with torch ops on the GPU, outside the timed region."""
     import torch
     from cloud_transformers_amd import ops

@@ -21,7 +21,7 @@
 // The data gradient runs the forward arrangement on a W^T copy.  The weight gradient sums over clouds and points: K = B*N is
 // cut into chunks, each chunk's partial [Co,Ci] tile goes to a slab and a second kernel adds the slabs in a fixed order
 // (deterministic).  The per-tensor maxima arrive as partial maxima (ct_amax_f32's per-block ones, or what the kernel that
-// wrote the operand left per channel) and are folded when the kernel starts.  DESIGN.md §4.9 has the measurements.
+// wrote the operand left per channel) and are folded when the kernel starts.  HISTORY.md §4.9 has the measurements.
 #include "ct_common.h"
 #include <cstdlib>
 #include <type_traits>

@@ -16,7 +16,7 @@
 //   * a 3D item is TWO 2D items: the z = 0 face (corners 0..3, cells Y + {0, sx, sy, sx + sy}) and the z = 1 face (the cells
 //     right behind them: z is the fastest axis).  A face is the 2D item body — four conv corners and 4 x 4 sums in registers —
 //     with the entry's values scaled by the face's z weight, so the register footprint is the 2D kernel's, not twice it
-//     (DESIGN §7's objection to a 3D item form); the entries are read twice (sequential 16-byte LDS reads);
+//     (HISTORY.md §7's objection to a 3D item form); the entries are read twice (sequential 16-byte LDS reads);
 //   * the key cotangent of a face: d/dx and d/dy are the 2D expressions times the face's z weight, d/dz is -+ the face's
 //     bilinear value (ct_corner_grad<3> regrouped by face: same terms, summed face by face).
 // Everything else is the 2D design: deterministic counting sort (per-wave histograms, returning LDS adds), weights w1 per

@@ -79,7 +79,7 @@ int ct_positions_bwd(const float* keys, const float* g_local_coord, float* g_key
  *   the tied contributions receives it — as in torch_scatter, whose CPU and CUDA
  *   paths differ in WHICH one.  Here: a single chance tie in a plane is awarded
  *   to the lowest point index; with more ties (duplicated points) the winner is
- *   unspecified.  DESIGN.md section 2 has the rule per kernel family.)
+ *   unspecified.  HISTORY.md §2 has the rule per kernel family.)
  *   DEVIATION, deliberate: a candidate whose product is exactly +-0 (a point exactly on a cell boundary: one corner weight is 0;
  *   or a feature that is exactly 0, e.g. under a padding mask) aimed at a cell whose maximum stays at the zero floor receives
  *   NOTHING here.  torch_scatter.scatter_max records it as the arg-max (0 == 0) and routes the cell's cotangent to it.  Values

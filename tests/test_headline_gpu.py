@@ -355,7 +355,7 @@ def test_zoo_head_shapes_at_full_size_against_oracle_planes(cfg, flags):
         # A point that lies EXACTLY on a cell boundary has corner weights of exactly 0: its product into the far cell is
         # +-0.0, and where that cell stays at the zero floor the three implementations disagree on purpose — torch_scatter
         # routes the cell's cotangent to the zero-valued candidate, torch's amax (the oracle) splits it with the floor, the
-        # kernels here route nothing.  Only that point's key cotangent can differ (0 * x carries no
+        # kernels here route nothing (HISTORY.md §2, INTEGRATION.md "Known deviations").  Only that point's key cotangent can differ (0 * x carries no
         # feature gradient): such points (a few per million) are left out of the g_keys comparison.
         lc_ref, _ = R.positions(keys[b:b + 1, h * dim:(h + 1) * dim].cpu(), W, 1, dim)
         on_edge = (lc_ref[0, 0] == 0).any(dim=0)                       # (N,)

@@ -2,7 +2,7 @@
 
 torch_scatter.scatter_max's backward (layers/cloud_transform.py:164-173 through torch_scatter) gives the cotangent of a cell to the
 single arg-max element it recorded; which of several bit-equal contributions that is differs between its CPU and CUDA kernels.
-The rule here, per family: the hot kernels repair a single chance tie in favour of the lowest point index and
+The rule here, per family (HISTORY.md §2): the hot kernels repair a single chance tie in favour of the lowest point index and
 redo anything beyond it with claims; there, and in the generic and quad kernels, the contribution whose compare-and-swap reaches
 the cell's word first wins (one winner, identity unspecified); the banded kernels award the lowest point index.
 
@@ -84,7 +84,7 @@ def test_one_winner_per_cell_and_channel(case):
 
 @pytest.mark.parametrize("flag", ["FORCE_HOT", "NO_HOT"])
 def test_a_zero_valued_candidate_does_not_win_a_cell_at_the_zero_floor(flag):
-    """DESIGN.md section 2, "Zero-valued candidates": a point exactly on a cell boundary (W = 9: (key + 1) * 4 is exact) sends a
+    """HISTORY.md §2, "Zero-valued candidates": a point exactly on a cell boundary (W = 9: (key + 1) * 4 is exact) sends a
     product of exactly 0 into the far cells; where those stay at the zero floor torch_scatter would route their cotangent to the
     point (0 == 0), torch's amax half of it, the kernels here none.  The expected values are the oracle's with the cotangent
     of the far cells removed."""

@@ -21,7 +21,7 @@ for B, N in [(8, 4096), (8, 2048), (2, 16384)]:
         cot = torch.randn(B, H * C, N, device="cuda")
         for name, tk in MODES:
             st = SplatSliceStep(keys, feat, cot, W, H, dim, "max", tickets=tk)
-            for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks
+            for _ in range(100):            # sustained load first: a short burst after idle runs at ramping clocks (HISTORY.md §5)
                 st.run()
             torch.cuda.synchronize()
             p = time_passes(st, iters=100)
