@@ -66,30 +66,13 @@ def parse():
 
 def time_passes(step, iters=200):
     """Average device time (ms) of each of the four ABI passes, measured with HIP events on the stream the kernels are launched
-    on (torch's current stream) — IN SEQUENCE: `iters` eager steps with an event between consecutive passes, so every kernel runs
-    behind the pass that produced its inputs, as inside the timed (graph-replayed) step.  Timing one pass `iters` times back to back
-    (rounds 1-5) read 3-9 % long: a kernel that follows itself finds its inputs colder than one that follows their producer
-    (profiles/r6_headline_replay_trace.txt: 185.7 us summed that way against 176.7 us inside the replays = the step)."""
-    import torch
-    fns = [getattr(step, name) for name in step.PASSES]
-    for _ in range(3):
-        for fn in fns:
-            fn()
-    torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)] for _ in range(iters)]
-    for it in range(iters):
-        ev[it][0].record()
-        for k, fn in enumerate(fns):
-            fn()
-            ev[it][k + 1].record()
-    torch.cuda.synchronize()
-    return {name: sum(ev[it][k].elapsed_time(ev[it][k + 1]) for it in range(iters)) / iters for k, name in enumerate(step.PASSES)}
-
-
-def time_passes_back_to_back(step, iters=200):
-    """The rounds 1-5 form: each pass `iters` times back to back (one kernel following itself).  Kept for the zoo sweeps
-    (tools/zoo_sweep.py): their 8-20 us kernels would leave the host's launch rate, not the device, in an event-per-pass reading,
-    and their rows stay comparable with profiles/r2..r5_zoo_sweep.txt."""
+    on (torch's current stream): each pass `iters` times back to back.  This reads 3-9 % LONGER than the same kernels inside the
+    timed (graph-replayed) step — a kernel that follows itself finds its inputs colder than one that follows their producer:
+    profiles/r6_headline_replay_trace.txt has the rocprofv3 durations inside the replays (they sum to the step) beside these loops'
+    — so the per-pass roofline fractions of the line are conservative.  What was tried instead and reads worse: an event between
+    the eager launches of a step (the markers keep consecutive kernels from overlapping their ramps: sum 189.8 us against the
+    step's 176.2), graph replays with one pass left out (the differences are marginal costs, not durations: dropping Splat forward
+    slows the pass behind it), events recorded inside a captured graph (external events: "disallowed in rocm")."""
     import torch
     res = {}
     for name in step.PASSES:
@@ -106,6 +89,9 @@ def time_passes_back_to_back(step, iters=200):
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / iters
     return res
+
+
+time_passes_back_to_back = time_passes      # (the zoo tools' name for it)
 
 
 def measured_traffic(kernel):
@@ -373,8 +359,8 @@ def run_op(args):
                        "per_gpu_batch": B, "parallelism": "replica-sharded clouds x%d (no collective)" % world,
                        "world_size_seen": world,
                        "hip_graph": graph is not None, "steps_per_graph": gs if multi is not None else 1,
-                       "order": "per-pass HIP-event timings (203 eager steps, an event between consecutive passes), then W warm-up steps, "
-                                "then the K timed steps"},
+                       "order": "per-pass HIP-event timings (203 launches of each pass back to back: 3-9 % longer than inside the "
+                                "replayed step, profiles/r6_headline_replay_trace.txt), then W warm-up steps, then the K timed steps"},
             "roofline": {"bound": "hbm", "kernel": step.KERNEL_OF.get(tags[dom], tags[dom]),
                          "pass": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -12,6 +12,9 @@ torch.manual_seed(0)
 keys = torch.tanh(torch.randn(B, H * dim, N, device="cuda"))
 feat = torch.randn(B, H * C, N, device="cuda")
 cot = torch.randn(B, H * C, N, device="cuda")
+if os.environ.get("CT_FLAGS"):        # ct_debug_set_flags bits (include/cloudct.h: CT_DEBUG_*), e.g. 2 = FORCE_HOT
+    from cloud_transformers_amd import _lib
+    _lib.load().ct_debug_set_flags(int(os.environ["CT_FLAGS"]))
 st = SplatSliceStep(keys, feat, cot, W, H, dim, reduce)
 tags = st.launch_tags()
 for _ in range(100):
@@ -21,5 +24,6 @@ p = time_passes(st, iters=100)
 tot = sum(p.values()) * 1e3
 alg = st.algorithmic_bytes()["total"]
 print(C, W, dim, "|", B, N, "|", {k: round(v * 1e3, 1) for k, v in p.items()}, "|", round(tot, 1), "|", round(alg / (tot * 1e-6) / 8e12, 3),
-      "| WIDE=%s SORTED=%s" % (os.environ.get("CLOUDCT_WIDE", "-"), os.environ.get("CLOUDCT_SORTED", "-")))
+      "| WIDE=%s SORTED=%s FLAGS=%s NSEG=%s" % (os.environ.get("CLOUDCT_WIDE", "-"), os.environ.get("CLOUDCT_SORTED", "-"),
+                                                 os.environ.get("CT_FLAGS", "-"), os.environ.get("CLOUDCT_SPLAT_BWD_NSEG", "-")))
 print("   ", tags)
