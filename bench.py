@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ddp-step", action="store_true", help="N > 1, mode op: do not attach the data-parallel training step")
     p.add_argument("--ddp-steps", type=int, default=10, help="timed steps of the attached data-parallel training step")
-    p.add_argument("--ddp-timeout", type=int, default=420, help="seconds the attached step may take before the line goes out without it")
+    p.add_argument("--ddp-timeout", type=int, default=240, help="seconds the attached step may take before the line goes out without it")
     p.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg")
     return p.parse_args()
 

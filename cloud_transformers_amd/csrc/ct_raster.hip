@@ -1414,6 +1414,10 @@ int run_scatter(RasterArgs a, const int* W, bool sum, hipStream_t st) {
         const int r = run_scatter_add_hot(a, g, st);
         if (r != CT_EINVAL) return r;
       }
+      if constexpr (DIM == 3 && FROM_KEYS) {
+        const int r = run_scatter_add_sorted3(a, g, st);      // small 3D grids, one sorted segment per plane
+        if (r != CT_EINVAL) return r;
+      }
       constexpr int kRegCh = 8;
       const bool aligned = ((((uintptr_t)a.src) | ((uintptr_t)a.pos.keys) | ((uintptr_t)a.tile_out)) & 15) == 0;
       if (FROM_KEYS && aligned && (a.N & 3) == 0 && a.N <= 4096 && (g.G & 3) == 0) {
@@ -2099,7 +2103,7 @@ bool sorted3_plan(int B, int H, int C, int N, const GridW<3>& g, bool gather, So
   p.nseg = nseg; p.ncg = ncg; p.n = n; p.lds = lds;
   if (forced) return true;
   // the sort is paid per workgroup, the gain per group: worth it where the chip fills and there are groups to spread it over
-  return planes * nseg * ncg >= 256 && ngroups / ncg >= 2;
+  return planes * nseg * ncg >= 256 && ngroups / ncg >= (gather ? 2 : 1);
 }
 
 size_t sorted3_workspace(int B, int H, int C, int N, const GridW<3>& g) {
@@ -2125,6 +2129,21 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
     else if (cube_of(GW) == 8) CT_LAUNCH((slice_bwd_sorted3_kernel<false, 8, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);         \
     else CT_LAUNCH((slice_bwd_sorted3_kernel<false, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);                 \
   } while (0)
+
+// The scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid) on ONE sorted segment per plane (there is no workspace for partial
+// tiles behind these entry points): the sorted kernel without its gather side; the channel groups share nothing.  Measured against
+// scatter_add_fx_reg (8^3 C32 B8 N2048, reduce=sum, tools/dev/zoo_shape.py): see profiles/r6_zoo_shape_checks.txt.
+int run_scatter_add_sorted3(RasterArgs a, const GridW<3>& g, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
+  Sorted3Plan p;
+  if (!hot_shape_ok(a, g.G, bits) || !sorted3_plan(a.B, a.H, a.C, a.N, g, false, p) || p.nseg != 1) return CT_EINVAL;
+  a.CC = 4; a.nchunks = a.C >> 2; a.ncg = p.ncg; a.nseg = 1; a.Nrow = a.N; a.tickets = nullptr; a.tile_in = nullptr;
+  a.g_pos = nullptr; a.gpos_stride = 0; a.sorted = nullptr;
+  dim3 wgrid(p.ncg, a.H, a.B);
+  CT_LAUNCH_SORTED3_(false, wgrid, p.lds, st, a, g);
+  note("scatter_add_sorted3");
+  return CT_OK;
+}
 
 // Slice backward on sorted segments.  CT_EINVAL: not eligible (the scatter form below takes the call).
 int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -151,3 +151,30 @@ def test_sorted3_slice_backward_with_non_finite_channels():
             assert float((a[fin] - r[fin]).abs().max()) <= 1e-4 * float(r[fin].abs().max()), ch
         else:
             assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), ch
+
+
+@pytest.mark.parametrize("cfg", [c for c in CASES if c[3] <= 2048], ids=str)
+def test_sorted3_splat_sum_forward_against_the_oracle(cfg, flags):
+    """Splat(reduce=sum) forward on a small 3D grid = the scatter-add side of the sorted kernel alone (no conv tile, no key
+    cotangent), one sorted segment per plane: layers/cloud_transform.py:164-173 with scatter_add_."""
+    from cloud_transformers_amd import ops
+    mod, lib = _lib()
+    B, H, C, N, W, pad, dup = cfg
+    torch.manual_seed(9)
+    keys = torch.tanh(torch.randn(B, H * 3, N) * (0.3 if dup else 1.0))
+    if dup:
+        keys[:, :, N // 2:] = keys[:, :, :N // 2]
+    feat = torch.randn(B, H * C, N)
+    p = (torch.rand(B, N) > 0.2).float() if pad else None
+    lc, idx = R.positions(keys, list(W), H, 3)
+    ref = R.splat(lc, idx, feat, p, list(W), H, 3, "sum")
+    outs = []
+    for _ in range(2):
+        flags(mod.DEBUG_FORCE_SORTED | mod.DEBUG_FORCE_HOT)
+        z = ops.splat_keys(keys.cuda(), feat.cuda(), p.cuda() if pad else None, list(W), H, 3, "sum")
+        tag = lib.ct_debug_last_launch().decode()
+        flags(0)
+        assert tag == "scatter_add_sorted3", tag
+        outs.append(z)
+    assert torch.equal(outs[0], outs[1]), "not bitwise reproducible"
+    assert per_channel_err(outs[0], ref, H * C) <= 1e-4
