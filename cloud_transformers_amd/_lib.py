@@ -76,6 +76,7 @@ DEBUG_NO_BAND = 4
 DEBUG_FORCE_BAND = 8
 DEBUG_NO_SORTED = 16
 DEBUG_FORCE_SORTED = 32
+DEBUG_FORCE_SORTED_SEG = 64
 
 _lock = threading.Lock()
 _lib = None

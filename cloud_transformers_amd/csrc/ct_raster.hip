@@ -1699,13 +1699,23 @@ int sorted_groups(long long planes, int C) {
   return ncg;
 }
 
+// sorted segments on small grids (ct_raster_sorted3d.h; defined with the 3D forms below)
+template <int DIM>
+size_t sorted3_workspace(int B, int H, int C, int N, const GridW<DIM>& g);
+template <int DIM>
+int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const GridW<DIM>& g, void* ws, size_t ws_bytes, hipStream_t st);
+
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<2>& g) {
   HotPlan hp;
   int ncg = 1;
   const int nseg = slice_bwd_segments(B, H, C, N, g.G, 2);
   if ((C & 3) || (N & 3) || (g.G & 3) || nseg == 0) return 0;
-  size_t sorted_need = 0;       // the sorted kernel's channel-group workgroups (few planes): partial g_keys
-  if (nseg == 1 && N <= 4096 && sorted_groups((long long)B * H, C) > 1) sorted_need = (size_t)sorted_groups((long long)B * H, C) * B * H * 2 * N * 4;
+  size_t sorted_need = sorted3_workspace<2>(B, H, C, N, g);       // sorted segments (taken at few planes, or forced: 0 where not legal)
+  // the sorted kernel's channel-group workgroups (few planes): partial g_keys
+  if (nseg == 1 && N <= 4096 && sorted_groups((long long)B * H, C) > 1) {
+    const size_t need1 = (size_t)sorted_groups((long long)B * H, C) * B * H * 2 * N * 4;
+    sorted_need = need1 > sorted_need ? need1 : sorted_need;
+  }
   if (!hot_bwd_plan(B * nseg, H, C, g.G, (size_t)g.G * 8, (size_t)(g.G + C + 2) * 4, CT_FUSED_LDS_BUDGET, hp, ncg)) return sorted_need;
   const size_t fused_need = (ncg > 1 ? (size_t)ncg * B * H * 2 * N * 4 : 0) + (nseg > 1 ? (size_t)nseg * B * H * C * g.G * 4 : 0);
   return fused_need > sorted_need ? fused_need : sorted_need;
@@ -1746,6 +1756,10 @@ int run_slice_bwd_hot(RasterArgs a, const float* grid, float* g_pos, const GridW
                          (uintptr_t)ws;
   const int nseg = slice_bwd_segments(a.B, a.H, a.C, a.N, g.G, 2);
   if (!hot_shape_ok(a, g.G, bits) || nseg == 0) return CT_EINVAL;
+  {
+    const int r = run_slice_bwd_sorted3<2>(a, grid, g_pos, g, ws, ws_bytes, st);      // small grids, few planes: sorted segments
+    if (r != CT_EINVAL) return r;
+  }
   // few workgroups (32 planes of 4096 points or less): one or two workgroups per plane lose to the split-N scatter +
   // gather pair (measured 67 vs 49 us on 64^2 C16, 49 vs 33 on 16^2 C16); long clouds are cut into segments (above)
   if ((long long)a.B * a.H * nseg < 64 && !(t_dbg_flags & CT_DEBUG_FORCE_HOT)) return CT_EINVAL;
@@ -2077,21 +2091,22 @@ struct Sorted3Plan {
   int nseg, ncg, n;
   size_t lds;
 };
-bool sorted3_plan(int B, int H, int C, int N, const GridW<3>& g, bool gather, Sorted3Plan& p) {
+bool sorted3_plan(int B, int H, int C, int N, int G, int dim, bool gather, Sorted3Plan& p) {
   static const int env = [] {
     const char* e = getenv("CLOUDCT_SORTED");
     return e ? atoi(e) : -1;
   }();
   const unsigned f = t_dbg_flags.load(std::memory_order_relaxed);
-  const bool forced = (f & CT_DEBUG_FORCE_SORTED) != 0;
+  const bool forced = (f & (dim == 3 ? CT_DEBUG_FORCE_SORTED : CT_DEBUG_FORCE_SORTED_SEG)) != 0;
   if ((f & CT_DEBUG_NO_SORTED) || (env == 0 && !forced)) return false;
-  if ((N & 3) || (C & 3) || (g.G & 3) || g.G > 1024) return false;
+  if (dim == 2 && !forced && (f & CT_DEBUG_FORCE_SORTED)) return false;      // (tests of the one-workgroup-per-plane 2D kernel)
+  if ((N & 3) || (C & 3) || (G & 3) || G > 1024) return false;
   int nseg = (N + kS3MaxPoints - 1) / kS3MaxPoints;
   while (nseg <= 64 && (N % nseg != 0 || ((N / nseg) & 3) != 0)) ++nseg;
   if (nseg > 64) return false;
   const int n = N / nseg;
-  if (n / 4 + (3 * g.G) / 4 > kS3MaxItems) return false;
-  const size_t lds = sort3_lds(g.G, n, C).total;
+  if (n / 4 + (3 * G) / 4 > kS3MaxItems) return false;
+  const size_t lds = sort3_lds(G, n, C, dim).total;
   if (lds > (size_t)kBigLdsBytes) return false;
   const long long planes = (long long)B * H;
   const int ngroups = C >> 2;
@@ -2106,10 +2121,11 @@ bool sorted3_plan(int B, int H, int C, int N, const GridW<3>& g, bool gather, So
   return planes * nseg * ncg >= 256 && ngroups / ncg >= (gather ? 2 : 1);
 }
 
-size_t sorted3_workspace(int B, int H, int C, int N, const GridW<3>& g) {
+template <int DIM>
+size_t sorted3_workspace(int B, int H, int C, int N, const GridW<DIM>& g) {
   Sorted3Plan p;
-  if (!sorted3_plan(B, H, C, N, g, true, p)) return 0;
-  return (p.ncg > 1 ? (size_t)p.ncg * B * H * 3 * N * 4 : 0) + (p.nseg > 1 ? (size_t)p.nseg * B * H * C * g.G * 4 : 0);
+  if (!sorted3_plan(B, H, C, N, g.G, DIM, true, p)) return 0;
+  return (p.ncg > 1 ? (size_t)p.ncg * B * H * DIM * N * 4 : 0) + (p.nseg > 1 ? (size_t)p.nseg * B * H * C * g.G * 4 : 0);
 }
 
 size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
@@ -2125,9 +2141,16 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
 
 #define CT_LAUNCH_SORTED3_(GATHERV, GRID, LDS, STREAM, ARGS, GW)                                                            \
   do {                                                                                                                     \
-    if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((slice_bwd_sorted3_kernel<true, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW); \
-    else if (cube_of(GW) == 8) CT_LAUNCH((slice_bwd_sorted3_kernel<false, 8, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);         \
-    else CT_LAUNCH((slice_bwd_sorted3_kernel<false, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);                 \
+    if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((slice_bwd_sorted_seg_kernel<true, 3, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW); \
+    else if (cube_of(GW) == 8) CT_LAUNCH((slice_bwd_sorted_seg_kernel<false, 3, 8, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);         \
+    else CT_LAUNCH((slice_bwd_sorted_seg_kernel<false, 3, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);           \
+  } while (0)
+// the same kernel on small 2D grids (DIM = 2: one face); the zoo's 16 x 16 known at compile time
+#define CT_LAUNCH_SORTED2S_(GATHERV, GRID, LDS, STREAM, ARGS, GW)                                                           \
+  do {                                                                                                                     \
+    if ((ARGS).pad_dtype != CT_PAD_NONE) CT_LAUNCH((slice_bwd_sorted_seg_kernel<true, 2, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW); \
+    else if ((GW).W[0] == 16 && (GW).W[1] == 16) CT_LAUNCH((slice_bwd_sorted_seg_kernel<false, 2, 16, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW); \
+    else CT_LAUNCH((slice_bwd_sorted_seg_kernel<false, 2, 0, GATHERV>), GRID, kS3Threads, LDS, STREAM, ARGS, GW);           \
   } while (0)
 
 // The scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid) on ONE sorted segment per plane (there is no workspace for partial
@@ -2136,7 +2159,7 @@ size_t slice_bwd_hot_workspace(int B, int H, int C, int N, const GridW<3>& g) {
 int run_scatter_add_sorted3(RasterArgs a, const GridW<3>& g, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)a.pos.keys | (uintptr_t)a.src | (uintptr_t)a.tile_out;
   Sorted3Plan p;
-  if (!hot_shape_ok(a, g.G, bits) || !sorted3_plan(a.B, a.H, a.C, a.N, g, false, p) || p.nseg != 1) return CT_EINVAL;
+  if (!hot_shape_ok(a, g.G, bits) || !sorted3_plan(a.B, a.H, a.C, a.N, g.G, 3, false, p) || p.nseg != 1) return CT_EINVAL;
   a.CC = 4; a.nchunks = a.C >> 2; a.ncg = p.ncg; a.nseg = 1; a.Nrow = a.N; a.tickets = nullptr; a.tile_in = nullptr;
   a.g_pos = nullptr; a.gpos_stride = 0; a.sorted = nullptr;
   dim3 wgrid(p.ncg, a.H, a.B);
@@ -2146,10 +2169,21 @@ int run_scatter_add_sorted3(RasterArgs a, const GridW<3>& g, hipStream_t st) {
 }
 
 // Slice backward on sorted segments.  CT_EINVAL: not eligible (the scatter form below takes the call).
-int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const GridW<3>& g, void* ws, size_t ws_bytes, hipStream_t st) {
+template <int DIM>
+int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const GridW<DIM>& g, void* ws, size_t ws_bytes, hipStream_t st) {
   Sorted3Plan p;
-  if (!sorted3_plan(a.B, a.H, a.C, a.N, g, true, p)) return CT_EINVAL;
-  const size_t gpos_n = (size_t)a.B * a.H * 3 * a.N;
+  if (!sorted3_plan(a.B, a.H, a.C, a.N, g.G, DIM, true, p)) return CT_EINVAL;
+  if constexpr (DIM == 2) {
+    // 2D: only where the one-workgroup-per-plane sorted kernel (ct_raster_sorted.h) would leave the chip part empty or split a
+    // plane's channel groups over workgroups that each sort the whole plane — few planes (the H16 blocks' 16 x 16 head): two
+    // 512-thread workgroups per CU on 2048-point segments instead (profiles/r6_zoo_shape_checks.txt).  CLOUDCT_SORTED2S=0: off.
+    static const int env2 = [] {
+      const char* e = getenv("CLOUDCT_SORTED2S");
+      return e ? atoi(e) : 1;
+    }();
+    if (!(t_dbg_flags & CT_DEBUG_FORCE_SORTED_SEG) && (env2 == 0 || (long long)a.B * a.H >= 256)) return CT_EINVAL;
+  }
+  const size_t gpos_n = (size_t)a.B * a.H * DIM * a.N;
   const size_t grid_n = (size_t)a.B * a.H * a.C * g.G;
   const size_t keys_need = p.ncg > 1 ? (size_t)p.ncg * gpos_n * 4 : 0, need = keys_need + (p.nseg > 1 ? (size_t)p.nseg * grid_n * 4 : 0);
   if (need > 0 && (!ws || ws_bytes < need)) return CT_EINVAL;
@@ -2163,13 +2197,18 @@ int run_slice_bwd_sorted3(RasterArgs a, const float* grid, float* g_pos, const G
   a.nseg = p.nseg; a.Nrow = a.N; a.N = p.n;
   const int per_wg = ((a.C >> 2) + p.ncg - 1) / p.ncg;
   const bool fold = (p.ncg > 1 || p.nseg > 1) && tickets_cover(a.tickets, (long long)a.B * a.H, p.ncg, p.nseg) &&
-                    fold_pays(p.ncg > 1 ? (size_t)p.ncg * 3 * a.N * 4 : 0) &&
+                    fold_pays(p.ncg > 1 ? (size_t)p.ncg * DIM * a.N * 4 : 0) &&
                     fold_pays(p.nseg > 1 ? (size_t)p.nseg * per_wg * 4 * g.G * 4 : 0);
   if (!fold) a.tickets = nullptr;
   a.fold_gpos = g_pos; a.fold_grid = g_grid;
   dim3 wgrid(p.ncg, a.H, a.B * p.nseg);
-  CT_LAUNCH_SORTED3_(true, wgrid, p.lds, st, a, g);
-  note(p.nseg > 1 ? "slice_bwd_sorted3_segments" : p.ncg > 1 ? "slice_bwd_sorted3_groups" : "slice_bwd_sorted3");
+  if constexpr (DIM == 3) {
+    CT_LAUNCH_SORTED3_(true, wgrid, p.lds, st, a, g);
+    note(p.nseg > 1 ? "slice_bwd_sorted3_segments" : p.ncg > 1 ? "slice_bwd_sorted3_groups" : "slice_bwd_sorted3");
+  } else {
+    CT_LAUNCH_SORTED2S_(true, wgrid, p.lds, st, a, g);
+    note(p.nseg > 1 ? "slice_bwd_sorted2s_segments" : p.ncg > 1 ? "slice_bwd_sorted2s_groups" : "slice_bwd_sorted2s");
+  }
   if (fold) {
     note("folded");
     return CT_OK;

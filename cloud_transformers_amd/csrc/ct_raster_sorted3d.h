@@ -43,7 +43,7 @@ struct Sort3Lds {
   size_t misc;     // unsigned[C] channel maxima | K | flag | scan scratch [64]
   size_t total;
 };
-__host__ __device__ inline Sort3Lds sort3_lds(int G, int n, int C) {
+__host__ __device__ inline Sort3Lds sort3_lds(int G, int n, int C, int dim = 3) {
   Sort3Lds L;
   size_t o = 0;
   const size_t tiles = (size_t)32 * G, tables = (size_t)8 * G + (size_t)4 * kS3MaxItems;
@@ -56,7 +56,7 @@ __host__ __device__ inline Sort3Lds sort3_lds(int G, int n, int C) {
     o += ((st > hist ? st : hist) + 15) & ~(size_t)15;
   }
   L.ab = o;  o += (size_t)8 * (n + 2);
-  L.cz = o;  o += ((size_t)4 * (n + 1) + 15) & ~(size_t)15;
+  L.cz = o;  o += dim == 3 ? (((size_t)4 * (n + 1) + 15) & ~(size_t)15) : 0;      // (2D: no third weight)
   L.misc = o; o += (size_t)4 * (C + 2 + 64 + 2);
   L.total = (o + 15) & ~(size_t)15;
   return L;
@@ -68,24 +68,33 @@ struct Plane3Keys {
   float fa[4], fb[4], fc[4];
   unsigned inside;
 };
-__device__ __forceinline__ void load_plane3_keys(const float* keys, const GridW<3>& g, size_t bh, int Nr, int so, int n, Plane3Keys& K) {
+template <int DIM>
+__device__ __forceinline__ void load_plane3_keys(const float* keys, const GridW<DIM>& g, size_t bh, int Nr, int so, int n, Plane3Keys& K) {
   const int tid = threadIdx.x;
   const bool has = (tid << 2) < n;
   const int n0 = has ? (tid << 2) : 0;
-  float k[3][4];
-  load_keys3(keys, bh, Nr, so + n0, k);
+  float k[DIM][4];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) {
+    const float4 t = *(const float4*)(keys + (bh * DIM + j) * Nr + so + n0);
+    k[j][0] = t.x; k[j][1] = t.y; k[j][2] = t.z; k[j][3] = t.w;
+  }
   K.inside = 0u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float w0, fx, fy, fz;
-    int f0, f1, f2;
-    ct_axis(k[0][i], g.hw[0], g.W[0], w0, fx, f0);
-    ct_axis(k[1][i], g.hw[1], g.W[1], w0, fy, f1);
-    ct_axis(k[2][i], g.hw[2], g.W[2], w0, fz, f2);
-    K.base[i] = (f0 * g.W[1] + f1) * g.W[2] + f2;
-    K.fa[i] = fx; K.fb[i] = fy; K.fc[i] = fz;
-    K.inside |= ((ct_key_mask(k[0][i]) != 0.0f ? 1u : 0u) | (ct_key_mask(k[1][i]) != 0.0f ? 2u : 0u) |
-                 (ct_key_mask(k[2][i]) != 0.0f ? 4u : 0u)) << (3 * i);
+    float w0, w1[3] = {0.0f, 0.0f, 0.0f};
+    int base = 0;
+    unsigned in = 0u;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      int f;
+      ct_axis(k[j][i], g.hw[j], g.W[j], w0, w1[j], f);
+      base = base * g.W[j] + f;                          // (axis 0 slowest: ct_corners)
+      in |= (ct_key_mask(k[j][i]) != 0.0f ? 1u : 0u) << j;
+    }
+    K.base[i] = base;
+    K.fa[i] = w1[0]; K.fb[i] = w1[1]; K.fc[i] = w1[2];
+    K.inside |= in << (3 * i);
   }
 }
 
@@ -99,6 +108,7 @@ struct Sorted3Plane {
 // Counting sort of the workgroup's points by base cell; the items dealt to the threads.  All kS3Threads threads call it.  K (max
 // contributions to a cell) is left in *s_k; the nC words in front of it (channel maxima) are cleared.  The tables alias the tile
 // and accumulator areas and the histograms the stage area: the caller puts a barrier between this and its first write to them.
+template <int DIM>
 __device__ __forceinline__ void sort3_plane(const Plane3Keys& PK, int n, int G, int sx, int sy, unsigned char* lds, const Sort3Lds& L,
                                             int nC, Sorted3Plane& S) {
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -161,14 +171,14 @@ __device__ __forceinline__ void sort3_plane(const Plane3Keys& PK, int n, int G, 
     }
     carry += all;
     if (Y0 + kS3Threads >= G2) {      // last round: every cell's count is in place
-      // K: contributions per cell = points based at the cell and at its seven lower neighbours (a wrapped neighbour index lands on
-      // a cell of the last row / column / slice, which is never a base: it reads zero)
-      const int off[8] = {0, sx, sy, sx + sy, 1, sx + 1, sy + 1, sx + sy + 1};
+      // K: contributions per cell = points based at the cell and at its 2^DIM - 1 lower neighbours (a wrapped neighbour index lands
+      // on a cell of the last row / column / slice, which is never a base: it reads zero)
+      const int off[8] = {0, sx, sy, sx + sy, 1, sx + 1, sy + 1, sx + sy + 1};      // (2D: sy = 1, the first four)
       unsigned kloc = 0u;
       for (int X = tid; X < G; X += kS3Threads) {
         unsigned c = 0u;
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
+        for (int v = 0; v < (1 << DIM); ++v)
           if (X >= off[v]) c += cnt[X - off[v]];
         kloc = max(kloc, c);
       }
@@ -243,6 +253,9 @@ __device__ __forceinline__ void scatter_float_channel3(const RasterArgs& a, cons
   }
 }
 
+#ifndef CT_S2_PREFETCH
+#define CT_S2_PREFETCH 1
+#endif
 #ifndef CT_S3_PREFETCH
 #define CT_S3_PREFETCH 0      // 1: the next group's rows requested during this group's first item (20 more live registers: spills)
 #endif
@@ -252,13 +265,24 @@ __device__ __forceinline__ void scatter_float_channel3(const RasterArgs& a, cons
 //   a.N: points of a segment (<= kS3MaxPoints), a.Nrow: row length, a.nseg / a.ncg: segments / channel-group workgroups per plane
 //   GATHER = false: the scatter-add alone (Splat(sum) forward, ct_slice_bwd_grid): no conv tile, no g_keys.
 // ---------------------------------------------------------------------------
-template <bool HAS_PAD, int W3, bool GATHER>
-__global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(RasterArgs a, GridW<3> g_arg) {
-  const GridW<3> g = grid3_of<W3>(g_arg);
+// DIM = 2: the same on a small 2D grid (the zoo's 16^2 C16 head at few planes): ONE face, no z weight — the 2D item body itself.
+template <int DIM, int WK>
+__device__ __forceinline__ GridW<DIM> seg_grid_of(const GridW<DIM>& g) {
+  if constexpr (DIM == 3) return grid3_of<WK>(g);
+  else return grid2_of<WK>(g);
+}
+template <bool HAS_PAD, int DIM, int WK, bool GATHER>
+__global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted_seg_kernel(RasterArgs a, GridW<DIM> g_arg) {
+  const GridW<DIM> g = seg_grid_of<DIM, WK>(g_arg);
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int G = g.G, n = a.N, C = a.C;
-  const int sy = g.W[2], sx = g.W[1] * g.W[2];
-  const Sort3Lds L = sort3_lds(G, n, C);
+  constexpr int kFaces = DIM == 3 ? 2 : 1;
+  // the next group's rows requested during this group's first item (20 more live registers): the 2D form with its grid known at
+  // compile time has them to spare (126 registers), the 3D form spills 27 with it (54 vs 49 us)
+  constexpr bool kPrefetch = CT_S3_PREFETCH != 0 || (DIM == 2 && WK > 0 && CT_S2_PREFETCH != 0);
+  // cell offsets of the in-face corners {0, sx, sy, sx + sy}; 3D: the z = 1 face is +1 (z fastest); 2D: x slowest, y fastest
+  const int sy = DIM == 3 ? g.W[DIM - 1] : 1, sx = DIM == 3 ? g.W[1] * g.W[DIM - 1] : g.W[1];
+  const Sort3Lds L = sort3_lds(G, n, C, DIM);
   float4* T4 = (float4*)(lds_raw + L.tile);
   int* acc = (int*)(lds_raw + L.acc);
   float4* Sg = (float4*)(lds_raw + L.stage);
@@ -297,12 +321,12 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
   CT_STAMP(0);
   CT_WG_STAMP(0);
   Plane3Keys PK;
-  load_plane3_keys(a.pos.keys, g, bh, Nr, so, n, PK);
+  load_plane3_keys<DIM>(a.pos.keys, g, bh, Nr, so, n, PK);
   float pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pv[i] = (HAS_PAD && has) ? ct_load_pad(a.pad, a.pad_dtype, (size_t)b * Nr + so + n0 + i) : 1.0f;
   Sorted3Plane S;
-  sort3_plane(PK, n, G, sx, sy, lds_raw, L, C, S);
+  sort3_plane<DIM>(PK, n, G, sx, sy, lds_raw, L, C, S);
   CT_STAMP(1);
   request(cgi);                                   // (behind the keys' use: see slice_bwd_sorted_kernel)
   const float Kf = (float)(*s_k);
@@ -312,12 +336,12 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       AB[rk[i]] = make_float2(PK.fa[i], PK.fb[i]);
-      CZ[rk[i]] = PK.fc[i];
+      if constexpr (DIM == 3) CZ[rk[i]] = PK.fc[i];
     }
   }
   if (tid == 0) {                                 // what the slots beyond an item's entries read
     AB[n] = make_float2(0.0f, 0.0f);
-    CZ[n] = 0.0f;
+    if constexpr (DIM == 3) CZ[n] = 0.0f;
     Sg[n] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   for (int i = tid; i < G; i += kS3Threads) ((int4*)acc)[i] = make_int4(0, 0, 0, 0);
@@ -381,20 +405,20 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
     // scaled by the face's z weight.  The next group's loads are issued one channel per entry of the first item's first face.
     auto item = [&](auto U) {
       constexpr int u = decltype(U)::value;
-      constexpr bool spread = CT_S3_PREFETCH && u == 0 && decltype(more)::value;
+      constexpr bool spread = kPrefetch && u == 0 && decltype(more)::value;
       unsigned it = S.item[u];
       asm volatile("" : "+v"(it));                  // (opaque per group: the unpacked fields are not kept across groups)
       const bool live = it != kS3NoItem;
       const int first = live ? (int)(it & 0xfffu) : n, ne = live ? (int)((it >> 12) & 3u) + 1 : 0, Y = live ? (int)(it >> 14) : 0;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
+      for (int f = 0; f < kFaces; ++f) {
         float4 cv[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) cv[v] = GATHER ? T4[Y + off2[v] + f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int e = ne > 0 ? first : n;
         float4 xn = Sg[e];
         float2 wn = AB[e];
-        float zn = CZ[e];
+        float zn = DIM == 3 ? CZ[e] : 0.0f;
         ct_f2 s01[4], s23[4];      // [corner of the face] x channels (0,1) / (2,3)
 #pragma unroll
         for (int v = 0; v < 4; ++v) s01[v] = s23[v] = ct_f2{0.0f, 0.0f};
@@ -410,16 +434,16 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
             e = j + 1 < ne ? first + j + 1 : n;
             xn = Sg[e];
             wn = AB[e];
-            zn = CZ[e];
+            if constexpr (DIM == 3) zn = CZ[e];
           }
           const float w1x = wf.x, w1y = wf.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
-          const float wz = f ? w1z : 1.0f - w1z;
+          const float wz = DIM == 2 ? 1.0f : (f ? w1z : 1.0f - w1z);
           const float cw2[4] = {w0x * w0y, w1x * w0y, w0x * w1y, w1x * w1y};      // (wx * wy) * wz: ct_corners<3>'s order
           const ct_f2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
           float gw[4];
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const float cw = cw2[v] * wz;
+            const float cw = DIM == 2 ? cw2[v] : cw2[v] * wz;
             const ct_f2 cwv = {cw, cw};
             s01[v] = __builtin_elementwise_fma(x01, cwv, s01[v]);
             s23[v] = __builtin_elementwise_fma(x23, cwv, s23[v]);
@@ -433,11 +457,17 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
             // ct_corner_grad<3> face by face: d/dx, d/dy = the face's 2D expressions x its z weight, d/dz = -+ its bilinear value
             const float gxf = __builtin_fmaf(gw[3] - gw[2], w1y, (gw[1] - gw[0]) * w0y);
             const float gyf = __builtin_fmaf(gw[3] - gw[1], w1x, (gw[2] - gw[0]) * w0x);
-            const float val = __builtin_fmaf(gw[3], cw2[3], __builtin_fmaf(gw[2], cw2[2], __builtin_fmaf(gw[1], cw2[1], gw[0] * cw2[0])));
-            gsx[u][j] = __builtin_fmaf(gxf, wz, gsx[u][j]);
-            gsy[u][j] = __builtin_fmaf(gyf, wz, gsy[u][j]);
-            gsz[u][j] = f ? gsz[u][j] + val : gsz[u][j] - val;
-            asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]), "+v"(gsz[u][j]));
+            if constexpr (DIM == 3) {
+              const float val = __builtin_fmaf(gw[3], cw2[3], __builtin_fmaf(gw[2], cw2[2], __builtin_fmaf(gw[1], cw2[1], gw[0] * cw2[0])));
+              gsx[u][j] = __builtin_fmaf(gxf, wz, gsx[u][j]);
+              gsy[u][j] = __builtin_fmaf(gyf, wz, gsy[u][j]);
+              gsz[u][j] = f ? gsz[u][j] + val : gsz[u][j] - val;
+              asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]), "+v"(gsz[u][j]));
+            } else {
+              gsx[u][j] += gxf;
+              gsy[u][j] += gyf;
+              asm volatile("" : "+v"(gsx[u][j]), "+v"(gsy[u][j]));
+            }
           }
           CT_SB;
         }
@@ -461,11 +491,14 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
     if (S.item[1] != kS3NoItem) item(std::integral_constant<int, 1>{});
     if (stamp) CT_STAMP(21);
     if (stamp) CT_WSTAMP(40 + (threadIdx.x >> 6));
-    if constexpr (decltype(more)::value && !CT_S3_PREFETCH) request(grp + ncg);
+    if constexpr (decltype(more)::value && !kPrefetch) request(grp + ncg);
     if (any_float) {           // block-uniform, rare: IEEE float atomics for a channel with inf / NaN (or beyond the fixed-point bound)
 #pragma unroll 1
       for (int cj = 0; cj < 4; ++cj)
-        if (iq[cj] == 0.0f) scatter_float_channel3<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(acc + cj * G), n, Nr, so);
+        if (iq[cj] == 0.0f) {
+          if constexpr (DIM == 3) scatter_float_channel3<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(acc + cj * G), n, Nr, so);
+          else scatter_float_channel<HAS_PAD>(a, g, bh, b, ch0 + cj, (float*)(acc + cj * G), 1, (size_t)so);
+        }
     }
     __syncthreads();
     if (stamp) CT_STAMP(22);
@@ -515,9 +548,9 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
         gk[i].y *= (rw[i] & kInsideY) ? 1.0f : 0.0f;
         gk[i].z *= (rw[i] & kInsideZ) ? 1.0f : 0.0f;
       }
-      st_part4(gp + (bh * 3 + 0) * Nr + so + n0, make_float4(gk[0].x, gk[1].x, gk[2].x, gk[3].x), fold_keys);
-      st_part4(gp + (bh * 3 + 1) * Nr + so + n0, make_float4(gk[0].y, gk[1].y, gk[2].y, gk[3].y), fold_keys);
-      st_part4(gp + (bh * 3 + 2) * Nr + so + n0, make_float4(gk[0].z, gk[1].z, gk[2].z, gk[3].z), fold_keys);
+      st_part4(gp + (bh * DIM + 0) * Nr + so + n0, make_float4(gk[0].x, gk[1].x, gk[2].x, gk[3].x), fold_keys);
+      st_part4(gp + (bh * DIM + 1) * Nr + so + n0, make_float4(gk[0].y, gk[1].y, gk[2].y, gk[3].y), fold_keys);
+      if constexpr (DIM == 3) st_part4(gp + (bh * 3 + 2) * Nr + so + n0, make_float4(gk[0].z, gk[1].z, gk[2].z, gk[3].z), fold_keys);
     }
   }
   CT_STAMP(4);
@@ -527,8 +560,8 @@ __global__ void __launch_bounds__(kS3Threads, 4) slice_bwd_sorted3_kernel(Raster
                                    fold_grid ? a.tickets + kTicketHalf + (bh * ncg + cgi) : nullptr, (unsigned)nsg, s_flag);
     if (f & 1u) {      // this segment's g_keys: the channel groups' partials, ascending
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        fold_rows(a.g_pos + (bh * 3 + j) * Nr + so, a.gpos_stride, ncg, a.fold_gpos + (bh * 3 + j) * Nr + so, n >> 2, nullptr);
+      for (int j = 0; j < DIM; ++j)
+        fold_rows(a.g_pos + (bh * DIM + j) * Nr + so, a.gpos_stride, ncg, a.fold_gpos + (bh * DIM + j) * Nr + so, n >> 2, nullptr);
     }
     if (f & 2u) {      // this workgroup's channel groups: the segments' partial tiles, ascending
       const size_t grid_n = (size_t)a.B * a.H * C * G;

@@ -120,6 +120,8 @@ int ct_splat_bwd_ex(const float* keys, const float* feat, const void* pad, int p
 #define CT_DEBUG_FORCE_BAND 8  /* try them first, on every layout they can take (small grids in the tests) */
 #define CT_DEBUG_NO_SORTED 16  /* keep the sorted-plane kernels (csrc/ct_raster_sorted.h) off */
 #define CT_DEBUG_FORCE_SORTED 32 /* use them on every layout they can take, however few (b,h) planes there are */
+#define CT_DEBUG_FORCE_SORTED_SEG 64 /* 2D: the sorted-SEGMENT kernel (csrc/ct_raster_sorted3d.h, DIM = 2) wherever it is legal; 3D grids
+                                        take it under CT_DEBUG_FORCE_SORTED already */
 void ct_debug_set_flags(unsigned flags);
 const char* ct_debug_last_launch(void);
 /* point segments of the hot Splat(max) backward (ct_splat_bwd_tk): 0 automatic, 1 never, n > 1: n wherever legal */

@@ -37,10 +37,11 @@ def per_channel_err(a, b, HC):
 
 
 def oracle(keys, z, cot, pad, W, H):
+    dim = len(W)
     k = keys.clone().requires_grad_(True)
     zz = z.clone().requires_grad_(True)
-    lc, idx = R.positions(k, list(W), H, 3)
-    R.slice_(lc, idx, zz, pad, list(W), H, 3).backward(cot)
+    lc, idx = R.positions(k, list(W), H, dim)
+    R.slice_(lc, idx, zz, pad, list(W), H, dim).backward(cot)
     return zz.grad, k.grad
 
 
@@ -49,15 +50,16 @@ def run(keys, z, cot, pad, W, H, C, tickets, fl):
     from cloud_transformers_amd.ops import _ptr, _stream
     mod, lib = _lib()
     B, _, N = keys.shape
+    dim = len(W)
     Wa = mod.int_array(list(W))
     lib.ct_debug_set_flags(fl)
     try:
-        nws = lib.ct_slice_bwd_workspace_bytes(B, H, C, N, 3, Wa)
+        nws = lib.ct_slice_bwd_workspace_bytes(B, H, C, N, dim, Wa)
         ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
         tk = torch.zeros(mod.TICKETS_BYTES // 4, device="cuda", dtype=torch.int32) if tickets else None
         g_z, g_k = torch.full_like(z, float("nan")), torch.full_like(keys, float("nan"))
         mod.check(lib.ct_slice_bwd_ps(_ptr(keys), _ptr(z), _ptr(pad), mod.PAD_F32 if pad is not None else 0, _ptr(cot), _ptr(g_z),
-                                      _ptr(g_k), _ptr(ws), nws, _ptr(tk), None, B, H, C, N, 3, Wa, _stream()), "ct_slice_bwd_ps")
+                                      _ptr(g_k), _ptr(ws), nws, _ptr(tk), None, B, H, C, N, dim, Wa, _stream()), "ct_slice_bwd_ps")
         tag = lib.ct_debug_last_launch().decode()
         torch.cuda.synchronize()
         if tickets:
@@ -178,3 +180,57 @@ def test_sorted3_splat_sum_forward_against_the_oracle(cfg, flags):
         outs.append(z)
     assert torch.equal(outs[0], outs[1]), "not bitwise reproducible"
     assert per_channel_err(outs[0], ref, H * C) <= 1e-4
+
+
+CASES_2D = [
+    # B, H, C, N, W, pad, duplicated points — the same kernel with DIM = 2 (one face) on small 2D grids
+    (2, 3, 8, 1024, (16, 16), False, False),
+    (1, 2, 16, 4096, (16, 16), False, False),          # two point segments per plane
+    (2, 2, 12, 516, (16, 24), True, False),            # non-square, padding mask, ragged last quad of threads
+    (1, 2, 8, 2048, (8, 8), False, True),              # heavy duplicates
+    (1, 1, 8, 6144, (16, 32), False, False),           # three segments on 512 cells
+    (1, 2, 8, 1024, (4, 4), False, False),
+]
+
+
+@pytest.mark.parametrize("cfg", CASES_2D, ids=str)
+@pytest.mark.parametrize("tickets", [False, True], ids=["sum_parts", "tickets"])
+def test_sorted_segments_2d_slice_backward_against_the_oracle(cfg, tickets):
+    mod, lib = _lib()
+    B, H, C, N, W, pad, dup = cfg
+    torch.manual_seed(11)
+    keys = torch.tanh(torch.randn(B, H * 2, N) * (0.3 if dup else 1.0))
+    if dup:
+        keys[:, :, N // 2:] = keys[:, :, :N // 2]
+    keys[0, 0, :8] = torch.tensor([-1.0, 1.0, -0.99999994, 0.99999994, 0.0, 0.5, -2.0, 3.0])
+    z = torch.randn(B, H * C, *W)
+    cot = torch.randn(B, H * C, N)
+    p = (torch.rand(B, N) > 0.2).float() if pad else None
+    gz_ref, gk_ref = oracle(keys, z, cot, p, W, H)
+    kd, zd, cd = keys.cuda(), z.cuda(), cot.cuda()
+    pd = p.cuda() if pad else None
+    outs = []
+    for _ in range(2):
+        g_z, g_k, tag = run(kd, zd, cd, pd, W, H, C, tickets, mod.DEBUG_FORCE_SORTED_SEG | mod.DEBUG_FORCE_HOT)
+        assert tag.startswith("slice_bwd_sorted2s"), tag
+        outs.append((g_z, g_k))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "not bitwise reproducible"
+    assert per_channel_err(outs[0][0], gz_ref, H * C) <= 1e-4
+    assert relerr(outs[0][1], gk_ref) <= 1e-4
+
+
+def test_sorted_segments_2d_against_the_one_workgroup_per_plane_kernel():
+    """The zoo's 16^2 C16 head at B8 H16 N4096 (the default takes sorted segments): against the 1024-thread sorted kernel with
+    channel groups (csrc/ct_raster_sorted.h, CLOUDCT-independent: forced by CT_DEBUG_FORCE_SORTED) to 1e-5."""
+    mod, lib = _lib()
+    B, H, C, N, W = 8, 16, 16, 4096, (16, 16)
+    torch.manual_seed(5)
+    keys = torch.tanh(torch.randn(B, H * 2, N, device="cuda"))
+    z = torch.randn(B, H * C, *W, device="cuda")
+    cot = torch.randn(B, H * C, N, device="cuda")
+    a = run(keys, z, cot, None, W, H, C, True, 0)
+    b = run(keys, z, cot, None, W, H, C, True, mod.DEBUG_FORCE_SORTED)
+    assert a[2].startswith("slice_bwd_sorted2s_segments"), a[2]
+    assert b[2].startswith("slice_bwd_sorted_groups"), b[2]
+    assert per_channel_err(a[0], b[0], H * C) <= 1e-5
+    assert relerr(a[1], b[1]) <= 1e-5

@@ -13,6 +13,10 @@ namespace ctdev {
 #ifndef CT_ONE_ARGS
 #define CT_ONE_ARGS RasterArgs, GridW<3>
 #endif
+#ifdef CT_ONE_2D
+#undef CT_ONE_ARGS
+#define CT_ONE_ARGS RasterArgs, GridW<2>
+#endif
 namespace ctdev {
 template __global__ void CT_ONE(CT_ONE_ARGS);
 }
