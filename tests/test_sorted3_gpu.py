@@ -234,3 +234,24 @@ def test_sorted_segments_2d_against_the_one_workgroup_per_plane_kernel():
     assert b[2].startswith("slice_bwd_sorted_groups"), b[2]
     assert per_channel_err(a[0], b[0], H * C) <= 1e-5
     assert relerr(a[1], b[1]) <= 1e-5
+
+
+def test_sorted_segments_2d_with_non_finite_channels():
+    """The 2D form takes the same IEEE float-atomic pass for a channel with inf / NaN (ct_raster_hot.h: scatter_float_channel)."""
+    mod, lib = _lib()
+    W, B, H, C, N = (16, 16), 1, 2, 8, 1024
+    g = torch.Generator().manual_seed(7)
+    keys = torch.tanh(torch.randn(B, H * 2, N, generator=g))
+    grid = torch.randn(B, H * C, *W, generator=g)
+    cot = torch.randn(B, H * C, N, generator=g)
+    cot[0, 1, 7] = float("inf")
+    cot[0, C + 6] *= 1e30
+    ref, _ = oracle(keys, grid, cot, None, W, H)
+    got, _, tag = run(keys.cuda(), grid.cuda(), cot.cuda(), None, W, H, C, False, mod.DEBUG_FORCE_SORTED_SEG | mod.DEBUG_FORCE_HOT)
+    assert tag.startswith("slice_bwd_sorted2s"), tag
+    got = got.cpu()
+    for ch in range(H * C):
+        a, r = got[0, ch].double(), ref[0, ch].double()
+        fin = torch.isfinite(r)
+        assert torch.equal(torch.isfinite(a), fin), ch
+        assert float((a[fin] - r[fin]).abs().max()) <= 1e-4 * float(r[fin].abs().max()), ch
