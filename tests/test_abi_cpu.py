@@ -140,3 +140,16 @@ def test_reference_import_paths_resolve():
     assert d.MultiHeadPool and e.PlaneTransformer and e.VolTransformer and e.AdaIn1dUpd
     assert f.Res3DBlock and f.Pool3DBlock and g.Res2DBlock and h.loss_chamfer and h.ChamferDist
     assert "AdaIn1dUpd" in str(type(e.AdaIn1dUpd(4, 8)))
+
+
+def test_debug_flag_constants_match_the_header():
+    """The CT_DEBUG_* bits of include/cloudct.h and the DEBUG_* constants the Python layer passes to ct_debug_set_flags are the
+    same numbers (a test that forces a kernel family with a stale constant would silently test another one)."""
+    import re
+    from cloud_transformers_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cloudct.h")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define CT_DEBUG_(\w+)\s+(\d+)", text)}
+    assert len(header) >= 7 and len(set(header.values())) == len(header)
+    for name, value in header.items():
+        assert getattr(_lib, "DEBUG_" + name) == value, name
+    assert _lib.ABI_VERSION == int(re.search(r"#define CT_ABI_VERSION\s+(\d+)", text).group(1))
