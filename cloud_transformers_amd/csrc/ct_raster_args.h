@@ -48,3 +48,27 @@ struct RasterArgs {
   const unsigned char* sorted;
   size_t sorted_stride;
 };
+
+// Workgroup -> (x, head, cloud) of a grid (X, H, B) whose X workgroups per (b, h) plane share that plane's keys (and, for
+// the scatter / gather pairs, its feature rows or its tile).  The launch order is x-fastest and consecutive workgroups go to
+// the 8 XCDs in turn (observed; speed only), so a plane's workgroups are given linear ids congruent mod 8: one XCD, one
+// L2 — what the plane's second and later workgroups re-read is then served there instead of from HBM (the single-channel
+// kernels of the C4 heads moved 1.6-3.1x the algorithmic bytes, profiles/r3_zoo_counters.txt).
+struct BlockXHB {
+  int x, h, b;
+};
+__device__ __forceinline__ BlockXHB block_xhb() {
+  BlockXHB r;
+  const unsigned X = gridDim.x, planes = gridDim.y * gridDim.z;
+  if (X > 1 && (planes & 7u) == 0) {
+    const unsigned L = blockIdx.x + X * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned grp = L / (8u * X), rem = L - grp * 8u * X;
+    const unsigned plane = grp * 8u + (rem & 7u);
+    r.x = (int)(rem >> 3);
+    r.h = (int)(plane % gridDim.y);
+    r.b = (int)(plane / gridDim.y);
+  } else {
+    r.x = blockIdx.x; r.h = blockIdx.y; r.b = blockIdx.z;
+  }
+  return r;
+}

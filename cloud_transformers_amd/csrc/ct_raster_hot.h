@@ -1281,8 +1281,10 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci_kernel(RasterArgs a,
   extern __shared__ __align__(16) float lds[];
   const int G = WT ? WT * WT : g.G, W1 = WT ? WT : g.W[1], N = a.N;
   float4* T4 = (float4*)lds;
-  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // (a plane's chunk x split workgroups on ONE XCD — block_xhb — re-read its keys, and its tile per split, from that L2)
+  const BlockXHB blk = block_xhb();
+  const int chunk = blk.x / a.nsplit, sp = blk.x % a.nsplit;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);            // multiple of 4

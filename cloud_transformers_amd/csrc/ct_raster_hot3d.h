@@ -883,8 +883,9 @@ __global__ void __launch_bounds__(kHotThreads, 4) gather_ci3_kernel(RasterArgs a
   extern __shared__ __align__(16) float lds[];
   const int G = g.G, N = a.N;
   float4* T4 = (float4*)lds;
-  const int chunk = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const BlockXHB blk = block_xhb();          // (one XCD per plane: see gather_ci_kernel)
+  const int chunk = blk.x / a.nsplit, sp = blk.x % a.nsplit;
+  const int h = blk.h, b = blk.b;
   const size_t bh = (size_t)b * a.H + h;
   const int c0 = chunk * a.CC;
   const int cc = min(a.CC, a.C - c0);
