@@ -2091,6 +2091,13 @@ bool sorted3_plan(int B, int H, int C, int N, int G, int dim, bool gather, Sorte
   // g_keys: its groups share nothing, one group per workgroup is fine)
   while (planes * nseg * ncg < 512 && ngroups / (2 * ncg) >= (gather ? 2 : 1)) ncg *= 2;
   if (forced && ncg == 1 && ngroups >= 2 && planes * nseg < 256) ncg = 2;      // tests: the group split on small shapes too
+  {
+    static const int env_ncg = [] {      // experiments: CLOUDCT_S3_NCG = channel-group workgroups per segment
+      const char* e = getenv("CLOUDCT_S3_NCG");
+      return e ? atoi(e) : 0;
+    }();
+    if (env_ncg > 0 && env_ncg <= ngroups) ncg = env_ncg;
+  }
   p.nseg = nseg; p.ncg = ncg; p.n = n; p.lds = lds;
   if (forced) return true;
   // the sort is paid per workgroup, the gain per group: worth it where the chip fills and there are groups to spread it over
