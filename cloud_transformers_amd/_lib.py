@@ -70,6 +70,7 @@ REDUCE = {"max": 0, "sum": 1}
 PAD_NONE, PAD_F32, PAD_I32 = 0, 1, 2
 BWD_ACCUMULATE_KEYS = 1
 TICKETS_BYTES = 65536
+OCC_WORKSPACE_BYTES = 4096
 DEBUG_NO_HOT = 1
 DEBUG_FORCE_HOT = 2
 DEBUG_NO_BAND = 4
@@ -234,6 +235,7 @@ SIGNATURES = {
     "ct_slice_lc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_slice_lc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _vp]),
     "ct_grid_occupancy": (_i, [_vp, ctypes.c_int64, _vp, _vp]),
+    "ct_grid_occupancy_ratio": (_i, [_vp, ctypes.c_int64, _f, _vp, _vp, _vp]),
     "ct_lattice_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ct_lattice_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_lattice_bwd_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -1221,6 +1221,63 @@ __global__ void __launch_bounds__(1024) occupancy_kernel(const float* grid, long
   }
 }
 
+// The occupancy statistic as the blocks report it — count / (B * C * H) as a float — in ONE launch: per-workgroup counts into the
+// caller's workspace, the last workgroup to arrive (ticket in word 0, handed back as zero) adds them and writes
+// float(count) * inv.  ct_grid_occupancy + `.float()` + `/ K` were a memset node, a kernel and two 5 us elementwise launches per
+// head and forward: 96 graph nodes per segmenter step for 24 numbers.
+constexpr int kOccBlocks = 256;
+__global__ void __launch_bounds__(1024) occupancy_ratio_kernel(const float* grid, long long n, float inv, float* out,
+                                                               unsigned long long* ws) {
+  __shared__ unsigned s_part[16];
+  __shared__ unsigned s_last;
+  unsigned local = 0;
+  const long long n4 = n >> 2;
+  const float4* g4 = (const float4*)grid;
+  if ((((uintptr_t)grid) & 15) == 0) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      const float4 v = g4[i];
+      local += (fabsf(v.x) > 1e-9f) + (fabsf(v.y) > 1e-9f) + (fabsf(v.z) > 1e-9f) + (fabsf(v.w) > 1e-9f);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      local += fabsf(grid[i]) > 1e-9f;
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      local += fabsf(grid[i]) > 1e-9f;
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_part[w];
+    __hip_atomic_store(ws + 1 + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial has left before the ticket is taken
+    const unsigned old = __hip_atomic_fetch_add((unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == gridDim.x - 1u;
+    if (old == gridDim.x - 1u) {
+      __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (s_last) {           // block-uniform: this workgroup arrived last
+    unsigned long long t = 0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
+      t += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned lo = (unsigned)t;              // (a launch counts < 2^32 elements per workgroup slot: n <= 2^31 here)
+    for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = lo;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long tot = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+      out[0] = (float)(long long)tot * inv;      // torch: count.float() * (1 / K)  (a float tensor divided by a Python number)
+    }
+  }
+}
+
 // zero the two statistics words at the head of every channel tile
 __global__ void zero_slots_kernel(float* tiles, size_t stride, size_t rows) {
   const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3065,6 +3122,19 @@ int ct_grid_occupancy(const float* grid, int64_t n, int64_t* count, ct_stream_t 
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(occupancy_kernel, dim3(blocks), dim3(1024), 0, st, grid, (long long)n, (unsigned long long*)count);
+  CT_CHECK_LAUNCH();
+  return CT_OK;
+}
+
+int ct_grid_occupancy_ratio(const float* grid, int64_t n, float inv_denominator, float* out, void* workspace, ct_stream_t s) {
+  if (!grid || !out || !workspace || n < 0 || n > (int64_t)0x7fffffff || ((uintptr_t)workspace & 7) != 0) return CT_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  CT_CLEAR_ERROR();
+  int blocks = (int)((n + 16383) / 16384);
+  if (blocks > kOccBlocks) blocks = kOccBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(occupancy_ratio_kernel, dim3(blocks), dim3(1024), 0, st, grid, (long long)n, inv_denominator, out,
+                     (unsigned long long*)workspace);
   CT_CHECK_LAUNCH();
   return CT_OK;
 }

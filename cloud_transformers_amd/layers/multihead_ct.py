@@ -148,7 +148,7 @@ class _MHCTCore(nn.Module):
                 and ops.mhct_core_supported(B, self.heads, self.in_feature_dim, lattice.size(2), ops.sizes_of(self.tensor_size, self.tensor_dim))):
             pre, count = ops.mhct_core(lattice, values, pts_padd, conv.weight, conv.bias, self.tensor_size, self.heads, self.tensor_dim)
             with torch.no_grad():
-                occ = count.float() / (B * self.in_feature_dim * self.heads)
+                occ = count * ops.occupancy_scale(B * self.in_feature_dim * self.heads)      # (one launch: int64 x float scalar -> float32)
             return pre, occ
         z = self.splat.forward_keys(lattice, values, pts_padd)
         occ = self._occupancy(z, B)
@@ -156,6 +156,8 @@ class _MHCTCore(nn.Module):
 
     def _occupancy(self, z, batch):
         with torch.no_grad():
+            if z.numel() < 2 ** 31:
+                return ops.grid_occupancy_ratio(z, batch * self.in_feature_dim * self.heads)
             return ops.grid_occupancy_count(z).float() / (batch * self.in_feature_dim * self.heads)
 
 

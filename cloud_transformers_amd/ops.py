@@ -1547,6 +1547,35 @@ def grid_occupancy_count(grid):
     return count
 
 
+_occ_ws = {}
+
+
+def occupancy_scale(denominator):
+    """float32(1) / float32(K) as a Python float: the scalar torch multiplies by when a float tensor is divided by the number K."""
+    import numpy as np
+    return float(np.float32(1.0) / np.float32(denominator))
+
+
+
+def grid_occupancy_ratio(grid, denominator):
+    """count(|z| > 1e-9) / denominator as a 0-dim float32 device tensor — the `occ` statistic of a block
+    (layers/multihead_ct.py:104-105) — in ONE launch (ct_grid_occupancy_ratio): `grid_occupancy_count(z).float() / K` is a
+    memset node, a kernel and two elementwise launches per head and forward.  Same arithmetic as torch's: float(count) * (1 / K)."""
+    _dev(grid)
+    grid = _f32c(grid)
+    key = (grid.device.index, torch.cuda.current_stream(grid.device).cuda_stream)
+    ws = _occ_ws.get(key)
+    if ws is None:          # zeroed once; the kernel hands its ticket back as zero; one workspace per stream (ordered launches)
+        ws = _occ_ws[key] = torch.zeros(_lib.OCC_WORKSPACE_BYTES // 8, device=grid.device, dtype=torch.int64)
+    out = torch.empty((), device=grid.device, dtype=torch.float32)
+    inv = occupancy_scale(denominator)
+    lib = _lib.load()
+    with _on(grid.device):
+        _lib.check(lib.ct_grid_occupancy_ratio(_ptr(grid), grid.numel(), inv, _ptr(out), _ptr(ws), _stream()),
+                   "ct_grid_occupancy_ratio")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # plane-resident MHCT core: Splat -> grouped conv -> Slice in one kernel (SURVEY 8(f)1)
 # ---------------------------------------------------------------------------

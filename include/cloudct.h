@@ -216,6 +216,12 @@ int ct_slice_lc_bwd(const float* local_coord, const int64_t* flat_idx, const flo
  * count[0] = number of elements with |z| > 1e-9 (the caller divides by B*C*H).
  * count is a device int64 and is overwritten. */
 int ct_grid_occupancy(const float* grid, int64_t n_elements, int64_t* count, ct_stream_t s);
+/* The same statistic as the blocks report it, in ONE launch: out[0] = float(count) * inv_denominator (what torch computes for
+ * `count.float() / (B*C*H)`, layers/multihead_ct.py:104-105), a device float that is overwritten.  `workspace`: CT_OCC_WORKSPACE_BYTES
+ * of device memory, 8-byte aligned, zeroed ONCE by the caller (per-workgroup counts and an arrival ticket that the kernel hands
+ * back as zero); launches that share a workspace must be ordered (one per stream).  n_elements <= 2^31 - 1. */
+#define CT_OCC_WORKSPACE_BYTES 4096
+int ct_grid_occupancy_ratio(const float* grid, int64_t n_elements, float inv_denominator, float* out, void* workspace, ct_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Lattice of an MHCT block: per-head rigid transform of (xyz + key residual) followed by tanh
