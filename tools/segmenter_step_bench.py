@@ -131,9 +131,21 @@ def main():
         g.replay()
         opt.step()
     graphed = timeit(graphed_step, 5)
+    # the WHOLE step — forward, loss, backward AND the optimizer — as one graph: no eager launches between replays (the hand-off
+    # graph -> eager kernels -> next graph idles the GPU 0.4-0.9 ms per step: tools/dev/step_timeline.py).  Valid where the learning
+    # rate is a constant or a device tensor (a Python-float rate is baked into the captured kernels).
+    whole = None
+    if os.environ.get("CT_STEP_WHOLE_GRAPH", "1") != "0":
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            fwd_bwd()
+            opt.step()
+        g2.replay()
+        whole = timeit(g2.replay, 5)
     print(f"S3DIS-shaped segmenter ({nparam / 1e6:.1f} M parameters, 12 MultiHeadUnion blocks), B{B} N{N}, 1x MI355X, fp32: "
           f"training step eager {eager:.1f} ms ({B * N / eager:.0f} k points/s) | fwd+bwd as one HIP graph + optimizer {graphed:.1f} ms "
-          f"({B * N / graphed:.0f} k points/s) | loss {float(static_loss):.3f}")
+          f"({B * N / graphed:.0f} k points/s) | loss {float(static_loss):.3f}"
+          + (f" | whole step (optimizer inside) as one HIP graph {whole:.2f} ms ({B * N / whole:.0f} k points/s)" if whole else ""))
 
 
 if __name__ == "__main__":
