@@ -30,8 +30,13 @@ def _dev(*tensors):
                 "got a %s tensor and there is no CPU fallback" % t.device.type)
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None):
+    """The raw hipStream_t the launch goes to: torch's current stream of `device` (default: the current device).  Through the two
+    C entry points directly: torch.cuda.current_stream().cuda_stream builds a Stream object and parses a device argument on
+    every call, 9 us of host time against 0.4 — at 250-400 launches per eager model step that was 2-3 ms of a host-bound step
+    (tools/dev/host_profile.py)."""
+    idx = device.index if device is not None and device.index is not None else torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 class _NoSwitch:
@@ -262,7 +267,7 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=N
     # the two gradients are independent and neither is a whole number of rounds of the chip's workgroup slots (1024 + 672
     # workgroups on 512 slots at 848 x 512): inside a HIP-graph capture they go to two streams and fill each other's tails
     if (PW_BWD_STREAMS and mine_x and mine_w and g_y.is_cuda and torch.cuda.is_current_stream_capturing()
-            and torch.cuda.current_stream(g_y.device).cuda_stream not in forked_streams):
+            and _stream(g_y.device) not in forked_streams):
         cur = torch.cuda.current_stream(g_y.device)
         side = _pw_side_stream(g_y.device)
         side.wait_stream(cur)
@@ -327,7 +332,7 @@ def raster_tickets(device, force=False):
     union block run side by side on their own streams, and autograd replays every backward on its forward's stream)."""
     if not RASTER_TICKETS and not force:
         return None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream(device))
     t = _tickets.get(key)
     if t is None:
         t = _tickets[key] = torch.zeros(_lib.TICKETS_BYTES // 4, device=device, dtype=torch.int32)
@@ -1563,7 +1568,7 @@ def grid_occupancy_ratio(grid, denominator):
     memset node, a kernel and two elementwise launches per head and forward.  Same arithmetic as torch's: float(count) * (1 / K)."""
     _dev(grid)
     grid = _f32c(grid)
-    key = (grid.device.index, torch.cuda.current_stream(grid.device).cuda_stream)
+    key = (grid.device.index, _stream(grid.device))
     ws = _occ_ws.get(key)
     if ws is None:          # zeroed once; the kernel hands its ticket back as zero; one workspace per stream (ordered launches)
         ws = _occ_ws[key] = torch.zeros(_lib.OCC_WORKSPACE_BYTES // 8, device=grid.device, dtype=torch.int64)
@@ -1605,7 +1610,7 @@ def mhct_core_workspace(device, B, H, C, N, W):
     """The forward's exchange workspace for a shape, allocated and initialised (counters zeroed) ONCE per device, STREAM and
     shape: every launch leaves the counters zeroed, and launches on one stream are ordered, so the buffer is reused — two
     blocks of one shape running side by side on two streams (the heads of a union block, user code) get a buffer each."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, B, H, C, N, tuple(W))
+    key = (device.index, _stream(device), B, H, C, N, tuple(W))
     ws = _core_ws.get(key)
     if ws is None:
         lib = _lib.load()
@@ -1631,11 +1636,11 @@ def mhct_core_check(raise_on_fault=True):
         st = ctypes.c_int(0)
         with torch.cuda.device(dev_index):
             _lib.check(lib.ct_mhct_core_status(_ptr(ws), ws.numel(), B, H, C, N, len(W), Wa, ctypes.byref(st),
-                                               torch.cuda.current_stream().cuda_stream), "ct_mhct_core_status")
+                                               _stream()), "ct_mhct_core_status")
             if st.value != 0:
                 bad.append(key)
                 _lib.check(lib.ct_mhct_core_workspace_init(_ptr(ws), ws.numel(), B, H, C, N, len(W), Wa,
-                                                           torch.cuda.current_stream().cuda_stream), "ct_mhct_core_workspace_init")
+                                                           _stream()), "ct_mhct_core_workspace_init")
     if bad and raise_on_fault:
         raise RuntimeError("ct_mhct_core_fwd: a cluster timed out waiting for its partners on %d workspace(s) %r; the affected "
                            "outputs hold NaN.  The workspaces were re-initialised." % (len(bad), bad[:2]))
