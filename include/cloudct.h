@@ -537,6 +537,12 @@ int ct_chamfer_bwd(const float* xyz1, const float* xyz2, const float* g_dist1, c
  * i32[B,n].  Preconditions as the reference (emd_cuda.cu:236-249): n % 1024 == 0,
  * B <= 512 -> CT_EPRECOND otherwise; iters >= 1.  The reference's 12 caller-allocated
  * scratch tensors (emd_module.py:41-54) become one opaque workspace.
+ * Results: the reference's own kernels (built for gfx950, oracle/Makefile `ref_emd`) return
+ * the same assignment exactly and the same distances (bit for bit against their
+ * -ffp-contract=off build, <= 2 ulp against the default-contraction one) wherever they are
+ * deterministic; where several bidders are within 1e-6 of a target's best increment the
+ * reference lets the last store win (emd_cuda.cu:181-194) — here: the highest bidder index,
+ * always (tests/test_emd_gpu.py, tests/golden/emd_reference.npz).
  * ---------------------------------------------------------------------- */
 size_t ct_emd_workspace_bytes(int B, int n);
 int ct_emd_fwd(const float* xyz1, const float* xyz2, float* dist, int32_t* assignment,

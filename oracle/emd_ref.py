@@ -16,6 +16,8 @@ def _lib():
     f32p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
     lib.emd_ref_forward.restype = ctypes.c_int
     lib.emd_ref_forward.argtypes = [f32p, f32p, f32p, i32p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+    lib.emd_ref_last_getmax_ties.restype = ctypes.c_longlong
+    lib.emd_ref_last_getmax_ties.argtypes = []
     lib.emd_ref_backward.restype = None
     lib.emd_ref_backward.argtypes = [f32p, f32p, f32p, i32p, f32p, ctypes.c_int, ctypes.c_int]
     return lib
@@ -35,6 +37,11 @@ def forward(xyz1, xyz2, eps, iters):
     st = _lib().emd_ref_forward(_p(xyz1, ctypes.c_float), _p(xyz2, ctypes.c_float), _p(dist, ctypes.c_float),
                                 _p(ass, ctypes.c_int), B, n, float(eps), int(iters))
     return st, dist, ass
+
+
+def last_getmax_ties():
+    """GetMax window ties seen by the last forward() (see emd_ref.c): 0 = the reference is deterministic on those inputs."""
+    return int(_lib().emd_ref_last_getmax_ties())
 
 
 def backward(xyz1, xyz2, grad_dist, assignment):

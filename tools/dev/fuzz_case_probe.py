@@ -6,7 +6,8 @@ import numpy as np, torch
 import tests.test_raster_gpu as T
 from oracle import ref_cpu as R
 from cloud_transformers_amd import ops
-cfg = (3, 2, 8, 4096, 3, (32, 8, 32), True, 'max')
+cfg = eval(sys.argv[1]) if len(sys.argv) > 1 else (3, 2, 8, 4096, 3, (32, 8, 32), True, 'max')      # a cfg tuple as tools/soak_fuzz.py prints it
+print('cfg', cfg)
 B, H, C, N, dim, W, use_pad, reduce = cfg
 g = torch.Generator().manual_seed((B * 1000003 + H * 10007 + C * 1009 + N * 31 + dim * 7 + sum(W)) % (2 ** 31))
 Wl = list(W)
@@ -20,8 +21,9 @@ z_ref = R.splat(lc, idx, f, pad, Wl, H, dim, reduce)
 o_ref = R.slice_(lc, idx, z_ref, pad, Wl, H, dim)
 (o_ref * cot_o).sum().backward()
 kc = keys0.cuda().requires_grad_(True); fc = feat0.cuda().requires_grad_(True)
-z = ops.splat_keys(kc, fc, pad.cuda(), Wl, H, dim, reduce)
-o = ops.slice_keys(kc, z, pad.cuda(), Wl, H, dim)
+padc = pad.cuda() if pad is not None else None
+z = ops.splat_keys(kc, fc, padc, Wl, H, dim, reduce)
+o = ops.slice_keys(kc, z, padc, Wl, H, dim)
 (o * cot_o.cuda()).sum().backward()
 print("z equal:", torch.equal(z.detach().cpu(), z_ref.detach()))
 for name, a, r in (("g_feat", fc.grad.cpu(), f.grad), ("g_keys", kc.grad.cpu(), k.grad), ("out", o.detach().cpu(), o_ref.detach())):
