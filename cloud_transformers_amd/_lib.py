@@ -301,6 +301,7 @@ SIGNATURES = {
     "ct_pw_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ct_pw_gemm": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_pw_gemm_rs": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "ct_pw_gemm_rs_add": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ct_amax_rows_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ct_pw_prep_weight_rs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
 }

@@ -52,6 +52,9 @@ struct PwArgs {
   // per-channel or per-(cloud, channel) maxima, ct_pw_prep_weight_rs's per-tile row / column maxima): every row gets its
   // own power-of-two scale, which factors out of the row's (column's) outputs exactly
   int rows_a, rows_b;
+  // ADD instantiation only: out = product + D, D laid out as C (same ldc, same z stride) — the data gradient of a layer whose
+  // input also feeds a skip connection takes the skip's cotangent here instead of leaving the sum to a separate pass
+  const float* D;
 #ifdef PW_STAMP
   unsigned long long* dbg;   // development builds: per-phase cycle sums of every wave (tools/dev/pw_stamp.py)
 #endif
@@ -233,7 +236,7 @@ __device__ __forceinline__ pw_h8 pw_frag(const _Float16* img, int row, int sw, i
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool ADD = false>
 __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 pw_lds[];
   // blocks that share an XCD (id % 8) take consecutive tiles: the M tiles of one [K, 128] operand panel run side by side on
@@ -444,6 +447,27 @@ __global__ void __launch_bounds__(kPwThreads, 4) pw_gemm_kernel(PwArgs a) {
   // D of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const float ib = ldexpf(1.f, -etab[128 + 32 * wn + r]);
   const int col = n0 + 32 * wn + r;
+  if constexpr (ADD) {
+    // the addend's 32 values of this lane requested together (the K loop's operand registers are dead here), then the stores
+    const float* D = a.D + z * a.c_zs;
+    float dv[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        dv[i][e] = (row < a.M && col < a.N) ? D[(size_t)row * a.ldc + col] : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lr = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h, row = m0 + lr;
+        const float ia = ldexpf(1.f, -etab[lr]);
+        if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][e] * ia * ib + dv[i][e];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -677,9 +701,9 @@ static bool pw_plan(int mode, int B, int Co, int Ci, int N, PwPlan& p) {
 // (A second, persistent 128 x 256 kernel lived here through round 4: faster stand-alone on wide weight gradients and at K >= 1024,
 // nothing inside the training steps — 17.2 / 15.2 / 32.6 vs 17.2 / 15.1 / 31.6 ms, profiles/r4_model_steps.txt — and dispatched
 // nowhere by default.  Out of the build since round 5: tools/dev/experiments/ct_pwgemm2.h.)
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool ADD = false>
 static int pw_launch(const PwArgs& a, int blocks, hipStream_t st) {
-  auto k = pw_gemm_kernel<AK, BK>;
+  auto k = pw_gemm_kernel<AK, BK, ADD>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) != hipSuccess) return CT_ELAUNCH;
@@ -757,6 +781,15 @@ int ct_pw_gemm(int mode, const float* a, const float* b, float* out, const float
 int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a, int rows_a,
                   const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co, int Ci,
                   int N, ct_stream_t s) {
+  return ct_pw_gemm_rs_add(mode, a, b, out, nullptr, amax_a, n_amax_a, rows_a, amax_b, n_amax_b, rows_b, workspace, workspace_bytes, B, Co, Ci,
+                           N, s);
+}
+
+// ct_pw_gemm_rs with out = product + addend (addend f32 laid out as out, 16-byte aligned, may NOT alias out; NULL: ct_pw_gemm_rs).
+// CT_PW_FWD / CT_PW_DGRAD / CT_PW_DGRAD_T only (the weight gradient's output is a fold of slabs): CT_EINVAL otherwise.
+int ct_pw_gemm_rs_add(int mode, const float* a, const float* b, float* out, const float* addend, const float* amax_a, int n_amax_a,
+                      int rows_a, const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co,
+                      int Ci, int N, ct_stream_t s) {
   PwPlan p;
   if (!a || !b || !out) return CT_EINVAL;
   if (!pw_plan(mode, B, Co, Ci, N, p)) return CT_EINVAL;
@@ -771,13 +804,15 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
     else rows_b = 0;              // a row-contiguous operand has one scale: its maxima are folded into one
     if (mode == CT_PW_DGRAD) rows_a = 0;      // (the maxima belong to W, the kernel reads the W^T this call writes)
   }
-  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CT_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)addend) & 15) return CT_EINVAL;
+  if (addend && (mode == CT_PW_WGRAD || addend == out)) return CT_EINVAL;
   if (p.ws && (!workspace || workspace_bytes < p.ws || ((uintptr_t)workspace & 15))) return CT_EWORKSPACE;
   CT_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)s;
   PwArgs g{};
   g.A = a; g.B = b; g.amax_a = amax_a; g.amax_b = amax_b; g.n_amax_a = n_amax_a; g.n_amax_b = n_amax_b;
   g.rows_a = rows_a; g.rows_b = rows_b;
+  g.D = addend;
 #ifdef PW_STAMP
   g.dbg = g_pw_dbg;
 #endif
@@ -786,16 +821,16 @@ int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const fl
   int rc;
   if (mode == CT_PW_FWD) {            // A = W [Co][Ci] (k contiguous), B = x[b] [Ci][N] (columns contiguous)
     g.lda = Ci; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Ci * N; g.C = out; g.ldc = N; g.c_zs = (long long)Co * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = addend ? pw_launch<true, false, true>(g, blocks, st) : pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD) {   // A = W^T [Ci][Co] written to the workspace (k = co contiguous), B = g_y[b] [Co][N]
     hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32), dim3(256), 0, st, a, (float*)workspace, Co, Ci);
     CT_CHECK_LAUNCH();
     g.A = (const float*)workspace;
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = addend ? pw_launch<true, false, true>(g, blocks, st) : pw_launch<true, false>(g, blocks, st);
   } else if (mode == CT_PW_DGRAD_T) {  // a IS W^T [Ci][Co] (ct_pw_prep_weight wrote it in the layer's forward)
     g.lda = Co; g.a_bs = 0; g.ldb = N; g.b_bs = (long long)Co * N; g.C = out; g.ldc = N; g.c_zs = (long long)Ci * N;
-    rc = pw_launch<true, false>(g, blocks, st);
+    rc = addend ? pw_launch<true, false, true>(g, blocks, st) : pw_launch<true, false>(g, blocks, st);
   } else {                            // A = g_y[b] [Co][N], B = x[b] [Ci][N]: both k (= point) contiguous
     g.lda = N; g.a_bs = (long long)Co * N; g.ldb = N; g.b_bs = (long long)Ci * N; g.ldc = Ci;
     g.C = p.ws ? (float*)workspace : out;

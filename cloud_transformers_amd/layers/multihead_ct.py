@@ -278,6 +278,7 @@ class MultiHeadAdaIn(_MHCTCore):
 
 # "auto" (default): only while a HIP graph is being captured — a replayed graph gains 3-4 % from the overlap, eager launches pay
 # for the stream switches on the host (the eager classifier step is 14 % slower with them); "1": always; "0": never
+SKIP_IN_DGRAD = os.environ.get("CLOUDCT_SKIP_IN_DGRAD", "1") != "0"      # "0": autograd sums the two cotangents of a block's input (A/B)
 HEAD_STREAMS = {"0": False, "1": True}.get(os.environ.get("CLOUDCT_HEAD_STREAMS", "auto"), "auto")
 _side_streams = {}
 
@@ -364,12 +365,20 @@ class MultiHeadUnion(_UnionBase):
 
     def forward(self, x, orig_pcd):
         x = self.prenorm(x)
-        residual = self.shortcut(x)
         pres, stats = [], []
         # the heads share x: one stacked GEMM for their keys_values_pred projections (and for its gradients)
         convs = [a.keys_values_pred[0] for a in self.attentions]
         kbs, vbs = [a.key_bn for a in self.attentions], [a.values_bn for a in self.attentions]
-        kvs = ops.union_keys_values(x, convs, kbs, vbs) if ops.union_keys_values_eligible(x, convs, kbs, vbs) else None
+        if ops.union_keys_values_eligible(x, convs, kbs, vbs):
+            if SKIP_IN_DGRAD and len(self.shortcut) == 0 and x.requires_grad and torch.is_grad_enabled():
+                # identity shortcut: x leaves the projections' node as an output too, so the shortcut's cotangent is added in the
+                # data gradient's epilogue (ops.UnionKeysValuesFn) — autograd's own sum was a 31 us pass per block on the
+                # segmenter's critical path (profiles/r6_skip_in_dgrad.txt)
+                residual, kvs = ops.union_keys_values(x, convs, kbs, vbs, passthrough=True)
+            else:
+                residual, kvs = self.shortcut(x), ops.union_keys_values(x, convs, kbs, vbs)
+        else:
+            residual, kvs = self.shortcut(x), None
         for r, s, _ in _run_heads([(lambda a=a, i=i: a._forward_pre(x, orig_pcd, None if kvs is None else kvs[i]))
                                    for i, a in enumerate(self.attentions)], x):
             pres.append(r)
@@ -432,9 +441,14 @@ class MultiHeadUnionAdaIn(_UnionBase):
 
     def _forward(self, x, style, orig_pcd):
         x = self.prenorm(x)
-        residual = forward_style(self.shortcut, x, style)
         pres, stats = [], []
-        kvs = self._fused_keys_values(x, style)
+        # (identity shortcut: its cotangent rides the stacked projections' data gradient, see MultiHeadUnion.forward)
+        skip = SKIP_IN_DGRAD and len(self.shortcut) == 0 and x.requires_grad and torch.is_grad_enabled()
+        kvs = self._fused_keys_values(x, style, passthrough=skip)
+        if skip and kvs is not None:
+            residual, kvs = kvs
+        else:
+            residual = forward_style(self.shortcut, x, style)
         for r, s, _ in _run_heads([(lambda a=a, i=i: a._forward_pre(x, style, orig_pcd, None if kvs is None else kvs[i]))
                                    for i, a in enumerate(self.attentions)], x):
             pres.append(r)
@@ -451,8 +465,9 @@ class MultiHeadUnionAdaIn(_UnionBase):
             joined = torch.cat([forward_style(n, p, style) for n, p in zip(afters, pres)], dim=1)
         return forward_style(self.after, joined, style, residual), stats
 
-    def _fused_keys_values(self, x, style):
-        """One stacked GEMM for all heads' keys_values_pred + their AdaIN norms (ops.UnionKeysValuesAdaInFn), or None."""
+    def _fused_keys_values(self, x, style, passthrough=False):
+        """One stacked GEMM for all heads' keys_values_pred + their AdaIN norms (ops.UnionKeysValuesAdaInFn), or None; with
+        passthrough: (x as an output of that node, the list)."""
         atts = list(self.attentions)
         if not (len(atts) > 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()):
             return None
@@ -470,5 +485,7 @@ class MultiHeadUnionAdaIn(_UnionBase):
                 return None
             eps = e
             args += [kvp[0].weight, kb[0].gamma_beta(style), vb[0].gamma_beta(style)]
-        outs = ops.UnionKeysValuesAdaInFn.apply(len(atts), x, eps, *args)
+        outs = ops.UnionKeysValuesAdaInFn.apply(-len(atts) if passthrough else len(atts), x, eps, *args)
+        if passthrough:
+            return outs[0], [(outs[1 + 2 * i], outs[2 + 2 * i]) for i in range(len(atts))]
         return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(atts))]

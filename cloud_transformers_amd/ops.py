@@ -183,9 +183,10 @@ def amax_of(t, rows=False):
     return amax_rows(t) if (rows and t.dim() == 3) else amax(t)
 
 
-def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
+def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N, addend=None):
     """ct_pw_gemm on contiguous float32 tensors: PW_FWD (a = W [Co,Ci], b = x [B,Ci,N]) -> y [B,Co,N]; PW_DGRAD (a = W,
-    b = g_y [B,Co,N]) -> g_x [B,Ci,N]; PW_WGRAD (a = g_y, b = x) -> g_W [Co,Ci].  amax_* from amax()."""
+    b = g_y [B,Co,N]) -> g_x [B,Ci,N]; PW_WGRAD (a = g_y, b = x) -> g_W [Co,Ci].  amax_* from amax().  addend (contiguous,
+    shaped as the output; not for PW_WGRAD): added in the kernel's epilogue (ct_pw_gemm_rs_add)."""
     lib = _lib.load()
     dev = b.device
     if mode == PW_FWD:
@@ -199,10 +200,13 @@ def pw_gemm(mode, a, b, amax_a, amax_b, B, Co, Ci, N):
     # per-row scales wherever the maxima are per row of the operand's k-contiguous arrangement (2-D: tag_amax, prep_weight)
     rows_a = _rows_of(amax_a, Co if mode in (PW_FWD, PW_WGRAD) else Ci) if mode != PW_DGRAD else 0
     rows_b = _rows_of(amax_b, Ci) if mode == PW_WGRAD else 0
+    if addend is not None:
+        assert mode != PW_WGRAD and addend.shape == out.shape and addend.is_contiguous() and addend.dtype == torch.float32
     with _on(dev):
-        _lib.check(lib.ct_pw_gemm_rs(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(amax_a), 0 if amax_a is None else amax_a.numel(), rows_a,
-                                     _ptr(amax_b), 0 if amax_b is None else amax_b.numel(), rows_b, _ptr(ws), nbytes, B, Co, Ci, N,
-                                     _stream()), "ct_pw_gemm_rs")
+        _lib.check(lib.ct_pw_gemm_rs_add(mode, _ptr(a), _ptr(b), _ptr(out), _ptr(addend), _ptr(amax_a),
+                                         0 if amax_a is None else amax_a.numel(), rows_a, _ptr(amax_b),
+                                         0 if amax_b is None else amax_b.numel(), rows_b, _ptr(ws), nbytes, B, Co, Ci, N, _stream()),
+                   "ct_pw_gemm_rs_add")
     return out
 
 
@@ -236,9 +240,10 @@ def pw_forward(W, x, need_dgrad=False):
     return pw_gemm(PW_FWD, W, x, am_w[0], am_x, B, Co, Ci, N), am_w, am_x, Wt
 
 
-def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=None):
+def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=None, add_gx=None):
     """(g_x, g_W) of pw_forward for the cotangent g_y [B,Co,N] (contiguous); am_g: g_y's maxima where the caller has them; Wt:
-    the transposed weight pw_forward made (else the data gradient writes its own through its workspace)."""
+    the transposed weight pw_forward made (else the data gradient writes its own through its workspace); add_gx: another
+    cotangent of x (a skip connection's), added to g_x inside the data gradient's epilogue where the kernel runs it."""
     Co, Ci = W.shape
     B, _, N = x.shape
     mine_x = need_x and pw_eligible(Co, Ci, N, PW_DGRAD)
@@ -249,13 +254,19 @@ def pw_backward(W, x, g_y, am_w, am_x, need_x=True, need_w=True, am_g=None, Wt=N
         am_w = (am_w, None)
     g_x = g_w = None
 
+    if add_gx is not None:
+        add_gx = _f32c(add_gx)
+
     def dgrad():
         if mine_x and Wt is not None and am_w is not None:
             # W^T's rows are W's columns: their maxima give the data gradient its per-row scales
-            return pw_gemm(PW_DGRAD_T, Wt, g_y, am_w[1] if am_w[1] is not None else am_w[0], am_g, B, Co, Ci, N)
+            return pw_gemm(PW_DGRAD_T, Wt, g_y, am_w[1] if am_w[1] is not None else am_w[0], am_g, B, Co, Ci, N, addend=add_gx)
         if mine_x:
-            return pw_gemm(PW_DGRAD, W, g_y, am_w[0] if am_w is not None else amax(W), am_g, B, Co, Ci, N)
-        return torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y) if need_x else None
+            return pw_gemm(PW_DGRAD, W, g_y, am_w[0] if am_w is not None else amax(W), am_g, B, Co, Ci, N, addend=add_gx)
+        if not need_x:
+            return add_gx
+        g = torch.bmm(W.t().unsqueeze(0).expand(B, -1, -1), g_y)
+        return g if add_gx is None else g + add_gx
 
     def wgrad():
         if mine_w:
@@ -838,7 +849,10 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, x, eps, *args):
+        ctx.passthrough = n < 0          # x itself as the first output: see UnionKeysValuesFn
+        n = abs(n)
         heads = [args[i * 3:(i + 1) * 3] for i in range(n)]
+        x_in = x
         x = _f32c(x)
         _dev(x)
         B, Cin, N = x.shape
@@ -866,10 +880,15 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         ctx.am = (am_w, am_x, Wt)
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
+        if ctx.passthrough:
+            return (x_in,) + tuple(outs)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
+        g_skip = None
+        if ctx.passthrough:
+            g_skip, gouts = gouts[0], gouts[1:]
         x, y, Wc = ctx.saved_tensors[:3]
         saved = ctx.saved_tensors[3:]
         B, Cin, N = x.shape
@@ -894,7 +913,8 @@ class UnionKeysValuesAdaInFn(torch.autograd.Function):
         with _on(x.device):
             _adain_group_bwd(items, B, N)
         g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[1], True,
-                                am_g=None if slots is None else slots.view(-1, Ct), Wt=ctx.am[2])
+                                am_g=None if slots is None else slots.view(-1, Ct), Wt=ctx.am[2],
+                                add_gx=g_skip if ctx.needs_input_grad[1] else None)
         grads, r0 = [None, g_x, None], 0
         for hi, Co in enumerate(ctx.couts):
             grads += [g_Wc[r0:r0 + Co].unsqueeze(-1), g_gbs[2 * hi], g_gbs[2 * hi + 1]]
@@ -1338,8 +1358,13 @@ class UnionKeysValuesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, group, x, *args):
+        # n < 0: -n heads AND x itself as the first output (the block's identity shortcut, layers/multihead_ct.py:170-176:
+        # its cotangent comes back here and rides the data gradient's epilogue instead of a separate add over three tensors)
+        ctx.passthrough = n < 0
+        n = abs(n)
         P = UnionKeysValuesFn.PER_HEAD
         heads = [args[i * P:(i + 1) * P] for i in range(n)]
+        x_in = x
         x = _f32c(x)
         _dev(x)
         B, Cin, N = x.shape
@@ -1368,10 +1393,15 @@ class UnionKeysValuesFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.couts = [h[0].size(0) for h in heads]
         ctx.group = group
+        if ctx.passthrough:
+            return (x_in,) + tuple(outs)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
+        g_skip = None
+        if ctx.passthrough:
+            g_skip, gouts = gouts[0], gouts[1:]
         x, y, Wc, count = ctx.saved_tensors[:4]
         saved = ctx.saved_tensors[4:]
         B, Cin, N = x.shape
@@ -1393,7 +1423,8 @@ class UnionKeysValuesFn(torch.autograd.Function):
         with _on(x.device):
             bn_grads = _bn_group_bwd(items, B, N, x.device, ctx.group, count)
         g_x, g_Wc = pw_backward(Wc, x, g_y, ctx.am[0], ctx.am[1], ctx.needs_input_grad[2], True,
-                                am_g=None if slots is None else slots.view(-1, g_y.shape[1]), Wt=ctx.am[2])   # g_Wc [sum Co, Cin]
+                                am_g=None if slots is None else slots.view(-1, g_y.shape[1]), Wt=ctx.am[2],
+                                add_gx=g_skip if ctx.needs_input_grad[2] else None)   # g_Wc [sum Co, Cin]
         grads, r0 = [None, None, g_x], 0
         for hi, Co in enumerate(ctx.couts):
             (gwk, gbk), (gwv, gbv) = bn_grads[2 * hi], bn_grads[2 * hi + 1]
@@ -1402,15 +1433,18 @@ class UnionKeysValuesFn(torch.autograd.Function):
         return tuple(grads)
 
 
-def union_keys_values(x, convs, key_bns, values_bns):
+def union_keys_values(x, convs, key_bns, values_bns, passthrough=False):
     """[(key_bn_i(y_i[:, :Ck]), values_bn_i(y_i[:, Ck:])) with y_i = conv_i(x)] for the heads of a union block through
-    UnionKeysValuesFn; the caller checked union_keys_values_eligible."""
+    UnionKeysValuesFn; the caller checked union_keys_values_eligible.  passthrough: -> (x', that list) with x' = x as an output
+    of the same node — the block's identity shortcut takes x' so that its cotangent is summed inside the data gradient."""
     args = []
     for conv, kb, vb in zip(convs, key_bns, values_bns):
         args.append(conv.weight)
         for bn in (kb, vb):
             args += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum]
-    outs = UnionKeysValuesFn.apply(len(convs), _sync_group(key_bns[0]), x, *args)
+    outs = UnionKeysValuesFn.apply(-len(convs) if passthrough else len(convs), _sync_group(key_bns[0]), x, *args)
+    if passthrough:
+        return outs[0], [(outs[1 + 2 * i], outs[2 + 2 * i]) for i in range(len(convs))]
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(convs))]
 
 

@@ -605,6 +605,14 @@ int ct_pw_prep_weight_rs(const float* w, float* wt, float* rowmax, float* colmax
 int ct_pw_gemm_rs(int mode, const float* a, const float* b, float* out, const float* amax_a, int n_amax_a, int rows_a,
                   const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B, int Co,
                   int Ci, int N, ct_stream_t s);
+/* ct_pw_gemm_rs with out = product + addend, the addend read in the kernel's epilogue (f32 laid out as `out`, 16-byte aligned,
+ * not `out` itself; NULL = ct_pw_gemm_rs).  For the data gradient of a projection whose INPUT also feeds a skip connection
+ * (layers/multihead_ct.py:170-198: `residual = shortcut(x)` beside `keys_values_pred(x)`): autograd's sum of the two cotangents
+ * of x — a pass over three tensors the size of x — becomes one more read inside the GEMM.  CT_PW_FWD / CT_PW_DGRAD /
+ * CT_PW_DGRAD_T; CT_PW_WGRAD (its output is a fold of slabs) -> CT_EINVAL. */
+int ct_pw_gemm_rs_add(int mode, const float* a, const float* b, float* out, const float* addend, const float* amax_a, int n_amax_a,
+                      int rows_a, const float* amax_b, int n_amax_b, int rows_b, void* workspace, size_t workspace_bytes, int B,
+                      int Co, int Ci, int N, ct_stream_t s);
 
 #ifdef __cplusplus
 }

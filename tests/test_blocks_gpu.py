@@ -209,7 +209,7 @@ def test_union_fusions_equal_the_per_head_path(kind):
     saved = (ops.union_keys_values_eligible, ops.bn_relu_eligible, M.MultiHeadUnionAdaIn._fused_keys_values, M.AdaIn1dUpd)
     ops.union_keys_values_eligible = lambda *a, **k: False
     ops.bn_relu_eligible = lambda *a, **k: False
-    M.MultiHeadUnionAdaIn._fused_keys_values = lambda self, x, style: None
+    M.MultiHeadUnionAdaIn._fused_keys_values = lambda self, x, style, **k: None
     M.AdaIn1dUpd = type("NotAdaIn", (), {})           # `type(n[0]) is AdaIn1dUpd` fails: the heads' after stacks run one by one
     try:
         plain = run()

@@ -369,3 +369,81 @@ def test_row_maxima_of_the_producers_reach_the_weight_gradient():
     assert bool((err <= BOUND * mag + 1e-44).all()), float((err / (mag + 1e-44)).max())
     refx, magx = _ref(1, W, x, gy)
     assert bool(((g_x.double() - refx).abs() <= BOUND * magx + 1e-44).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 208, 512, 1024), (3, 52, 36, 260), (8, 848, 512, 4096), (1, 260, 44, 1028), (1, 4, 4, 4)])
+@pytest.mark.parametrize("mode", [0, 1, 3])
+def test_addend_in_the_epilogue_is_the_product_plus_the_addend_bit_for_bit(shape, mode):
+    """ct_pw_gemm_rs_add (out = product + addend, the addend read in the kernel's epilogue): exactly fl(product + addend) of the
+    SAME kernel's product, for the forward and both data-gradient arrangements; the weight gradient refuses an addend."""
+    from cloud_transformers_amd import _lib, ops
+    B, Co, Ci, N = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 11 + Co + mode)
+    W = torch.randn(Co, Ci, device="cuda", generator=g) / Ci ** 0.5
+    x = torch.randn(B, Ci, N, device="cuda", generator=g)
+    gy = torch.randn(B, Co, N, device="cuda", generator=g)
+    if mode == 0:
+        a, b, am_a, am_b = W, x, ops.amax(W), ops.amax(x)
+    elif mode == 1:
+        a, b, am_a, am_b = W, gy, ops.amax(W), ops.amax(gy)
+    else:
+        (rowmax, colmax), Wt = ops.prep_weight(W, True)
+        if Wt is None:
+            pytest.skip("no prepared transpose for this weight")
+        a, b, am_a, am_b = Wt, gy, colmax, ops.amax(gy)
+    plain = ops.pw_gemm(mode, a, b, am_a, am_b, B, Co, Ci, N)
+    add = torch.randn(plain.shape, device="cuda", generator=g) * 3
+    fused = ops.pw_gemm(mode, a, b, am_a, am_b, B, Co, Ci, N, addend=add)
+    assert torch.equal(fused, plain + add)
+    lib = _lib.load()
+    p = ops._ptr
+    ws = torch.empty(max(lib.ct_pw_gemm_workspace_bytes(2, B, Co, Ci, N), 16), device="cuda", dtype=torch.uint8)
+    gw = torch.empty(Co, Ci, device="cuda")
+    assert lib.ct_pw_gemm_rs_add(2, p(gy), p(x), p(gw), p(gw), None, 0, 0, None, 0, 0, p(ws), ws.numel(), B, Co, Ci, N, None) == -1      # CT_EINVAL
+    assert lib.ct_pw_gemm_rs_add(0, p(W), p(x), p(plain), p(plain), None, 0, 0, None, 0, 0, None, 0, B, Co, Ci, N, None) == -1   # addend aliases out
+
+
+def test_union_block_with_the_shortcut_summed_in_the_data_gradient(monkeypatch):
+    """MultiHeadUnion (identity shortcut): the block's input leaves the stacked projections' node as an output too and the
+    shortcut's cotangent is added in the data gradient's epilogue (ops.UnionKeysValuesFn passthrough) — outputs and every
+    gradient equal the path where autograd sums the two cotangents, the input's gradient bit for bit."""
+    from cloud_transformers_amd.layers import multihead_ct as M
+    from cloud_transformers_amd.layers.pointwise import convert_pointwise
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(M, "SKIP_IN_DGRAD", flag)
+        torch.manual_seed(3)
+        blk = convert_pointwise(M.MultiHeadUnion(model_dim=128, features_dims=[4, 8], heads=[4, 4], tensor_sizes=[16, 8],
+                                                  model_dim_out=128, tensor_dims=[2, 3]).cuda()).train()
+        x = torch.randn(2, 128, 1024, device="cuda", requires_grad=True)
+        pcd = torch.rand(2, 3, 1024, device="cuda") * 2 - 1
+        y, _ = blk(x, pcd)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").reshape(y.shape)).sum().backward()
+        res[flag] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+    assert torch.equal(res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1])
+    for a, b in zip(res[False][2], res[True][2]):
+        assert torch.equal(a, b)
+
+
+def test_adain_union_block_with_the_shortcut_summed_in_the_data_gradient(monkeypatch):
+    """MultiHeadUnionAdaIn, same as above: identical outputs and gradients (input, style, parameters) either way."""
+    from cloud_transformers_amd.layers import multihead_ct as M
+    from cloud_transformers_amd.layers.pointwise import convert_pointwise
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(M, "SKIP_IN_DGRAD", flag)
+        torch.manual_seed(5)
+        blk = convert_pointwise(M.MultiHeadUnionAdaIn(model_dim=128, features_dims=[4, 8], heads=[4, 4], tensor_sizes=[16, 8],
+                                                      model_dim_out=128, tensor_dims=[2, 3], n_latent=64).cuda()).train()
+        x = torch.randn(2, 128, 1024, device="cuda", requires_grad=True)
+        style = torch.randn(2, 64, device="cuda", requires_grad=True)
+        pcd = torch.rand(2, 3, 1024, device="cuda") * 2 - 1
+        y, _ = blk(x, style, pcd)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").reshape(y.shape)).sum().backward()
+        res[flag] = (y.detach(), x.grad.clone(), style.grad.clone(), [p.grad.clone() for p in blk.parameters() if p.grad is not None])
+    assert torch.equal(res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+    assert len(res[False][3]) == len(res[True][3])
+    for a, b in zip(res[False][3], res[True][3]):
+        assert torch.equal(a, b)
