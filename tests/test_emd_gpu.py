@@ -234,7 +234,7 @@ def _reference_forward(ext, xyz1, xyz2, eps, iters):
 def test_hip_emd_equals_the_references_kernels_live(build):
     """The reference's kernels and ct_emd_fwd side by side on this GPU, on clouds that are NOT in the fixture: wherever the oracle
     counts no GetMax window tie (the reference's one race) the two must return the same assignment, and the strict build the
-    same distances bit for bit; forward only — the reference's backward is the formula of test_matches_oracle."""
+    same distances bit for bit; then the reference's backward kernel on the same assignment against ct_emd_bwd."""
     from cloud_transformers_amd.emd import emdModule
     ext = _load_reference_ext(build)
     checked = 0
@@ -254,5 +254,18 @@ def test_hip_emd_equals_the_references_kernels_live(build):
         else:
             ulp = (dist.view(torch.int32).long() - d_ref.view(torch.int32).long()).abs().max()
             assert int(ulp) <= 2
+        # backward (emd_cuda.cu:284-316 through emd.cpp's `backward`, emd_module.py:60-70): one float atomicAdd per coordinate,
+        # each address written once -> bit for bit
+        g = torch.rand(B, n, device="cuda")
+        ar = ac.clone().requires_grad_(True)
+        d2, _ = emdModule()(ar, bc, eps, iters)
+        (d2 * g).sum().backward()
+        g_ref = torch.zeros_like(ac)
+        assert ext.backward(ac, bc, g_ref, g.contiguous(), a_ref) == 1
+        torch.cuda.synchronize()
+        if build.endswith("strict"):
+            assert torch.equal(ar.grad, g_ref)
+        else:
+            assert float((ar.grad - g_ref).abs().max()) <= 1e-6
         checked += 1
     assert checked >= 4
