@@ -35,8 +35,13 @@ def _stream(device=None):
     C entry points directly: torch.cuda.current_stream().cuda_stream builds a Stream object and parses a device argument on
     every call, 9 us of host time against 0.4 — at 250-400 launches per eager model step that was 2-3 ms of a host-bound step
     (tools/dev/host_profile.py)."""
-    idx = device.index if device is not None and device.index is not None else torch._C._cuda_getDevice()
-    return torch._C._cuda_getCurrentRawStream(idx)
+    idx = device.index if device is not None and device.index is not None else _cuda_get_device()
+    return _cuda_raw_stream(idx)
+
+
+# (private entry points of torch._C, present since torch 1.x; a build without them takes the public, slower route)
+_cuda_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_cuda_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
 
 
 class _NoSwitch:
