@@ -44,6 +44,9 @@
  * equal it exactly (tests/test_oracle_golden.py: the pin on the reference's own kernels run on an MI355X). */
 static long long g_getmax_ties = 0;
 long long emd_ref_last_getmax_ties(void) { return g_getmax_ties; }
+/* experiment switch (tools/dev/emd_reference_soak.py): 1 = the LOWEST bidder index wins a GetMax window tie instead of the highest */
+static int g_tie_lowest = 0;
+void emd_ref_set_tie_lowest(int v) { g_tie_lowest = v; }
 
 int emd_ref_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment,
                     int B, int n, float eps, int iters) {
@@ -89,7 +92,7 @@ int emd_ref_forward(const float* xyz1, const float* xyz2, float* dist, int* assi
         const int t = bid[j];
         const float bi = bid_inc[j], mi = max_inc[t];
         if (bi - 1e-6 <= mi && mi <= bi + 1e-6) {
-          max_idx[t] = j;   /* ascending j: the highest wins */
+          if (!(g_tie_lowest && qual[t] > 0)) max_idx[t] = j;   /* ascending j: the highest wins (experiment: the lowest) */
           if (qual[t]++ == 1) ++g_getmax_ties;
         }
       }

@@ -18,6 +18,8 @@ def _lib():
     lib.emd_ref_forward.argtypes = [f32p, f32p, f32p, i32p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
     lib.emd_ref_last_getmax_ties.restype = ctypes.c_longlong
     lib.emd_ref_last_getmax_ties.argtypes = []
+    lib.emd_ref_set_tie_lowest.restype = None
+    lib.emd_ref_set_tie_lowest.argtypes = [ctypes.c_int]
     lib.emd_ref_backward.restype = None
     lib.emd_ref_backward.argtypes = [f32p, f32p, f32p, i32p, f32p, ctypes.c_int, ctypes.c_int]
     return lib
@@ -42,6 +44,11 @@ def forward(xyz1, xyz2, eps, iters):
 def last_getmax_ties():
     """GetMax window ties seen by the last forward() (see emd_ref.c): 0 = the reference is deterministic on those inputs."""
     return int(_lib().emd_ref_last_getmax_ties())
+
+
+def set_tie_lowest(flag):
+    """experiment: GetMax window ties to the lowest bidder index (default: the highest) — tools/dev/emd_reference_soak.py"""
+    _lib().emd_ref_set_tie_lowest(int(bool(flag)))
 
 
 def backward(xyz1, xyz2, grad_dist, assignment):
