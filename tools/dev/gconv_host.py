@@ -45,3 +45,18 @@ f = lambda: torch.nn.functional.conv2d(xr, m.weight, m.bias, padding=1, groups=G
 t("MIOpen forward (grad)", f)
 t("MIOpen forward + backward", lambda: f().backward(g))
 print("ws_bytes", ws_bytes)
+
+if len(sys.argv) > 1 and sys.argv[1] == "profile":
+    import cProfile, io, pstats
+    torch.autograd.set_multithreading_enabled(False)
+    pr = cProfile.Profile()
+    for _ in range(50):
+        m(x).backward(g)
+    pr.enable()
+    for _ in range(500):
+        m(x).backward(g)
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).strip_dirs().sort_stats("tottime").print_stats(28)
+    print("\n".join(l[:150] for l in s.getvalue().splitlines()[2:44]))
