@@ -58,7 +58,7 @@ _NO_SWITCH = _NoSwitch()
 def _on(device):
     """Context that makes `device` current for the launch: a no-op object when it already is (the usual case;
     half the host cost of torch.cuda.device(), 0.6 vs 1.4 us per op)."""
-    if device.index is None or device.index == torch.cuda.current_device():
+    if device.index is None or device.index == _cuda_get_device():
         return _NO_SWITCH
     return torch.cuda.device(device)
 
